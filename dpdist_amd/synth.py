@@ -1,0 +1,163 @@
+"""Deterministic synthetic inputs and decoder weight sets (numpy only).
+
+These are the workloads of SURVEY.md section 8(d):
+
+* S1 "random patches"  -- parity config 2 (B=32 pairs of 64 points, 2 % of pcB snapped onto voxel
+  boundaries / just outside the cube).
+* S2 "ModelNet-shaped" -- training configs 3-4: restates the reference trainer's batch recipe
+  (`train_multi_gpu_pc_compare_dist.py:747-766`: pcA = 64 surface samples, pcB = 32 surface +
+  16 near-surface + 16 far points, labels_AB = [0]*32 + distances) on analytic surfaces, because
+  the ModelNet `*_dist_c_scaled.txt` files are not in the reference tree.
+* weight sets `xavier_tf` (what `tf.contrib.layers.xavier_initializer` gives the four "1xW conv"
+  kernels, `utils/tf_util.py:90-91`) and `wide` (outputs spread over [0, 2], both relu6
+  saturations exercised).
+
+Weights are returned in the reference's TF variable layout (`[1,2503,1,1024]`, `[1,1,1024,1024]`
+x2, `[1,1,1024,3]` + biases) keyed by the TF variable names, so the same dict feeds the oracle
+(reference under the stub), the restatement and `DPDistModel.load_tf_state_dict`.
+"""
+import math
+
+import numpy as np
+
+TF_SCOPE = "pc_compare/dpdist_local/mapper_conv%d/%s"
+
+
+def tf_shapes(E_plus_D=2503, mlp=(1024, 1024, 1024), out=3):
+    return [[1, E_plus_D, 1, mlp[0]], [1, 1, mlp[0], mlp[1]], [1, 1, mlp[1], mlp[2]],
+            [1, 1, mlp[2], out]]
+
+
+def _dense_fan_in(shape):
+    return shape[1] * shape[2]
+
+
+def make_weights(kind="xavier_tf", E_plus_D=2503, mlp=(1024, 1024, 1024), out=3):
+    """dict TF-variable-name -> float32 array.  Recipes fixed by SURVEY.md 8(d)."""
+    shapes = tf_shapes(E_plus_D, mlp, out)
+    w = {}
+    if kind == "xavier_tf":
+        rng = np.random.default_rng(2)
+        for l, shp in enumerate(shapes, 1):
+            recept = shp[0] * shp[1]
+            fan_in, fan_out = shp[2] * recept, shp[3] * recept
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            w[TF_SCOPE % (l, "weights")] = rng.uniform(-lim, lim, shp).astype(np.float32)
+            w[TF_SCOPE % (l, "biases")] = np.zeros(shp[3], np.float32)
+    elif kind == "wide":
+        rng = np.random.default_rng(3)
+        gains = [16.0, 1.0, 1.0, 4.0]
+        for l, shp in enumerate(shapes, 1):
+            fan_in = _dense_fan_in(shp)
+            w[TF_SCOPE % (l, "weights")] = (rng.standard_normal(shp).astype(np.float32)
+                                            * np.float32(math.sqrt(2.0 / fan_in) * gains[l - 1]))
+            w[TF_SCOPE % (l, "biases")] = np.zeros(shp[3], np.float32)
+        w[TF_SCOPE % (4, "biases")][:] = 3.0
+    else:
+        raise ValueError(kind)
+    return w
+
+
+BOUNDARY_SET = np.array([-1.0, -0.75, -0.5, -0.25, 0.0, 0.25, 0.5, 0.75, 1.0, 1.05, -1.05],
+                        dtype=np.float32)
+
+
+def s1_random_patches(B=32, N=64, seed=0):
+    """S1: uniform(-0.9, 0.9) clouds; 2 % of pcB entries overwritten with cell-boundary values."""
+    rng = np.random.default_rng(seed)
+    pcA = rng.uniform(-0.9, 0.9, (B, N, 3)).astype(np.float32)
+    pcB = rng.uniform(-0.9, 0.9, (B, N, 3)).astype(np.float32)
+    r1 = np.random.default_rng(seed + 1)
+    hit = r1.random((B, N, 3)) < 0.02
+    vals = BOUNDARY_SET[r1.integers(0, len(BOUNDARY_SET), (B, N, 3))]
+    pcB = np.where(hit, vals, pcB).astype(np.float32)
+    return pcA, pcB
+
+
+def boundary_cloud(B=2, N=64, seed=7):
+    """Every coordinate of pcB sits exactly on a voxel face or just outside the cube."""
+    rng = np.random.default_rng(seed)
+    pcA = rng.uniform(-0.9, 0.9, (B, N, 3)).astype(np.float32)
+    pcB = BOUNDARY_SET[rng.integers(0, len(BOUNDARY_SET), (B, N, 3))].astype(np.float32)
+    return pcA, pcB
+
+
+# ------------------------------------------------------------------------------------------
+# S2: analytic surfaces with exact point-to-surface distance
+# ------------------------------------------------------------------------------------------
+def _rot_y(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float64)
+
+
+def _sample_sphere(rng, n, r):
+    v = rng.standard_normal((n, 3))
+    return r * v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def _sample_box(rng, n, h):
+    """uniform-ish samples on the surface of the axis-aligned box with half extents h"""
+    p = rng.uniform(-1, 1, (n, 3)) * h
+    ax = rng.integers(0, 3, n)
+    sg = rng.choice([-1.0, 1.0], n)
+    p[np.arange(n), ax] = sg * h[ax]
+    return p
+
+
+def _dist_sphere(p, r):
+    return np.abs(np.linalg.norm(p, axis=1) - r)
+
+
+def _dist_box(p, h):
+    q = np.abs(p) - h
+    outside = np.linalg.norm(np.maximum(q, 0.0), axis=1)
+    inside = np.minimum(np.max(q, axis=1), 0.0)
+    return np.abs(outside + inside)
+
+
+def s2_modelnet_shaped(B=64, N=64, seed=100):
+    """(pcA, pcB, labels_AB) following the trainer's recipe on spheres/boxes of extent <= 0.8.
+
+    Per pair: a shape (sphere radius 0.3-0.7 or box half-extents 0.2-0.55), a random y-rotation
+    and a shift U(-0.1,0.1)^3 (`modelnet_dataset.py:87,91`); pcA = N surface samples; pcB = N/2
+    other surface samples + N/4 near-surface points (distance in (0.001, 0.1)) + N/4 points
+    uniform in the unit ball with distance > 0.1; labels = exact distance to the surface.
+    """
+    rng = np.random.default_rng(seed)
+    H, Qn = N // 2, N // 4
+    pcA = np.zeros((B, N, 3), np.float32)
+    pcB = np.zeros((B, N, 3), np.float32)
+    lab = np.zeros((B, N), np.float32)
+    for b in range(B):
+        is_sphere = rng.random() < 0.5
+        if is_sphere:
+            r = rng.uniform(0.3, 0.7)
+            samp = lambda n: _sample_sphere(rng, n, r)          # noqa: E731
+            dist = lambda p: _dist_sphere(p, r)                 # noqa: E731
+        else:
+            h = rng.uniform(0.2, 0.55, 3)
+            samp = lambda n: _sample_box(rng, n, h)             # noqa: E731
+            dist = lambda p: _dist_box(p, h)                    # noqa: E731
+        R = _rot_y(rng.uniform(0, 2 * math.pi))
+        shift = rng.uniform(-0.1, 0.1, 3)
+        surfA, surfB = samp(N), samp(H)
+        # near-surface: push surface samples along a random direction until 0.001 < d < 0.1
+        near = np.zeros((0, 3))
+        while len(near) < Qn:
+            c = samp(4 * Qn) + rng.standard_normal((4 * Qn, 3)) * 0.04
+            d = dist(c)
+            near = np.concatenate([near, c[(d > 0.001) & (d < 0.1)]])
+        near = near[:Qn]
+        far = np.zeros((0, 3))
+        while len(far) < Qn:
+            c = rng.standard_normal((8 * Qn, 3))
+            c = c / np.linalg.norm(c, axis=1, keepdims=True) * rng.random((8 * Qn, 1)) ** (1 / 3)
+            c = c * 0.85
+            d = dist(c)
+            far = np.concatenate([far, c[d > 0.1]])
+        far = far[:Qn]
+        B_local = np.concatenate([surfB, near, far])
+        lab[b] = np.concatenate([np.zeros(H), dist(near), dist(far)]).astype(np.float32)
+        pcA[b] = (surfA @ R.T + shift).astype(np.float32)
+        pcB[b] = (B_local @ R.T + shift).astype(np.float32)
+    return pcA, pcB, lab
