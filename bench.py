@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""DPDist hot-path benchmark: query-points/sec of the full training step (fwd + bwd + Adam) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: B pairs of 64-point clouds per GPU
+(BASELINE.json metric: "query-points/sec (DPDist fwd+bwd), 64-pt patches K=5^3, batch 32"): 3DmFV encode of
+2B clouds, 5^3-window gather + shared-MLP decoder for 2*B*64 query points, L1 loss on the AB half, backward to the
+8 decoder variables, gradient all-reduce (N>1) and the TF-form Adam update.  Inputs are resident in HBM before the
+timed region.  value = 2*B*64 * N * K / max-over-ranks(time).  Weak scaling: per-GPU batch fixed.
+
+Extra objects on the JSON line:
+  roofline     -- the fp32 MFMA GEMM kernel family (gemm_f32_kernel<...>): algorithmic flops of the GEMM launches
+                  of a step / their summed duration, measured with hipEvent pairs recorded in-stream around each
+                  launch (library profiler, separate pass of the same K steps); peak = 157.3 TFLOP/s fp32 MFMA.
+  cpu_baseline -- the oracle (oracle/restate.py, torch-CPU) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def gemm_flops_per_step(B, N, E3, H):
+    """Algorithmic flops of the GEMM launches of one training step (true K = 2503, layer 4 excluded:
+    it is not a GEMM launch).  fwd: Q rows x (E3*H + 2*H*H); bwd on BN rows: dH chain 2*H*H, dW E3*H + 2*H*H."""
+    Q, BN = 2 * B * N, B * N
+    fwd = 2.0 * Q * (E3 * H + 2 * H * H)
+    bwd = 2.0 * BN * (2 * H * H) + 2.0 * BN * (E3 * H + 2 * H * H)
+    return fwd + bwd, 3 + 2 + 3
+
+
+def cpu_baseline(B, N, budget_s=20.0):
+    """Oracle fwd+bwd (training mode) on the host cores; bounded sample, reported in query-points/sec."""
+    import numpy as np  # noqa: F401
+    from dpdist_amd import synth
+    from oracle import restate as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    pcA, pcB, lab = synth.s2_modelnet_shaped(B, N, 100)
+    W = R.as_torch_weights(synth.make_weights("xavier_tf"), torch.float32, requires_grad=True)
+    a, b, l = torch.tensor(pcA), torch.tensor(pcB), torch.tensor(lab)
+
+    def one():
+        pred, _ = R.get_model(a, b, W)
+        ls, _ = R.get_loss(pred, l)
+        torch.autograd.grad(ls, list(W.values()))
+
+    one()   # page-in / warm-up, not timed
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 40:
+            break
+    return {"value": round(2 * B * N * n / el, 1), "unit": "query-points/sec", "cores": cores, "kind": "port",
+            "sample": "%d fwd+bwd steps of the torch-CPU oracle at B=%d (same S2 workload), %.1f s" % (n, B, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="pairs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the DPDist path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dpdist_amd import lib, synth
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    L = lib.load()
+
+    B, N = a.batch, 64
+    P = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev)
+    g = torch.Generator().manual_seed(1234)            # same random-init weights on every rank (replicated variables)
+    P.reset_parameters_tf(generator=g)
+    tr = DPDistTrainer(P, B, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4)
+    pcA, pcB, lab = synth.s2_modelnet_shaped(B, N, 100 + rank)
+    pcA, pcB, lab = (torch.tensor(x, device=dev) for x in (pcA, pcB, lab))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.step(pcA, pcB, lab)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(pcA, pcB, lab)
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss = tr.loss.cpu().numpy()
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        L.dpd_prof_enable(1)
+        for _ in range(a.steps):
+            tr.forward()
+            tr.backward(lab.reshape(-1))
+        torch.cuda.synchronize()
+        ms, fl = ctypes.c_double(0), ctypes.c_double(0)
+        n = L.dpd_prof_collect(ctypes.byref(ms), ctypes.byref(fl))
+        L.dpd_prof_enable(0)
+        alg, per_step = gemm_flops_per_step(B, N, 2503, 1024)
+        if n > 0 and ms.value > 0:
+            launches = n
+            ach = alg * a.steps / (ms.value * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel<BM,BN,32,...> (fp32 v_mfma_f32_32x32x2)",
+                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
+                    "alg_gflop_per_launch": round(alg / per_step / 1e9, 3),
+                    "gemm_ms_per_step": round(ms.value / a.steps, 4)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        qps = 2.0 * B * N * world * a.steps / el
+        out = {"metric": "query-points/sec (DPDist fwd+bwd)", "value": round(qps, 1), "unit": "query-points/sec",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "DPDist training step (3DmFV 8^3 + 5^3-window decoder 2503-1024-1024-1024-3, "
+                                      "fwd both directions + bwd AB half + Adam), S2 ModelNet-shaped clouds",
+                          "pairs_per_gpu": B, "global_batch": B * world, "num_point": N, "query_points_per_step": 2 * B * N * world,
+                          "parallelism": "dp%d" % world, "loss_samples_last": round(float(loss[0]), 6)},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(B, N)
+            except Exception as e:   # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

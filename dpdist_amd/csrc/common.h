@@ -1,0 +1,60 @@
+// Shared helpers for the dpdist_hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dpdist_capi.h"
+
+#define DPD_CHECK_LAUNCH()                          \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+#define DPD_HIP(call)                               \
+    do {                                            \
+        hipError_t e__ = (call);                    \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+namespace dpd {
+
+constexpr int kWave = 64;   // CDNA wavefront
+constexpr int kNumXCD = 8;  // MI355X: 8 XCDs, block b runs on XCD b % 8 (speed only, never correctness)
+
+// Axis centres of the m-cell grid on [-1,1], restating numpy's arithmetic in double exactly:
+//   np.linspace(-1,1,m,False)+1/m == np.arange(-1,1,2/m)+(2/m)/2 == (-1 + i*(2/m)) + 1/m
+// (utils/dpdist_util.py:42 and :987-988), then cast to float32 like tf.constant(x, tf.float32).
+struct GridAxis {
+    float c[16];
+    float half;  // |c[0]-c[1]|/2 in float32 (utils/dpdist_util.py:468)
+};
+
+inline GridAxis make_axis(int m) {
+    GridAxis a{};
+    const double step = 2.0 / (double)m;
+    for (int i = 0; i < m && i < 16; ++i) {
+        volatile double v = (double)i * step;  // volatile: no FMA contraction on the host
+        v = v + (-1.0);
+        v = v + 1.0 / (double)m;
+        a.c[i] = (float)v;
+    }
+    a.half = (m > 1) ? fabsf(a.c[0] - a.c[1]) / 2.0f : 1.0f;
+    return a;
+}
+
+// bijective XCD-aware remap of a 1-D block id: each XCD gets a contiguous chunk of logical ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk / kNumXCD, r = nblk % kNumXCD;
+    const int xcd = bid % kNumXCD, loc = bid / kNumXCD;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace dpd

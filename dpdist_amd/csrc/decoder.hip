@@ -1,0 +1,222 @@
+// Implicit-surface decoder: shared MLP  KP(=2503 padded) -> H -> H -> H -> 3, relu6/3, mask.  Forward and backward.
+//
+// Replaces utils/dpdist_util.py:513-544 (four tf_util.conv2d "1xW VALID conv" == dense layers,
+// utils/tf_util.py:161-228), :691 (relu6/3), :695-698 (split + mask) and TF's autodiff of them.
+//
+// The three wide layers run on the fp32 MFMA GEMM of gemm_f32.hip (bias+ReLU / ReLU-gate fused in the epilogue);
+// the 3-wide output layer and the bias gradients are small HBM-bound kernels in this file.
+// Algorithmic work per query row (H = 1024): 4 663 296 MAC forward.  Activations h1,h2,h3 [Q,H] stay in HBM
+// (16.8 MB each at Q = 4096, resident in the 256 MiB Infinity Cache) for the backward pass.
+#include "common.h"
+
+namespace dpd {
+
+int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+             int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
+             size_t ws_bytes, hipStream_t s);
+
+// process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
+// a tuning knob (dpd_set_gemm_plan), never needed for correctness.
+enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 = 4, OP_BWD_DW23 = 5, OP_COUNT = 6 };
+static int g_plan_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0};
+static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1};
+
+// ---- output layer: y = h3 W4 + b4 ; pred = clip(y,0,6)/3 * mask.  One wave per row. ----------------------
+__global__ __launch_bounds__(256) void out_fwd_kernel(const float* __restrict__ h3, const float* __restrict__ W4,
+                                                       const float* __restrict__ b4, const float* __restrict__ mask,
+                                                       float* __restrict__ y, float* __restrict__ pred, int Q, int H) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Q) return;
+    const float* h = h3 + (size_t)row * H;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int k = lane; k < H; k += 64) {
+        const float x = h[k];
+        a0 += x * W4[k * 3 + 0];
+        a1 += x * W4[k * 3 + 1];
+        a2 += x * W4[k * 3 + 2];
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane < 3) {
+        const float v = (lane == 0 ? a0 : (lane == 1 ? a1 : a2)) + b4[lane];
+        y[(size_t)row * 3 + lane] = v;
+        pred[(size_t)row * 3 + lane] = fminf(fmaxf(v, 0.f), 6.f) / 3.0f * mask[row];   // relu6(y)/3 (:691) * mask (:697)
+    }
+}
+
+// dy = dpred * mask * [0 < y < 6] / 3 ;  g3 = (dy W4^T) * [h3 > 0].  One wave per row.
+__global__ __launch_bounds__(256) void out_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ mask,
+                                                       const float* __restrict__ y, const float* __restrict__ h3,
+                                                       const float* __restrict__ W4, float* __restrict__ dy,
+                                                       float* __restrict__ g3, int Qb, int H) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Qb) return;
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float yv = y[(size_t)row * 3 + c];
+        d[c] = (yv > 0.f && yv < 6.f) ? dpred[(size_t)row * 3 + c] * mask[row] / 3.0f : 0.f;   // relu6 gradient is 1 on (0,6)
+    }
+    if (lane < 3) dy[(size_t)row * 3 + lane] = d[lane];
+    const float* h = h3 + (size_t)row * H;
+    float* g = g3 + (size_t)row * H;
+    for (int k = lane; k < H; k += 64) {
+        const float v = d[0] * W4[k * 3] + d[1] * W4[k * 3 + 1] + d[2] * W4[k * 3 + 2];
+        g[k] = (h[k] > 0.f) ? v : 0.f;
+    }
+}
+
+// Column sums in two deterministic stages.  Stage 1: block (colblock, chunk) -> partial[chunk][...].
+//   NW = 0: partial[chunk][n]     = sum_r g[r][n]                       (bias gradient)
+//   NW = 3: partial[chunk][n*3+c] = sum_r a[r][n] * w[r*3+c]            (dW4 = h3^T dy)
+constexpr int kColChunks = 16;
+
+template <int NW>
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a, int lda, const float* __restrict__ w,
+                                                      int R, int Ncols, float* __restrict__ partial) {
+    __shared__ float red[4][64 * (NW ? NW : 1)];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rs = threadIdx.x >> 6, chunk = blockIdx.y;
+    const int rper = (R + kColChunks - 1) / kColChunks;
+    const int r0 = chunk * rper, r1 = min(R, r0 + rper);
+    float acc[NW ? NW : 1];
+#pragma unroll
+    for (int c = 0; c < (NW ? NW : 1); ++c) acc[c] = 0.f;
+    if (col < Ncols) {
+        for (int r = r0 + rs; r < r1; r += 4) {
+            const float x = a[(size_t)r * lda + col];
+            if (NW == 0) acc[0] += x;
+            else {
+#pragma unroll
+                for (int c = 0; c < NW; ++c) acc[c] += x * w[(size_t)r * NW + c];
+            }
+        }
+    }
+    constexpr int W = NW ? NW : 1;
+#pragma unroll
+    for (int c = 0; c < W; ++c) red[rs][(threadIdx.x & 63) * W + c] = acc[c];
+    __syncthreads();
+    if (rs == 0 && col < Ncols) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const int i = (threadIdx.x & 63) * W + c;
+            partial[((size_t)chunk * Ncols + col) * W + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kColChunks; ++c) s += partial[(size_t)c * n + i];
+    out[i] = s;
+}
+
+// dy [R,3] column sums (db4): single block
+__global__ __launch_bounds__(256) void dy_colsum_kernel(const float* __restrict__ dy, int R, float* __restrict__ db) {
+    __shared__ float red[4][3];
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int r = threadIdx.x; r < R; r += 256) {
+        a[0] += dy[(size_t)r * 3]; a[1] += dy[(size_t)r * 3 + 1]; a[2] += dy[(size_t)r * 3 + 2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a[c] = wave_sum(a[c]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = a[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) db[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+static size_t colsum_ws_floats(int ncols, int nw) { return (size_t)kColChunks * ncols * (nw ? nw : 1); }
+
+}  // namespace dpd
+
+extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
+    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 3 || split_k < 1 || split_k > 8) return DPD_E_DIM;
+    dpd::g_plan_tile[op] = tile;
+    dpd::g_plan_split[op] = split_k;
+    return 0;
+}
+
+extern "C" size_t dpd_workspace_bytes(int Q, int KP, int H) {
+    (void)Q;
+    const size_t slabs = (size_t)8 * (size_t)(KP > H ? KP : H) * H * sizeof(float);   // split-K <= 8 of the largest dW
+    const size_t cols = dpd::colsum_ws_floats(H, 3) * sizeof(float);
+    return slabs + cols + 256;
+}
+
+extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
+                               int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* stream) {
+    using namespace dpd;
+    if (!X || !mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
+    if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
+    if (Q <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
+    if ((H & 63) || (KP & 3) || dtype != 0) return DPD_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    // layer 1..3: h = relu(in W + b)   (tf_util.conv2d: conv2d + bias_add + relu, utils/tf_util.py:213-227)
+    if (int rc = gemm_f32(0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, 1, g_plan_tile[OP_FWD_L1],
+                          nullptr, 0, s)) return rc;
+    if (int rc = gemm_f32(0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, 1, g_plan_tile[OP_FWD_L23], nullptr, 0, s)) return rc;
+    if (int rc = gemm_f32(0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, 1, g_plan_tile[OP_FWD_L23], nullptr, 0, s)) return rc;
+    hipLaunchKernelGGL(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1,
+                                    const float* h2, const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p,
+                                    int dtype, float* dy, float* g3, float* g2, float* g1, float* dX, void* stream) {
+    using namespace dpd;
+    if (!dpred || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
+    if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
+    if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
+    if ((H & 63) || (KP & 3) || dtype != 0) return DPD_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(out_bwd_kernel, dim3((Qb + 3) / 4), dim3(256), 0, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H);
+    DPD_CHECK_LAUNCH();
+    // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0]
+    if (int rc = gemm_f32(0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s)) return rc;
+    if (int rc = gemm_f32(0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s)) return rc;
+    if (dX) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
+        if (int rc = gemm_f32(0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, 1, g_plan_tile[OP_BWD_DX], nullptr, 0, s)) return rc;
+    }
+    return 0;
+}
+
+extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
+                                       int dtype, float* dW, float* db, void* ws, size_t ws_bytes, void* stream) {
+    using namespace dpd;
+    if (!act || !g || !dW || !db) return DPD_E_NULL;
+    if (layer < 1 || layer > 4 || Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
+    if (dtype != 0) return DPD_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (layer == 4) {
+        if (Nout != 3) return DPD_E_DIM;
+        if (!ws || ws_bytes < colsum_ws_floats(Kin, 3) * sizeof(float)) return DPD_E_WORKSPACE;
+        float* part = (float*)ws;
+        hipLaunchKernelGGL(colsum_stage1<3>, dim3((Kin + 63) / 64, kColChunks), dim3(256), 0, s, act, lda, g, Qb, Kin, part);
+        DPD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(colsum_stage2, dim3((Kin * 3 + 255) / 256), dim3(256), 0, s, (const float*)part, Kin * 3, dW);
+        DPD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dy_colsum_kernel, dim3(1), dim3(256), 0, s, g, Qb, db);
+        DPD_CHECK_LAUNCH();
+        return 0;
+    }
+    if ((Nout & 3) || (Kin & 3) || (lda & 3)) return DPD_E_UNSUPPORTED;
+    const int op = (layer == 1) ? OP_BWD_DW1 : OP_BWD_DW23;
+    const int split = g_plan_split[op];
+    const size_t slab_bytes = (split > 1) ? (size_t)split * Kin * Nout * sizeof(float) : 0;
+    const size_t col_bytes = colsum_ws_floats(Nout, 0) * sizeof(float);
+    if (!ws || ws_bytes < slab_bytes + col_bytes) return DPD_E_WORKSPACE;
+    // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout]
+    if (int rc = gemm_f32(1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, split, g_plan_tile[op], ws,
+                          slab_bytes, s)) return rc;
+    float* part = (float*)((char*)ws + slab_bytes);
+    hipLaunchKernelGGL(colsum_stage1<0>, dim3((Nout + 63) / 64, kColChunks), dim3(256), 0, s, g, Nout, (const float*)nullptr,
+                       Qb, Nout, part);
+    DPD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_stage2, dim3((Nout + 255) / 256), dim3(256), 0, s, (const float*)part, Nout, db);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}

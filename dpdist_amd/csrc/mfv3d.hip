@@ -1,0 +1,471 @@
+// 3D modified Fisher Vector encoder (forward + backward), one workgroup per cloud.
+//
+// Replaces utils/dpdist_util.py:22-141 (get_3dmfv_tf with full_fv=True, normalize=True) and its TF autodiff.
+//
+// Data layout in HBM: pts [C,N,3] fp32 (768 B per 64-point cloud), fv [C,G,20] fp32 (40 KB per cloud for m=8).
+// Algorithmic HBM bytes per cloud: N*12 read + G*80 written.  The kernel is latency/VALU bound (N*G pdf
+// evaluations ~ 1.3 MFLOP per cloud), not a roofline kernel; it exists to keep the [B,N,G,3] TF tiles
+// (5 x 12.6 MB at B=32) out of HBM altogether.
+//
+// Mapping (wave64):
+//   pass 1  lane <-> point:    every thread owns (point n, quarter of the Gaussians) and sums p_ng -> denominators
+//   pass 2  lane <-> Gaussian: every thread owns a Gaussian and walks the N points (LDS broadcast reads),
+//                              keeping the 20 running statistics (sum/max/min) in registers -> no cross-lane
+//                              reductions at all for the per-Gaussian sums
+//   norm    power-1/2 per value, L2 over the Gaussian axis per channel (wave shuffle + LDS across 4 waves)
+//   store   staged through LDS ([G][21], conflict-free) and written with coalesced float4 stores
+#include "common.h"
+
+namespace dpd {
+
+constexpr int kF = DPD_FV_CHANNELS;  // 20
+constexpr int kFP = kF + 1;          // padded LDS row
+constexpr int kThreads = 256;
+
+struct MfvConst {
+    GridAxis ax;
+    int N, m, G;
+    float sigma;
+    float lognorm;   // 0.5*D*log(2*pi) + D*log(sigma)
+    float w;         // 1/G
+    float dpi_den;   // sqrt(w) * N            (:78)
+    float mu_scale;  // 1/sqrt(w)              (:98)
+    float sig_scale; // 1/sqrt(2w)             (:109)
+};
+
+__device__ __forceinline__ void gauss_centre(const MfvConst& k, int g, float& cx, float& cy, float& cz) {
+    // g = i*m*m + j*m + t  ->  (x,y,z) = (l[j], l[i], l[t])   (np.meshgrid 'xy' indexing, :47-48)
+    const int m = k.m;
+    const int i = g / (m * m), j = (g / m) % m, t = g % m;
+    cx = k.ax.c[j];
+    cy = k.ax.c[i];
+    cz = k.ax.c[t];
+}
+
+__device__ __forceinline__ float pdf(const MfvConst& k, float zx, float zy, float zz) {
+    // MultivariateNormalDiag.prob (:69-71): exp(-0.5*sum z^2 - (0.5*D*log 2pi + sum log sigma)), fp32 like TF
+    return expf(-0.5f * (zx * zx + zy * zy + zz * zz) - k.lognorm);
+}
+
+__device__ __forceinline__ float pnorm(float x) {
+    // sign(x) * max(|x|,1e-12)^0.5  (:119-121)
+    const float s = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    return s * sqrtf(fmaxf(fabsf(x), 1e-12f));
+}
+
+// All per-(point, Gaussian) quantities of utils/dpdist_util.py:69-100, evaluated by ONE routine so that the
+// forward statistics and the backward tie tests see bit-identical values (the library is built with
+// -ffp-contract=off: no FMA contraction, like TF's op-by-op evaluation).
+struct PG {
+    float z[3], a[3], b[3];
+    float pw, Q, dpi;
+};
+
+__device__ __forceinline__ PG eval_pg(const MfvConst& k, float x, float y, float zc, float cx, float cy, float cz,
+                                      float den) {
+    PG r;
+    r.z[0] = (x - cx) / k.sigma;
+    r.z[1] = (y - cy) / k.sigma;
+    r.z[2] = (zc - cz) / k.sigma;
+    r.pw = pdf(k, r.z[0], r.z[1], r.z[2]) * k.w;    // :73
+    r.Q = r.pw / den;                                // :74
+    r.dpi = (r.Q - k.w) / k.dpi_den;                 // :78
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        r.a[d] = r.Q * r.z[d];                       // :87
+        r.b[d] = r.Q * (r.z[d] * r.z[d] - 1.0f);     // :100
+    }
+    return r;
+}
+
+// dynamic LDS: pts[N*3] | denom[N] | part[4*N] | stage[G*21] | chred[4*20] | chscale[20]
+__global__ __launch_bounds__(kThreads) void mfv3d_fwd_kernel(const float* __restrict__ pts, float* __restrict__ fv,
+                                                              MfvConst k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = k.N, G = k.G;
+    float* s_pts = sm;
+    float* s_den = s_pts + ((N * 3 + 3) & ~3);
+    float* s_part = s_den + N;
+    float* s_stage = s_part + 4 * N;
+    float* s_chred = s_stage + G * kFP;
+    float* s_scale = s_chred + 4 * kF;
+
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const float* p = pts + (size_t)c * N * 3;
+    for (int i = tid; i < N * 3; i += kThreads) s_pts[i] = p[i];
+    __syncthreads();
+
+    // ---- pass 1: denominators sum_g w*p_ng  (:73-74) -------------------------------------------
+    const int gq = (G + 3) / 4;
+    for (int idx = tid; idx < 4 * N; idx += kThreads) {
+        const int n = idx % N, sl = idx / N;
+        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], z = s_pts[n * 3 + 2];
+        float acc = 0.f;
+        const int g1 = min(G, (sl + 1) * gq);
+        for (int g = sl * gq; g < g1; ++g) {
+            float cx, cy, cz;
+            gauss_centre(k, g, cx, cy, cz);
+            acc += pdf(k, (x - cx) / k.sigma, (y - cy) / k.sigma, (z - cz) / k.sigma) * k.w;
+        }
+        s_part[sl * N + n] = acc;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += kThreads) s_den[n] = (s_part[n] + s_part[N + n]) + (s_part[2 * N + n] + s_part[3 * N + n]);
+    __syncthreads();
+
+    // ---- pass 2: per-Gaussian statistics over the points ------------------------------------------
+    float chsq[kF];
+#pragma unroll
+    for (int f = 0; f < kF; ++f) chsq[f] = 0.f;
+
+    const float invN = 1.0f / (float)N;
+    for (int g = tid; g < G; g += kThreads) {
+        float cx, cy, cz;
+        gauss_centre(k, g, cx, cy, cz);
+        float pi_s = 0.f, pi_mx = -INFINITY;
+        float mu_s[3] = {0.f, 0.f, 0.f}, mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
+        float sg_s[3] = {0.f, 0.f, 0.f}, sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
+        for (int n = 0; n < N; ++n) {
+            const PG q = eval_pg(k, s_pts[n * 3], s_pts[n * 3 + 1], s_pts[n * 3 + 2], cx, cy, cz, s_den[n]);
+            pi_s += q.dpi;
+            pi_mx = fmaxf(pi_mx, q.dpi);
+            if (q.dpi != q.dpi) pi_mx = q.dpi;   // fmaxf drops NaN; tf.reduce_max propagates it
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                mu_s[d] += q.a[d]; mu_mx[d] = fmaxf(mu_mx[d], q.a[d]); mu_mn[d] = fminf(mu_mn[d], q.a[d]);
+                sg_s[d] += q.b[d]; sg_mx[d] = fmaxf(sg_mx[d], q.b[d]); sg_mn[d] = fminf(sg_mn[d], q.b[d]);
+                if (q.a[d] != q.a[d]) { mu_mx[d] = q.a[d]; mu_mn[d] = q.a[d]; }
+                if (q.b[d] != q.b[d]) { sg_mx[d] = q.b[d]; sg_mn[d] = q.b[d]; }
+            }
+        }
+        float v[kF];
+        v[0] = pi_s * invN;                                                     // :81 (reduce_mean)
+        v[1] = pi_mx;                                                           // :80
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {                                           // :89-98, :102-109
+            v[2 + d] = (mu_s[d] * invN) * k.mu_scale;
+            v[5 + d] = mu_mx[d] * k.mu_scale;
+            v[8 + d] = mu_mn[d] * k.mu_scale;
+            v[11 + d] = (sg_s[d] * invN) * k.sig_scale;
+            v[14 + d] = sg_mx[d] * k.sig_scale;
+            v[17 + d] = sg_mn[d] * k.sig_scale;
+        }
+#pragma unroll
+        for (int f = 0; f < kF; ++f) {
+            const float s = pnorm(v[f]);
+            s_stage[g * kFP + f] = s;
+            chsq[f] += s * s;
+        }
+    }
+
+    // ---- L2 normalisation over the Gaussian axis, per channel (:124-126) ----------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int f = 0; f < kF; ++f) {
+        const float s = wave_sum(chsq[f]);
+        if (lane == 0) s_chred[wave * kF + f] = s;
+    }
+    __syncthreads();
+    if (tid < kF) {
+        const float ss = (s_chred[tid] + s_chred[kF + tid]) + (s_chred[2 * kF + tid] + s_chred[3 * kF + tid]);
+        s_scale[tid] = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    }
+    __syncthreads();
+
+    // ---- coalesced store: fv[c][g][f], 4 consecutive f of one g per thread ---------------------------
+    float* out = fv + (size_t)c * G * kF;
+    for (int i4 = tid; i4 < G * kF / 4; i4 += kThreads) {
+        const int e = i4 * 4, g = e / kF, f = e % kF;
+        float4 o;
+        o.x = s_stage[g * kFP + f] * s_scale[f];
+        o.y = s_stage[g * kFP + f + 1] * s_scale[f + 1];
+        o.z = s_stage[g * kFP + f + 2] * s_scale[f + 2];
+        o.w = s_stage[g * kFP + f + 3] * s_scale[f + 3];
+        *reinterpret_cast<float4*>(out + e) = o;
+    }
+}
+
+static int make_const(int N, int m, float sigma, MfvConst& k) {
+    if (m < 1 || m > 10) return DPD_E_UNSUPPORTED;
+    if (N < 1 || N > 4096) return DPD_E_UNSUPPORTED;
+    if (!(sigma > 0.f)) return DPD_E_DIM;
+    k.ax = make_axis(m);
+    k.N = N; k.m = m; k.G = m * m * m;
+    k.sigma = sigma;
+    const double D = 3.0;
+    k.lognorm = (float)(0.5 * D * log(2.0 * M_PI) + D * log((double)sigma));
+    k.w = 1.0f / (float)k.G;
+    k.dpi_den = sqrtf(k.w) * (float)N;
+    k.mu_scale = 1.0f / sqrtf(k.w);
+    k.sig_scale = 1.0f / sqrtf(2.0f * k.w);
+    return 0;
+}
+
+static size_t fwd_lds_bytes(int N, int G) {
+    return (size_t)(((N * 3 + 3) & ~3) + N + 4 * N + G * kFP + 4 * kF + kF + 4) * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward: dfv [C,G,20] -> dpts [C,N,3].  Everything the forward produced is recomputed (cheap) instead
+// of being saved.  Chain (TF autodiff of :69-126):
+//   fv = s * scale_f,  s = pnorm(v)        -> ds = scale_f * (dfv - fv_hat * <dfv, fv_hat>_G)  (zero if sum < eps)
+//   v  = stat(raw) * const                 -> d raw: mean -> 1/N to every point, max/min -> ties share evenly
+//   raw quantities depend on Q_ng and z_ng -> dQ_ng, dz_ng (direct)
+//   Q_ng = wp_ng / sum_g wp_ng             -> dwp_ng = (dQ_ng - sum_g' dQ_ng' Q_ng') / den_n
+//   p_ng = exp(-0.5 |z|^2 - c)             -> dz_ng += -z_ng * p_ng * dp_ng ;  dx_n = sum_g dz_ng / sigma
+//
+// Two kernels per cloud-block to keep registers sane:
+//   pass A (lane <-> Gaussian): recompute stats (incl. tie counts), turn dfv into per-Gaussian coefficient
+//           records in LDS;   pass B (lane <-> point, 4 Gaussian-slices): accumulate dQ.Q and dz per point.
+// Both live in one kernel; coefficient records are kept in LDS ([G][41]).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRec = 41;  // per-Gaussian record: 20 upstream grads wrt the raw statistics + 20 selected values + pad
+
+__global__ __launch_bounds__(kThreads) void mfv3d_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ dfv,
+                                                              float* __restrict__ dpts, MfvConst k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = k.N, G = k.G;
+    float* s_pts = sm;
+    float* s_den = s_pts + ((N * 3 + 3) & ~3);
+    float* s_part = s_den + N;            // [4*N] scratch (denominators, then dQ.Q partials)
+    float* s_rec = s_part + 4 * N;        // [G*kRec]
+    float* s_chred = s_rec + G * kRec;    // [4*2*20]
+    float* s_ch = s_chred + 8 * kF;       // [2*20]: scale_f, dot_f
+    float* s_acc = s_ch + 2 * kF;         // [4*N*3] dz partials
+
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* p = pts + (size_t)c * N * 3;
+    const float* df = dfv + (size_t)c * G * kF;
+    for (int i = tid; i < N * 3; i += kThreads) s_pts[i] = p[i];
+    __syncthreads();
+
+    const int gq = (G + 3) / 4;
+    for (int idx = tid; idx < 4 * N; idx += kThreads) {
+        const int n = idx % N, sl = idx / N;
+        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], z = s_pts[n * 3 + 2];
+        float acc = 0.f;
+        const int g1 = min(G, (sl + 1) * gq);
+        for (int g = sl * gq; g < g1; ++g) {
+            float cx, cy, cz;
+            gauss_centre(k, g, cx, cy, cz);
+            acc += pdf(k, (x - cx) / k.sigma, (y - cy) / k.sigma, (z - cz) / k.sigma) * k.w;
+        }
+        s_part[sl * N + n] = acc;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += kThreads) s_den[n] = (s_part[n] + s_part[N + n]) + (s_part[2 * N + n] + s_part[3 * N + n]);
+    __syncthreads();
+
+    // ---- pass A.1: recompute the power-normalised statistics s[g][f] (into rec[0..19]) + channel sums ----
+    const float invN = 1.0f / (float)N;
+    float chsq[kF], chdot[kF];
+#pragma unroll
+    for (int f = 0; f < kF; ++f) { chsq[f] = 0.f; chdot[f] = 0.f; }
+    for (int g = tid; g < G; g += kThreads) {
+        float cx, cy, cz;
+        gauss_centre(k, g, cx, cy, cz);
+        float pi_s = 0.f, pi_mx = -INFINITY;
+        float mu_s[3] = {0.f, 0.f, 0.f}, mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
+        float sg_s[3] = {0.f, 0.f, 0.f}, sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
+        for (int n = 0; n < N; ++n) {
+            const PG q = eval_pg(k, s_pts[n * 3], s_pts[n * 3 + 1], s_pts[n * 3 + 2], cx, cy, cz, s_den[n]);
+            pi_s += q.dpi;
+            pi_mx = fmaxf(pi_mx, q.dpi);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                mu_s[d] += q.a[d]; mu_mx[d] = fmaxf(mu_mx[d], q.a[d]); mu_mn[d] = fminf(mu_mn[d], q.a[d]);
+                sg_s[d] += q.b[d]; sg_mx[d] = fmaxf(sg_mx[d], q.b[d]); sg_mn[d] = fminf(sg_mn[d], q.b[d]);
+            }
+        }
+        // raw selected values (before the constant scales), needed again for the tie test in pass B
+        float raw[kF], v[kF];
+        raw[0] = pi_s * invN; raw[1] = pi_mx;
+        v[0] = raw[0]; v[1] = raw[1];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            raw[2 + d] = mu_s[d] * invN;  raw[5 + d] = mu_mx[d];  raw[8 + d] = mu_mn[d];
+            raw[11 + d] = sg_s[d] * invN; raw[14 + d] = sg_mx[d]; raw[17 + d] = sg_mn[d];
+            v[2 + d] = raw[2 + d] * k.mu_scale;   v[5 + d] = raw[5 + d] * k.mu_scale;   v[8 + d] = raw[8 + d] * k.mu_scale;
+            v[11 + d] = raw[11 + d] * k.sig_scale; v[14 + d] = raw[14 + d] * k.sig_scale; v[17 + d] = raw[17 + d] * k.sig_scale;
+        }
+#pragma unroll
+        for (int f = 0; f < kF; ++f) {
+            const float s = pnorm(v[f]);
+            s_rec[g * kRec + f] = s;            // temporarily: s
+            s_rec[g * kRec + kF + f] = raw[f];  // selected raw value
+            chsq[f] += s * s;
+            chdot[f] += s * df[g * kF + f];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < kF; ++f) {
+        const float a = wave_sum(chsq[f]), b = wave_sum(chdot[f]);
+        if (lane == 0) { s_chred[wave * 2 * kF + f] = a; s_chred[wave * 2 * kF + kF + f] = b; }
+    }
+    __syncthreads();
+    if (tid < 2 * kF)
+        s_ch[tid] = (s_chred[tid] + s_chred[2 * kF + tid]) + (s_chred[4 * kF + tid] + s_chred[6 * kF + tid]);
+    __syncthreads();
+
+    // ---- pass A.2: dfv -> gradient wrt the raw per-Gaussian statistics (rec[0..19]) --------------------
+    for (int g = tid; g < G; g += kThreads) {
+#pragma unroll
+        for (int f = 0; f < kF; ++f) {
+            const float ss = s_ch[f], dot = s_ch[kF + f];
+            const float s = s_rec[g * kRec + f];
+            const float dy = df[g * kF + f];
+            float ds;
+            if (ss >= 1e-12f) {           // y = s * rsqrt(ss): ds = rs*dy - s * dot * rs^3   (tf.nn.l2_normalize)
+                const float rs = 1.0f / sqrtf(ss);
+                ds = rs * dy - s * dot * rs * rs * rs;
+            } else {                      // clamp active: y = s * 1e6
+                ds = dy * 1e6f;
+            }
+            float cst = 1.0f;
+            if (f >= 2 && f < 11) cst = k.mu_scale;
+            if (f >= 11) cst = k.sig_scale;
+            // s = sign(v) * max(|v|,1e-12)^0.5: dv = ds * 0.5/sqrt(|v|) where |v| >= 1e-12 (tf.maximum sends the
+            // gradient to |v| only when |v| >= eps; tf.sign has zero gradient)
+            const float v = s_rec[g * kRec + kF + f] * cst;   // same expression as the forward
+            float dv = 0.f;
+            if (fabsf(v) >= 1e-12f) dv = ds * 0.5f / sqrtf(fabsf(v));
+            float dr = dv * cst;
+            if (f == 0 || (f >= 2 && f < 5) || (f >= 11 && f < 14)) dr *= invN;   // mean -> every point gets 1/N
+            s_rec[g * kRec + f] = dr;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass B.0: tie counts for max/min statistics (lane <-> Gaussian) -> fold 1/count into rec ------
+    for (int g = tid; g < G; g += kThreads) {
+        float cx, cy, cz;
+        gauss_centre(k, g, cx, cy, cz);
+        int cnt[kF];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) cnt[f] = 0;
+        for (int n = 0; n < N; ++n) {
+            const PG q = eval_pg(k, s_pts[n * 3], s_pts[n * 3 + 1], s_pts[n * 3 + 2], cx, cy, cz, s_den[n]);
+            cnt[1] += (q.dpi == s_rec[g * kRec + kF + 1]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                cnt[5 + d] += (q.a[d] == s_rec[g * kRec + kF + 5 + d]);
+                cnt[8 + d] += (q.a[d] == s_rec[g * kRec + kF + 8 + d]);
+                cnt[14 + d] += (q.b[d] == s_rec[g * kRec + kF + 14 + d]);
+                cnt[17 + d] += (q.b[d] == s_rec[g * kRec + kF + 17 + d]);
+            }
+        }
+        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const int f = mm[i];
+            s_rec[g * kRec + f] = s_rec[g * kRec + f] / (float)max(cnt[f], 1);
+        }
+    }
+    __syncthreads();
+
+    // ---- pass B.1: lane <-> point.  dQ_ng and direct dz_ng; accumulate sum_g dQ*Q per point -------------
+    // B.1 computes T_n = sum_g dQ_ng Q_ng; B.2 the final dz with dwp = (dQ - T_n)/den.
+    for (int idx = tid; idx < 4 * N; idx += kThreads) {
+        const int n = idx % N, sl = idx / N;
+        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], zc = s_pts[n * 3 + 2];
+        const float den = s_den[n];
+        float T = 0.f;
+        const int g1 = min(G, (sl + 1) * gq);
+        for (int g = sl * gq; g < g1; ++g) {
+            float cx, cy, cz;
+            gauss_centre(k, g, cx, cy, cz);
+            const PG q = eval_pg(k, x, y, zc, cx, cy, cz, den);
+            const float* r = s_rec + g * kRec;
+            float dQ = (r[0] + ((q.dpi == r[kF + 1]) ? r[1] : 0.f)) / k.dpi_den;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float ga = r[2 + d] + ((q.a[d] == r[kF + 5 + d]) ? r[5 + d] : 0.f) + ((q.a[d] == r[kF + 8 + d]) ? r[8 + d] : 0.f);
+                const float gb = r[11 + d] + ((q.b[d] == r[kF + 14 + d]) ? r[14 + d] : 0.f) + ((q.b[d] == r[kF + 17 + d]) ? r[17 + d] : 0.f);
+                dQ += ga * q.z[d] + gb * (q.z[d] * q.z[d] - 1.0f);
+            }
+            T += dQ * q.Q;
+        }
+        s_part[sl * N + n] = T;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 4 * N; idx += kThreads) {
+        const int n = idx % N, sl = idx / N;
+        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], zc = s_pts[n * 3 + 2];
+        const float den = s_den[n];
+        const float T = (s_part[n] + s_part[N + n]) + (s_part[2 * N + n] + s_part[3 * N + n]);
+        float dz[3] = {0.f, 0.f, 0.f};
+        const int g1 = min(G, (sl + 1) * gq);
+        for (int g = sl * gq; g < g1; ++g) {
+            float cx, cy, cz;
+            gauss_centre(k, g, cx, cy, cz);
+            const PG q = eval_pg(k, x, y, zc, cx, cy, cz, den);
+            const float* r = s_rec + g * kRec;
+            const float pw = q.pw, Q = q.Q;
+            const float* z = q.z;
+            float dQ = (r[0] + ((q.dpi == r[kF + 1]) ? r[1] : 0.f)) / k.dpi_den;
+            float ga[3], gb[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                ga[d] = r[2 + d] + ((q.a[d] == r[kF + 5 + d]) ? r[5 + d] : 0.f) + ((q.a[d] == r[kF + 8 + d]) ? r[8 + d] : 0.f);
+                gb[d] = r[11 + d] + ((q.b[d] == r[kF + 14 + d]) ? r[14 + d] : 0.f) + ((q.b[d] == r[kF + 17 + d]) ? r[17 + d] : 0.f);
+                dQ += ga[d] * z[d] + gb[d] * (z[d] * z[d] - 1.0f);
+            }
+            // Q = wp/den, den = sum wp  ->  d wp_ng = (dQ_ng - T_n) / den ;  wp = w*exp(-0.5|z|^2 - c)  ->  dz += -z * wp * dwp
+            const float dwp = (dQ - T) / den;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dz[d] += Q * (ga[d] + 2.0f * gb[d] * z[d]) - z[d] * pw * dwp;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) s_acc[(sl * N + n) * 3 + d] = dz[d];
+    }
+    __syncthreads();
+    float* out = dpts + (size_t)c * N * 3;
+    for (int i = tid; i < N * 3; i += kThreads) {
+        const float s = (s_acc[i] + s_acc[N * 3 + i]) + (s_acc[2 * N * 3 + i] + s_acc[3 * N * 3 + i]);
+        out[i] = s / k.sigma;   // z = (x - mu)/sigma
+    }
+}
+
+static size_t bwd_lds_bytes(int N, int G) {
+    return (size_t)(((N * 3 + 3) & ~3) + N + 4 * N + G * kRec + 8 * kF + 2 * kF + 4 * N * 3 + 4) * sizeof(float);
+}
+
+template <typename K>
+static int set_lds(K kern, size_t lds) {
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return DPD_E_UNSUPPORTED;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+}  // namespace dpd
+
+extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma, float* fv, void* stream) {
+    using namespace dpd;
+    if (!pts || !fv) return DPD_E_NULL;
+    if (C <= 0) return DPD_E_DIM;
+    MfvConst k{};
+    if (int rc = make_const(N, m, sigma, k)) return rc;
+    const size_t lds = fwd_lds_bytes(N, k.G);
+    if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
+    hipLaunchKernelGGL(mfv3d_fwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, fv, k);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, int m, float sigma, float* dpts,
+                             void* stream) {
+    using namespace dpd;
+    if (!pts || !dfv || !dpts) return DPD_E_NULL;
+    if (C <= 0) return DPD_E_DIM;
+    MfvConst k{};
+    if (int rc = make_const(N, m, sigma, k)) return rc;
+    const size_t lds = bwd_lds_bytes(N, k.G);
+    if (int rc = set_lds(mfv3d_bwd_kernel, lds)) return rc;
+    hipLaunchKernelGGL(mfv3d_bwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, dfv, dpts, k);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,100 @@
+"""ctypes binding of libdpdist_hip.so (the C ABI of include/dpdist_capi.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+Thin typed wrappers (`ops_*`) take torch CUDA tensors, check dtype/contiguity and pass raw device
+pointers + the current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdpdist_hip.so")
+
+_ERR = {-1: "DPD_E_NULL (null pointer)", -2: "DPD_E_DIM (bad dimension)",
+        -3: "DPD_E_UNSUPPORTED (unsupported size/configuration)", -4: "DPD_E_WORKSPACE (workspace too small)"}
+
+
+class DecoderParams(Structure):
+    _fields_ = [(n, c_void_p) for n in ("W1p", "b1", "W2", "b2", "W3", "b3", "W4", "b4")]
+
+
+# name -> (restype, argtypes); mirrors include/dpdist_capi.h one to one
+SIGNATURES = {
+    "dpd_version": (c_char_p, []),
+    "dpd_padded_width": (c_int, [c_int]),
+    "dpd_mfv3d_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "dpd_mfv3d_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "dpd_patch_rows_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
+    "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p]),
+    "dpd_decoder_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_int, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dpd_decoder_bwd_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     POINTER(DecoderParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+    "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpd_l1_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "dpd_adam_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
+                            c_float, c_void_p]),
+    "dpd_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                             c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dpd_set_gemm_plan": (c_int, [c_int, c_int, c_int]),
+    "dpd_prof_enable": (c_int, [c_int]),
+    "dpd_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libdpdist_hip.so not found at %s -- run `python -m dpdist_amd.build` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here == header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+    raise RuntimeError("%s failed: hipError_t %d" % (what, rc))
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def req(t, dtype=None, name="tensor"):
+    import torch
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (dpdist_amd has no CPU path)" % name)
+    if dtype is None:
+        dtype = torch.float32
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def make_params(W1p, b1, W2, b2, W3, b3, W4, b4):
+    return DecoderParams(*[t.data_ptr() for t in (W1p, b1, W2, b2, W3, b3, W4, b4)])

@@ -1,0 +1,142 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/dpdist_capi.h).
+
+All tensors are torch CUDA float32 (int32 for `vox`), contiguous; outputs are allocated with torch's
+caching allocator and the kernels are enqueued on torch's current HIP stream.
+"""
+import torch
+
+from . import lib as L
+
+F = 20
+
+
+def padded_width(k):
+    return L.load().dpd_padded_width(int(k))
+
+
+def mfv3d_fwd(pts, m, sigma):
+    """pts [C,N,3] -> fv [C,m^3,20]   (utils/dpdist_util.py:22-141)"""
+    L.req(pts, name="pts")
+    C, N, _ = pts.shape
+    fv = torch.empty(C, m ** 3, F, device=pts.device, dtype=torch.float32)
+    L.check(L.load().dpd_mfv3d_fwd(L.ptr(pts), C, N, m, float(sigma), L.ptr(fv), L.cur_stream()), "dpd_mfv3d_fwd")
+    return fv
+
+
+def mfv3d_bwd(pts, dfv, m, sigma):
+    L.req(pts, name="pts"), L.req(dfv, name="dfv")
+    C, N, _ = pts.shape
+    dpts = torch.empty_like(pts)
+    L.check(L.load().dpd_mfv3d_bwd(L.ptr(pts), L.ptr(dfv), C, N, m, float(sigma), L.ptr(dpts), L.cur_stream()),
+            "dpd_mfv3d_bwd")
+    return dpts
+
+
+def patch_rows_fwd(q, fv, m, k, KP=None, out=None):
+    """q [C,N,3], fv [C,m^3,20] -> X [C*N,KP], mask [C*N], vox [C*N] int32   (:911-930, :459-492, :434-457)"""
+    L.req(q, name="q"), L.req(fv, name="fv")
+    C, N, _ = q.shape
+    KP = KP or padded_width(k)
+    if out is None:
+        X = torch.empty(C * N, KP, device=q.device, dtype=torch.float32)
+        mask = torch.empty(C * N, device=q.device, dtype=torch.float32)
+        vox = torch.empty(C * N, device=q.device, dtype=torch.int32)
+    else:
+        X, mask, vox = out
+    L.check(L.load().dpd_patch_rows_fwd(L.ptr(q), L.ptr(fv), C, N, m, k, KP, L.ptr(X), L.ptr(mask), L.ptr(vox),
+                                        L.cur_stream()), "dpd_patch_rows_fwd")
+    return X, mask, vox
+
+
+def patch_rows_bwd(dX, vox, C, N, m, k, want_dq=True, want_dfv=True):
+    L.req(dX, name="dX"), L.req(vox, torch.int32, "vox")
+    KP = dX.shape[1]
+    dq = torch.empty(C, N, 3, device=dX.device, dtype=torch.float32) if want_dq else None
+    dfv = torch.empty(C, m ** 3, F, device=dX.device, dtype=torch.float32) if want_dfv else None
+    L.check(L.load().dpd_patch_rows_bwd(L.ptr(dX), L.ptr(vox), C, N, m, k, KP, L.ptr(dq), L.ptr(dfv), L.cur_stream()),
+            "dpd_patch_rows_bwd")
+    return dq, dfv
+
+
+def decoder_fwd(X, mask, params, H, bufs=None):
+    """X [Q,KP] -> (h1,h2,h3 [Q,H], y [Q,3], pred [Q,3])   (:513-544, :691, :695-698)"""
+    L.req(X, name="X"), L.req(mask, name="mask")
+    Q, KP = X.shape
+    if bufs is None:
+        h1, h2, h3 = (torch.empty(Q, H, device=X.device, dtype=torch.float32) for _ in range(3))
+        y = torch.empty(Q, 3, device=X.device, dtype=torch.float32)
+        pred = torch.empty(Q, 3, device=X.device, dtype=torch.float32)
+    else:
+        h1, h2, h3, y, pred = bufs
+    p = L.make_params(*params)
+    L.check(L.load().dpd_decoder_fwd(L.ptr(X), L.ptr(mask), Q, KP, H, p, 0, L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(y),
+                                     L.ptr(pred), L.cur_stream()), "dpd_decoder_fwd")
+    return h1, h2, h3, y, pred
+
+
+def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None):
+    """dpred [Qb,3] (first Qb rows) -> dy [Qb,3], g3,g2,g1 [Qb,H], dX [Qb,KP] or None"""
+    L.req(dpred, name="dpred")
+    Qb = dpred.shape[0]
+    H = h1.shape[1]
+    dev = dpred.device
+    if bufs is None:
+        dy = torch.empty(Qb, 3, device=dev, dtype=torch.float32)
+        g3, g2, g1 = (torch.empty(Qb, H, device=dev, dtype=torch.float32) for _ in range(3))
+        dX = torch.empty(Qb, KP, device=dev, dtype=torch.float32) if want_dX else None
+    else:
+        dy, g3, g2, g1, dX = bufs
+    p = L.make_params(*params)
+    L.check(L.load().dpd_decoder_bwd_data(L.ptr(dpred), L.ptr(mask), L.ptr(y), L.ptr(h1), L.ptr(h2), L.ptr(h3), Qb, KP, H,
+                                          p, 0, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), L.cur_stream()),
+            "dpd_decoder_bwd_data")
+    return dy, g3, g2, g1, dX
+
+
+def workspace(Q, KP, H, device):
+    n = L.load().dpd_workspace_bytes(Q, KP, H)
+    return torch.empty((n + 3) // 4, device=device, dtype=torch.float32)
+
+
+def decoder_bwd_weights(layer, act, g, Qb, dW, db, ws):
+    """dW/db of one layer from its input activation `act` [>=Qb, Kin] and output gradient `g` [Qb, Nout]."""
+    Kin, Nout = dW.shape
+    L.check(L.load().dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), Qb, Kin, Nout, 0, L.ptr(dW),
+                                             L.ptr(db), L.ptr(ws), ws.numel() * 4, L.cur_stream()),
+            "dpd_decoder_bwd_weights(layer=%d)" % layer)
+
+
+def l1_loss(pred, labels, mode=0, gscale=1.0, dpred=None, loss=None):
+    """pred [2*BN,3], labels [BN] -> loss [2] = (loss_samples, loss_pred); dpred per `mode` (:962-980)"""
+    L.req(pred, name="pred"), L.req(labels, name="labels")
+    BN = labels.numel()
+    if loss is None:
+        loss = torch.empty(2, device=pred.device, dtype=torch.float32)
+    if mode and dpred is None:
+        dpred = torch.empty(BN * (1 if mode == 1 else 2), 3, device=pred.device, dtype=torch.float32)
+    L.check(L.load().dpd_l1_loss(L.ptr(pred), L.ptr(labels), BN, mode, float(gscale), L.ptr(loss), L.ptr(dpred),
+                                 L.cur_stream()), "dpd_l1_loss")
+    return loss, dpred
+
+
+def adam_tf(p, g, m, v, lr_t, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0):
+    L.check(L.load().dpd_adam_tf(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), float(lr_t), b1, b2, eps,
+                                 float(gscale), L.cur_stream()), "dpd_adam_tf")
+
+
+def gemm_f32(A, B, transA=False, transB=False, bias=None, gate=None, epilogue=0, split_k=1, tile=0, out=None):
+    """C = epi(op(A) op(B)) on the fp32 MFMA kernel (building block; see include/dpdist_capi.h)."""
+    L.req(A, name="A"), L.req(B, name="B")
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    C = out if out is not None else torch.empty(M, N, device=A.device, dtype=torch.float32)
+    ws = torch.empty(split_k * M * N if split_k > 1 else 1, device=A.device, dtype=torch.float32)
+    L.check(L.load().dpd_gemm_f32(int(transA), int(transB), M, N, K, L.ptr(A), A.stride(0), L.ptr(B), B.stride(0),
+                                  L.ptr(C), C.stride(0), L.ptr(bias), L.ptr(gate), epilogue, split_k, tile, L.ptr(ws),
+                                  ws.numel() * 4, L.cur_stream()), "dpd_gemm_f32")
+    return C
+
+
+def set_gemm_plan(op, tile, split_k=1):
+    L.check(L.load().dpd_set_gemm_plan(op, tile, split_k), "dpd_set_gemm_plan")

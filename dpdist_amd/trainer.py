@@ -1,0 +1,133 @@
+"""Allocation-free DPDist training step on the HIP C ABI (the reference's `sess.run(train_op_s)` hot loop).
+
+One `step(pcA, pcB, labels, noise)` = what `train_multi_gpu_pc_compare_dist.py:786` executes per batch:
+    get_model (encoder x2, window gather, decoder both directions)         models/dpdist_and_aue.py:31-86
+    get_loss  (loss_samples = mean |pred_AB[...,0] - labels|)              utils/dpdist_util.py:962-980
+    compute_gradients(loss_samples, the 8 'pc_compare' variables)         train_multi_gpu...:274-277
+    average over towers -> RCCL all-reduce (ddp.py)                        :936-974
+    AdamOptimizer.apply_gradients with the staircase learning rate        :216,301,976-990
+Only the AB half of the rows carries gradient (loss_samples reads pred_listAB only), so the backward GEMMs run on
+B*N rows while the forward runs on 2*B*N.
+
+Backward schedule (chosen for overlap, not for autodiff order): dH chain g3 -> g2 -> g1, then dW1 (largest bucket,
+all-reduce launched immediately), then dW2, dW3, dW4 (second bucket), then one fused Adam over the flat buffer.
+"""
+import math
+
+import torch
+
+from . import lib as L
+from .ddp import BucketReducer
+from .model import DPDistParams
+
+
+def learning_rate(step, base=1e-4, decay_step=300 * 512, decay_rate=0.5, floor=1e-7):
+    """train_multi_gpu_pc_compare_dist.py:976-990: exponential_decay(base, batch, DECAY_STEP, DECAY_RATE, staircase=True), clipped."""
+    return max(base * decay_rate ** math.floor(step / decay_step), floor)
+
+
+class DPDistTrainer:
+    def __init__(self, params: DPDistParams, batch_size, num_point=64, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4,
+                 decay_step=300 * 512, decay_rate=0.5, beta1=0.9, beta2=0.999, eps=1e-8, group=None, distributed=None):
+        self.P = params
+        dev = params.flat.device
+        self.B, self.N = int(batch_size), int(num_point)
+        self.m = int(math.ceil(Embedding_Size ** (1 / 3) - 1e-9))
+        self.k, self.sigma = params.k, float(sigma3dmfv)
+        self.hp = (base_lr, decay_step, decay_rate, beta1, beta2, eps)
+        self.t = 0
+        B, N, H, KP = self.B, self.N, params.H, params.KP
+        C, Q, BN = 2 * B, 2 * B * N, B * N
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)   # noqa: E731
+        self.pts, self.q = f(C, N, 3), f(C, N, 3)
+        self.fv = f(C, self.m ** 3, 20)
+        self.X, self.mask = f(Q, KP), f(Q)
+        self.vox = torch.empty(Q, device=dev, dtype=torch.int32)
+        self.h1, self.h2, self.h3 = f(Q, H), f(Q, H), f(Q, H)
+        self.y, self.pred = f(Q, 3), f(Q, 3)
+        self.dpred, self.dy = f(BN, 3), f(BN, 3)
+        self.g1, self.g2, self.g3 = f(BN, H), f(BN, H), f(BN, H)
+        self.loss = f(2)
+        self.grad = torch.zeros(params.numel, device=dev, dtype=torch.float32)
+        self.m_state = torch.zeros_like(self.grad)
+        self.v_state = torch.zeros_like(self.grad)
+        self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H) + 3) // 4, device=dev, dtype=torch.float32)
+        import torch.distributed as dist
+        use_dist = dist.is_initialized() if distributed is None else distributed
+        self.reducer = BucketReducer(self.grad, params.bucket_bounds, group) if use_dist else None
+        self._cparams = L.make_params(*params.views())
+        self._gviews = params.views(self.grad)
+
+    # -- pieces (each enqueues kernels on the current stream; no host sync, no allocation) -----------------
+    def _load_batch(self, pcA, pcB, noise):
+        B = self.B
+        if noise is None:
+            self.pts[:B].copy_(pcA)
+        else:
+            torch.add(pcA, noise, out=self.pts[:B])
+        self.pts[B:].copy_(pcB)
+        self.q[:B].copy_(pcB)
+        self.q[B:].copy_(pcA)
+
+    def forward(self):
+        lib, s, P = L.load(), L.cur_stream(), self.P
+        C, N, Q = 2 * self.B, self.N, 2 * self.B * self.N
+        L.check(lib.dpd_mfv3d_fwd(L.ptr(self.pts), C, N, self.m, self.sigma, L.ptr(self.fv), s), "dpd_mfv3d_fwd")
+        L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP, L.ptr(self.X),
+                                       L.ptr(self.mask), L.ptr(self.vox), s), "dpd_patch_rows_fwd")
+        L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, 0, L.ptr(self.h1),
+                                    L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), s), "dpd_decoder_fwd")
+
+    def backward(self, labels):
+        lib, s, P = L.load(), L.cur_stream(), self.P
+        BN = self.B * self.N
+        L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
+        L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
+                                         L.ptr(self.h3), BN, P.KP, P.H, self._cparams, 0, L.ptr(self.dy), L.ptr(self.g3),
+                                         L.ptr(self.g2), L.ptr(self.g1), None, s), "dpd_decoder_bwd_data")
+        d, wsb = self._gviews, self.ws.numel() * 4
+
+        def dw(layer, act, g, dW, db):
+            L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], 0,
+                                                L.ptr(dW), L.ptr(db), L.ptr(self.ws), wsb, L.cur_stream()),
+                    "dpd_decoder_bwd_weights(%d)" % layer)
+
+        dw(1, self.X, self.g1, d[0], d[1])
+        if self.reducer:
+            self.reducer.reduce_async(0)
+        dw(2, self.h1, self.g2, d[2], d[3])
+        dw(3, self.h2, self.g3, d[4], d[5])
+        dw(4, self.h3, self.dy, d[6], d[7])
+        if self.reducer:
+            self.reducer.reduce_async(1)
+
+    def apply_gradients(self):
+        base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
+        lr = learning_rate(self.t, base_lr, decay_step, decay_rate)     # global_step before the increment (TF semantics)
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        gscale = 1.0
+        if self.reducer:
+            self.reducer.wait()
+            gscale = self.reducer.grad_scale
+        L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
+                                     self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
+
+    @torch.no_grad()
+    def step(self, pcA, pcB, labels, noise=None):
+        """One training step.  Returns the device tensor [loss_samples, loss_pred] of THIS rank's shard (no host sync)."""
+        self._load_batch(pcA, pcB, noise)
+        self.forward()
+        self.backward(labels.reshape(-1))
+        self.apply_gradients()
+        return self.loss
+
+    @torch.no_grad()
+    def evaluate(self, pcA, pcB, labels, noise=None):
+        """Forward only (eval_one_epoch_3d, train_multi_gpu...:809-873): returns [loss_samples, loss_pred] and pred_AB[...,0]."""
+        self._load_batch(pcA, pcB, noise)
+        self.forward()
+        BN = self.B * self.N
+        L.check(L.load().dpd_l1_loss(L.ptr(self.pred), L.ptr(labels.reshape(-1)), BN, 0, 1.0, L.ptr(self.loss), None,
+                                     L.cur_stream()), "dpd_l1_loss")
+        return self.loss, self.pred[:BN, 0].view(self.B, self.N)

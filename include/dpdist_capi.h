@@ -1,0 +1,151 @@
+/*
+ * dpdist_capi.h -- C ABI of the MI355X-native DPDist hot path (libdpdist_hip.so).
+ *
+ * The reference (dahliau/DPDist) has no FFI: its boundary is the Python model-module contract
+ *     models/dpdist_and_aue.py:23-86,203-204   placeholder_inputs / get_model / get_loss
+ * whose body is ~60 primitive TensorFlow ops in utils/dpdist_util.py.  Each entry point below
+ * replaces one group of those ops (file:line cited per function); dpdist_amd/model.py re-assembles
+ * them behind the same get_model/get_loss signatures.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major float32 unless stated otherwise;
+ *   - the caller owns every buffer (the library never allocates, frees or keeps global state);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and is asynchronous;
+ *   - return value: 0 = ok, <0 = argument error (DPD_E_*), >0 = the hipError_t of the failing call;
+ *   - thread-safe / re-entrant: safe from several host threads on distinct streams.
+ *
+ * Shapes: C clouds of N points; grid side m (G = m^3 Gaussians == voxels); window side k;
+ *   F = 20 Fisher features per Gaussian; E = k^3*F (2500); rows Q = C*N query points, row r = c*N+n
+ *   is query point n of query-cloud c evaluated against the Fisher vector fv[c].
+ *   The module contract stacks clouds as  pts = [pcA+noise ; pcB],  q = [pcB ; pcA]  (C = 2B).
+ *   Decoder input row layout (internal, 16-byte friendly):  X[r] = [ emb(E) | q-centre (3) | 0-pad ]
+ *   with leading dimension KP = dpd_padded_width(k) (2512 for k=5).  W1 is held in the matching
+ *   row order: W1p[0:E] = tf_weights1[3:3+E], W1p[E:E+3] = tf_weights1[0:3], zero pad rows.
+ */
+#ifndef DPDIST_CAPI_H
+#define DPDIST_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPD_FV_CHANNELS 20
+#define DPD_OUT_CHANNELS 3
+
+enum {
+    DPD_OK = 0,
+    DPD_E_NULL = -1,      /* a required pointer is NULL */
+    DPD_E_DIM = -2,       /* non-positive or inconsistent dimension */
+    DPD_E_UNSUPPORTED = -3, /* m > 10, k even, k > 7, N > 4096, widths not a multiple of 64 ... */
+    DPD_E_WORKSPACE = -4  /* workspace too small (see dpd_workspace_bytes) */
+};
+
+/* library version / build target, e.g. "dpdist_hip 0.1 gfx950" */
+const char* dpd_version(void);
+
+/* KP: leading dimension of the decoder input rows for window side k (k^3*20+3 rounded up to 16). */
+int dpd_padded_width(int k);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3DmFV encoder.  Replaces utils/dpdist_util.py:22-141 (get_3dmfv_tf, full_fv, normalize=True).
+ *   pts [C,N,3] -> fv [C,m^3,20]; Gaussians on the fixed grid of :42-51, uniform weights 1/m^3.
+ *   A point further than ~1.7 from every centre underflows every pdf and yields NaN exactly as the
+ *   reference does (0/0 at :74).                                                                  */
+int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma, float* fv, void* stream);
+
+/* Backward of the encoder (TF autodiff of :69-126): dfv [C,m^3,20] -> dpts [C,N,3] (overwritten).
+ * Max/min gradients are split evenly among ties, like tf.reduce_max/min.                        */
+int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, int m, float sigma, float* dpts,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Query -> voxel lookup + local-window gather.  Replaces local_z_3d (utils/dpdist_util.py:911-930),
+ * get_pc_grid_binary_mask_from_centers (:459-492) and get_emb_and_concat (:434-457) WITHOUT
+ * materialising the [C,m^3,k^3*20] window tensor.
+ *   q [C,N,3], fv [C,m^3,20] -> X [Q,KP] rows, mask [Q] (1/0), vox [Q] (voxel id, 0 if outside). */
+int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
+                       float* mask, int32_t* vox, void* stream);
+
+/* Backward of the gather: dX [Q,KP] -> dq [C,N,3] (overwritten; = dX[:,E:E+3]) and
+ * dfv [C,m^3,20] (overwritten; scatter-add of the window columns).  Either output may be NULL.  */
+int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, int N, int m, int k, int KP, float* dq,
+                       float* dfv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit decoder (shared MLP).  Replaces tf_util.conv2d x4 (utils/dpdist_util.py:513-544,
+ * utils/tf_util.py:161-228), relu6/3 (:691) and the mask multiply (:695-698).
+ *   X [Q,KP] -> h1,h2,h3 [Q,H] (post-ReLU, kept for backward), y [Q,3] (pre-activation),
+ *   pred [Q,3] = clip(y,0,6)/3 * mask.   W1p [KP,H], W2,W3 [H,H], W4 [H,3], biases [H],[H],[H],[3].
+ *   H must be a multiple of 64.  dtype: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32).     */
+typedef struct dpd_decoder_params {
+    const float* W1p; const float* b1;
+    const float* W2;  const float* b2;
+    const float* W3;  const float* b3;
+    const float* W4;  const float* b4;
+} dpd_decoder_params;
+
+int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
+                    int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* stream);
+
+/* Backward, data chain: dpred [Qb,3] for the FIRST Qb rows (training mode: Qb = Q/2, only the AB half
+ * carries gradient, train_multi_gpu_pc_compare_dist.py:274-277; as-loss mode: Qb = Q).
+ * Produces the pre-activation gradients g3,g2,g1 [Qb,H] and dy [Qb,3]; if dX != NULL also
+ * dX [Qb,KP] = g1 * W1p^T (as-loss mode, TF autodiff through :516).                              */
+int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,
+                         const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p, int dtype,
+                         float* dy, float* g3, float* g2, float* g1, float* dX, void* stream);
+
+/* Backward, weight gradients of ONE layer (1..4) from the buffers above:
+ *   layer 1: dW [KP,H] = X^T g1, db = colsum(g1);  2: h1^T g2;  3: h2^T g3;  4: dW [H,3] = h3^T dy.
+ * `act` is the layer's input activation (X, h1, h2 or h3) with leading dimension lda, `g` its
+ * pre-activation output gradient.  dW/db are overwritten.  ws: dpd_workspace_bytes() bytes.      */
+int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
+                            int dtype, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+
+/* Scratch needed by dpd_decoder_bwd_weights / dpd_gemm_f32 (split-K slabs) for the given sizes. */
+size_t dpd_workspace_bytes(int Q, int KP, int H);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses.  Replaces utils/dpdist_util.py:962-980.  pred [2*BN,3] (AB rows first), labels [BN].
+ *   loss[0] = loss_samples = mean |pred_AB[:,0] - labels|        (:972)
+ *   loss[1] = loss_pred    = (mean pred_AB[:,0] + mean pred_BA[:,0]) / 2      (:976-977)
+ * mode 0: no gradient.  mode 1 (training): dpred [BN,3] = d loss_samples / d pred_AB * gscale.
+ * mode 2 (as-loss): dpred [2*BN,3] = d loss_pred / d pred * gscale.                              */
+int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float gscale, float* loss,
+                float* dpred, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * tf.train.AdamOptimizer step (epsilon-hat form), train_multi_gpu_pc_compare_dist.py:216,301:
+ *   g' = g * gscale;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr_t m / (sqrt(v)+eps)
+ * with lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller.  n elements (any n).              */
+int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
+                float eps, float gscale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Building block, exported for tests and roofline measurement: C = epi(op(A) op(B)), fp32 MFMA.
+ *   transA = 0: A is [M,K] (lda);  1: A is stored [K,M].   transB = 0: B is [K,N];  1: B is [N,K].
+ *   epilogue: 0 none, 1 +bias[n], 2 relu(+bias[n]), 3 multiply by (gate[m,n] > 0) (ldg = ldc).
+ *   K, N, lda, ldb, ldc multiples of 4; split_k >= 1 (slabs in ws, reduced by a second kernel,
+ *   epilogue applied after the reduction); tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64.   */
+int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                 float* Cout, int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* Tuning knob (the library's only process-wide state; never needed for correctness): GEMM tile / split-K per
+ * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3.
+ * tile as in dpd_gemm_f32 (0 = auto); split_k only applies to ops 4 and 5.                                   */
+int dpd_set_gemm_plan(int op, int tile, int split_k);
+
+/* Opt-in profiler for the roofline measurement (bench.py): when enabled, every GEMM kernel launch is bracketed
+ * by a hipEvent pair on its own stream.  dpd_prof_collect waits for them and returns the launch count and the
+ * summed durations [ms] / flops (2*M*N*K as launched) since dpd_prof_enable(1).                              */
+int dpd_prof_enable(int on);
+int dpd_prof_collect(double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPDIST_CAPI_H */

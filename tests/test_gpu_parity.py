@@ -1,0 +1,339 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
+
+Bar (BASELINE.json north_star / SURVEY 8d): fp32, max abs err <= 1e-4 on predicted distances; on the `wide`
+weight set additionally max rel err <= 1e-4 on unsaturated outputs.  Integer work (voxel ids, masks) is bit exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dpdist_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ABS_TOL = 1e-4
+REL_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    from dpdist_amd import lib
+    lib.load()     # raises if the HIP extension is missing -- never fall back
+    return torch.device("cuda:0")
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _cu(a, dev):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+
+
+def _model(dev, wk="wide", m=8, mlp=(1024, 1024, 1024)):
+    from dpdist_amd.model import DPDistModel
+    mod = DPDistModel(Embedding_Size=m ** 3, k=5, localSNmlp=mlp, device=dev)
+    mod.load_tf_state_dict(synth.make_weights(wk, mlp=mlp))
+    return mod
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+@pytest.mark.parametrize("m", [8, 5])
+def test_mfv3d_golden(dev, golden_dir, m):
+    from dpdist_amd import ops
+    d = _g(golden_dir, "fv_cases.npz")
+    fv = ops.mfv3d_fwd(_cu(d["points"], dev), m, 0.125).cpu().numpy()
+    assert np.abs(fv - d["fv_m%d_f64" % m]).max() <= 3e-6
+    assert np.abs(fv - d["fv_m%d_f32" % m]).max() <= 3e-6
+
+
+def test_mfv3d_vs_oracle_full_batch(dev):
+    from dpdist_amd import ops
+    from oracle import restate as R
+    pcA, pcB = synth.s1_random_patches(32, 64, 0)
+    pts = np.concatenate([pcA, pcB])
+    fv = ops.mfv3d_fwd(_cu(pts, dev), 8, 0.125).cpu().numpy()
+    ref = R.mfv3d(torch.tensor(pts, dtype=torch.float64)).numpy()
+    assert np.abs(fv - ref).max() <= 3e-6
+    # L2 normalisation property: every channel has unit norm over the Gaussian axis
+    assert np.abs(np.sqrt((fv.astype(np.float64) ** 2).sum(1)) - 1.0).max() <= 1e-5
+
+
+def test_mfv3d_nan_semantics(dev):
+    """Reference behaviour: a point far outside underflows every pdf -> NaN; (1.2,1.2,1.2) stays finite."""
+    from dpdist_amd import ops
+    pts = torch.zeros(2, 64, 3, device=dev)
+    pts[0, 0] = 3.0
+    pts[1, 0] = 1.2
+    fv = ops.mfv3d_fwd(pts, 8, 0.125)
+    assert torch.isnan(fv[0]).any() and not torch.isnan(fv[1]).any()
+
+
+def test_mfv3d_permutation_invariance(dev):
+    from dpdist_amd import ops
+    pcA, _ = synth.s1_random_patches(8, 64, 3)
+    perm = np.random.default_rng(0).permutation(64)
+    a = ops.mfv3d_fwd(_cu(pcA, dev), 8, 0.125)
+    b = ops.mfv3d_fwd(_cu(pcA[:, perm], dev), 8, 0.125)
+    assert (a - b).abs().max().item() <= 2e-6
+
+
+def test_mfv3d_backward_vs_oracle(dev):
+    from dpdist_amd import ops
+    from oracle import restate as R
+    rng = np.random.default_rng(4)
+    pcA, _ = synth.s1_random_patches(4, 64, 5)
+    pcA[3] = pcA[3, :1]                    # all points identical: every max/min is a 64-way tie
+    dfv = rng.standard_normal((4, 512, 20)).astype(np.float32)
+    p = torch.tensor(pcA, dtype=torch.float64, requires_grad=True)
+    (R.mfv3d(p) * torch.tensor(dfv, dtype=torch.float64)).sum().backward()
+    got = ops.mfv3d_bwd(_cu(pcA, dev), _cu(dfv, dev), 8, 0.125).cpu().numpy()
+    ref = p.grad.numpy()
+    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------------ lookup + gather
+@pytest.mark.parametrize("case", ["s1", "boundary"])
+@pytest.mark.parametrize("m", [8, 5])
+def test_patch_rows_bit_exact(dev, case, m):
+    from dpdist_amd import ops
+    from oracle import restate as R
+    pcA, pcB = synth.s1_random_patches(8, 64, 0) if case == "s1" else synth.boundary_cloud(8, 64, 7)
+    fv = torch.tensor(np.random.default_rng(1).standard_normal((8, m ** 3, 20)).astype(np.float32))
+    X, mask, vox = ops.patch_rows_fwd(_cu(pcB, dev), fv.to(dev), m, 5)
+    v, msk, loc = R.voxel_lookup(torch.tensor(pcB), m)
+    emb = R.local_window(fv, m, 5)
+    rows = torch.gather(emb, 1, v[..., None].expand(-1, -1, emb.shape[-1])).reshape(8 * 64, -1).numpy()
+    X = X.cpu().numpy()
+    assert np.array_equal(mask.cpu().numpy(), msk.reshape(-1).numpy())
+    assert np.array_equal(vox.cpu().numpy().astype(np.int64), v.reshape(-1).numpy())
+    assert np.array_equal(X[:, :2500], rows)                          # pure data movement: bit exact
+    assert np.array_equal(X[:, 2500:2503], loc.reshape(-1, 3).numpy())
+    assert not X[:, 2503:].any()
+
+
+def test_patch_rows_backward_is_transpose(dev):
+    """<gather(fv), dX> == <fv, scatter(dX)> (adjoint identity) and dq = the xyz columns."""
+    from dpdist_amd import ops
+    rng = np.random.default_rng(2)
+    _, pcB = synth.s1_random_patches(4, 64, 0)
+    fv = _cu(rng.standard_normal((4, 512, 20)), dev)
+    dX = _cu(rng.standard_normal((256, 2512)), dev)
+    X, mask, vox = ops.patch_rows_fwd(_cu(pcB, dev), fv, 8, 5)
+    dq, dfv = ops.patch_rows_bwd(dX, vox, 4, 64, 8, 5)
+    lhs = (X[:, :2500].double() * dX[:, :2500].double()).sum().item()
+    rhs = (fv.double() * dfv.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+    assert torch.equal(dq.reshape(-1, 3), dX[:, 2500:2503])
+
+
+# ------------------------------------------------------------------------------------------------ GEMM building block
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
+def test_gemm_f32(dev, tile, mode):
+    from dpdist_amd import ops
+    rng = np.random.default_rng(10)
+    M, N, K = 328, 192, 200            # ragged against every tile size; asymmetric operands catch transposes
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    a = _cu(A.T if mode == "TN" else A, dev)
+    b = _cu(Bm.T if mode == "NT" else Bm, dev)
+    for split in (1, 3):
+        c = ops.gemm_f32(a, b, transA=(mode == "TN"), transB=(mode == "NT"), tile=tile, split_k=split).cpu().numpy()
+        assert np.abs(c - ref).max() <= 2e-4, (mode, tile, split)
+    bias = _cu(rng.standard_normal(N), dev)
+    gate = _cu(rng.standard_normal((M, N)), dev)
+    c = ops.gemm_f32(a, b, transA=(mode == "TN"), transB=(mode == "NT"), tile=tile, bias=bias, epilogue=2).cpu().numpy()
+    assert np.abs(c - np.maximum(ref + bias.cpu().numpy(), 0)).max() <= 2e-4
+    c = ops.gemm_f32(a, b, transA=(mode == "TN"), transB=(mode == "NT"), tile=tile, gate=gate, epilogue=3, split_k=2).cpu().numpy()
+    assert np.abs(c - ref * (gate.cpu().numpy() > 0)).max() <= 2e-4
+
+
+def test_gemm_layer1_shape_is_fmaf_exact(dev):
+    """fp32 MFMA accumulates like an fmaf chain: compare with float64 at the real layer-1 shape."""
+    from dpdist_amd import ops
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((512, 2512)).astype(np.float32) * 0.05
+    W = rng.standard_normal((2512, 1024)).astype(np.float32) * 0.3
+    c = ops.gemm_f32(_cu(A, dev), _cu(W, dev)).cpu().numpy()
+    ref = A.astype(np.float64) @ W.astype(np.float64)
+    assert np.abs(c - ref).max() <= 5e-5
+
+
+# ------------------------------------------------------------------------------------------------ module contract, forward
+def _check_pred(got, ref, wide):
+    err = np.abs(got - ref)
+    assert err.max() <= ABS_TOL, err.max()
+    if wide:
+        uns = (ref > 1e-3) & (ref < 2.0 - 1e-3)
+        assert (err[uns] / np.abs(ref[uns])).max() <= REL_TOL
+
+
+@pytest.mark.parametrize("case", ["s1", "boundary"])
+@pytest.mark.parametrize("wk", ["xavier_tf", "wide"])
+def test_forward_golden(dev, golden_dir, case, wk):
+    d = _g(golden_dir, "path_fwd_%s_%s.npz" % (case, wk))
+    mod = _model(dev, wk)
+    with torch.no_grad():
+        ps = mod(_cu(d["pcA"], dev), _cu(d["pcB"], dev))
+    for n in ("pred_listAB", "pred_listBA"):
+        got = ps[n].cpu().numpy()
+        assert got.shape == (2, 64, 1, 3)
+        _check_pred(got, d[n + "_f64"], wk == "wide")
+        _check_pred(got, d[n + "_f32"], wk == "wide")
+
+
+@pytest.mark.parametrize("m", [8, 5])
+def test_forward_golden_mlp64(dev, golden_dir, m):
+    d = _g(golden_dir, "path_fwd_mlp64_m%d.npz" % m)
+    mod = _model(dev, "wide", m=m, mlp=(64, 64, 64))
+    with torch.no_grad():
+        ps = mod(_cu(d["pcA"], dev), _cu(d["pcB"], dev))
+    _check_pred(ps["pred_listAB"].cpu().numpy(), d["pred_listAB_f64"], True)
+    _check_pred(ps["pred_listBA"].cpu().numpy(), d["pred_listBA_f64"], True)
+
+
+@pytest.mark.parametrize("wk", ["xavier_tf", "wide"])
+def test_forward_config2_full_batch_vs_oracle(dev, wk):
+    """BASELINE config 2: B=32 S1 'random patches', fp32 forward, numerics within 1e-4 of the oracle."""
+    from oracle import restate as R
+    pcA, pcB = synth.s1_random_patches(32, 64, 0)
+    W = synth.make_weights(wk)
+    ref, _ = R.get_model(torch.tensor(pcA), torch.tensor(pcB), R.as_torch_weights(W))
+    mod = _model(dev, wk)
+    with torch.no_grad():
+        ps = mod(_cu(pcA, dev), _cu(pcB, dev))
+    for n in ("pred_listAB", "pred_listBA"):
+        _check_pred(ps[n].cpu().numpy(), ref[n].numpy(), wk == "wide")
+    if wk == "wide":   # both relu6 saturations are exercised
+        ab = ps["pred_listAB"][..., 0].cpu().numpy()
+        assert (ab == 0).mean() > 0.05 and (ab == 2.0).any()
+
+
+def test_forward_properties_full_size(dev):
+    """Size-independent properties at B=64: permuting cloud A's points leaves AB unchanged and permutes BA;
+    points outside the cube predict exactly 0."""
+    pcA, pcB, _ = synth.s2_modelnet_shaped(64, 64, 100)
+    pcB[:, 5] = 1.5
+    mod = _model(dev, "wide")
+    perm = np.random.default_rng(1).permutation(64)
+    with torch.no_grad():
+        a = mod(_cu(pcA, dev), _cu(pcB, dev))
+        b = mod(_cu(pcA[:, perm], dev), _cu(pcB, dev))
+    assert (a["pred_listAB"] - b["pred_listAB"]).abs().max().item() <= 2e-4
+    assert (a["pred_listBA"][:, perm] - b["pred_listBA"]).abs().max().item() <= 2e-4
+    assert a["pred_listAB"][:, 5].abs().max().item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ losses + gradients
+def test_losses_and_input_gradients_golden(dev, golden_dir):
+    """As-loss mode (iterative_PCRNet_ours.py:248-257): d loss_pred / d (input1, input2, add_noise)."""
+    from dpdist_amd import model as M
+    d = _g(golden_dir, "path_bwd_s2_wide.npz")
+    mod = _model(dev, "wide")
+    pcA = _cu(d["pcA"], dev).requires_grad_(True)
+    pcB = _cu(d["pcB"], dev).requires_grad_(True)
+    noise = _cu(d["noise"], dev).requires_grad_(True)
+    M.reset_default_graph()
+    ps = mod(pcA, pcB, add_noise=noise)
+    ls_t, lp = M.get_loss(ps, {}, _cu(d["labels"], dev))
+    ls = M.get_collection("loss_samples")[0]
+    assert abs(ls.item() - float(d["loss_samples_f64"])) <= 2e-5
+    assert abs(lp.item() - float(d["loss_pred_f64"])) <= 2e-5
+    assert ls_t.shape == (2, 64)
+    gA, gB, gN = torch.autograd.grad(lp, [pcA, pcB, noise])
+    for g, n in ((gA, "d_pcA"), (gB, "d_pcB"), (gN, "d_noise")):
+        ref = d[n + "_f64"]
+        assert np.abs(g.cpu().numpy() - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), n
+
+
+def test_weight_gradients_golden(dev, golden_dir):
+    """Training mode (train_multi_gpu_pc_compare_dist.py:274-277): d loss_samples / d the 8 variables, TF layout."""
+    from dpdist_amd import model as M
+    d = _g(golden_dir, "path_bwd_s2_wide.npz")
+    mod = _model(dev, "wide")
+    M.reset_default_graph()
+    ps = mod(_cu(d["pcA"], dev), _cu(d["pcB"], dev), add_noise=_cu(d["noise"], dev))
+    M.get_loss(ps, {}, _cu(d["labels"], dev))
+    ls = M.get_collection("loss_samples")[0]
+    (gflat,) = torch.autograd.grad(ls, [mod.params_.flat])
+    gsd = mod.params_.tf_state_dict(gflat)
+    for n, g in gsd.items():
+        short = n.split("/")[-2][-1] + ("w" if n.endswith("weights") else "b")
+        g2 = g.reshape(-1, g.shape[-1]) if g.ndim == 4 else g
+        nrm = float(d["g%s_norm_f64" % short])
+        tol = 2e-4 * max(1.0, nrm)
+        assert abs(np.sqrt((g2.astype(np.float64) ** 2).sum()) - nrm) <= tol, n
+        if g.ndim == 4:
+            assert np.abs(g2[:16, :16] - d["g%s_corner_f64" % short]).max() <= tol, n
+            assert np.abs(g2[-16:, -16:] - d["g%s_tail_f64" % short]).max() <= tol, n
+            assert np.abs(g2.sum(0) - d["g%s_colsum_f64" % short]).max() <= tol * 30, n
+            assert np.abs(g2.sum(1) - d["g%s_rowsum_f64" % short]).max() <= tol * 30, n
+        else:
+            assert np.abs(g2 - d["g%s_f64" % short]).max() <= tol, n
+
+
+def test_trainer_steps_vs_oracle(dev):
+    """Three full training steps (fwd, L1 loss, bwd on the AB half, TF-form Adam) against the oracle + numpy Adam."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer, learning_rate
+    from oracle import restate as R
+    B = 4
+    pcA, pcB, lab = synth.s2_modelnet_shaped(B, 64, 100)
+    W0 = synth.make_weights("wide")
+    P = DPDistParams(device=dev)
+    P.load_tf_state_dict(W0)
+    tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+    Wt = {n: torch.tensor(a, dtype=torch.float64, requires_grad=True) for n, a in W0.items()}
+    ms = {n: np.zeros_like(a, dtype=np.float64) for n, a in W0.items()}
+    vs = {n: np.zeros_like(a, dtype=np.float64) for n, a in W0.items()}
+    for t in range(1, 4):
+        loss = tr.step(_cu(pcA, dev), _cu(pcB, dev), _cu(lab, dev)).cpu().numpy()
+        pred, _ = R.get_model(torch.tensor(pcA, dtype=torch.float64), torch.tensor(pcB, dtype=torch.float64), Wt)
+        ls, lp = R.get_loss(pred, torch.tensor(lab, dtype=torch.float64))
+        assert abs(loss[0] - ls.item()) <= 5e-5 and abs(loss[1] - lp.item()) <= 5e-5, (t, loss, ls.item())
+        names = sorted(Wt)
+        gs = torch.autograd.grad(ls, [Wt[n] for n in names])
+        for n, g in zip(names, gs):
+            p = Wt[n].detach().numpy()
+            R.adam_tf_step(p, g.numpy(), ms[n], vs[n], t, learning_rate(t - 1, 1e-3))
+    got = P.tf_state_dict()
+    for n in Wt:
+        ref = Wt[n].detach().numpy()
+        assert np.abs(got[n] - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), n
+        assert np.abs(got[n] - W0[n]).max() > 0 or n.endswith("biases")
+
+
+def test_adam_kernel(dev):
+    from dpdist_amd import ops
+    from oracle import restate as R
+    rng = np.random.default_rng(0)
+    n = 4099
+    p, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    P, G = _cu(np.pad(p, (0, 1)), dev)[:n], _cu(np.pad(g, (0, 1)), dev)[:n]
+    Mst, V = torch.zeros_like(P), torch.zeros_like(P)
+    pr, m, v = p.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in (1, 2, 3):
+        import math
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam_tf(P, G, Mst, V, lr_t, gscale=0.5)
+        R.adam_tf_step(pr, g.astype(np.float64) * 0.5, m, v, t, 1e-3)
+    assert np.abs(P.cpu().numpy() - pr).max() <= 1e-6
+
+
+def test_error_behaviour(dev):
+    """Errors are loud: CPU tensors, unsupported sizes and non-contiguous inputs raise."""
+    from dpdist_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.mfv3d_fwd(torch.zeros(1, 64, 3), 8, 0.125)
+    with pytest.raises(RuntimeError):
+        ops.mfv3d_fwd(torch.zeros(1, 64, 3, device=dev), 11, 0.125)
+    with pytest.raises(RuntimeError):
+        ops.mfv3d_fwd(torch.zeros(1, 3, 64, device=dev).transpose(1, 2), 8, 0.125)
+    with pytest.raises(RuntimeError):
+        ops.patch_rows_fwd(torch.zeros(1, 64, 3, device=dev), torch.zeros(1, 512, 20, device=dev), 8, 4)
