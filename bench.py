@@ -43,13 +43,13 @@ def gemm_flops_per_step(B, N, E3, H):
     return fwd + bwd, 3 + 2 + 3
 
 
-def cpu_baseline(B, N, budget_s=20.0):
-    """Oracle fwd+bwd (training mode) on the host cores; bounded sample, reported in query-points/sec."""
-    import numpy as np  # noqa: F401
+def cpu_baseline(B, N, budget_s=24.0):
+    """Oracle fwd+bwd (training mode) on the host cores; bounded sample, reported in query-points/sec.
+    torch-CPU collapses when given every hardware thread of a large box, so a few intra-op thread counts are tried
+    inside the budget and the best is reported (cores = the thread count that produced the number)."""
     from dpdist_amd import synth
     from oracle import restate as R
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
     pcA, pcB, lab = synth.s2_modelnet_shaped(B, N, 100)
     W = R.as_torch_weights(synth.make_weights("xavier_tf"), torch.float32, requires_grad=True)
     a, b, l = torch.tensor(pcA), torch.tensor(pcB), torch.tensor(lab)
@@ -59,17 +59,29 @@ def cpu_baseline(B, N, budget_s=20.0):
         ls, _ = R.get_loss(pred, l)
         torch.autograd.grad(ls, list(W.values()))
 
-    one()   # page-in / warm-up, not timed
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 40:
+    cands = sorted({min(ncpu, c) for c in (8, 32, 96)})
+    best = None
+    t_start = time.perf_counter()
+    for nt in cands:
+        torch.set_num_threads(nt)
+        one()   # page-in / warm-up, not timed
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            one()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s / len(cands) / 2 or n >= 20:
+                break
+        qps = 2 * B * N * n / el
+        if best is None or qps > best[0]:
+            best = (qps, nt, n, el)
+        if time.perf_counter() - t_start > budget_s:
             break
-    return {"value": round(2 * B * N * n / el, 1), "unit": "query-points/sec", "cores": cores, "kind": "port",
-            "sample": "%d fwd+bwd steps of the torch-CPU oracle at B=%d (same S2 workload), %.1f s" % (n, B, el)}
+    qps, nt, n, el = best
+    return {"value": round(qps, 1), "unit": "query-points/sec", "cores": nt, "kind": "port",
+            "sample": "%d fwd+bwd steps of the torch-CPU oracle at B=%d (same S2 workload) in %.1f s with %d threads "
+                      "(best of %s threads; host has %d hardware threads)" % (n, B, el, nt, cands, ncpu)}
 
 
 def main():

@@ -5,6 +5,14 @@
 
 #include "../../include/dpdist_capi.h"
 
+// hipGetLastError() is sticky per host thread: a benign error left behind by another library (e.g. the framework
+// probing devices) must not be reported as ours, so the state is cleared right before each launch.
+#define DPD_LAUNCH(...)                             \
+    do {                                            \
+        (void)hipGetLastError();                    \
+        hipLaunchKernelGGL(__VA_ARGS__);            \
+    } while (0)
+
 #define DPD_CHECK_LAUNCH()                          \
     do {                                            \
         hipError_t e__ = hipGetLastError();         \

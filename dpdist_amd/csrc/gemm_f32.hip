@@ -86,7 +86,9 @@ struct TileStage {
     }
 };
 
-template <int BM, int BN, int BK, bool AK, bool BKC>
+// ABL: ablation switches for tools/gemm_bench.py (results are WRONG when != 0): bit0 = no global loads after the
+// first K-tile, bit1 = no LDS refill + no barrier in the loop.
+template <int BM, int BN, int BK, bool AK, bool BKC, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;   // 2x2 wave grid
     constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
@@ -132,30 +134,45 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
-        if (it + 1 < nt) {  // prefetch the next K-tile into registers while this one is multiplied
+        if (it + 1 < nt && !(ABL & 1)) {  // prefetch the next K-tile into registers while this one is multiplied
             sa.load(g.A, g.lda, m0, kbeg + (it + 1) * BK, g.M, kend, tid);
             sb.load(g.B, g.ldb, n0, kbeg + (it + 1) * BK, g.N, kend, tid);
         }
         const float* as = As + cur * A_BUF + half * LDA + wm0 + l31;
         const float* bs = Bs + cur * B_BUF + half * LDB + wn0 + l31;
+        // MFMA operand fragments are double-buffered in registers: the ds_reads of k-step kk+2 are issued before
+        // the MFMAs of step kk, so the 64-cycle MFMAs never wait on LDS latency (one wave per SIMD has no other
+        // wave to hide it).  The LDS write of the prefetched K-tile is issued half way through the step so that it
+        // overlaps the remaining MFMAs instead of trailing them.
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+            const int c = (kk >> 1) & 1, n = c ^ 1;
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[kk * LDA + i * 32];
+                for (int i = 0; i < TM; ++i) a[n][i] = as[(kk + 2) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[kk * LDB + j * 32];
+                for (int j = 0; j < TN; ++j) b[n][j] = bs[(kk + 2) * LDB + j * 32];
+            }
+            if (kk == BK / 2 && it + 1 < nt && !(ABL & 2)) {
+                sa.store(As + (cur ^ 1) * A_BUF, tid);
+                sb.store(Bs + (cur ^ 1) * B_BUF, tid);
+            }
+            // pin the order [ds_reads of step kk+2 | MFMAs of step kk]: left alone, the machine scheduler sinks the
+            // reads back to just before their use and every step stalls on LDS latency
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (it + 1 < nt) {
-            sa.store(As + (cur ^ 1) * A_BUF, tid);
-            sb.store(Bs + (cur ^ 1) * B_BUF, tid);
-        }
-        __syncthreads();
+        if (!(ABL & 2)) __syncthreads();
     }
 
     // epilogue: acc[i][j][r] is C[row = (r&3) + 8*(r>>2) + 4*half][col = l31] of the 32x32 tile
@@ -223,12 +240,12 @@ struct GemmProf {
 };
 static GemmProf g_prof;
 
-template <int BM, int BN, int BK, bool AK, bool BKC>
+template <int BM, int BN, int BK, bool AK, bool BKC, int ABL = 0>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     using StA = TileStage<BM, BK, AK>;
     using StB = TileStage<BN, BK, BKC>;
     constexpr size_t lds = (size_t)(2 * BK * StA::LD + 2 * BK * StB::LD) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, BK, AK, BKC>;
+    auto kern = gemm_f32_kernel<BM, BN, BK, AK, BKC, ABL>;
     if (lds > 64 * 1024) {
         static bool done = false;  // benign race: idempotent attribute
         if (!done) {
@@ -241,7 +258,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     const int nblk = tilesM * tilesN * g.split_k;
     const bool prof = g_prof.on && g_prof.n < GemmProf::kMax;
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, s, g);
+    DPD_LAUNCH(kern, dim3(nblk), dim3(256), lds, s, g);
     if (prof) {
         (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
         g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
@@ -256,6 +273,12 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 1: return launch_cfg<128, 128, 32, AK, BKC>(g, s);
         case 2: return launch_cfg<128, 64, 32, AK, BKC>(g, s);
         case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);
+        case 11: return launch_cfg<128, 128, 32, AK, BKC, 1>(g, s);   // ablations (wrong results, timing only)
+        case 21: return launch_cfg<128, 128, 32, AK, BKC, 2>(g, s);
+        case 31: return launch_cfg<128, 128, 32, AK, BKC, 3>(g, s);
+        case 13: return launch_cfg<64, 64, 32, AK, BKC, 1>(g, s);
+        case 23: return launch_cfg<64, 64, 32, AK, BKC, 2>(g, s);
+        case 33: return launch_cfg<64, 64, 32, AK, BKC, 3>(g, s);
         default: return DPD_E_UNSUPPORTED;
     }
 }
@@ -279,13 +302,13 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     if (epilogue == EPI_GATE && !gate) return DPD_E_NULL;
     if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;
 
-    if (tile == 0) {  // largest tile among the most efficient coverings
-        const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-        double best = -1.0;
-        for (int c = 0; c < 3; ++c) {
-            const double e = tile_eff(M, N, bm[c], bn[c], split_k);
-            if (e > best + 1e-9) { best = e; tile = c + 1; }
-        }
+    if (tile == 0) {
+        // Measured on MI355X (tools/gemm_bench.py, profiles/): the 64x64 tile (4 resident blocks = 16 waves per CU)
+        // beats 128x64 and 128x128 at every decoder shape (112 vs 100 vs 90 TFLOP/s on layer 1) because the other
+        // blocks' MFMAs cover each block's barrier / global-load latency; MFMA is so slow in fp32 that the extra L2
+        // traffic of the small tile (16 flop/B) is irrelevant.  Larger tiles only when the grid would not fill.
+        (void)tile_eff;
+        tile = 3;
     }
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
@@ -306,7 +329,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     if (split_k > 1) {
         const long total4 = (long)M * N / 4;
         const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, split_k, (long)M * N, M,
+        DPD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, split_k, (long)M * N, M,
                            N, C, ldc, bias, gate, epilogue);
         return (int)hipGetLastError();
     }

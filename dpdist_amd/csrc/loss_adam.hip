@@ -90,7 +90,7 @@ extern "C" int dpd_l1_loss(const float* pred, const float* labels, int BN, int m
     if (!pred || !labels || !loss) return DPD_E_NULL;
     if (BN <= 0 || mode < 0 || mode > 2) return DPD_E_DIM;
     if (mode != 0 && !dpred) return DPD_E_NULL;
-    hipLaunchKernelGGL(dpd::l1_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, labels, BN, mode, gscale, loss,
+    DPD_LAUNCH(dpd::l1_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, labels, BN, mode, gscale, loss,
                        dpred);
     DPD_CHECK_LAUNCH();
     return 0;
@@ -104,7 +104,7 @@ extern "C" int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t 
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(dpd::adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t,
+    DPD_LAUNCH(dpd::adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t,
                        b1, b2, eps, gscale);
     DPD_CHECK_LAUNCH();
     return 0;

@@ -48,7 +48,9 @@ __device__ __forceinline__ float pdf(const MfvConst& k, float zx, float zy, floa
 }
 
 __device__ __forceinline__ float pnorm(float x) {
-    // sign(x) * max(|x|,1e-12)^0.5  (:119-121)
+    // sign(x) * max(|x|,1e-12)^0.5  (:119-121).  NaN in -> NaN out, as in the oracle (sign(NaN) = NaN there); the
+    // only source of NaN is the reference's own 0/0 for a point that underflows every pdf.
+    if (x != x) return x;
     const float s = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
     return s * sqrtf(fmaxf(fabsf(x), 1e-12f));
 }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void mfv3d_fwd_kernel(const float* __rest
     __syncthreads();
     if (tid < kF) {
         const float ss = (s_chred[tid] + s_chred[kF + tid]) + (s_chred[2 * kF + tid] + s_chred[3 * kF + tid]);
-        s_scale[tid] = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        s_scale[tid] = (ss != ss) ? ss : 1.0f / sqrtf(fmaxf(ss, 1e-12f));   // NaN poisons the whole channel, as in TF
     }
     __syncthreads();
 
@@ -451,7 +453,7 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     if (int rc = make_const(N, m, sigma, k)) return rc;
     const size_t lds = fwd_lds_bytes(N, k.G);
     if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
-    hipLaunchKernelGGL(mfv3d_fwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, fv, k);
+    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, fv, k);
     DPD_CHECK_LAUNCH();
     return 0;
 }
@@ -465,7 +467,7 @@ extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, i
     if (int rc = make_const(N, m, sigma, k)) return rc;
     const size_t lds = bwd_lds_bytes(N, k.G);
     if (int rc = set_lds(mfv3d_bwd_kernel, lds)) return rc;
-    hipLaunchKernelGGL(mfv3d_bwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, dfv, dpts, k);
+    DPD_LAUNCH(mfv3d_bwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, dfv, dpts, k);
     DPD_CHECK_LAUNCH();
     return 0;
 }

@@ -105,7 +105,7 @@ extern "C" int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N,
     if (C <= 0 || N <= 0) return DPD_E_DIM;
     if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
     if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
-    hipLaunchKernelGGL(patch_rows_fwd_kernel, dim3(C * N), dim3(128), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
+    DPD_LAUNCH(patch_rows_fwd_kernel, dim3(C * N), dim3(128), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
                        KP, make_axis(m));
     DPD_CHECK_LAUNCH();
     return 0;
@@ -120,13 +120,13 @@ extern "C" int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, in
     if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
     if (dfv) {
         const int slices = 4;
-        hipLaunchKernelGGL(patch_rows_bwd_kernel, dim3(C * slices), dim3(256), (size_t)N * sizeof(int), (hipStream_t)stream,
+        DPD_LAUNCH(patch_rows_bwd_kernel, dim3(C * slices), dim3(256), (size_t)N * sizeof(int), (hipStream_t)stream,
                            dX, vox, dfv, N, m, k, KP, slices);
         DPD_CHECK_LAUNCH();
     }
     if (dq) {
         const int Q = C * N;
-        hipLaunchKernelGGL(patch_rows_dq_kernel, dim3((Q * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dX, dq, Q,
+        DPD_LAUNCH(patch_rows_dq_kernel, dim3((Q * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dX, dq, Q,
                            KP, k * k * k * kF);
         DPD_CHECK_LAUNCH();
     }

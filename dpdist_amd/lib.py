@@ -58,6 +58,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libdpdist_hip.so not found at %s -- run `python -m dpdist_amd.build` "
                            "(there is no CPU fallback)" % LIB_PATH)
+    # Load order matters: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Import
+    # torch FIRST so that our DT_NEEDED entries resolve to the HIP runtime torch already initialised; loading this
+    # library first would pull /opt/rocm's runtime next to torch's and every launch would fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here == header/library mismatch

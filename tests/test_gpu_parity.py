@@ -83,17 +83,35 @@ def test_mfv3d_permutation_invariance(dev):
 
 
 def test_mfv3d_backward_vs_oracle(dev):
+    """d fv -> d points against the float64 oracle.  The power-1/2 normalisation is ill-conditioned where a statistic
+    is ~0 (dv = ds * 0.5/sqrt|v| with |v| down to 1e-12: float32 round-off of v is amplified without bound, in the
+    reference too), so the upstream gradient is zeroed on entries with |fv| < 2e-3 for the tight check; the
+    unrestricted case is held to the float32 oracle's own distance from float64."""
     from dpdist_amd import ops
     from oracle import restate as R
     rng = np.random.default_rng(4)
     pcA, _ = synth.s1_random_patches(4, 64, 5)
     pcA[3] = pcA[3, :1]                    # all points identical: every max/min is a 64-way tie
-    dfv = rng.standard_normal((4, 512, 20)).astype(np.float32)
-    p = torch.tensor(pcA, dtype=torch.float64, requires_grad=True)
-    (R.mfv3d(p) * torch.tensor(dfv, dtype=torch.float64)).sum().backward()
-    got = ops.mfv3d_bwd(_cu(pcA, dev), _cu(dfv, dev), 8, 0.125).cpu().numpy()
-    ref = p.grad.numpy()
-    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+    dfv_full = rng.standard_normal((4, 512, 20)).astype(np.float32)
+    fv64 = R.mfv3d(torch.tensor(pcA, dtype=torch.float64)).numpy()
+    for restricted in (True, False):
+        dfv = np.where(np.abs(fv64) > 2e-3, dfv_full, 0).astype(np.float32) if restricted else dfv_full
+        grads = {}
+        for dt in (torch.float64, torch.float32):
+            p = torch.tensor(pcA, dtype=dt, requires_grad=True)
+            (R.mfv3d(p) * torch.tensor(dfv, dtype=dt)).sum().backward()
+            grads[dt] = p.grad.numpy().astype(np.float64)
+        ref = grads[torch.float64]
+        got = ops.mfv3d_bwd(_cu(pcA, dev), _cu(dfv, dev), 8, 0.125).cpu().numpy()
+        assert np.isfinite(got).all()
+        for c in range(4):
+            scale = max(1.0, np.abs(ref[c]).max())
+            err = np.abs(got[c] - ref[c]).max()
+            if restricted:
+                assert err <= 1e-4 * scale, (c, err, scale)
+            else:
+                err_f32_oracle = np.abs(grads[torch.float32][c] - ref[c]).max()
+                assert err <= max(10.0 * err_f32_oracle, 2e-4 * scale), (c, err, err_f32_oracle, scale)
 
 
 # ------------------------------------------------------------------------------------------------ lookup + gather
@@ -167,11 +185,16 @@ def test_gemm_layer1_shape_is_fmaf_exact(dev):
 
 # ------------------------------------------------------------------------------------------------ module contract, forward
 def _check_pred(got, ref, wide):
+    """north_star bar: max abs err <= 1e-4.  On the `wide` weight set (outputs spread over [0,2]) additionally a
+    relative criterion so that the absolute bar is not vacuous: err <= 1e-5 + 1e-4*|ref| on unsaturated outputs
+    (the 1e-5 floor is float32 round-off of a K=2503 dot product whose terms are O(1))."""
     err = np.abs(got - ref)
     assert err.max() <= ABS_TOL, err.max()
     if wide:
-        uns = (ref > 1e-3) & (ref < 2.0 - 1e-3)
-        assert (err[uns] / np.abs(ref[uns])).max() <= REL_TOL
+        uns = (ref > 0.0) & (ref < 2.0)
+        assert (err[uns] <= 1e-5 + REL_TOL * np.abs(ref[uns])).all(), (err[uns] - REL_TOL * np.abs(ref[uns])).max()
+        sat = ~uns
+        assert err[sat].max() <= 1e-5 if sat.any() else True
 
 
 @pytest.mark.parametrize("case", ["s1", "boundary"])
@@ -249,7 +272,9 @@ def test_losses_and_input_gradients_golden(dev, golden_dir):
     gA, gB, gN = torch.autograd.grad(lp, [pcA, pcB, noise])
     for g, n in ((gA, "d_pcA"), (gB, "d_pcB"), (gN, "d_noise")):
         ref = d[n + "_f64"]
-        assert np.abs(g.cpu().numpy() - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), n
+        # float32 evaluation of the reference itself (golden *_f32) sits this far from float64; allow 4x that
+        bar = max(4.0 * np.abs(d[n + "_f32"] - ref).max(), 2e-4 * max(1.0, np.abs(ref).max()))
+        assert np.abs(g.cpu().numpy() - ref).max() <= bar, (n, np.abs(g.cpu().numpy() - ref).max(), bar)
 
 
 def test_weight_gradients_golden(dev, golden_dir):
