@@ -1,0 +1,124 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every declared symbol, host logic (parameter layout,
+TF interchange, schedules, argument errors).  No GPU compute calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from dpdist_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dpdist_amd import build, lib as L
+    build.build(verbose=False)          # hipcc cross-compiles gfx950 without a GPU
+    return L.load()
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "dpdist_capi.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from dpdist_amd import lib as L
+    names = _header_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libdpdist_hip.so does not export %s" % n
+        assert n in L.SIGNATURES, "lib.py has no ctypes signature for %s" % n
+    assert sorted(L.SIGNATURES) == names
+
+
+def test_host_only_entry_points(lib):
+    assert lib.dpd_version().decode().startswith("dpdist_hip")
+    assert lib.dpd_padded_width(5) == 2512 and lib.dpd_padded_width(3) == 544
+    assert lib.dpd_workspace_bytes(4096, 2512, 1024) >= 2 * 2512 * 1024 * 4
+    assert lib.dpd_set_gemm_plan(99, 0, 1) < 0          # argument errors are negative codes
+    assert lib.dpd_set_gemm_plan(4, 0, 2) == 0
+
+
+def test_null_and_dim_errors_without_gpu(lib):
+    """Argument validation happens before any HIP call, so it can be exercised on the CPU box."""
+    assert lib.dpd_mfv3d_fwd(None, 1, 64, 8, 0.125, None, None) == -1            # DPD_E_NULL
+    assert lib.dpd_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, 1, 0, None, 0, None) == -1
+    assert lib.dpd_l1_loss(None, None, 0, 0, 1.0, None, None, None) == -1
+    assert lib.dpd_adam_tf(None, None, None, None, 4, 0.1, 0.9, 0.999, 1e-8, 1.0, None) == -1
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    from dpdist_amd import ops
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.mfv3d_fwd(torch.zeros(1, 64, 3), 8, 0.125)
+    with pytest.raises(RuntimeError):
+        ops.adam_tf(torch.zeros(8), torch.zeros(8), torch.zeros(8), torch.zeros(8), 1e-3) if False else ops.patch_rows_fwd(
+            torch.zeros(1, 64, 3), torch.zeros(1, 512, 20), 8, 5)
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from dpdist_amd import lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.load()
+
+
+@pytest.mark.parametrize("mlp", [(64, 64, 64), (128, 128, 128)])
+def test_param_layout_round_trip(mlp):
+    from dpdist_amd.model import DPDistParams, TF_NAME
+    W = synth.make_weights("wide", mlp=mlp)
+    P = DPDistParams(k=5, mlp=mlp, device="cpu", init=None)
+    P.load_tf_state_dict(W)
+    back = P.tf_state_dict()
+    assert sorted(back) == sorted(W)
+    for n in W:
+        assert back[n].shape == W[n].shape and np.array_equal(back[n], W[n]), n
+    # internal layout: window rows first, xyz rows after, zero pad rows; flat buckets cover everything
+    W1p = P.view("W1p").numpy()
+    w1 = W[TF_NAME % (1, "weights")].reshape(2503, mlp[0])
+    assert np.array_equal(W1p[:2500], w1[3:]) and np.array_equal(W1p[2500:2503], w1[:3]) and not W1p[2503:].any()
+    assert P.KP == 2512 and P.bucket_bounds[0] == 0 and P.bucket_bounds[-1] == P.numel
+    assert P.bucket_bounds[1] == 2512 * mlp[0] + mlp[0]
+    assert all(off % 4 == 0 for off, _, _ in P._segments.values())
+
+
+def test_xavier_init_matches_tf_limits():
+    from dpdist_amd.model import DPDistParams, TF_NAME
+    P = DPDistParams(k=5, mlp=(64, 64, 64), device="cpu")
+    sd = P.tf_state_dict()
+    lim1 = np.sqrt(6.0 / (2503 + 2503 * 64))     # utils/tf_util.py:90-91 on a [1,2503,1,64] kernel
+    w1 = sd[TF_NAME % (1, "weights")]
+    assert np.abs(w1).max() <= lim1 * (1 + 1e-6) and np.abs(w1).max() > 0.9 * lim1
+    assert not sd[TF_NAME % (1, "biases")].any()
+
+
+def test_learning_rate_schedule():
+    from dpdist_amd.trainer import learning_rate
+    from oracle import restate as R
+    for step in (0, 1, 153599, 153600, 153601, 2 * 153600, 20 * 153600):
+        assert learning_rate(step) == R.learning_rate(step)
+    assert learning_rate(0) == 1e-4 and learning_rate(153600) == 5e-5 and learning_rate(10 ** 9) == 1e-7
+
+
+def test_get_model_rejects_off_path_branches():
+    from dpdist_amd import model as M
+    a = torch.zeros(1, 64, 3)
+    for kw in (dict(pn="pointnet", k=5), dict(k=0), dict(k=5, conv_version=2), dict(k=5, bn=1), dict(k=5, bn=0, full_fv=False)):
+        with pytest.raises(NotImplementedError):
+            M.get_model(a, a, True, **({"bn": 0, **kw}))
+
+
+def test_synth_is_deterministic_and_shaped():
+    a1, b1, l1 = synth.s2_modelnet_shaped(4, 64, 100)
+    a2, b2, l2 = synth.s2_modelnet_shaped(4, 64, 100)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(l1, l2)
+    assert a1.shape == (4, 64, 3) and l1.shape == (4, 64)
+    assert not l1[:, :32].any() and (l1[:, 32:48] > 0.001).all() and (l1[:, 32:48] < 0.1).all() and (l1[:, 48:] > 0.1).all()
+    assert np.abs(a1).max() <= 1.0        # inside the Gaussian grid's cube
+    pcA, pcB = synth.s1_random_patches(32, 64, 0)
+    assert np.isin(pcB, synth.BOUNDARY_SET).mean() > 0.01

@@ -1,0 +1,79 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  The bucketed all-reduce + 1/world scaling of ddp.py must
+reproduce the full-batch gradient (mean of equal shard means), the role of average_gradients in the reference
+(train_multi_gpu_pc_compare_dist.py:936-974)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dpdist_amd import synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat_grad(P, pcA, pcB, lab, mlp):
+    """per-shard gradient of loss_samples from the oracle, laid out in the product's flat/bucket layout"""
+    from oracle import restate as R
+    W = R.as_torch_weights(synth.make_weights("wide", mlp=mlp), torch.float64, requires_grad=True)
+    pred, _ = R.get_model(torch.tensor(pcA, dtype=torch.float64), torch.tensor(pcB, dtype=torch.float64), W)
+    ls, _ = R.get_loss(pred, torch.tensor(lab, dtype=torch.float64))
+    names = sorted(W)
+    g = torch.autograd.grad(ls, [W[n] for n in names])
+    P.load_tf_state_dict({n: gg.numpy() for n, gg in zip(names, g)})    # reuse the layout code: grads -> flat
+    return P.flat.detach().clone()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from dpdist_amd.ddp import BucketReducer, shard_range
+    from dpdist_amd.model import DPDistParams
+    mlp = (64, 64, 64)
+    GB = 4
+    pcA, pcB, lab = synth.s2_modelnet_shaped(GB, 64, 100)
+    lo, hi = shard_range(GB, rank, world)
+    P = DPDistParams(k=5, mlp=mlp, device="cpu", init=None)
+    flat = _flat_grad(P, pcA[lo:hi], pcB[lo:hi], lab[lo:hi], mlp).float()
+    red = BucketReducer(flat, P.bucket_bounds)
+    red.reduce_async(0)          # layer-1 bucket first, as in trainer.backward
+    red.reduce_async(1)
+    red.wait()
+    flat *= red.grad_scale
+    if rank == 0:
+        full = _flat_grad(P, pcA, pcB, lab, mlp).float()
+        out.put((float((flat - full).abs().max()), float(full.abs().max()), red.world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_full_batch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale, world = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert world == 2
+    assert err <= 1e-6 * max(1.0, scale), (err, scale)
+
+
+def test_shard_range():
+    from dpdist_amd.ddp import shard_range
+    assert [shard_range(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 4)
