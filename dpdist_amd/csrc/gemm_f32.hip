@@ -46,6 +46,18 @@ struct TileStage {
     static constexpr int LD = KCONTIG ? BMN + 1 : BMN + 4;
     float4 r[NV];
 
+    // interior tiles: no bounds checks (wave-uniform decision made by the caller)
+    __device__ __forceinline__ void load_fast(const float* __restrict__ p, int ld, int mn0, int k0, int tid) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * 256;
+            const float* src;
+            if (KCONTIG) src = p + (size_t)(mn0 + idx / (BK / 4)) * ld + k0 + (idx % (BK / 4)) * 4;
+            else src = p + (size_t)(k0 + idx / (BMN / 4)) * ld + mn0 + (idx % (BMN / 4)) * 4;
+            r[v] = *reinterpret_cast<const float4*>(src);
+        }
+    }
+
     __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int mn0, int k0, int MN, int Kend,
                                          int tid) {
 #pragma unroll
@@ -86,6 +98,32 @@ struct TileStage {
     }
 };
 
+// Epilogue of one 32x32 MFMA tile: acc[r] is C[row0 + (r&3) + 8*(r>>2) + 4*half][col].  The gate / bias values are
+// fetched up front with clamped (always valid) addresses so that the 16 loads are in flight together instead of
+// one dependent L2 round trip per row.
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col, int half) {
+    if (col >= g.N) return;
+    float* Cz = g.C + (size_t)z * g.slab_stride;
+    const int epi = g.epi;
+    const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
+    float gv[16];
+    if (epi == EPI_GATE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
+            gv[r] = g.gate[(size_t)row * g.ldc + col];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r] + bv;
+        if (epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (epi == EPI_GATE) v = (gv[r] > 0.f) ? v : 0.f;
+        if (row < g.M) Cz[(size_t)row * g.ldc + col] = v;
+    }
+}
+
 // ABL: ablation switches for tools/gemm_bench.py (results are WRONG when != 0): bit0 = no global loads after the
 // first K-tile, bit1 = no LDS refill + no barrier in the loop.
 template <int BM, int BN, int BK, bool AK, bool BKC, int ABL = 0>
@@ -124,6 +162,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
     StA sa;
     StB sb;
     sa.load(g.A, g.lda, m0, kbeg, g.M, kend, tid);
@@ -135,8 +174,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
         if (it + 1 < nt && !(ABL & 1)) {  // prefetch the next K-tile into registers while this one is multiplied
-            sa.load(g.A, g.lda, m0, kbeg + (it + 1) * BK, g.M, kend, tid);
-            sb.load(g.B, g.ldb, n0, kbeg + (it + 1) * BK, g.N, kend, tid);
+            const int kn = kbeg + (it + 1) * BK;
+            if ((ABL & 8) && interior && kn + BK <= kend) {
+                sa.load_fast(g.A, g.lda, m0, kn, tid);
+                sb.load_fast(g.B, g.ldb, n0, kn, tid);
+            } else {
+                sa.load(g.A, g.lda, m0, kn, g.M, kend, tid);
+                sb.load(g.B, g.ldb, n0, kn, g.N, kend, tid);
+            }
         }
         const float* as = As + cur * A_BUF + half * LDA + wm0 + l31;
         const float* bs = Bs + cur * B_BUF + half * LDB + wn0 + l31;
@@ -158,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[n][j] = bs[(kk + 2) * LDB + j * 32];
             }
-            if (kk == BK / 2 && it + 1 < nt && !(ABL & 2)) {
+            if (kk == ((ABL & 4) ? BK - 4 : BK / 2) && it + 1 < nt && !(ABL & 2)) {
                 sa.store(As + (cur ^ 1) * A_BUF, tid);
                 sb.store(Bs + (cur ^ 1) * B_BUF, tid);
             }
@@ -175,27 +220,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (!(ABL & 2)) __syncthreads();
     }
 
-    // epilogue: acc[i][j][r] is C[row = (r&3) + 8*(r>>2) + 4*half][col = l31] of the 32x32 tile
-    float* Cz = g.C + (size_t)z * g.slab_stride;
-    const int epi = g.epi;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn0 + j * 32 + l31;
-        if (col >= g.N) continue;
-        const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                if (epi == EPI_GATE) v = (g.gate[(size_t)row * g.ldc + col] > 0.f) ? v : 0.f;
-                Cz[(size_t)row * g.ldc + col] = v;
-            }
-        }
-    }
+        for (int j = 0; j < TN; ++j) store_tile(g, acc[i][j], z, m0 + wm0 + i * 32, n0 + wn0 + j * 32 + l31, half);
 }
 
 // out[m,n] = epi( sum_z slab[z][m,n] ); N % 4 == 0, slabs are dense [M,N].
@@ -228,6 +256,209 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// =========================================================================================================
+// LDS-DMA kernel: (32*WR) x (32*WC) x 32 tiles, one 32x32 MFMA tile per wave, 4-stage LDS ring fed by
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write).
+//
+//   * every wave issues PPW = (BM+BN)/8/(WR*WC) 1-KiB DMA pieces per K-tile, THREE K-tiles ahead of the MFMAs;
+//     a K-tile has two full tile-times (~3 us) to land before it is needed;
+//   * ONE raw s_barrier per K-tile, placed in the MIDDLE of the tile (between k-blocks 1 and 2): it certifies that
+//     K-tile t+1 has landed for every wave and that everybody is past K-tile t-1 (whose stage is then refilled).
+//     The fragments of k-block 2 are read before the barrier and the first fragments of K-tile t+1 are read during
+//     k-block 3, so the MFMA stream never waits at a tile boundary even when all waves of a CU run in lock step;
+//   * the DMA writes LDS lane-linearly, so layouts are chosen on the SOURCE address:
+//       K-contiguous operand  -> image [BMN rows][8 x 16-B slots], slot XOR-swizzled with (row>>1)&7; one
+//                                ds_read_b128 per lane then carries the operand of FOUR k-steps: the k order inside
+//                                an 8-deep block is permuted (half-wave h takes k = 8kb+4h+s at step s), which is
+//                                legal because A and B use the same permutation of the contraction index;
+//       MN-contiguous operand -> image [32 k][BMN] dense, ds_read_b32 per k-step (conflict free);
+//   * out-of-range rows/columns are CLAMPED on the source address (garbage rows/cols are never stored), so there is
+//     no predication in the loop; K must be a multiple of 32 (the decoder pads 2503 -> 2528 for this);
+//   * WR x WC = 4x4 (1024 threads, 128x128, 32 flop per L2 byte, one block per CU with 4 waves per SIMD),
+//     4x2 (128x64) and 2x2 (64x64) cover the smaller grids.
+// =========================================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// One 1-KiB LDS-DMA piece: LDS[dst + lane*16] <- 16 bytes at this lane's source address.
+// Inline asm on purpose: with the builtin, hipcc knows an LDS write is pending and drains vmcnt(0) before the next
+// ds_read, which serialises the ring.  Here the pieces are invisible to its waitcnt bookkeeping and are retired by the
+// counted s_waitcnt vmcnt(N) in the K-loop (every piece is one VM_CNT event).  M0 is written in the same statement
+// that uses it and restored afterwards.
+__device__ __forceinline__ void dma_piece(const float* src, unsigned dst_bytes) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst_bytes)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// MFMA operand fragments of one 8-deep k-block kb for the 32 rows/cols starting at mn0w (wave offset in the tile)
+template <bool KCONTIG, int BMN>
+__device__ __forceinline__ void load_frag(const float* img, int mn0w, int l31, int half, int kb, float (&f)[4]) {
+    if (KCONTIG) {
+        const int row = mn0w + l31;
+        const int slot = (2 * kb + half) ^ ((row >> 1) & 7);
+        const float4 v = *reinterpret_cast<const float4*>(img + row * 32 + slot * 4);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = img[(8 * kb + 4 * half + s) * BMN + mn0w + l31];
+    }
+}
+
+// ABL (timing-only ablations, wrong results): bit0 no in-loop DMA, bit1 no mid-tile wait/barrier,
+// bit2 DMA replaced by plain global loads into registers (same L2 traffic, no LDS write)
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
+    constexpr int BM = 32 * WR, BN = 32 * WC, BK = 32, NW = WR * WC;   // NS-stage ring (3 or 4)
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    constexpr int A_IMG = BM * BK, B_IMG = BN * BK, STAGE = A_IMG + B_IMG;   // floats
+    constexpr int PA = BM / 8, PB = BN / 8;                                  // 1-KiB pieces per K-tile
+    constexpr int PPW = (PA + PB) / NW;                                      // pieces per wave per K-tile
+    static_assert((PA + PB) % NW == 0, "piece split");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave / WC) * 32, wn0 = (wave % WC) * 32;
+
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int per_z = tilesM * tilesN;
+    const int sid = xcd_remap(blockIdx.x, per_z * g.split_k);
+    const int z = sid / per_z, t = sid % per_z;
+    const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
+    const int kbeg = z * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
+    const int nt = (kend - kbeg) / BK;
+
+    // this wave's DMA pieces: piece p = wave + j*NW; p < PA -> A piece p, else B piece p-PA
+    const float* src[PPW];
+    size_t step[PPW];
+    unsigned dst[PPW];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int p = wave + j * NW;
+        const bool isA = p < PA;
+        const int c = isA ? p : p - PA;
+        const bool kc = isA ? AK : BKC;
+        const float* base = isA ? g.A : g.B;
+        const int ld = isA ? g.lda : g.ldb;
+        const int mn0 = isA ? m0 : n0;
+        const int MN = isA ? g.M : g.N;
+        const int BMN = isA ? BM : BN;
+        dst[j] = lds_base + (unsigned)((isA ? 0 : A_IMG) + c * 256) * 4u;
+        if (kc) {
+            const int row = c * 8 + (lane >> 3), slot = lane & 7;
+            src[j] = base + (size_t)min(mn0 + row, MN - 1) * ld + kbeg + 4 * (slot ^ ((row >> 1) & 7));
+            step[j] = 32;
+        } else {
+            const int lin = c * 256 + lane * 4;
+            src[j] = base + (size_t)(kbeg + lin / BMN) * ld + min(mn0 + lin % BMN, MN - 4);
+            step[j] = (size_t)32 * ld;
+        }
+    }
+    float4 sink = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            if (ABL & 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src[j]);
+                sink.x += v.x; sink.y += v.y; sink.z += v.z; sink.w += v.w;
+            } else {
+                dma_piece(src[j], dst[j] + (unsigned)(stage * STAGE) * 4u);
+            }
+            src[j] += step[j];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // prologue: K-tiles 0 .. NS-2 in flight; wait for tile 0
+    if (0 < nt) issue(0);
+    if (1 < nt) issue(1);
+    if (NS == 4 && 2 < nt) issue(2);
+    if (NS == 4 && nt > 2) wait_vmcnt<2 * PPW>();
+    else if (nt > 1) wait_vmcnt<PPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    float fa[2][4], fb[2][4];
+    load_frag<AK, BM>(smem, wm0, l31, half, 0, fa[0]);
+    load_frag<BKC, BN>(smem + A_IMG, wn0, l31, half, 0, fb[0]);
+
+    for (int it = 0; it < nt; ++it) {
+        const float* sA = smem + (it % NS) * STAGE;
+        const float* sB = sA + A_IMG;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int c = kb & 1, n = c ^ 1;
+            if (kb < 3) {
+                load_frag<AK, BM>(sA, wm0, l31, half, kb + 1, fa[n]);
+                load_frag<BKC, BN>(sB, wn0, l31, half, kb + 1, fb[n]);
+            } else if (it + 1 < nt) {   // first fragments of the next K-tile (certified landed at this tile's barrier)
+                const float* nA = smem + ((it + 1) % NS) * STAGE;
+                load_frag<AK, BM>(nA, wm0, l31, half, 0, fa[n]);
+                load_frag<BKC, BN>(nA + A_IMG, wn0, l31, half, 0, fb[n]);
+            }
+            if (kb == 2) {
+                // mid-tile sync: my pieces of K-tile it+1 have landed once only tile it+2's may be outstanding
+                if (!(ABL & 2)) {
+                    if (NS == 4 && it + 2 < nt) wait_vmcnt<PPW>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (it + NS - 1 < nt && !(ABL & 1)) issue((it + NS - 1) % NS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][s2], fb[c][s2], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (ABL & 4) acc[0] += (sink.x + sink.y) + (sink.z + sink.w);
+    store_tile(g, acc, z, m0 + wm0, n0 + wn0 + l31, half);
+}
+
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
+static int launch_dma(const GemmArgs& g, hipStream_t s) {
+    constexpr int BM = 32 * WR, BN = 32 * WC;
+    constexpr size_t lds = NS * (size_t)(BM + BN) * 32 * sizeof(float);
+    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL>;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            done = true;
+        }
+    }
+    const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.split_k;
+    DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
+    return (int)hipGetLastError();
+}
+
 // Opt-in in-stream profiler (bench.py's roofline leg): a hipEvent pair around every GEMM kernel launch, on the
 // stream the kernel is launched on.  Off by default; costs two event records per launch when on.
 struct GemmProf {
@@ -256,23 +487,25 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     }
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int nblk = tilesM * tilesN * g.split_k;
-    const bool prof = g_prof.on && g_prof.n < GemmProf::kMax;
-    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
     DPD_LAUNCH(kern, dim3(nblk), dim3(256), lds, s, g);
-    if (prof) {
-        (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
-        g_prof.flops[g_prof.n] = 2.0 * g.M * g.N * g.K;
-        ++g_prof.n;
-    }
     return (int)hipGetLastError();
 }
 
 template <bool AK, bool BKC>
 static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
     switch (tile) {
+        case 4: return launch_dma<2, 2, 4, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 64 KiB  (2 blocks/CU)
+        case 5: return launch_dma<4, 4, 4, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 128 KiB (1 block/CU)
+        case 6: return launch_dma<4, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x64,  512 thr, 72 KiB  (2 blocks/CU)
+        case 7: return launch_dma<2, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x128, 512 thr, 72 KiB  (2 blocks/CU)
+        case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
+        case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
         case 1: return launch_cfg<128, 128, 32, AK, BKC>(g, s);
         case 2: return launch_cfg<128, 64, 32, AK, BKC>(g, s);
         case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);
+        case 43: return launch_cfg<64, 64, 32, AK, BKC, 4>(g, s);     // experiments (correct results)
+        case 83: return launch_cfg<64, 64, 32, AK, BKC, 8>(g, s);
+        case 123: return launch_cfg<64, 64, 32, AK, BKC, 12>(g, s);
         case 11: return launch_cfg<128, 128, 32, AK, BKC, 1>(g, s);   // ablations (wrong results, timing only)
         case 21: return launch_cfg<128, 128, 32, AK, BKC, 2>(g, s);
         case 31: return launch_cfg<128, 128, 32, AK, BKC, 3>(g, s);
@@ -310,6 +543,8 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         (void)tile_eff;
         tile = 3;
     }
+    if (tile >= 4 && tile <= 9 && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
+        tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
@@ -321,6 +556,18 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     } else {
         g.k_chunk = (K + 31) / 32 * 32; g.C = C; g.ldc = ldc; g.slab_stride = 0; g.epi = epilogue;
     }
+    // profiler bracket: the GEMM kernel AND, with split-K, its reduce kernel (both belong to this GEMM)
+    const bool prof = g_prof.on && g_prof.n < GemmProf::kMax;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+    struct ProfEnd {
+        bool on; hipStream_t s; double fl;
+        ~ProfEnd() {
+            if (!on) return;
+            (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
+            g_prof.flops[g_prof.n] = fl;
+            ++g_prof.n;
+        }
+    } prof_end{prof, s, 2.0 * M * N * K};
     int rc;
     if (!transA && !transB) rc = launch_tile<true, false>(tile, g, s);       // NN: A[M,K], B[K,N]
     else if (!transA && transB) rc = launch_tile<true, true>(tile, g, s);    // NT: A[M,K], B[N,K]

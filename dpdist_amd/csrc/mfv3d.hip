@@ -80,88 +80,137 @@ __device__ __forceinline__ PG eval_pg(const MfvConst& k, float x, float y, float
     return r;
 }
 
-// dynamic LDS: pts[N*3] | denom[N] | part[4*N] | stage[G*21] | chred[4*20] | chscale[20]
-__global__ __launch_bounds__(kThreads) void mfv3d_fwd_kernel(const float* __restrict__ pts, float* __restrict__ fv,
-                                                              MfvConst k) {
+// ---------------------------------------------------------------------------------------------------------
+// Forward kernel: one workgroup of 1024 threads (16 waves = 4 per SIMD) per cloud.
+//
+// The Gaussians have diagonal covariance on a product grid, so the responsibility factorises exactly:
+//     Q_ng = w p_ng / sum_g' w p_ng' = (ex[n][j]/Sx[n]) * (ey[n][i]/Sy[n]) * (ez[n][t]/Sz[n]),
+//     e_a[n][i] = exp(-z_a^2/2),  S_a[n] = sum_i e_a[n][i]          (constants and the weight w cancel)
+// which replaces N*G = 32 768 expf + divisions per cloud (:69-74) by 3*N*m = 1 536 of each.  The result differs from
+// the reference's fp32 evaluation by a few ulp of Q; the reference's failure mode is reproduced explicitly:
+// if w*p_ng underflows to 0 for EVERY Gaussian of some point (0/0 at :74) the whole descriptor is NaN.
+//
+//   tables  zq[a][n][i] = { z = (p[n][a]-l_i)/sigma , q = e/S }  (float2, one ds_read_b64 per axis per pair)
+//   pass 2  wave <-> 32 Gaussians; lane&31 <-> Gaussian, lane>>5 <-> half of the points; 20 running statistics in
+//           registers; the two halves are merged with one __shfl_xor(.,32) per statistic
+//   norm    power-1/2, per-channel L2 over the Gaussian axis (shuffle within the wave, LDS across the 16 waves)
+//   store   staged through LDS [G][21] (conflict free), coalesced float4 stores
+// dynamic LDS (floats): zq[3*N*m*2] | S[3*N] | minz2[3*N] | stage[G*21] | chred[16*20] | scale[20] | flag
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kFwdThreads = 1024;
+
+__global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __restrict__ pts, float* __restrict__ fv,
+                                                                 MfvConst k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int N = k.N, G = k.G;
-    float* s_pts = sm;
-    float* s_den = s_pts + ((N * 3 + 3) & ~3);
-    float* s_part = s_den + N;
-    float* s_stage = s_part + 4 * N;
-    float* s_chred = s_stage + G * kFP;
-    float* s_scale = s_chred + 4 * kF;
+    const int N = k.N, G = k.G, m = k.m;
+    float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][N][m]
+    float* s_S = sm + 6 * N * m;                    // [3][N]
+    float* s_mz = s_S + 3 * N;                      // [3][N] min_i z^2
+    float* s_stage = s_mz + 3 * N;                  // [G][21]
+    float* s_chred = s_stage + G * kFP;             // [16][20]
+    float* s_scale = s_chred + 16 * kF;             // [20]
+    int* s_bad = reinterpret_cast<int*>(s_scale + kF);
 
     const int tid = threadIdx.x, c = blockIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const float* p = pts + (size_t)c * N * 3;
-    for (int i = tid; i < N * 3; i += kThreads) s_pts[i] = p[i];
-    __syncthreads();
-
-    // ---- pass 1: denominators sum_g w*p_ng  (:73-74) -------------------------------------------
-    const int gq = (G + 3) / 4;
-    for (int idx = tid; idx < 4 * N; idx += kThreads) {
-        const int n = idx % N, sl = idx / N;
-        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], z = s_pts[n * 3 + 2];
-        float acc = 0.f;
-        const int g1 = min(G, (sl + 1) * gq);
-        for (int g = sl * gq; g < g1; ++g) {
-            float cx, cy, cz;
-            gauss_centre(k, g, cx, cy, cz);
-            acc += pdf(k, (x - cx) / k.sigma, (y - cy) / k.sigma, (z - cz) / k.sigma) * k.w;
-        }
-        s_part[sl * N + n] = acc;
+    if (tid == 0) *s_bad = 0;
+    for (int e = tid; e < 3 * N * m; e += kFwdThreads) {
+        const int a = e / (N * m), n = (e / m) % N, i = e % m;
+        const float z = (p[n * 3 + a] - k.ax.c[i]) / k.sigma;    // (batch_points - batch_mu) / batch_sig  (:87)
+        s_zq[e] = make_float2(z, expf(-0.5f * (z * z)));
     }
     __syncthreads();
-    for (int n = tid; n < N; n += kThreads) s_den[n] = (s_part[n] + s_part[N + n]) + (s_part[2 * N + n] + s_part[3 * N + n]);
+    for (int e = tid; e < 3 * N; e += kFwdThreads) {              // e = a*N + n
+        float S = 0.f, mz = INFINITY;
+        for (int i = 0; i < m; ++i) {
+            const float2 v = s_zq[e * m + i];
+            S += v.y;
+            mz = fminf(mz, v.x * v.x);
+            if (v.x != v.x) mz = v.x;
+        }
+        s_S[e] = S;
+        s_mz[e] = mz;
+    }
     __syncthreads();
+    for (int e = tid; e < 3 * N * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[e / m];
+    for (int n = tid; n < N; n += kFwdThreads) {
+        // the reference's 0/0: every w*p_ng == 0  <=>  the largest one is (p is monotone in -|z|^2)
+        const float pmax = pdf(k, sqrtf(s_mz[n]), sqrtf(s_mz[N + n]), sqrtf(s_mz[2 * N + n]));
+        if (!(pmax * k.w > 0.f)) atomicOr(s_bad, 1);             // also catches NaN inputs
+    }
+    __syncthreads();
+    const float2* zqx = s_zq;
+    const float2* zqy = s_zq + N * m;
+    const float2* zqz = s_zq + 2 * N * m;
 
-    // ---- pass 2: per-Gaussian statistics over the points ------------------------------------------
+    // ---- per-Gaussian statistics over the points ---------------------------------------------------------------
     float chsq[kF];
 #pragma unroll
     for (int f = 0; f < kF; ++f) chsq[f] = 0.f;
-
     const float invN = 1.0f / (float)N;
-    for (int g = tid; g < G; g += kThreads) {
-        float cx, cy, cz;
-        gauss_centre(k, g, cx, cy, cz);
+    const float inv_dpi = 1.0f / k.dpi_den;
+    const int hpts = (N + 1) / 2;
+    const int half = lane >> 5;
+    for (int gbase = wave * 32; gbase < G; gbase += 16 * 32) {
+        const int g = gbase + (lane & 31);
+        const bool live = g < G;
+        const int gg = live ? g : 0;
+        const int i = gg / (m * m), j = (gg / m) % m, t = gg % m;   // centre (x,y,z) = (l[j], l[i], l[t])  (:47-48)
         float pi_s = 0.f, pi_mx = -INFINITY;
         float mu_s[3] = {0.f, 0.f, 0.f}, mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
         float sg_s[3] = {0.f, 0.f, 0.f}, sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
-        for (int n = 0; n < N; ++n) {
-            const PG q = eval_pg(k, s_pts[n * 3], s_pts[n * 3 + 1], s_pts[n * 3 + 2], cx, cy, cz, s_den[n]);
-            pi_s += q.dpi;
-            pi_mx = fmaxf(pi_mx, q.dpi);
-            if (q.dpi != q.dpi) pi_mx = q.dpi;   // fmaxf drops NaN; tf.reduce_max propagates it
+        const int n1 = min(N, (half + 1) * hpts);
+        for (int n = half * hpts; n < n1; ++n) {
+            const float2 vx = zqx[n * m + j], vy = zqy[n * m + i], vz = zqz[n * m + t];
+            const float z[3] = {vx.x, vy.x, vz.x};
+            const float Q = (vx.y * vy.y) * vz.y;                              // :73-74, factorised
+            const float dpi = (Q - k.w) * inv_dpi;                             // :78
+            pi_s += dpi;
+            pi_mx = fmaxf(pi_mx, dpi);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                mu_s[d] += q.a[d]; mu_mx[d] = fmaxf(mu_mx[d], q.a[d]); mu_mn[d] = fminf(mu_mn[d], q.a[d]);
-                sg_s[d] += q.b[d]; sg_mx[d] = fmaxf(sg_mx[d], q.b[d]); sg_mn[d] = fminf(sg_mn[d], q.b[d]);
-                if (q.a[d] != q.a[d]) { mu_mx[d] = q.a[d]; mu_mn[d] = q.a[d]; }
-                if (q.b[d] != q.b[d]) { sg_mx[d] = q.b[d]; sg_mn[d] = q.b[d]; }
+                const float a = Q * z[d];                                       // :87
+                const float b = Q * (z[d] * z[d] - 1.0f);                       // :100
+                mu_s[d] += a; mu_mx[d] = fmaxf(mu_mx[d], a); mu_mn[d] = fminf(mu_mn[d], a);
+                sg_s[d] += b; sg_mx[d] = fmaxf(sg_mx[d], b); sg_mn[d] = fminf(sg_mn[d], b);
             }
         }
-        float v[kF];
-        v[0] = pi_s * invN;                                                     // :81 (reduce_mean)
-        v[1] = pi_mx;                                                           // :80
+        // merge the two point halves (lanes l and l^32 hold the same Gaussian)
+        pi_s += __shfl_xor(pi_s, 32, 64);
+        pi_mx = fmaxf(pi_mx, __shfl_xor(pi_mx, 32, 64));
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {                                           // :89-98, :102-109
-            v[2 + d] = (mu_s[d] * invN) * k.mu_scale;
-            v[5 + d] = mu_mx[d] * k.mu_scale;
-            v[8 + d] = mu_mn[d] * k.mu_scale;
-            v[11 + d] = (sg_s[d] * invN) * k.sig_scale;
-            v[14 + d] = sg_mx[d] * k.sig_scale;
-            v[17 + d] = sg_mn[d] * k.sig_scale;
+        for (int d = 0; d < 3; ++d) {
+            mu_s[d] += __shfl_xor(mu_s[d], 32, 64);
+            sg_s[d] += __shfl_xor(sg_s[d], 32, 64);
+            mu_mx[d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], 32, 64));
+            mu_mn[d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], 32, 64));
+            sg_mx[d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], 32, 64));
+            sg_mn[d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], 32, 64));
         }
+        if (live && half == 0) {
+            float v[kF];
+            v[0] = pi_s * invN;                                                 // :81 reduce_mean
+            v[1] = pi_mx;                                                       // :80
 #pragma unroll
-        for (int f = 0; f < kF; ++f) {
-            const float s = pnorm(v[f]);
-            s_stage[g * kFP + f] = s;
-            chsq[f] += s * s;
+            for (int d = 0; d < 3; ++d) {                                       // :89-98, :102-109
+                v[2 + d] = (mu_s[d] * invN) * k.mu_scale;
+                v[5 + d] = mu_mx[d] * k.mu_scale;
+                v[8 + d] = mu_mn[d] * k.mu_scale;
+                v[11 + d] = (sg_s[d] * invN) * k.sig_scale;
+                v[14 + d] = sg_mx[d] * k.sig_scale;
+                v[17 + d] = sg_mn[d] * k.sig_scale;
+            }
+#pragma unroll
+            for (int f = 0; f < kF; ++f) {
+                const float s = pnorm(v[f]);
+                s_stage[g * kFP + f] = s;
+                chsq[f] += s * s;
+            }
         }
     }
 
-    // ---- L2 normalisation over the Gaussian axis, per channel (:124-126) ----------------------------
-    const int lane = tid & 63, wave = tid >> 6;
+    // ---- L2 normalisation over the Gaussian axis, per channel (:124-126) ---------------------------------------
 #pragma unroll
     for (int f = 0; f < kF; ++f) {
         const float s = wave_sum(chsq[f]);
@@ -169,20 +218,25 @@ __global__ __launch_bounds__(kThreads) void mfv3d_fwd_kernel(const float* __rest
     }
     __syncthreads();
     if (tid < kF) {
-        const float ss = (s_chred[tid] + s_chred[kF + tid]) + (s_chred[2 * kF + tid] + s_chred[3 * kF + tid]);
-        s_scale[tid] = (ss != ss) ? ss : 1.0f / sqrtf(fmaxf(ss, 1e-12f));   // NaN poisons the whole channel, as in TF
+        float ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) ss += s_chred[w * kF + tid];
+        s_scale[tid] = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
     }
     __syncthreads();
 
-    // ---- coalesced store: fv[c][g][f], 4 consecutive f of one g per thread ---------------------------
+    // ---- coalesced store: fv[c][g][f], 4 consecutive f of one g per thread ---------------------------------------
     float* out = fv + (size_t)c * G * kF;
-    for (int i4 = tid; i4 < G * kF / 4; i4 += kThreads) {
+    const bool bad = *s_bad != 0;
+    const float qnan = __int_as_float(0x7fc00000);
+    for (int i4 = tid; i4 < G * kF / 4; i4 += kFwdThreads) {
         const int e = i4 * 4, g = e / kF, f = e % kF;
         float4 o;
         o.x = s_stage[g * kFP + f] * s_scale[f];
         o.y = s_stage[g * kFP + f + 1] * s_scale[f + 1];
         o.z = s_stage[g * kFP + f + 2] * s_scale[f + 2];
         o.w = s_stage[g * kFP + f + 3] * s_scale[f + 3];
+        if (bad) o = make_float4(qnan, qnan, qnan, qnan);   // 0/0 at :74 poisons every statistic of the cloud
         *reinterpret_cast<float4*>(out + e) = o;
     }
 }
@@ -203,8 +257,8 @@ static int make_const(int N, int m, float sigma, MfvConst& k) {
     return 0;
 }
 
-static size_t fwd_lds_bytes(int N, int G) {
-    return (size_t)(((N * 3 + 3) & ~3) + N + 4 * N + G * kFP + 4 * kF + kF + 4) * sizeof(float);
+static size_t fwd_lds_bytes(int N, int m, int G) {
+    return (size_t)(6 * N * m + 6 * N + G * kFP + 16 * kF + kF + 4) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -451,9 +505,9 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     if (C <= 0) return DPD_E_DIM;
     MfvConst k{};
     if (int rc = make_const(N, m, sigma, k)) return rc;
-    const size_t lds = fwd_lds_bytes(N, k.G);
+    const size_t lds = fwd_lds_bytes(N, m, k.G);
     if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
-    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, fv, k);
+    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k);
     DPD_CHECK_LAUNCH();
     return 0;
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void patch_rows_dq_kernel(const float* __restr
 
 }  // namespace dpd
 
-extern "C" int dpd_padded_width(int k) { return (k * k * k * DPD_FV_CHANNELS + 3 + 15) / 16 * 16; }
+extern "C" int dpd_padded_width(int k) { return (k * k * k * DPD_FV_CHANNELS + 3 + 31) / 32 * 32; }
 
 extern "C" int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
                                   float* mask, int32_t* vox, void* stream) {

@@ -52,7 +52,7 @@ class DPDistParams(nn.Module):
             raise NotImplementedError("decoder widths must be equal and a multiple of 64, got %s" % (self.mlp,))
         self.H = self.mlp[0]
         self.E = self.k ** 3 * F
-        self.KP = (self.E + 3 + 15) // 16 * 16
+        self.KP = (self.E + 3 + 31) // 32 * 32       # == dpd_padded_width(k): whole 32-deep K-tiles
         H = self.H
         shapes = [("W1p", (self.KP, H)), ("b1", (H,)), ("W2", (H, H)), ("b2", (H,)), ("W3", (H, H)), ("b3", (H,)),
                   ("W4", (H, 3)), ("b4", (3,))]

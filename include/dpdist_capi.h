@@ -19,7 +19,7 @@
  *   is query point n of query-cloud c evaluated against the Fisher vector fv[c].
  *   The module contract stacks clouds as  pts = [pcA+noise ; pcB],  q = [pcB ; pcA]  (C = 2B).
  *   Decoder input row layout (internal, 16-byte friendly):  X[r] = [ emb(E) | q-centre (3) | 0-pad ]
- *   with leading dimension KP = dpd_padded_width(k) (2512 for k=5).  W1 is held in the matching
+ *   with leading dimension KP = dpd_padded_width(k) (2528 for k=5: a whole number of 32-deep K-tiles).  W1 is held in the matching
  *   row order: W1p[0:E] = tf_weights1[3:3+E], W1p[E:E+3] = tf_weights1[0:3], zero pad rows.
  */
 #ifndef DPDIST_CAPI_H
@@ -46,7 +46,7 @@ enum {
 /* library version / build target, e.g. "dpdist_hip 0.1 gfx950" */
 const char* dpd_version(void);
 
-/* KP: leading dimension of the decoder input rows for window side k (k^3*20+3 rounded up to 16). */
+/* KP: leading dimension of the decoder input rows for window side k (k^3*20+3 rounded up to 32). */
 int dpd_padded_width(int k);
 
 /* ---------------------------------------------------------------------------------------------
@@ -129,14 +129,16 @@ int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr
  *   transA = 0: A is [M,K] (lda);  1: A is stored [K,M].   transB = 0: B is [K,N];  1: B is [N,K].
  *   epilogue: 0 none, 1 +bias[n], 2 relu(+bias[n]), 3 multiply by (gate[m,n] > 0) (ldg = ldc).
  *   K, N, lda, ldb, ldc multiples of 4; split_k >= 1 (slabs in ws, reduced by a second kernel,
- *   epilogue applied after the reduction); tile: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64.   */
+ *   epilogue applied after the reduction); tile: 0 = auto; register-staged kernels 1 = 128x128, 2 = 128x64,
+ *   3 = 64x64; LDS-DMA ring kernels (K % 32 == 0, else 3 is used) 4 = 64x64/4-stage, 5 = 128x128/4-stage,
+ *   6 = 128x64, 7 = 64x128, 8 = 64x64/3-stage, 9 = 128x128/3-stage.                                */
 int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* Cout, int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile,
                  void* ws, size_t ws_bytes, void* stream);
 
 /* Tuning knob (the library's only process-wide state; never needed for correctness): GEMM tile / split-K per
  * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3.
- * tile as in dpd_gemm_f32 (0 = auto); split_k only applies to ops 4 and 5.                                   */
+ * tile as in dpd_gemm_f32 (0 = auto); split_k only applies to ops 4 and 5.  Defaults are the measured best.                                   */
 int dpd_set_gemm_plan(int op, int tile, int split_k);
 
 /* Opt-in profiler for the roofline measurement (bench.py): when enabled, every GEMM kernel launch is bracketed

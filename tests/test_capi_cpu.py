@@ -37,8 +37,8 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_host_only_entry_points(lib):
     assert lib.dpd_version().decode().startswith("dpdist_hip")
-    assert lib.dpd_padded_width(5) == 2512 and lib.dpd_padded_width(3) == 544
-    assert lib.dpd_workspace_bytes(4096, 2512, 1024) >= 2 * 2512 * 1024 * 4
+    assert lib.dpd_padded_width(5) == 2528 and lib.dpd_padded_width(3) == 544
+    assert lib.dpd_workspace_bytes(4096, 2528, 1024) >= 2 * 2528 * 1024 * 4
     assert lib.dpd_set_gemm_plan(99, 0, 1) < 0          # argument errors are negative codes
     assert lib.dpd_set_gemm_plan(4, 0, 2) == 0
 
@@ -82,8 +82,8 @@ def test_param_layout_round_trip(mlp):
     W1p = P.view("W1p").numpy()
     w1 = W[TF_NAME % (1, "weights")].reshape(2503, mlp[0])
     assert np.array_equal(W1p[:2500], w1[3:]) and np.array_equal(W1p[2500:2503], w1[:3]) and not W1p[2503:].any()
-    assert P.KP == 2512 and P.bucket_bounds[0] == 0 and P.bucket_bounds[-1] == P.numel
-    assert P.bucket_bounds[1] == 2512 * mlp[0] + mlp[0]
+    assert P.KP == 2528 and P.bucket_bounds[0] == 0 and P.bucket_bounds[-1] == P.numel
+    assert P.bucket_bounds[1] == 2528 * mlp[0] + mlp[0]
     assert all(off % 4 == 0 for off, _, _ in P._segments.values())
 
 

@@ -140,7 +140,7 @@ def test_patch_rows_backward_is_transpose(dev):
     rng = np.random.default_rng(2)
     _, pcB = synth.s1_random_patches(4, 64, 0)
     fv = _cu(rng.standard_normal((4, 512, 20)), dev)
-    dX = _cu(rng.standard_normal((256, 2512)), dev)
+    dX = _cu(rng.standard_normal((256, 2528)), dev)
     X, mask, vox = ops.patch_rows_fwd(_cu(pcB, dev), fv, 8, 5)
     dq, dfv = ops.patch_rows_bwd(dX, vox, 4, 64, 8, 5)
     lhs = (X[:, :2500].double() * dX[:, :2500].double()).sum().item()
@@ -150,12 +150,12 @@ def test_patch_rows_backward_is_transpose(dev):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM building block
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
 def test_gemm_f32(dev, tile, mode):
     from dpdist_amd import ops
     rng = np.random.default_rng(10)
-    M, N, K = 328, 192, 200            # ragged against every tile size; asymmetric operands catch transposes
+    M, N, K = 328, 196, 224            # ragged in M and N against every tile size; asymmetric operands catch transposes
     A = rng.standard_normal((M, K)).astype(np.float32)
     Bm = rng.standard_normal((K, N)).astype(np.float32)
     ref = A.astype(np.float64) @ Bm.astype(np.float64)
@@ -176,9 +176,9 @@ def test_gemm_layer1_shape_is_fmaf_exact(dev):
     """fp32 MFMA accumulates like an fmaf chain: compare with float64 at the real layer-1 shape."""
     from dpdist_amd import ops
     rng = np.random.default_rng(11)
-    A = rng.standard_normal((512, 2512)).astype(np.float32) * 0.05
-    W = rng.standard_normal((2512, 1024)).astype(np.float32) * 0.3
-    c = ops.gemm_f32(_cu(A, dev), _cu(W, dev)).cpu().numpy()
+    A = rng.standard_normal((512, 2528)).astype(np.float32) * 0.05
+    W = rng.standard_normal((2528, 1024)).astype(np.float32) * 0.3
+    c = ops.gemm_f32(_cu(A, dev), _cu(W, dev), tile=4).cpu().numpy()
     ref = A.astype(np.float64) @ W.astype(np.float64)
     assert np.abs(c - ref).max() <= 5e-5
 

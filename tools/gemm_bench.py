@@ -23,7 +23,7 @@ def main():
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(",")]
     dev = torch.device("cuda:0")
-    Q, BN, KP, H = 2 * a.batch * 64, a.batch * 64, 2512, 1024
+    Q, BN, KP, H = 2 * a.batch * 64, a.batch * 64, 2528, 1024
     r = lambda *s: torch.randn(*s, device=dev)   # noqa: E731
     shapes = [
         ("fwd_L1  NN", (r(Q, KP), r(KP, H), False, False)),
