@@ -13,7 +13,7 @@ namespace dpd {
 
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
-             size_t ws_bytes, hipStream_t s);
+             size_t ws_bytes, hipStream_t s, float* colsum = nullptr);
 
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
@@ -49,10 +49,18 @@ __global__ __launch_bounds__(256) void out_fwd_kernel(const float* __restrict__ 
 }
 
 // dy = dpred * mask * [0 < y < 6] / 3 ;  g3 = (dy W4^T) * [h3 > 0].  One wave per row.
+struct ZeroList {   // small accumulators cleared by the first kernel of the backward chain (saves memset launches)
+    float* p[5];
+    int n[5];
+};
+
 __global__ __launch_bounds__(256) void out_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ mask,
                                                        const float* __restrict__ y, const float* __restrict__ h3,
                                                        const float* __restrict__ W4, float* __restrict__ dy,
-                                                       float* __restrict__ g3, int Qb, int H) {
+                                                       float* __restrict__ g3, int Qb, int H, ZeroList zl) {
+    if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
+        for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
+    }
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Qb) return;
     float d[3];
@@ -104,6 +112,54 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ a
         for (int c = 0; c < W; ++c) {
             const int i = (threadIdx.x & 63) * W + c;
             partial[((size_t)chunk * Ncols + col) * W + c] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        }
+    }
+}
+
+// Single-launch variant: every (column block, row chunk) adds its partial with one atomic per output element
+// (output must be zero on entry).  Used for db3 and dW4/db4 inside the backward data chain.
+template <int NW>
+__global__ __launch_bounds__(256) void colsum_atomic(const float* __restrict__ a, int lda, const float* __restrict__ w,
+                                                      int R, int Ncols, float* __restrict__ out, float* __restrict__ wsum) {
+    constexpr int W = NW ? NW : 1;
+    __shared__ float red[4][64 * W];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rs = threadIdx.x >> 6, chunk = blockIdx.y;
+    const int rper = (R + gridDim.y - 1) / gridDim.y;
+    const int r0 = chunk * rper, r1 = min(R, r0 + rper);
+    float acc[W];
+#pragma unroll
+    for (int c = 0; c < W; ++c) acc[c] = 0.f;
+    if (col < Ncols) {
+        for (int r = r0 + rs; r < r1; r += 4) {
+            const float x = a[(size_t)r * lda + col];
+            if (NW == 0) acc[0] += x;
+            else {
+#pragma unroll
+                for (int c = 0; c < NW; ++c) acc[c] += x * w[(size_t)r * NW + c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < W; ++c) red[rs][(threadIdx.x & 63) * W + c] = acc[c];
+    __syncthreads();
+    if (rs == 0 && col < Ncols) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const int i = (threadIdx.x & 63) * W + c;
+            atomicAdd(out + (size_t)col * W + c, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+        }
+    }
+    if (NW && wsum && blockIdx.x == 0) {   // column sums of w itself (db4 = colsum(dy)), one block column does it
+        float s[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) s[c] = 0.f;
+        for (int r = r0 + threadIdx.x; r < r1; r += 256)
+#pragma unroll
+            for (int c = 0; c < W; ++c) s[c] += w[(size_t)r * NW + c];
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            s[c] = wave_sum(s[c]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(wsum + c, s[c]);
         }
     }
 }
@@ -171,18 +227,35 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
 
 extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1,
                                     const float* h2, const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p,
-                                    int dtype, float* dy, float* g3, float* g2, float* g1, float* dX, void* stream) {
+                                    int dtype, float* dy, float* g3, float* g2, float* g1, float* dX,
+                                    const dpd_small_grads* sg, void* stream) {
     using namespace dpd;
     if (!dpred || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
     if ((H & 63) || (KP & 3) || dtype != 0) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    DPD_LAUNCH(out_bwd_kernel, dim3((Qb + 3) / 4), dim3(256), 0, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H);
+    float* db1 = sg ? sg->db1 : nullptr;
+    float* db2 = sg ? sg->db2 : nullptr;
+    float* db3 = sg ? sg->db3 : nullptr;
+    float* dW4 = sg ? sg->dW4 : nullptr;
+    float* db4 = sg ? sg->db4 : nullptr;
+    ZeroList zl{{db1, db2, db3, dW4, db4}, {H, H, H, H * 3, 3}};
+    DPD_LAUNCH(out_bwd_kernel, dim3((Qb + 3) / 4), dim3(256), 0, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl);
     DPD_CHECK_LAUNCH();
-    // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0]
-    if (int rc = gemm_f32(0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s)) return rc;
-    if (int rc = gemm_f32(0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s)) return rc;
+    const int chunks = 16;
+    if (db3) {   // db3 = colsum(g3)
+        DPD_LAUNCH(colsum_atomic<0>, dim3((H + 63) / 64, chunks), dim3(256), 0, s, (const float*)g3, H, (const float*)nullptr, Qb, H,
+                   db3, (float*)nullptr);
+        DPD_CHECK_LAUNCH();
+    }
+    if (dW4) {   // dW4 = h3^T dy, db4 = colsum(dy)
+        DPD_LAUNCH(colsum_atomic<3>, dim3((H + 63) / 64, chunks), dim3(256), 0, s, h3, H, (const float*)dy, Qb, H, dW4, db4);
+        DPD_CHECK_LAUNCH();
+    }
+    // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0];  db2 / db1 = column sums, fused into the epilogue
+    if (int rc = gemm_f32(0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s, db2)) return rc;
+    if (int rc = gemm_f32(0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s, db1)) return rc;
     if (dX) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
         if (int rc = gemm_f32(0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, 1, g_plan_tile[OP_BWD_DX], nullptr, 0, s)) return rc;
     }
@@ -192,7 +265,8 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
 extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
                                        int dtype, float* dW, float* db, void* ws, size_t ws_bytes, void* stream) {
     using namespace dpd;
-    if (!act || !g || !dW || !db) return DPD_E_NULL;
+    if (!act || !g || !dW) return DPD_E_NULL;
+    if (layer == 4 && !db) return DPD_E_NULL;
     if (layer < 1 || layer > 4 || Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype != 0) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -212,11 +286,12 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     const int op = (layer == 1) ? OP_BWD_DW1 : OP_BWD_DW23;
     const int split = g_plan_split[op];
     const size_t slab_bytes = (split > 1) ? (size_t)split * Kin * Nout * sizeof(float) : 0;
-    const size_t col_bytes = colsum_ws_floats(Nout, 0) * sizeof(float);
-    if (!ws || ws_bytes < slab_bytes + col_bytes) return DPD_E_WORKSPACE;
+    const size_t col_bytes = db ? colsum_ws_floats(Nout, 0) * sizeof(float) : 0;
+    if ((slab_bytes + col_bytes) && (!ws || ws_bytes < slab_bytes + col_bytes)) return DPD_E_WORKSPACE;
     // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout]
     if (int rc = gemm_f32(1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, split, g_plan_tile[op], ws,
                           slab_bytes, s)) return rc;
+    if (!db) return 0;   // bias gradient already produced by dpd_decoder_bwd_data (fused)
     float* part = (float*)((char*)ws + slab_bytes);
     DPD_LAUNCH(colsum_stage1<0>, dim3((Nout + 63) / 64, kColChunks), dim3(256), 0, s, g, Nout, (const float*)nullptr,
                        Qb, Nout, part);

@@ -29,6 +29,7 @@ struct GemmArgs {
     float* C;
     const float* bias;
     const float* gate;
+    float* colsum;    // optional [N]: += column sums of the stored values (atomics; caller zeroes it)
     int M, N, K;
     int lda, ldb, ldc;
     int epi;
@@ -101,8 +102,9 @@ struct TileStage {
 // Epilogue of one 32x32 MFMA tile: acc[r] is C[row0 + (r&3) + 8*(r>>2) + 4*half][col].  The gate / bias values are
 // fetched up front with clamped (always valid) addresses so that the 16 loads are in flight together instead of
 // one dependent L2 round trip per row.
-__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col, int half) {
-    if (col >= g.N) return;
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col_in, int half) {
+    const bool col_ok = col_in < g.N;
+    const int col = col_ok ? col_in : g.N - 1;      // clamp instead of returning: all 64 lanes reach the shuffle
     float* Cz = g.C + (size_t)z * g.slab_stride;
     const int epi = g.epi;
     const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
@@ -114,13 +116,21 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc,
             gv[r] = g.gate[(size_t)row * g.ldc + col];
         }
     }
+    float cs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[r] + bv;
         if (epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (epi == EPI_GATE) v = (gv[r] > 0.f) ? v : 0.f;
-        if (row < g.M) Cz[(size_t)row * g.ldc + col] = v;
+        if (row < g.M && col_ok) {
+            Cz[(size_t)row * g.ldc + col] = v;
+            cs += v;
+        }
+    }
+    if (g.colsum) {   // bias gradient fused into the dH GEMM: 32-row partial per wave, one atomic per column
+        cs += __shfl_xor(cs, 32, 64);
+        if (half == 0 && col_ok) atomicAdd(g.colsum + col, cs);
     }
 }
 
@@ -525,7 +535,7 @@ static double tile_eff(int M, int N, int BM, int BN, int split) {
 
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
-             size_t ws_bytes, hipStream_t s) {
+             size_t ws_bytes, hipStream_t s, float* colsum) {
     if (!A || !B || !C) return DPD_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || split_k < 1) return DPD_E_DIM;
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3)) return DPD_E_UNSUPPORTED;
@@ -547,6 +557,8 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
+    g.colsum = (split_k > 1) ? nullptr : colsum;
+    if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.split_k = split_k;
     if (split_k > 1) {
@@ -618,5 +630,5 @@ extern "C" int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const f
                             int ldb, float* Cout, int ldc, const float* bias, const float* gate, int epilogue,
                             int split_k, int tile, void* ws, size_t ws_bytes, void* stream) {
     return dpd::gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, Cout, ldc, bias, gate, epilogue, split_k, tile, ws,
-                         ws_bytes, (hipStream_t)stream);
+                         ws_bytes, (hipStream_t)stream, nullptr);
 }

@@ -94,7 +94,30 @@ __global__ __launch_bounds__(256) void patch_rows_dq_kernel(const float* __restr
     if (i < Q * 3) dq[i] = dX[(size_t)(i / 3) * KP + E + i % 3];
 }
 
+// pts = [pcA + noise ; pcB] (encoder input), q = [pcB ; pcA] (query clouds): models/dpdist_and_aue.py:45,56-61,69
+__global__ __launch_bounds__(256) void stack_clouds_kernel(const float* __restrict__ pcA, const float* __restrict__ pcB,
+                                                            const float* __restrict__ noise, int n, float* __restrict__ pts,
+                                                            float* __restrict__ q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = pcA[i], b = pcB[i];
+    pts[i] = noise ? a + noise[i] : a;
+    pts[n + i] = b;
+    q[i] = b;
+    q[n + i] = a;
+}
+
 }  // namespace dpd
+
+extern "C" int dpd_stack_clouds(const float* pcA, const float* pcB, const float* noise, int B, int N, float* pts, float* q,
+                                void* stream) {
+    if (!pcA || !pcB || !pts || !q) return DPD_E_NULL;
+    if (B <= 0 || N <= 0) return DPD_E_DIM;
+    const int n = B * N * 3;
+    DPD_LAUNCH(dpd::stack_clouds_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pcA, pcB, noise, n, pts, q);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int dpd_padded_width(int k) { return (k * k * k * DPD_FV_CHANNELS + 3 + 31) / 32 * 32; }
 

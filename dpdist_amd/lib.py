@@ -19,6 +19,10 @@ class DecoderParams(Structure):
     _fields_ = [(n, c_void_p) for n in ("W1p", "b1", "W2", "b2", "W3", "b3", "W4", "b4")]
 
 
+class SmallGrads(Structure):
+    _fields_ = [(n, c_void_p) for n in ("db1", "db2", "db3", "dW4", "db4")]
+
+
 # name -> (restype, argtypes); mirrors include/dpdist_capi.h one to one
 SIGNATURES = {
     "dpd_version": (c_char_p, []),
@@ -33,7 +37,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_bwd_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      POINTER(DecoderParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p]),
+                                     POINTER(SmallGrads), c_void_p]),
+    "dpd_stack_clouds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -102,3 +107,7 @@ def req(t, dtype=None, name="tensor"):
 
 def make_params(W1p, b1, W2, b2, W3, b3, W4, b4):
     return DecoderParams(*[t.data_ptr() for t in (W1p, b1, W2, b2, W3, b3, W4, b4)])
+
+
+def make_small_grads(db1, db2, db3, dW4, db4):
+    return SmallGrads(*[None if t is None else t.data_ptr() for t in (db1, db2, db3, dW4, db4)])

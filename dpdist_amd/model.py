@@ -131,8 +131,8 @@ class _DPDistFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pcA, pcB, noise, flat, P, m, k, sigma):
         B, N, _ = pcA.shape
-        pts = torch.cat([pcA + noise if noise is not None else pcA, pcB], 0).contiguous()   # dpdist_and_aue.py:45,56-61
-        q = torch.cat([pcB, pcA], 0).contiguous()          # AB half queries pcB, BA half queries the UN-noised pcA (:69)
+        # pts = [pcA+noise ; pcB] (dpdist_and_aue.py:45,56-61); q = [pcB ; pcA]: the BA half queries the UN-noised pcA (:69)
+        pts, q = ops.stack_clouds(pcA, pcB, noise)
         fv = ops.mfv3d_fwd(pts, m, sigma)
         X, mask, vox = ops.patch_rows_fwd(q, fv, m, k, P.KP)
         params = P.views(flat)
@@ -156,16 +156,17 @@ class _DPDistFn(torch.autograd.Function):
         dpred = dpred.contiguous()
         Q = dpred.shape[0]
         params = P.views(flat)
-        dy, g3, g2, g1, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, P.KP, need_in)
-        dflat = None
+        dflat, d, small = None, None, None
         if need_w:
             dflat = torch.zeros_like(flat)
-            ws = ops.workspace(Q, P.KP, P.H, flat.device)
             d = P.views(dflat)
-            ops.decoder_bwd_weights(1, X, g1, Q, d[0], d[1], ws)
-            ops.decoder_bwd_weights(2, h1, g2, Q, d[2], d[3], ws)
-            ops.decoder_bwd_weights(3, h2, g3, Q, d[4], d[5], ws)
-            ops.decoder_bwd_weights(4, h3, dy, Q, d[6], d[7], ws)
+            small = (d[1], d[3], d[5], d[6], d[7])     # db1, db2, db3, dW4, db4 come out of the data chain (fused)
+        dy, g3, g2, g1, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, P.KP, need_in, small_grads=small)
+        if need_w:
+            ws = ops.workspace(Q, P.KP, P.H, flat.device)
+            ops.decoder_bwd_weights(1, X, g1, Q, d[0], None, ws)
+            ops.decoder_bwd_weights(2, h1, g2, Q, d[2], None, ws)
+            ops.decoder_bwd_weights(3, h2, g3, Q, d[4], None, ws)
         gA = gB = gN = None
         if need_in:
             dq, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k)

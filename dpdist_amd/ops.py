@@ -74,8 +74,22 @@ def decoder_fwd(X, mask, params, H, bufs=None):
     return h1, h2, h3, y, pred
 
 
-def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None):
-    """dpred [Qb,3] (first Qb rows) -> dy [Qb,3], g3,g2,g1 [Qb,H], dX [Qb,KP] or None"""
+def stack_clouds(pcA, pcB, noise=None):
+    """-> pts [2B,N,3] = [pcA+noise ; pcB], q [2B,N,3] = [pcB ; pcA]   (dpdist_and_aue.py:45,56-61,69)"""
+    L.req(pcA, name="pcA"), L.req(pcB, name="pcB")
+    if noise is not None:
+        L.req(noise, name="add_noise")
+    B, N, _ = pcA.shape
+    pts = torch.empty(2 * B, N, 3, device=pcA.device, dtype=torch.float32)
+    q = torch.empty_like(pts)
+    L.check(L.load().dpd_stack_clouds(L.ptr(pcA), L.ptr(pcB), L.ptr(noise), B, N, L.ptr(pts), L.ptr(q), L.cur_stream()),
+            "dpd_stack_clouds")
+    return pts, q
+
+
+def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None, small_grads=None):
+    """dpred [Qb,3] (first Qb rows) -> dy [Qb,3], g3,g2,g1 [Qb,H], dX [Qb,KP] or None.
+    small_grads = (db1, db2, db3, dW4, db4) tensors (or None each) to be filled by the fused epilogues."""
     L.req(dpred, name="dpred")
     Qb = dpred.shape[0]
     H = h1.shape[1]
@@ -87,8 +101,9 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None)
     else:
         dy, g3, g2, g1, dX = bufs
     p = L.make_params(*params)
+    sg = L.make_small_grads(*small_grads) if small_grads is not None else None
     L.check(L.load().dpd_decoder_bwd_data(L.ptr(dpred), L.ptr(mask), L.ptr(y), L.ptr(h1), L.ptr(h2), L.ptr(h3), Qb, KP, H,
-                                          p, 0, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), L.cur_stream()),
+                                          p, 0, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), sg, L.cur_stream()),
             "dpd_decoder_bwd_data")
     return dy, g3, g2, g1, dX
 

@@ -57,17 +57,14 @@ class DPDistTrainer:
         self.reducer = BucketReducer(self.grad, params.bucket_bounds, group) if use_dist else None
         self._cparams = L.make_params(*params.views())
         self._gviews = params.views(self.grad)
+        gv = self._gviews
+        self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7])
 
     # -- pieces (each enqueues kernels on the current stream; no host sync, no allocation) -----------------
     def _load_batch(self, pcA, pcB, noise):
-        B = self.B
-        if noise is None:
-            self.pts[:B].copy_(pcA)
-        else:
-            torch.add(pcA, noise, out=self.pts[:B])
-        self.pts[B:].copy_(pcB)
-        self.q[:B].copy_(pcB)
-        self.q[B:].copy_(pcA)
+        L.check(L.load().dpd_stack_clouds(L.ptr(L.req(pcA, name="pcA")), L.ptr(L.req(pcB, name="pcB")),
+                                          None if noise is None else L.ptr(L.req(noise, name="add_noise")), self.B, self.N,
+                                          L.ptr(self.pts), L.ptr(self.q), L.cur_stream()), "dpd_stack_clouds")
 
     def forward(self):
         lib, s, P = L.load(), L.cur_stream(), self.P
@@ -82,22 +79,22 @@ class DPDistTrainer:
         lib, s, P = L.load(), L.cur_stream(), self.P
         BN = self.B * self.N
         L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
+        # data chain; db1..db3, dW4, db4 fall out of it (fused epilogues / one small kernel)
         L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
                                          L.ptr(self.h3), BN, P.KP, P.H, self._cparams, 0, L.ptr(self.dy), L.ptr(self.g3),
-                                         L.ptr(self.g2), L.ptr(self.g1), None, s), "dpd_decoder_bwd_data")
+                                         L.ptr(self.g2), L.ptr(self.g1), None, self._csmall, s), "dpd_decoder_bwd_data")
         d, wsb = self._gviews, self.ws.numel() * 4
 
-        def dw(layer, act, g, dW, db):
+        def dw(layer, act, g, dW):
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], 0,
-                                                L.ptr(dW), L.ptr(db), L.ptr(self.ws), wsb, L.cur_stream()),
+                                                L.ptr(dW), None, L.ptr(self.ws), wsb, L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
-        dw(1, self.X, self.g1, d[0], d[1])
+        dw(1, self.X, self.g1, d[0])
         if self.reducer:
-            self.reducer.reduce_async(0)
-        dw(2, self.h1, self.g2, d[2], d[3])
-        dw(3, self.h2, self.g3, d[4], d[5])
-        dw(4, self.h3, self.dy, d[6], d[7])
+            self.reducer.reduce_async(0)      # bucket 0 = dW1p + db1 (db1 was finished by the data chain)
+        dw(2, self.h1, self.g2, d[2])
+        dw(3, self.h2, self.g3, d[4])
         if self.reducer:
             self.reducer.reduce_async(1)
 

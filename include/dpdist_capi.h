@@ -49,6 +49,11 @@ const char* dpd_version(void);
 /* KP: leading dimension of the decoder input rows for window side k (k^3*20+3 rounded up to 32). */
 int dpd_padded_width(int k);
 
+/* Input stacking of the module contract (models/dpdist_and_aue.py:45,56-61,69): pcA, pcB, noise [B,N,3]
+ * (noise may be NULL) -> pts [2B,N,3] = [pcA+noise ; pcB] (encoder input), q [2B,N,3] = [pcB ; pcA] (queries).  */
+int dpd_stack_clouds(const float* pcA, const float* pcB, const float* noise, int B, int N, float* pts, float* q,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 3DmFV encoder.  Replaces utils/dpdist_util.py:22-141 (get_3dmfv_tf, full_fv, normalize=True).
  *   pts [C,N,3] -> fv [C,m^3,20]; Gaussians on the fixed grid of :42-51, uniform weights 1/m^3.
@@ -93,15 +98,24 @@ int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, con
 /* Backward, data chain: dpred [Qb,3] for the FIRST Qb rows (training mode: Qb = Q/2, only the AB half
  * carries gradient, train_multi_gpu_pc_compare_dist.py:274-277; as-loss mode: Qb = Q).
  * Produces the pre-activation gradients g3,g2,g1 [Qb,H] and dy [Qb,3]; if dX != NULL also
- * dX [Qb,KP] = g1 * W1p^T (as-loss mode, TF autodiff through :516).                              */
+ * dX [Qb,KP] = g1 * W1p^T (as-loss mode, TF autodiff through :516).
+ * `sg` (may be NULL) lists the small gradients that fall out of this chain for free and are then written here
+ * (overwritten): db3/db2/db1 [H] = column sums of g3/g2/g1 (fused into the dH GEMM epilogues, fp32 atomics),
+ * dW4 [H,3] = h3^T dy, db4 [3].  Any member may be NULL.                                          */
+typedef struct dpd_small_grads {
+    float* db1; float* db2; float* db3; float* dW4; float* db4;
+} dpd_small_grads;
+
 int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,
                          const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p, int dtype,
-                         float* dy, float* g3, float* g2, float* g1, float* dX, void* stream);
+                         float* dy, float* g3, float* g2, float* g1, float* dX, const dpd_small_grads* sg,
+                         void* stream);
 
 /* Backward, weight gradients of ONE layer (1..4) from the buffers above:
  *   layer 1: dW [KP,H] = X^T g1, db = colsum(g1);  2: h1^T g2;  3: h2^T g3;  4: dW [H,3] = h3^T dy.
  * `act` is the layer's input activation (X, h1, h2 or h3) with leading dimension lda, `g` its
- * pre-activation output gradient.  dW/db are overwritten.  ws: dpd_workspace_bytes() bytes.      */
+ * pre-activation output gradient.  dW/db are overwritten; db may be NULL for layers 1-3 when it was already
+ * produced by dpd_decoder_bwd_data.  ws: dpd_workspace_bytes() bytes.                              */
 int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
                             int dtype, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
 
