@@ -106,8 +106,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the DPDist path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("DPD_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -126,7 +128,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +140,7 @@ def main():
         tr.step(pcA, pcB, lab)
     sync()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -164,7 +166,7 @@ def main():
                     "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
                     "alg_gflop_per_launch": round(alg / per_step / 1e9, 3),
                     "gemm_ms_per_step": round(ms.value / a.steps, 4)}
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     if rank == 0:
@@ -183,7 +185,7 @@ def main():
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -26,18 +26,20 @@ def shard_range(global_batch, rank, world):
 class BucketReducer:
     """All-reduce slices of one flat gradient buffer, asynchronously with respect to the compute stream."""
 
-    def __init__(self, flat_grad, bounds, group=None):
+    def __init__(self, flat_grad, bounds, group=None, force=False):
         self.flat = flat_grad
         self.bounds = list(bounds)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        # force=True issues the collectives even for a single rank (exercises the RCCL/stream plumbing on one GPU)
+        self.active = dist.is_initialized() and (self.world > 1 or force)
+        self.comm_stream = torch.cuda.Stream() if (self.cuda and self.active) else None
         self._pending = []
 
     def reduce_async(self, bucket):
         """Call right after the kernels producing bucket `bucket` were enqueued on the current stream."""
-        if self.world == 1:
+        if not self.active:
             return
         lo, hi = self.bounds[bucket], self.bounds[bucket + 1]
         view = self.flat[lo:hi]

@@ -54,7 +54,9 @@ class DPDistTrainer:
         self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H) + 3) // 4, device=dev, dtype=torch.float32)
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
-        self.reducer = BucketReducer(self.grad, params.bucket_bounds, group) if use_dist else None
+        import os
+        self.reducer = BucketReducer(self.grad, params.bucket_bounds, group,
+                                     force=os.environ.get("DPD_FORCE_DIST") == "1") if use_dist else None
         self._cparams = L.make_params(*params.views())
         self._gviews = params.views(self.grad)
         gv = self._gviews
