@@ -316,6 +316,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -335,10 +337,10 @@ __device__ __forceinline__ void load_frag(const float* img, int mn0w, int l31, i
 
 // ABL (timing-only ablations, wrong results): bit0 no in-loop DMA, bit1 no mid-tile wait/barrier,
 // bit2 DMA replaced by plain global loads into registers (same L2 traffic, no LDS write)
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, bool STAGGER = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     constexpr int BM = 32 * WR, BN = 32 * WC, BK = 32, NW = WR * WC;   // NS-stage ring (3 or 4)
-    static_assert(NS == 3 || NS == 4, "ring depth");
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
     constexpr int A_IMG = BM * BK, B_IMG = BN * BK, STAGE = A_IMG + B_IMG;   // floats
     constexpr int PA = BM / 8, PB = BN / 8;                                  // 1-KiB pieces per K-tile
     constexpr int PPW = (PA + PB) / NW;                                      // pieces per wave per K-tile
@@ -406,12 +408,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     // prologue: K-tiles 0 .. NS-2 in flight; wait for tile 0
-    if (0 < nt) issue(0);
-    if (1 < nt) issue(1);
-    if (NS == 4 && 2 < nt) issue(2);
-    if (NS == 4 && nt > 2) wait_vmcnt<2 * PPW>();
-    else if (nt > 1) wait_vmcnt<PPW>();
-    else wait_vmcnt<0>();
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nt) issue(p);
+    {
+        const int later = min(NS - 2, nt - 1);        // tiles after tile 0 that are in flight
+        if (later >= 3) wait_vmcnt<3 * PPW>();
+        else if (later == 2) wait_vmcnt<2 * PPW>();
+        else if (later == 1) wait_vmcnt<PPW>();
+        else wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
 
     float fa[2][4], fb[2][4];
@@ -435,11 +441,26 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
             if (kb == 2) {
                 // mid-tile sync: my pieces of K-tile it+1 have landed once only tile it+2's may be outstanding
                 if (!(ABL & 2)) {
-                    if (NS == 4 && it + 2 < nt) wait_vmcnt<PPW>();
-                    else wait_vmcnt<0>();
+                    if (!(ABL & 8)) {   // tiles it+2 .. it+NS-2 may stay in flight
+                        const int later = min(NS - 3, nt - 2 - it);
+                        if (later >= 2) wait_vmcnt<2 * PPW>();
+                        else if (later == 1) wait_vmcnt<PPW>();
+                        else wait_vmcnt<0>();
+                    }
                     __builtin_amdgcn_s_barrier();
                 }
-                if (it + NS - 1 < nt && !(ABL & 1)) issue((it + NS - 1) % NS);
+            }
+            // Refill of the stage freed by that barrier (K-tile it+NS-1), STAGGERED over the four k-blocks that
+            // follow it: the 16 waves of a CU leave the barrier together, and if they all issued their DMA pieces
+            // right there the in-order waves would sit behind the address unit's queue with the MFMA pipes idle.
+            // Wave slot s = wave&3 issues at kb 2,3 of this iteration or kb 0,1 of the next one.
+            if (!(ABL & 1)) {
+                const int slot = STAGGER ? (wave & 3) : 0;
+                if (kb >= 2) {
+                    if (slot == kb - 2 && it + NS - 1 < nt) issue((it + NS - 1) % NS);
+                } else {
+                    if (slot == kb + 2 && it >= 1 && it + NS - 2 < nt) issue((it + NS - 2) % NS);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -451,11 +472,11 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     store_tile(g, acc, z, m0 + wm0, n0 + wn0 + l31, half);
 }
 
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, bool STAGGER = false>
 static int launch_dma(const GemmArgs& g, hipStream_t s) {
     constexpr int BM = 32 * WR, BN = 32 * WC;
     constexpr size_t lds = NS * (size_t)(BM + BN) * 32 * sizeof(float);
-    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL>;
+    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL, STAGGER>;
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -510,6 +531,14 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 7: return launch_dma<2, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x128, 512 thr, 72 KiB  (2 blocks/CU)
         case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
         case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
+        case 10: return launch_dma<4, 4, 5, AK, BKC>(g, s);  // LDS-DMA ring, 128x128, 1024 thr, 160 KiB (all of a CU's LDS)
+        case 109: return launch_dma<4, 4, 4, AK, BKC, 0, true>(g, s);    // staggered refill (measured slower: A/B reference)
+        case 15: return launch_dma<4, 4, 3, AK, BKC, 1>(g, s);   // timing-only ablations of the 128x128 kernel
+        case 25: return launch_dma<4, 4, 3, AK, BKC, 2>(g, s);
+        case 35: return launch_dma<4, 4, 3, AK, BKC, 3>(g, s);
+        case 45: return launch_dma<4, 4, 3, AK, BKC, 4>(g, s);
+        case 85: return launch_dma<4, 4, 3, AK, BKC, 8>(g, s);
+        case 95: return launch_dma<4, 4, 3, AK, BKC, 9>(g, s);
         case 1: return launch_cfg<128, 128, 32, AK, BKC>(g, s);
         case 2: return launch_cfg<128, 64, 32, AK, BKC>(g, s);
         case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);
@@ -553,7 +582,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         (void)tile_eff;
         tile = 3;
     }
-    if (tile >= 4 && tile <= 9 && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
+    if (tile >= 4 && tile <= 10 && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
         tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;

@@ -145,7 +145,7 @@ int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr
  *   K, N, lda, ldb, ldc multiples of 4; split_k >= 1 (slabs in ws, reduced by a second kernel,
  *   epilogue applied after the reduction); tile: 0 = auto; register-staged kernels 1 = 128x128, 2 = 128x64,
  *   3 = 64x64; LDS-DMA ring kernels (K % 32 == 0, else 3 is used) 4 = 64x64/4-stage, 5 = 128x128/4-stage,
- *   6 = 128x64, 7 = 64x128, 8 = 64x64/3-stage, 9 = 128x128/3-stage.                                */
+ *   6 = 128x64, 7 = 64x128, 8 = 64x64/3-stage, 9 = 128x128/3-stage, 10 = 128x128/5-stage.                               */
 int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* Cout, int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile,
                  void* ws, size_t ws_bytes, void* stream);
