@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--plan", default="", help="GEMM plan overrides for tuning, e.g. '0:10,1:9:1' = op:tile[:split_k]")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +119,9 @@ def main():
     from dpdist_amd.trainer import DPDistTrainer
     L = lib.load()
 
+    for item in filter(None, a.plan.split(",")):
+        f = [int(x) for x in item.split(":")]
+        lib.check(L.dpd_set_gemm_plan(f[0], f[1], f[2] if len(f) > 2 else 1), "dpd_set_gemm_plan")
     B, N = a.batch, 64
     P = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev)
     g = torch.Generator().manual_seed(1234)            # same random-init weights on every rank (replicated variables)

@@ -19,12 +19,12 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
 enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 = 4, OP_BWD_DW23 = 5, OP_COUNT = 6 };
 // Defaults measured on MI355X at B=32 (tools/gemm_bench.py, profiles/): LDS-DMA ring kernels everywhere;
-//   fwd L1 (4096x1024x2528)  128x128 16-wave 5-stage ring  ~119 TFLOP/s    fwd L2/3 (K=1024) 128x128 3-stage  ~118
+//   fwd L1 (4096x1024x2528)  128x128 16-wave 3-stage ring  ~127 TFLOP/s    fwd L2/3 (K=1024) 128x128 3-stage  ~120
 //   bwd dH (2048x1024x1024)   64x64  3-stage               ~ 93..106       bwd dX            64x64 3-stage    ~103
 //   bwd dW1 (2528x1024x2048)  64x64  3-stage, split-K 2    ~102            bwd dW2/3         64x64 3-stage    ~ 97
 // (run-to-run spread between boxes is ~10 %; the ranking inside one run is stable.  DMA kernels need K % 32 == 0;
 //  gemm_f32 falls back to the register-staged 64x64 kernel otherwise.)
-static int g_plan_tile[OP_COUNT] = {10, 9, 8, 8, 8, 8};
+static int g_plan_tile[OP_COUNT] = {9, 9, 8, 8, 8, 8};
 static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 2, 1};
 
 // ---- output layer: y = h3 W4 + b4 ; pred = clip(y,0,6)/3 * mask.  One wave per row. ----------------------
@@ -195,7 +195,7 @@ static size_t colsum_ws_floats(int ncols, int nw) { return (size_t)kColChunks * 
 }  // namespace dpd
 
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
-    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 10 || split_k < 1 || split_k > 8) return DPD_E_DIM;
+    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 20 || split_k < 1 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;
     return 0;

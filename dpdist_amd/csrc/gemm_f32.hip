@@ -337,8 +337,9 @@ __device__ __forceinline__ void load_frag(const float* img, int mn0w, int l31, i
 
 // ABL (timing-only ablations, wrong results): bit0 no in-loop DMA, bit1 no mid-tile wait/barrier,
 // bit2 DMA replaced by plain global loads into registers (same L2 traffic, no LDS write)
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, bool STAGGER = false>
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
+    constexpr bool PRIO = (WR * WC >= 16) && !(ABL & 64);
     constexpr int BM = 32 * WR, BN = 32 * WC, BK = 32, NW = WR * WC;   // NS-stage ring (3 or 4)
     static_assert(NS >= 3 && NS <= 5, "ring depth");
     constexpr int A_IMG = BM * BK, B_IMG = BN * BK, STAGE = A_IMG + B_IMG;   // floats
@@ -406,6 +407,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    long long dbg_wait = 0, dbg_bar = 0;
+    const long long dbg_t0 = (ABL & 32) ? __builtin_readcyclecounter() : 0;
 
     // prologue: K-tiles 0 .. NS-2 in flight; wait for tile 0
 #pragma unroll
@@ -441,42 +444,65 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
             if (kb == 2) {
                 // mid-tile sync: my pieces of K-tile it+1 have landed once only tile it+2's may be outstanding
                 if (!(ABL & 2)) {
+                    long long t0 = 0, t1 = 0, t2 = 0;
+                    if (ABL & 32) t0 = __builtin_readcyclecounter();
                     if (!(ABL & 8)) {   // tiles it+2 .. it+NS-2 may stay in flight
                         const int later = min(NS - 3, nt - 2 - it);
                         if (later >= 2) wait_vmcnt<2 * PPW>();
                         else if (later == 1) wait_vmcnt<PPW>();
                         else wait_vmcnt<0>();
                     }
+                    if (ABL & 32) t1 = __builtin_readcyclecounter();
                     __builtin_amdgcn_s_barrier();
+                    if (ABL & 32) {
+                        t2 = __builtin_readcyclecounter();
+                        dbg_wait += t1 - t0;
+                        dbg_bar += t2 - t1;
+                    }
                 }
             }
-            // Refill of the stage freed by that barrier (K-tile it+NS-1), STAGGERED over the four k-blocks that
-            // follow it: the 16 waves of a CU leave the barrier together, and if they all issued their DMA pieces
-            // right there the in-order waves would sit behind the address unit's queue with the MFMA pipes idle.
-            // Wave slot s = wave&3 issues at kb 2,3 of this iteration or kb 0,1 of the next one.
-            if (!(ABL & 1)) {
-                const int slot = STAGGER ? (wave & 3) : 0;
-                if (kb >= 2) {
-                    if (slot == kb - 2 && it + NS - 1 < nt) issue((it + NS - 1) % NS);
-                } else {
-                    if (slot == kb + 2 && it >= 1 && it + NS - 2 < nt) issue((it + NS - 2) % NS);
-                }
+            // refill of the stage freed by that barrier with K-tile it+NS-1 (issuing it later / staggered over the
+            // following k-blocks was measured 7 % slower: the data then has less time to land)
+            if (kb == 2 && !(ABL & 1) && it + NS - 1 < nt) issue((it + NS - 1) % NS);
+            // MFMA issue is arbitrated by priority, then age.  With equal priorities the oldest wave of a SIMD runs its
+            // whole barrier interval first and the youngest runs last and ALONE, with nobody to cover its LDS/barrier
+            // stalls.  Priority falls as a wave advances through the interval (k-blocks 2,3,0,1 -> 3,2,1,0), so laggards
+            // overtake leaders and the four waves of a SIMD reach the barrier together (+6 % on the 16-wave kernels,
+            // neutral to slightly negative on the 4-wave ones, where other workgroups already fill the gaps).
+            if (PRIO) {
+                if (kb == 2) __builtin_amdgcn_s_setprio(3);
+                else if (kb == 3) __builtin_amdgcn_s_setprio(2);
+                else if (kb == 0) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 16) {   // data-path-only ablation: consume the fragments with 4 VALU ops instead of 4 MFMAs
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][s2], fb[c][s2], acc, 0, 0, 0);
+                for (int s2 = 0; s2 < 4; ++s2) acc[s2] += fa[c][s2] * fb[c][s2];
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][s2], fb[c][s2], acc, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (ABL & 4) acc[0] += (sink.x + sink.y) + (sink.z + sink.w);
+    if ((ABL & 32) && lane == 0 && g.colsum) {   // debug: per-wave cycles [total, vmcnt wait, barrier wait]
+        float* d = g.colsum + ((size_t)blockIdx.x * NW + wave) * 4;
+        d[0] = (float)(__builtin_readcyclecounter() - dbg_t0);
+        d[1] = (float)dbg_wait;
+        d[2] = (float)dbg_bar;
+        d[3] = (float)nt;
+        return;
+    }
     store_tile(g, acc, z, m0 + wm0, n0 + wn0 + l31, half);
 }
 
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, bool STAGGER = false>
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
 static int launch_dma(const GemmArgs& g, hipStream_t s) {
     constexpr int BM = 32 * WR, BN = 32 * WC;
     constexpr size_t lds = NS * (size_t)(BM + BN) * 32 * sizeof(float);
-    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL, STAGGER>;
+    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL>;
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -532,8 +558,13 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
         case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
         case 10: return launch_dma<4, 4, 5, AK, BKC>(g, s);  // LDS-DMA ring, 128x128, 1024 thr, 160 KiB (all of a CU's LDS)
-        case 109: return launch_dma<4, 4, 4, AK, BKC, 0, true>(g, s);    // staggered refill (measured slower: A/B reference)
-        case 15: return launch_dma<4, 4, 3, AK, BKC, 1>(g, s);   // timing-only ablations of the 128x128 kernel
+        case 19: return launch_dma<4, 4, 3, AK, BKC, 64>(g, s);    // 9 / 10 / 5 without the progress-based s_setprio
+        case 20: return launch_dma<4, 4, 5, AK, BKC, 64>(g, s);
+        case 15: return launch_dma<4, 4, 4, AK, BKC, 64>(g, s);
+        case 325: return launch_dma<4, 4, 4, AK, BKC, 32>(g, s);   // s_memtime instrumentation (debug buffer in colsum)
+        case 165: return launch_dma<4, 4, 4, AK, BKC, 16>(g, s);   // data path only (no MFMA): L2 -> LDS -> VGPR rate
+        case 164: return launch_dma<2, 2, 4, AK, BKC, 16>(g, s);
+        case 115: return launch_dma<4, 4, 3, AK, BKC, 1>(g, s);   // timing-only ablations of the 128x128 kernel
         case 25: return launch_dma<4, 4, 3, AK, BKC, 2>(g, s);
         case 35: return launch_dma<4, 4, 3, AK, BKC, 3>(g, s);
         case 45: return launch_dma<4, 4, 3, AK, BKC, 4>(g, s);
@@ -582,7 +613,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         (void)tile_eff;
         tile = 3;
     }
-    if (tile >= 4 && tile <= 10 && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
+    if (((tile >= 4 && tile <= 10) || tile == 15 || tile == 19 || tile == 20) && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
         tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
@@ -653,6 +684,11 @@ extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
     return g_prof.n;
+}
+
+extern "C" int dpd_gemm_f32_dbg(int M, int N, int K, const float* A, const float* B, float* Cout, float* dbg, int tile,
+                                void* stream) {
+    return dpd::gemm_f32(0, 0, M, N, K, A, K, B, N, Cout, N, nullptr, nullptr, 0, 1, tile, nullptr, 0, (hipStream_t)stream, dbg);
 }
 
 extern "C" int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
