@@ -79,6 +79,112 @@ __global__ __launch_bounds__(256) void out_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// Fused output-layer backward: ONE pass over h3 produces dy, g3 AND the per-block partial sums of
+//   db3 = colsum(g3), dW4 = h3^T dy, db4 = colsum(dy)
+// (block = 32 rows, 4 waves x 8 rows; lane owns columns lane+64j).  Partials go to `scratch` [nblk][4H+4] and are
+// summed in fixed order by small_grads_reduce -> deterministic, no atomics, no memset.  H <= 1024.
+constexpr int kOBRows = 8;
+constexpr int kOBMaxJ = 16;
+
+__global__ __launch_bounds__(256) void out_bwd_fused_kernel(const float* __restrict__ dpred, const float* __restrict__ mask,
+                                                             const float* __restrict__ y, const float* __restrict__ h3,
+                                                             const float* __restrict__ W4, float* __restrict__ dy,
+                                                             float* __restrict__ g3, int Qb, int H, ZeroList zl,
+                                                             float* __restrict__ scratch) {
+    extern __shared__ float s_acc[];   // [4H + 4]
+    if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
+        for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nj = H / 64;
+    float w4[kOBMaxJ][3], s3[kOBMaxJ], a4[kOBMaxJ][3];
+#pragma unroll
+    for (int j = 0; j < kOBMaxJ; ++j) {
+        s3[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a4[j][c] = 0.f; w4[j][c] = (j < nj) ? W4[(lane + 64 * j) * 3 + c] : 0.f; }
+    }
+    float dsum[3] = {0.f, 0.f, 0.f};
+    for (int rr = 0; rr < kOBRows / 4; ++rr) {
+        const int row = blockIdx.x * kOBRows + wave * (kOBRows / 4) + rr;
+        if (row >= Qb) break;
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float yv = y[(size_t)row * 3 + c];
+            d[c] = (yv > 0.f && yv < 6.f) ? dpred[(size_t)row * 3 + c] * mask[row] / 3.0f : 0.f;   // relu6 gradient is 1 on (0,6)
+            dsum[c] += d[c];
+        }
+        if (lane < 3) dy[(size_t)row * 3 + lane] = d[lane];
+        const float* h = h3 + (size_t)row * H;
+        float* g = g3 + (size_t)row * H;
+#pragma unroll
+        for (int j = 0; j < kOBMaxJ; ++j) {
+            if (j < nj) {
+                const int k = lane + 64 * j;
+                const float hv = h[k];
+                const float v = d[0] * w4[j][0] + d[1] * w4[j][1] + d[2] * w4[j][2];
+                const float gv = (hv > 0.f) ? v : 0.f;
+                g[k] = gv;
+                s3[j] += gv;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a4[j][c] += hv * d[c];
+            }
+        }
+    }
+    // fixed-order reduction over the 4 waves
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < kOBMaxJ; ++j) {
+                if (j < nj) {
+                    const int k = lane + 64 * j;
+                    if (w == 0) {
+                        s_acc[k] = s3[j];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) s_acc[H + k * 3 + c] = a4[j][c];
+                    } else {
+                        s_acc[k] += s3[j];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) s_acc[H + k * 3 + c] += a4[j][c];
+                    }
+                }
+            }
+            if (lane < 3) {
+                const float v = (lane == 0) ? dsum[0] : ((lane == 1) ? dsum[1] : dsum[2]);
+                if (w == 0) s_acc[4 * H + lane] = v;
+                else s_acc[4 * H + lane] += v;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = scratch + (size_t)blockIdx.x * (4 * H + 4);
+    for (int i = threadIdx.x; i < 4 * H + 3; i += 256) out[i] = s_acc[i];
+}
+
+// out[i] = sum_b scratch[b][i] in a fixed order: 16 outputs x 16 block-slices per workgroup, LDS tree at the end
+__global__ __launch_bounds__(256) void small_grads_reduce(const float* __restrict__ scratch, int nblk, int H,
+                                                           float* __restrict__ db3, float* __restrict__ dW4,
+                                                           float* __restrict__ db4) {
+    __shared__ float red[16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + li;
+    const int n = 4 * H + 3;
+    float s = 0.f;
+    if (i < n)
+        for (int b = sl; b < nblk; b += 16) s += scratch[(size_t)b * (4 * H + 4) + i];
+    red[sl][li] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][li];
+        if (i < H) { if (db3) db3[i] = t; }
+        else if (i < 4 * H) { if (dW4) dW4[i - H] = t; }
+        else if (db4) db4[i - 4 * H] = t;
+    }
+}
+
 // Column sums in two deterministic stages.  Stage 1: block (colblock, chunk) -> partial[chunk][...].
 //   NW = 0: partial[chunk][n]     = sum_r g[r][n]                       (bias gradient)
 //   NW = 3: partial[chunk][n*3+c] = sum_r a[r][n] * w[r*3+c]            (dW4 = h3^T dy)
@@ -241,18 +347,30 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     float* db3 = sg ? sg->db3 : nullptr;
     float* dW4 = sg ? sg->dW4 : nullptr;
     float* db4 = sg ? sg->db4 : nullptr;
-    ZeroList zl{{db1, db2, db3, dW4, db4}, {H, H, H, H * 3, 3}};
-    DPD_LAUNCH(out_bwd_kernel, dim3((Qb + 3) / 4), dim3(256), 0, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl);
-    DPD_CHECK_LAUNCH();
-    const int chunks = 16;
-    if (db3) {   // db3 = colsum(g3)
-        DPD_LAUNCH(colsum_atomic<0>, dim3((H + 63) / 64, chunks), dim3(256), 0, s, (const float*)g3, H, (const float*)nullptr, Qb, H,
-                   db3, (float*)nullptr);
+    const int nblk = (Qb + kOBRows - 1) / kOBRows;
+    const bool fused = (db3 || dW4 || db4) && H <= 64 * kOBMaxJ && (size_t)nblk * (4 * H + 4) <= (size_t)Qb * H;
+    if (fused) {
+        // one pass over h3: dy, g3 and block partials of db3 / dW4 / db4 (g2 is free until the first dH GEMM: scratch)
+        ZeroList zl{{db1, db2, nullptr, nullptr, nullptr}, {H, H, 0, 0, 0}};
+        DPD_LAUNCH(out_bwd_fused_kernel, dim3(nblk), dim3(256), (size_t)(4 * H + 4) * sizeof(float), s, dpred, mask, y, h3,
+                   p->W4, dy, g3, Qb, H, zl, g2);
         DPD_CHECK_LAUNCH();
-    }
-    if (dW4) {   // dW4 = h3^T dy, db4 = colsum(dy)
-        DPD_LAUNCH(colsum_atomic<3>, dim3((H + 63) / 64, chunks), dim3(256), 0, s, h3, H, (const float*)dy, Qb, H, dW4, db4);
+        DPD_LAUNCH(small_grads_reduce, dim3((4 * H + 3 + 15) / 16), dim3(256), 0, s, (const float*)g2, nblk, H, db3, dW4, db4);
         DPD_CHECK_LAUNCH();
+    } else {
+        ZeroList zl{{db1, db2, db3, dW4, db4}, {H, H, H, H * 3, 3}};
+        DPD_LAUNCH(out_bwd_kernel, dim3((Qb + 3) / 4), dim3(256), 0, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl);
+        DPD_CHECK_LAUNCH();
+        const int chunks = 16;
+        if (db3) {   // db3 = colsum(g3)
+            DPD_LAUNCH(colsum_atomic<0>, dim3((H + 63) / 64, chunks), dim3(256), 0, s, (const float*)g3, H, (const float*)nullptr, Qb,
+                       H, db3, (float*)nullptr);
+            DPD_CHECK_LAUNCH();
+        }
+        if (dW4) {   // dW4 = h3^T dy, db4 = colsum(dy)
+            DPD_LAUNCH(colsum_atomic<3>, dim3((H + 63) / 64, chunks), dim3(256), 0, s, h3, H, (const float*)dy, Qb, H, dW4, db4);
+            DPD_CHECK_LAUNCH();
+        }
     }
     // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0];  db2 / db1 = column sums, fused into the epilogue
     if (int rc = gemm_f32(0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s, db2)) return rc;
