@@ -337,10 +337,10 @@ __device__ __forceinline__ void load_frag(const float* img, int mn0w, int l31, i
 
 // ABL (timing-only ablations, wrong results): bit0 no in-loop DMA, bit1 no mid-tile wait/barrier,
 // bit2 DMA replaced by plain global loads into registers (same L2 traffic, no LDS write)
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     constexpr bool PRIO = (WR * WC >= 16) && !(ABL & 64);
-    constexpr int BM = 32 * WR, BN = 32 * WC, BK = 32, NW = WR * WC;   // NS-stage ring (3 or 4)
+    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, BK = 32, NW = WR * WC;   // wave tile (32*TM) x (32*TN)
     static_assert(NS >= 3 && NS <= 5, "ring depth");
     constexpr int A_IMG = BM * BK, B_IMG = BN * BK, STAGE = A_IMG + B_IMG;   // floats
     constexpr int PA = BM / 8, PB = BN / 8;                                  // 1-KiB pieces per K-tile
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave / WC) * 32, wn0 = (wave % WC) * 32;
+    const int wm0 = (wave / WC) * 32 * TM, wn0 = (wave % WC) * 32 * TN;
 
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int per_z = tilesM * tilesN;
@@ -404,9 +404,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     long long dbg_wait = 0, dbg_bar = 0;
     const long long dbg_t0 = (ABL & 32) ? __builtin_readcyclecounter() : 0;
 
@@ -423,23 +427,24 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     }
     __builtin_amdgcn_s_barrier();
 
-    float fa[2][4], fb[2][4];
-    load_frag<AK, BM>(smem, wm0, l31, half, 0, fa[0]);
-    load_frag<BKC, BN>(smem + A_IMG, wn0, l31, half, 0, fb[0]);
+    float fa[2][TM][4], fb[2][TN][4];
+    auto frags = [&](const float* stA, int kb, int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) load_frag<AK, BM>(stA, wm0 + 32 * i, l31, half, kb, fa[buf][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) load_frag<BKC, BN>(stA + A_IMG, wn0 + 32 * j, l31, half, kb, fb[buf][j]);
+    };
+    frags(smem, 0, 0);
 
     for (int it = 0; it < nt; ++it) {
         const float* sA = smem + (it % NS) * STAGE;
-        const float* sB = sA + A_IMG;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const int c = kb & 1, n = c ^ 1;
             if (kb < 3) {
-                load_frag<AK, BM>(sA, wm0, l31, half, kb + 1, fa[n]);
-                load_frag<BKC, BN>(sB, wn0, l31, half, kb + 1, fb[n]);
+                frags(sA, kb + 1, n);
             } else if (it + 1 < nt) {   // first fragments of the next K-tile (certified landed at this tile's barrier)
-                const float* nA = smem + ((it + 1) % NS) * STAGE;
-                load_frag<AK, BM>(nA, wm0, l31, half, 0, fa[n]);
-                load_frag<BKC, BN>(nA + A_IMG, wn0, l31, half, 0, fb[n]);
+                frags(smem + ((it + 1) % NS) * STAGE, 0, n);
             }
             if (kb == 2) {
                 // mid-tile sync: my pieces of K-tile it+1 have landed once only tile it+2's may be outstanding
@@ -478,15 +483,20 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             if (ABL & 16) {   // data-path-only ablation: consume the fragments with 4 VALU ops instead of 4 MFMAs
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc[s2] += fa[c][s2] * fb[c][s2];
+                for (int s2 = 0; s2 < 4; ++s2) acc[0][0][s2] += fa[c][0][s2] * fb[c][0][s2];
             } else {
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][s2], fb[c][s2], acc, 0, 0, 0);
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][s2], fb[c][j][s2], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (ABL & 4) acc[0] += (sink.x + sink.y) + (sink.z + sink.w);
+    if (ABL & 4) acc[0][0][0] += (sink.x + sink.y) + (sink.z + sink.w);
     if ((ABL & 32) && lane == 0 && g.colsum) {   // debug: per-wave cycles [total, vmcnt wait, barrier wait]
         float* d = g.colsum + ((size_t)blockIdx.x * NW + wave) * 4;
         d[0] = (float)(__builtin_readcyclecounter() - dbg_t0);
@@ -495,14 +505,17 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         d[3] = (float)nt;
         return;
     }
-    store_tile(g, acc, z, m0 + wm0, n0 + wn0 + l31, half);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) store_tile(g, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
 }
 
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0>
+template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, int TM = 1, int TN = 1>
 static int launch_dma(const GemmArgs& g, hipStream_t s) {
-    constexpr int BM = 32 * WR, BN = 32 * WC;
+    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
     constexpr size_t lds = NS * (size_t)(BM + BN) * 32 * sizeof(float);
-    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL>;
+    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL, TM, TN>;
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -558,6 +571,10 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
         case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
         case 10: return launch_dma<4, 4, 5, AK, BKC>(g, s);  // LDS-DMA ring, 128x128, 1024 thr, 160 KiB (all of a CU's LDS)
+        case 11: return launch_dma<2, 4, 3, AK, BKC, 0, 2, 1>(g, s);   // 128x128, 8 waves of 64x32 (2 accumulators), 96 KiB
+        case 12: return launch_dma<2, 2, 3, AK, BKC, 0, 2, 2>(g, s);   // 128x128, 4 waves of 64x64 (4 accumulators), 96 KiB
+        case 13: return launch_dma<2, 2, 3, AK, BKC, 0, 2, 1>(g, s);   // 128x64,  4 waves of 64x32, 72 KiB (2 blocks/CU)
+        case 14: return launch_dma<4, 2, 3, AK, BKC, 0, 1, 2>(g, s);   // 128x128, 8 waves of 32x64
         case 19: return launch_dma<4, 4, 3, AK, BKC, 64>(g, s);    // 9 / 10 / 5 without the progress-based s_setprio
         case 20: return launch_dma<4, 4, 5, AK, BKC, 64>(g, s);
         case 15: return launch_dma<4, 4, 4, AK, BKC, 64>(g, s);
@@ -576,10 +593,10 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 43: return launch_cfg<64, 64, 32, AK, BKC, 4>(g, s);     // experiments (correct results)
         case 83: return launch_cfg<64, 64, 32, AK, BKC, 8>(g, s);
         case 123: return launch_cfg<64, 64, 32, AK, BKC, 12>(g, s);
-        case 11: return launch_cfg<128, 128, 32, AK, BKC, 1>(g, s);   // ablations (wrong results, timing only)
+        case 111: return launch_cfg<128, 128, 32, AK, BKC, 1>(g, s);   // ablations (wrong results, timing only)
         case 21: return launch_cfg<128, 128, 32, AK, BKC, 2>(g, s);
         case 31: return launch_cfg<128, 128, 32, AK, BKC, 3>(g, s);
-        case 13: return launch_cfg<64, 64, 32, AK, BKC, 1>(g, s);
+        case 113: return launch_cfg<64, 64, 32, AK, BKC, 1>(g, s);
         case 23: return launch_cfg<64, 64, 32, AK, BKC, 2>(g, s);
         case 33: return launch_cfg<64, 64, 32, AK, BKC, 3>(g, s);
         default: return DPD_E_UNSUPPORTED;
@@ -613,7 +630,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         (void)tile_eff;
         tile = 3;
     }
-    if (((tile >= 4 && tile <= 10) || tile == 15 || tile == 19 || tile == 20) && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
+    if (tile >= 4 && tile <= 20 && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
         tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;

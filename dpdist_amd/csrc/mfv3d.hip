@@ -20,7 +20,6 @@ namespace dpd {
 
 constexpr int kF = DPD_FV_CHANNELS;  // 20
 constexpr int kFP = kF + 1;          // padded LDS row
-constexpr int kThreads = 256;
 
 struct MfvConst {
     GridAxis ax;
@@ -53,31 +52,6 @@ __device__ __forceinline__ float pnorm(float x) {
     if (x != x) return x;
     const float s = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
     return s * sqrtf(fmaxf(fabsf(x), 1e-12f));
-}
-
-// All per-(point, Gaussian) quantities of utils/dpdist_util.py:69-100, evaluated by ONE routine so that the
-// forward statistics and the backward tie tests see bit-identical values (the library is built with
-// -ffp-contract=off: no FMA contraction, like TF's op-by-op evaluation).
-struct PG {
-    float z[3], a[3], b[3];
-    float pw, Q, dpi;
-};
-
-__device__ __forceinline__ PG eval_pg(const MfvConst& k, float x, float y, float zc, float cx, float cy, float cz,
-                                      float den) {
-    PG r;
-    r.z[0] = (x - cx) / k.sigma;
-    r.z[1] = (y - cy) / k.sigma;
-    r.z[2] = (zc - cz) / k.sigma;
-    r.pw = pdf(k, r.z[0], r.z[1], r.z[2]) * k.w;    // :73
-    r.Q = r.pw / den;                                // :74
-    r.dpi = (r.Q - k.w) / k.dpi_den;                 // :78
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        r.a[d] = r.Q * r.z[d];                       // :87
-        r.b[d] = r.Q * (r.z[d] * r.z[d] - 1.0f);     // :100
-    }
-    return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -262,229 +236,230 @@ static size_t fwd_lds_bytes(int N, int m, int G) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Backward: dfv [C,G,20] -> dpts [C,N,3].  Everything the forward produced is recomputed (cheap) instead
-// of being saved.  Chain (TF autodiff of :69-126):
-//   fv = s * scale_f,  s = pnorm(v)        -> ds = scale_f * (dfv - fv_hat * <dfv, fv_hat>_G)  (zero if sum < eps)
+// Backward: dfv [C,G,20] -> dpts [C,N,3].  Everything the forward produced is recomputed from the same
+// factorised tables instead of being saved.  Chain (TF autodiff of :69-126):
+//   fv = s * rsqrt(ss_f),  s = pnorm(v)    -> ds = rs*dfv - s * <s,dfv>_G * rs^3            (tf.nn.l2_normalize)
 //   v  = stat(raw) * const                 -> d raw: mean -> 1/N to every point, max/min -> ties share evenly
-//   raw quantities depend on Q_ng and z_ng -> dQ_ng, dz_ng (direct)
-//   Q_ng = wp_ng / sum_g wp_ng             -> dwp_ng = (dQ_ng - sum_g' dQ_ng' Q_ng') / den_n
-//   p_ng = exp(-0.5 |z|^2 - c)             -> dz_ng += -z_ng * p_ng * dp_ng ;  dx_n = sum_g dz_ng / sigma
-//
-// Two kernels per cloud-block to keep registers sane:
-//   pass A (lane <-> Gaussian): recompute stats (incl. tie counts), turn dfv into per-Gaussian coefficient
-//           records in LDS;   pass B (lane <-> point, 4 Gaussian-slices): accumulate dQ.Q and dz per point.
-// Both live in one kernel; coefficient records are kept in LDS ([G][41]).
+//   raw statistics depend on Q_ng, z_ng    -> dQ_ng and the direct part of dz_ng
+//   Q_ng = wp_ng / sum_g wp_ng             -> through the normalisation: dz_ngd -= z_ngd Q_ng (dQ_ng - T_n),
+//                                             T_n = sum_g dQ_ng Q_ng ;   dx_n = sum_g dz_ng / sigma
+// Same mapping as the forward (1024 threads; wave <-> 32 Gaussians, lane>>5 <-> half of the points), so the per-
+// Gaussian gradient record (20 + 20 floats) lives in REGISTERS; the per-point sums over Gaussians are 32-lane
+// xor-shuffle reductions + a fixed-order sum over the 16 waves.  Needs G <= 512 (m <= 8).
+// dynamic LDS (floats): zq[6*N*m] | S[3*N] | chred[16*40] | ch[40] | T[N] | part[16*N*3]
 // ------------------------------------------------------------------------------------------------------
-constexpr int kRec = 41;  // per-Gaussian record: 20 upstream grads wrt the raw statistics + 20 selected values + pad
+struct PQ {   // per-(point, Gaussian) quantities from the tables (identical expressions in every pass -> exact tie tests)
+    float z[3], a[3], b[3], Q, dpi;
+};
 
-__global__ __launch_bounds__(kThreads) void mfv3d_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ dfv,
-                                                              float* __restrict__ dpts, MfvConst k) {
+__device__ __forceinline__ PQ eval_pq(const float2 vx, const float2 vy, const float2 vz, float w, float inv_dpi) {
+    PQ r;
+    r.z[0] = vx.x; r.z[1] = vy.x; r.z[2] = vz.x;
+    r.Q = (vx.y * vy.y) * vz.y;
+    r.dpi = (r.Q - w) * inv_dpi;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        r.a[d] = r.Q * r.z[d];
+        r.b[d] = r.Q * (r.z[d] * r.z[d] - 1.0f);
+    }
+    return r;
+}
+
+__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of this half-wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ dfv,
+                                                                 float* __restrict__ dpts, MfvConst k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int N = k.N, G = k.G;
-    float* s_pts = sm;
-    float* s_den = s_pts + ((N * 3 + 3) & ~3);
-    float* s_part = s_den + N;            // [4*N] scratch (denominators, then dQ.Q partials)
-    float* s_rec = s_part + 4 * N;        // [G*kRec]
-    float* s_chred = s_rec + G * kRec;    // [4*2*20]
-    float* s_ch = s_chred + 8 * kF;       // [2*20]: scale_f, dot_f
-    float* s_acc = s_ch + 2 * kF;         // [4*N*3] dz partials
+    const int N = k.N, G = k.G, m = k.m;
+    float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][N][m]
+    float* s_S = sm + 6 * N * m;                    // [3][N]
+    float* s_chred = s_S + 3 * N;                   // [16][40]
+    float* s_ch = s_chred + 16 * 2 * kF;            // [40]: ss_f, dot_f
+    float* s_T = s_ch + 2 * kF;                     // [N]
+    float* s_part = s_T + N;                        // [16][N][3]
 
     const int tid = threadIdx.x, c = blockIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const float* p = pts + (size_t)c * N * 3;
-    const float* df = dfv + (size_t)c * G * kF;
-    for (int i = tid; i < N * 3; i += kThreads) s_pts[i] = p[i];
-    __syncthreads();
-
-    const int gq = (G + 3) / 4;
-    for (int idx = tid; idx < 4 * N; idx += kThreads) {
-        const int n = idx % N, sl = idx / N;
-        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], z = s_pts[n * 3 + 2];
-        float acc = 0.f;
-        const int g1 = min(G, (sl + 1) * gq);
-        for (int g = sl * gq; g < g1; ++g) {
-            float cx, cy, cz;
-            gauss_centre(k, g, cx, cy, cz);
-            acc += pdf(k, (x - cx) / k.sigma, (y - cy) / k.sigma, (z - cz) / k.sigma) * k.w;
-        }
-        s_part[sl * N + n] = acc;
+    for (int e = tid; e < 3 * N * m; e += kFwdThreads) {
+        const int a = e / (N * m), n = (e / m) % N, i = e % m;
+        const float z = (p[n * 3 + a] - k.ax.c[i]) / k.sigma;
+        s_zq[e] = make_float2(z, expf(-0.5f * (z * z)));
     }
     __syncthreads();
-    for (int n = tid; n < N; n += kThreads) s_den[n] = (s_part[n] + s_part[N + n]) + (s_part[2 * N + n] + s_part[3 * N + n]);
+    for (int e = tid; e < 3 * N; e += kFwdThreads) {
+        float S = 0.f;
+        for (int i = 0; i < m; ++i) S += s_zq[e * m + i].y;
+        s_S[e] = S;
+    }
     __syncthreads();
+    for (int e = tid; e < 3 * N * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[e / m];
+    __syncthreads();
+    const float2* zqx = s_zq;
+    const float2* zqy = s_zq + N * m;
+    const float2* zqz = s_zq + 2 * N * m;
 
-    // ---- pass A.1: recompute the power-normalised statistics s[g][f] (into rec[0..19]) + channel sums ----
-    const float invN = 1.0f / (float)N;
-    float chsq[kF], chdot[kF];
-#pragma unroll
-    for (int f = 0; f < kF; ++f) { chsq[f] = 0.f; chdot[f] = 0.f; }
-    for (int g = tid; g < G; g += kThreads) {
-        float cx, cy, cz;
-        gauss_centre(k, g, cx, cy, cz);
+    const int g = wave * 32 + (lane & 31);
+    const bool live = g < G;
+    const int gg = live ? g : 0;
+    const int gi = gg / (m * m), gj = (gg / m) % m, gt = gg % m;
+    const float invN = 1.0f / (float)N, inv_dpi = 1.0f / k.dpi_den;
+    const int hpts = (N + 1) / 2;
+    const int nbeg = half * hpts, nend = min(N, (half + 1) * hpts);
+
+    // ---- P1: statistics (both half-waves end up with the merged values) ----------------------------------
+    float raw[kF];
+    {
         float pi_s = 0.f, pi_mx = -INFINITY;
         float mu_s[3] = {0.f, 0.f, 0.f}, mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
         float sg_s[3] = {0.f, 0.f, 0.f}, sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
-        for (int n = 0; n < N; ++n) {
-            const PG q = eval_pg(k, s_pts[n * 3], s_pts[n * 3 + 1], s_pts[n * 3 + 2], cx, cy, cz, s_den[n]);
-            pi_s += q.dpi;
-            pi_mx = fmaxf(pi_mx, q.dpi);
+        for (int n = nbeg; n < nend; ++n) {
+            const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+            pi_s += q.dpi; pi_mx = fmaxf(pi_mx, q.dpi);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 mu_s[d] += q.a[d]; mu_mx[d] = fmaxf(mu_mx[d], q.a[d]); mu_mn[d] = fminf(mu_mn[d], q.a[d]);
                 sg_s[d] += q.b[d]; sg_mx[d] = fmaxf(sg_mx[d], q.b[d]); sg_mn[d] = fminf(sg_mn[d], q.b[d]);
             }
         }
-        // raw selected values (before the constant scales), needed again for the tie test in pass B
-        float raw[kF], v[kF];
+        pi_s += __shfl_xor(pi_s, 32, 64);
+        pi_mx = fmaxf(pi_mx, __shfl_xor(pi_mx, 32, 64));
         raw[0] = pi_s * invN; raw[1] = pi_mx;
-        v[0] = raw[0]; v[1] = raw[1];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            raw[2 + d] = mu_s[d] * invN;  raw[5 + d] = mu_mx[d];  raw[8 + d] = mu_mn[d];
-            raw[11 + d] = sg_s[d] * invN; raw[14 + d] = sg_mx[d]; raw[17 + d] = sg_mn[d];
-            v[2 + d] = raw[2 + d] * k.mu_scale;   v[5 + d] = raw[5 + d] * k.mu_scale;   v[8 + d] = raw[8 + d] * k.mu_scale;
-            v[11 + d] = raw[11 + d] * k.sig_scale; v[14 + d] = raw[14 + d] * k.sig_scale; v[17 + d] = raw[17 + d] * k.sig_scale;
-        }
-#pragma unroll
-        for (int f = 0; f < kF; ++f) {
-            const float s = pnorm(v[f]);
-            s_rec[g * kRec + f] = s;            // temporarily: s
-            s_rec[g * kRec + kF + f] = raw[f];  // selected raw value
-            chsq[f] += s * s;
-            chdot[f] += s * df[g * kF + f];
+            mu_s[d] += __shfl_xor(mu_s[d], 32, 64);
+            sg_s[d] += __shfl_xor(sg_s[d], 32, 64);
+            raw[2 + d] = mu_s[d] * invN;
+            raw[5 + d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], 32, 64));
+            raw[8 + d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], 32, 64));
+            raw[11 + d] = sg_s[d] * invN;
+            raw[14 + d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], 32, 64));
+            raw[17 + d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], 32, 64));
         }
     }
+    // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv -------------------------------------------------
+    const float* df = dfv + ((size_t)c * G + gg) * kF;
+    float dr[kF];   // becomes the gradient w.r.t. the raw statistics
+    {
+        const bool mine = live && half == 0;
+#pragma unroll
+        for (int f = 0; f < kF; ++f) {
+            const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
+            const float sv = pnorm(raw[f] * cst);
+            const float dy = mine ? df[f] : 0.f;
+            const float a = wave_sum(mine ? sv * sv : 0.f), b = wave_sum(sv * dy);
+            if (lane == 0) { s_chred[wave * 2 * kF + f] = a; s_chred[wave * 2 * kF + kF + f] = b; }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * kF) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_chred[w * 2 * kF + tid];
+        s_ch[tid] = t;
+    }
+    __syncthreads();
+    // ---- P2: dfv -> gradient w.r.t. the raw statistics -------------------------------------------------------
 #pragma unroll
     for (int f = 0; f < kF; ++f) {
-        const float a = wave_sum(chsq[f]), b = wave_sum(chdot[f]);
-        if (lane == 0) { s_chred[wave * 2 * kF + f] = a; s_chred[wave * 2 * kF + kF + f] = b; }
-    }
-    __syncthreads();
-    if (tid < 2 * kF)
-        s_ch[tid] = (s_chred[tid] + s_chred[2 * kF + tid]) + (s_chred[4 * kF + tid] + s_chred[6 * kF + tid]);
-    __syncthreads();
-
-    // ---- pass A.2: dfv -> gradient wrt the raw per-Gaussian statistics (rec[0..19]) --------------------
-    for (int g = tid; g < G; g += kThreads) {
-#pragma unroll
-        for (int f = 0; f < kF; ++f) {
-            const float ss = s_ch[f], dot = s_ch[kF + f];
-            const float s = s_rec[g * kRec + f];
-            const float dy = df[g * kF + f];
-            float ds;
-            if (ss >= 1e-12f) {           // y = s * rsqrt(ss): ds = rs*dy - s * dot * rs^3   (tf.nn.l2_normalize)
-                const float rs = 1.0f / sqrtf(ss);
-                ds = rs * dy - s * dot * rs * rs * rs;
-            } else {                      // clamp active: y = s * 1e6
-                ds = dy * 1e6f;
-            }
-            float cst = 1.0f;
-            if (f >= 2 && f < 11) cst = k.mu_scale;
-            if (f >= 11) cst = k.sig_scale;
-            // s = sign(v) * max(|v|,1e-12)^0.5: dv = ds * 0.5/sqrt(|v|) where |v| >= 1e-12 (tf.maximum sends the
-            // gradient to |v| only when |v| >= eps; tf.sign has zero gradient)
-            const float v = s_rec[g * kRec + kF + f] * cst;   // same expression as the forward
-            float dv = 0.f;
-            if (fabsf(v) >= 1e-12f) dv = ds * 0.5f / sqrtf(fabsf(v));
-            float dr = dv * cst;
-            if (f == 0 || (f >= 2 && f < 5) || (f >= 11 && f < 14)) dr *= invN;   // mean -> every point gets 1/N
-            s_rec[g * kRec + f] = dr;
+        const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
+        const float v = raw[f] * cst;
+        const float sv = pnorm(v);
+        const float ss = s_ch[f], dot = s_ch[kF + f];
+        const float dy = live ? df[f] : 0.f;
+        float ds;
+        if (ss >= 1e-12f) {
+            const float rs = 1.0f / sqrtf(ss);
+            ds = rs * dy - sv * dot * rs * rs * rs;
+        } else {
+            ds = dy * 1e6f;                       // clamp active: y = s * rsqrt(1e-12)
         }
+        // s = sign(v) max(|v|,1e-12)^0.5: gradient reaches v only where |v| >= 1e-12 (tf.maximum), tf.sign has none
+        float dv = 0.f;
+        if (fabsf(v) >= 1e-12f) dv = ds * 0.5f / sqrtf(fabsf(v));
+        float d = dv * cst;
+        if (f == 0 || (f >= 2 && f < 5) || (f >= 11 && f < 14)) d *= invN;   // reduce_mean: 1/N to every point
+        dr[f] = live ? d : 0.f;
     }
-    __syncthreads();
-
-    // ---- pass B.0: tie counts for max/min statistics (lane <-> Gaussian) -> fold 1/count into rec ------
-    for (int g = tid; g < G; g += kThreads) {
-        float cx, cy, cz;
-        gauss_centre(k, g, cx, cy, cz);
-        int cnt[kF];
+    // ---- P1b: tie counts of the max/min statistics (tf.reduce_max/min split the gradient evenly) --------------
+    {
+        float cnt[13];
 #pragma unroll
-        for (int f = 0; f < kF; ++f) cnt[f] = 0;
-        for (int n = 0; n < N; ++n) {
-            const PG q = eval_pg(k, s_pts[n * 3], s_pts[n * 3 + 1], s_pts[n * 3 + 2], cx, cy, cz, s_den[n]);
-            cnt[1] += (q.dpi == s_rec[g * kRec + kF + 1]);
+        for (int i = 0; i < 13; ++i) cnt[i] = 0.f;
+        for (int n = nbeg; n < nend; ++n) {
+            const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+            cnt[0] += (q.dpi == raw[1]) ? 1.f : 0.f;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                cnt[5 + d] += (q.a[d] == s_rec[g * kRec + kF + 5 + d]);
-                cnt[8 + d] += (q.a[d] == s_rec[g * kRec + kF + 8 + d]);
-                cnt[14 + d] += (q.b[d] == s_rec[g * kRec + kF + 14 + d]);
-                cnt[17 + d] += (q.b[d] == s_rec[g * kRec + kF + 17 + d]);
+                cnt[1 + d] += (q.a[d] == raw[5 + d]) ? 1.f : 0.f;
+                cnt[4 + d] += (q.a[d] == raw[8 + d]) ? 1.f : 0.f;
+                cnt[7 + d] += (q.b[d] == raw[14 + d]) ? 1.f : 0.f;
+                cnt[10 + d] += (q.b[d] == raw[17 + d]) ? 1.f : 0.f;
             }
         }
         const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
-            const int f = mm[i];
-            s_rec[g * kRec + f] = s_rec[g * kRec + f] / (float)max(cnt[f], 1);
+            const float ctot = cnt[i] + __shfl_xor(cnt[i], 32, 64);
+            dr[mm[i]] = dr[mm[i]] / fmaxf(ctot, 1.f);
         }
     }
-    __syncthreads();
-
-    // ---- pass B.1: lane <-> point.  dQ_ng and direct dz_ng; accumulate sum_g dQ*Q per point -------------
-    // B.1 computes T_n = sum_g dQ_ng Q_ng; B.2 the final dz with dwp = (dQ - T_n)/den.
-    for (int idx = tid; idx < 4 * N; idx += kThreads) {
-        const int n = idx % N, sl = idx / N;
-        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], zc = s_pts[n * 3 + 2];
-        const float den = s_den[n];
-        float T = 0.f;
-        const int g1 = min(G, (sl + 1) * gq);
-        for (int g = sl * gq; g < g1; ++g) {
-            float cx, cy, cz;
-            gauss_centre(k, g, cx, cy, cz);
-            const PG q = eval_pg(k, x, y, zc, cx, cy, cz, den);
-            const float* r = s_rec + g * kRec;
-            float dQ = (r[0] + ((q.dpi == r[kF + 1]) ? r[1] : 0.f)) / k.dpi_den;
+    // ---- P3: T_n = sum_g dQ_ng Q_ng ---------------------------------------------------------------------------
+    for (int n = nbeg; n < nend; ++n) {
+        const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+        float dQ = (dr[0] + ((q.dpi == raw[1]) ? dr[1] : 0.f)) * inv_dpi;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float ga = r[2 + d] + ((q.a[d] == r[kF + 5 + d]) ? r[5 + d] : 0.f) + ((q.a[d] == r[kF + 8 + d]) ? r[8 + d] : 0.f);
-                const float gb = r[11 + d] + ((q.b[d] == r[kF + 14 + d]) ? r[14 + d] : 0.f) + ((q.b[d] == r[kF + 17 + d]) ? r[17 + d] : 0.f);
-                dQ += ga * q.z[d] + gb * (q.z[d] * q.z[d] - 1.0f);
-            }
-            T += dQ * q.Q;
+        for (int d = 0; d < 3; ++d) {
+            const float ga = dr[2 + d] + ((q.a[d] == raw[5 + d]) ? dr[5 + d] : 0.f) + ((q.a[d] == raw[8 + d]) ? dr[8 + d] : 0.f);
+            const float gb = dr[11 + d] + ((q.b[d] == raw[14 + d]) ? dr[14 + d] : 0.f) + ((q.b[d] == raw[17 + d]) ? dr[17 + d] : 0.f);
+            dQ += ga * q.z[d] + gb * (q.z[d] * q.z[d] - 1.0f);
         }
-        s_part[sl * N + n] = T;
+        const float t = half_sum32(live ? dQ * q.Q : 0.f);
+        if ((lane & 31) == 0) s_part[wave * N + n] = t;
     }
     __syncthreads();
-    for (int idx = tid; idx < 4 * N; idx += kThreads) {
-        const int n = idx % N, sl = idx / N;
-        const float x = s_pts[n * 3], y = s_pts[n * 3 + 1], zc = s_pts[n * 3 + 2];
-        const float den = s_den[n];
-        const float T = (s_part[n] + s_part[N + n]) + (s_part[2 * N + n] + s_part[3 * N + n]);
-        float dz[3] = {0.f, 0.f, 0.f};
-        const int g1 = min(G, (sl + 1) * gq);
-        for (int g = sl * gq; g < g1; ++g) {
-            float cx, cy, cz;
-            gauss_centre(k, g, cx, cy, cz);
-            const PG q = eval_pg(k, x, y, zc, cx, cy, cz, den);
-            const float* r = s_rec + g * kRec;
-            const float pw = q.pw, Q = q.Q;
-            const float* z = q.z;
-            float dQ = (r[0] + ((q.dpi == r[kF + 1]) ? r[1] : 0.f)) / k.dpi_den;
-            float ga[3], gb[3];
+    for (int n = tid; n < N; n += kFwdThreads) {
+        float t = 0.f;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                ga[d] = r[2 + d] + ((q.a[d] == r[kF + 5 + d]) ? r[5 + d] : 0.f) + ((q.a[d] == r[kF + 8 + d]) ? r[8 + d] : 0.f);
-                gb[d] = r[11 + d] + ((q.b[d] == r[kF + 14 + d]) ? r[14 + d] : 0.f) + ((q.b[d] == r[kF + 17 + d]) ? r[17 + d] : 0.f);
-                dQ += ga[d] * z[d] + gb[d] * (z[d] * z[d] - 1.0f);
-            }
-            // Q = wp/den, den = sum wp  ->  d wp_ng = (dQ_ng - T_n) / den ;  wp = w*exp(-0.5|z|^2 - c)  ->  dz += -z * wp * dwp
-            const float dwp = (dQ - T) / den;
+        for (int w = 0; w < 16; ++w) t += s_part[w * N + n];
+        s_T[n] = t;
+    }
+    __syncthreads();
+    // ---- P4: dz_ngd = Q (ga + 2 gb z) - z Q (dQ - T_n), summed over the Gaussians ------------------------------
+    for (int n = nbeg; n < nend; ++n) {
+        const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+        float dQ = (dr[0] + ((q.dpi == raw[1]) ? dr[1] : 0.f)) * inv_dpi;
+        float ga[3], gb[3];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) dz[d] += Q * (ga[d] + 2.0f * gb[d] * z[d]) - z[d] * pw * dwp;
+        for (int d = 0; d < 3; ++d) {
+            ga[d] = dr[2 + d] + ((q.a[d] == raw[5 + d]) ? dr[5 + d] : 0.f) + ((q.a[d] == raw[8 + d]) ? dr[8 + d] : 0.f);
+            gb[d] = dr[11 + d] + ((q.b[d] == raw[14 + d]) ? dr[14 + d] : 0.f) + ((q.b[d] == raw[17 + d]) ? dr[17 + d] : 0.f);
+            dQ += ga[d] * q.z[d] + gb[d] * (q.z[d] * q.z[d] - 1.0f);
         }
+        const float u = dQ - s_T[n];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) s_acc[(sl * N + n) * 3 + d] = dz[d];
+        for (int d = 0; d < 3; ++d) {
+            const float dz = live ? q.Q * (ga[d] + 2.0f * gb[d] * q.z[d]) - q.z[d] * q.Q * u : 0.f;
+            const float t = half_sum32(dz);
+            if ((lane & 31) == 0) s_part[(wave * N + n) * 3 + d] = t;
+        }
     }
     __syncthreads();
     float* out = dpts + (size_t)c * N * 3;
-    for (int i = tid; i < N * 3; i += kThreads) {
-        const float s = (s_acc[i] + s_acc[N * 3 + i]) + (s_acc[2 * N * 3 + i] + s_acc[3 * N * 3 + i]);
-        out[i] = s / k.sigma;   // z = (x - mu)/sigma
+    for (int i = tid; i < N * 3; i += kFwdThreads) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_part[w * N * 3 + i];
+        out[i] = t / k.sigma;   // z = (x - mu)/sigma
     }
 }
 
-static size_t bwd_lds_bytes(int N, int G) {
-    return (size_t)(((N * 3 + 3) & ~3) + N + 4 * N + G * kRec + 8 * kF + 2 * kF + 4 * N * 3 + 4) * sizeof(float);
+static size_t bwd_lds_bytes(int N, int m) {
+    return (size_t)(6 * N * m + 3 * N + 16 * 2 * kF + 2 * kF + N + 16 * N * 3 + 4) * sizeof(float);
 }
 
 template <typename K>
@@ -519,9 +494,10 @@ extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, i
     if (C <= 0) return DPD_E_DIM;
     MfvConst k{};
     if (int rc = make_const(N, m, sigma, k)) return rc;
-    const size_t lds = bwd_lds_bytes(N, k.G);
+    if (k.G > 512) return DPD_E_UNSUPPORTED;   // per-Gaussian gradient record lives in registers: one Gaussian per lane pair
+    const size_t lds = bwd_lds_bytes(N, m);
     if (int rc = set_lds(mfv3d_bwd_kernel, lds)) return rc;
-    DPD_LAUNCH(mfv3d_bwd_kernel, dim3(C), dim3(kThreads), lds, (hipStream_t)stream, pts, dfv, dpts, k);
+    DPD_LAUNCH(mfv3d_bwd_kernel, dim3(C), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, dfv, dpts, k);
     DPD_CHECK_LAUNCH();
     return 0;
 }

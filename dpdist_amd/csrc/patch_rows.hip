@@ -64,23 +64,26 @@ __global__ __launch_bounds__(128) void patch_rows_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void patch_rows_bwd_kernel(const float* __restrict__ dX, const int32_t* __restrict__ vox,
                                                               float* __restrict__ dfv, int N, int m, int k, int KP,
                                                               int slices) {
-    extern __shared__ int s_vox[];   // [N] voxel ids of the cloud's queries
+    extern __shared__ int s_vox[];   // [N] voxel coordinates of the cloud's queries, packed (a0 | a1<<8 | a2<<16)
     const int c = blockIdx.x / slices, sl = blockIdx.x % slices, tid = threadIdx.x;
     const int G = m * m * m, h = (k - 1) / 2;
-    for (int n = tid; n < N; n += 256) s_vox[n] = vox[(size_t)c * N + n];
+    for (int n = tid; n < N; n += 256) {
+        const int v = vox[(size_t)c * N + n];
+        s_vox[n] = (v / (m * m)) | (((v / m) % m) << 8) | ((v % m) << 16);
+    }
     __syncthreads();
     const int gper = (G + slices - 1) / slices;
     const int gbeg = sl * gper, gend = min(G, gbeg + gper);
+    const float* dXc = dX + (size_t)c * N * KP;
     for (int item = tid; item < (gend - gbeg) * 5; item += 256) {
         const int g = gbeg + item / 5, part = item % 5;
-        const int g0 = g / (m * m), g1 = (g / m) % m, g2 = g % m;
+        const int g0 = g / (m * m) + h, g1 = (g / m) % m + h, g2 = g % m + h;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int n = 0; n < N; ++n) {
-            const int v = s_vox[n];
-            const int d0 = g0 - v / (m * m) + h, d1 = g1 - (v / m) % m + h, d2 = g2 - v % m + h;
+            const int pv = s_vox[n];
+            const int d0 = g0 - (pv & 255), d1 = g1 - ((pv >> 8) & 255), d2 = g2 - (pv >> 16);
             if ((unsigned)d0 < (unsigned)k && (unsigned)d1 < (unsigned)k && (unsigned)d2 < (unsigned)k) {
-                const int nb = (d0 * k + d1) * k + d2;
-                const float4 x = *reinterpret_cast<const float4*>(dX + ((size_t)c * N + n) * KP + nb * kF + part * 4);
+                const float4 x = *reinterpret_cast<const float4*>(dXc + (size_t)n * KP + ((d0 * k + d1) * k + d2) * kF + part * 4);
                 acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
             }
         }
@@ -142,7 +145,7 @@ extern "C" int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, in
     if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1) || N > 8192) return DPD_E_UNSUPPORTED;
     if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
     if (dfv) {
-        const int slices = 4;
+        const int slices = 8;
         DPD_LAUNCH(patch_rows_bwd_kernel, dim3(C * slices), dim3(256), (size_t)N * sizeof(int), (hipStream_t)stream,
                            dX, vox, dfv, N, m, k, KP, slices);
         DPD_CHECK_LAUNCH();

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""DPDist as a frozen loss (pcrnet-registration/iterative_PCRNet_ours.py:229-257): forward both directions + backward to
+the INPUT clouds (decoder dX chain on all 2*B*N rows, window scatter, encoder backward).  GPU only.
+
+    python tools/asloss_bench.py [--batch 16] [--steps 50]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from dpdist_amd import synth  # noqa: E402
+from dpdist_amd.model import DPDistLoss, DPDistModel  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)     # run_train_and_eval_PCRNet.bash:18,72
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    model = DPDistModel(device=dev)
+    model.load_tf_state_dict(synth.make_weights("wide"))
+    loss_fn = DPDistLoss(model)
+    pcA, pcB, _ = synth.s2_modelnet_shaped(a.batch, 64, 100)
+    src = torch.tensor(pcA, device=dev, requires_grad=True)
+    tmpl = torch.tensor(pcB, device=dev)
+
+    def step():
+        src.grad = None
+        loss = loss_fn(src, tmpl)
+        loss.backward()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        l = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"mode": "as-loss (fwd + bwd to inputs)", "batch": a.batch, "ms_per_step": round(el / a.steps * 1e3, 4),
+                      "query_points_per_sec": round(2 * a.batch * 64 * a.steps / el, 1), "loss_pred": round(float(l), 6),
+                      "grad_norm": round(float(src.grad.norm()), 6)}))
+
+
+if __name__ == "__main__":
+    main()
