@@ -427,7 +427,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     }
     __builtin_amdgcn_s_barrier();
 
-    float fa[2][TM][4], fb[2][TN][4];
+    constexpr bool DEEP = (ABL & 512) == 0;   // 4-deep fragment ring, operands requested TWO k-blocks ahead (ABL 512: one ahead)
+    float fa[DEEP ? 4 : 2][TM][4], fb[DEEP ? 4 : 2][TN][4];
     auto frags = [&](const float* stA, int kb, int buf) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) load_frag<AK, BM>(stA, wm0 + 32 * i, l31, half, kb, fa[buf][i]);
@@ -435,13 +436,26 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) load_frag<BKC, BN>(stA + A_IMG, wn0 + 32 * j, l31, half, kb, fb[buf][j]);
     };
     frags(smem, 0, 0);
+    if (DEEP) frags(smem, 1, 1);
 
     for (int it = 0; it < nt; ++it) {
         const float* sA = smem + (it % NS) * STAGE;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const int c = kb & 1, n = c ^ 1;
-            if (kb < 3) {
+            const int c = DEEP ? kb : (kb & 1), n = DEEP ? ((kb + 2) & 3) : (c ^ 1);
+            if (DEEP) {
+                // k-blocks 0,1 request k-blocks 2,3 of this tile; k-blocks 2,3 request 0,1 of the next tile (after
+                // this tile's barrier, which certifies that tile)
+                if (kb < 2) frags(sA, kb + 2, n);
+            } else if (ABL & 256) {           // timing-only ablation: no LDS fragment reads in the loop (stale operands)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[n][i][s2] = fa[c][i][s2];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[n][j][s2] = fb[c][j][s2];
+                }
+            } else if (kb < 3) {
                 frags(sA, kb + 1, n);
             } else if (it + 1 < nt) {   // first fragments of the next K-tile (certified landed at this tile's barrier)
                 frags(smem + ((it + 1) % NS) * STAGE, 0, n);
@@ -469,6 +483,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
             // refill of the stage freed by that barrier with K-tile it+NS-1 (issuing it later / staggered over the
             // following k-blocks was measured 7 % slower: the data then has less time to land)
             if (kb == 2 && !(ABL & 1) && it + NS - 1 < nt) issue((it + NS - 1) % NS);
+            if (DEEP && kb >= 2 && it + 1 < nt) frags(smem + ((it + 1) % NS) * STAGE, kb - 2, n);
             // MFMA issue is arbitrated by priority, then age.  With equal priorities the oldest wave of a SIMD runs its
             // whole barrier interval first and the youngest runs last and ALONE, with nobody to cover its LDS/barrier
             // stalls.  Priority falls as a wave advances through the interval (k-blocks 2,3,0,1 -> 3,2,1,0), so laggards
@@ -578,6 +593,12 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 19: return launch_dma<4, 4, 3, AK, BKC, 64>(g, s);    // 9 / 10 / 5 without the progress-based s_setprio
         case 20: return launch_dma<4, 4, 5, AK, BKC, 64>(g, s);
         case 15: return launch_dma<4, 4, 4, AK, BKC, 64>(g, s);
+        case 5129: return launch_dma<4, 4, 3, AK, BKC, 512>(g, s);   // fragments only ONE k-block ahead (A/B reference)
+        case 5125: return launch_dma<4, 4, 4, AK, BKC, 512>(g, s);
+        case 5128: return launch_dma<2, 2, 3, AK, BKC, 512>(g, s);
+        case 2569: return launch_dma<4, 4, 3, AK, BKC, 256>(g, s);   // no LDS reads in the loop
+        case 2579: return launch_dma<4, 4, 3, AK, BKC, 257>(g, s);   // + no in-loop DMA
+        case 2589: return launch_dma<4, 4, 3, AK, BKC, 258>(g, s);   // no LDS reads, no barrier
         case 325: return launch_dma<4, 4, 4, AK, BKC, 32>(g, s);   // s_memtime instrumentation (debug buffer in colsum)
         case 165: return launch_dma<4, 4, 4, AK, BKC, 16>(g, s);   // data path only (no MFMA): L2 -> LDS -> VGPR rate
         case 164: return launch_dma<2, 2, 4, AK, BKC, 16>(g, s);
@@ -630,7 +651,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         (void)tile_eff;
         tile = 3;
     }
-    if (tile >= 4 && tile <= 20 && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
+    if (((tile >= 4 && tile <= 20) || tile > 2000) && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
         tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
