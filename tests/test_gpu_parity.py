@@ -362,3 +362,87 @@ def test_error_behaviour(dev):
         ops.mfv3d_fwd(torch.zeros(1, 3, 64, device=dev).transpose(1, 2), 8, 0.125)
     with pytest.raises(RuntimeError):
         ops.patch_rows_fwd(torch.zeros(1, 64, 3, device=dev), torch.zeros(1, 512, 20, device=dev), 8, 4)
+
+
+# ------------------------------------------------------------------------------------------------ shapes / edge cases
+def _oracle_forward(pcA, pcB, W, m=8, k=5, noise=None):
+    from oracle import restate as R
+    n = None if noise is None else torch.tensor(noise)
+    ref, _ = R.get_model(torch.tensor(pcA), torch.tensor(pcB), R.as_torch_weights(W), add_noise=n, m=m, k=k)
+    return ref
+
+
+def test_config1_single_pair_forward(dev):
+    """BASELINE config 1: one 'chair-like' pair, B=1, forward only."""
+    pcA, pcB, _ = synth.s2_modelnet_shaped(1, 64, 100)
+    W = synth.make_weights("wide")
+    mod = _model(dev, "wide")
+    with torch.no_grad():
+        ps = mod(_cu(pcA, dev), _cu(pcB, dev))
+    ref = _oracle_forward(pcA, pcB, W)
+    for n in ("pred_listAB", "pred_listBA"):
+        assert ps[n].shape == (1, 64, 1, 3)
+        _check_pred(ps[n].cpu().numpy(), ref[n].numpy(), True)
+
+
+@pytest.mark.parametrize("N", [32, 100, 200])
+def test_ragged_point_counts(dev, N):
+    """num_point other than 64 (not a multiple of the wavefront): every kernel is shape generic."""
+    rng = np.random.default_rng(N)
+    pcA = rng.uniform(-0.9, 0.9, (3, N, 3)).astype(np.float32)
+    pcB = rng.uniform(-1.1, 1.1, (3, N, 3)).astype(np.float32)          # some queries outside the cube
+    noise = (rng.standard_normal((3, N, 3)) * 0.01).astype(np.float32)
+    W = synth.make_weights("wide")
+    mod = _model(dev, "wide")
+    with torch.no_grad():
+        ps = mod(_cu(pcA, dev), _cu(pcB, dev), add_noise=_cu(noise, dev))
+    ref = _oracle_forward(pcA, pcB, W, noise=noise)
+    for n in ("pred_listAB", "pred_listBA"):
+        _check_pred(ps[n].cpu().numpy(), ref[n].numpy(), True)
+
+
+def test_window_k3(dev):
+    """K=3 window (27*20+3 = 543 inputs, KP = 544)."""
+    from dpdist_amd.model import DPDistModel
+    pcA, pcB = synth.s1_random_patches(4, 64, 3)
+    W = synth.make_weights("wide", E_plus_D=543, mlp=(128, 128, 128))
+    mod = DPDistModel(Embedding_Size=512, k=3, localSNmlp=(128, 128, 128), device=dev)
+    mod.load_tf_state_dict(W)
+    assert mod.params_.KP == 544
+    with torch.no_grad():
+        ps = mod(_cu(pcA, dev), _cu(pcB, dev))
+    ref = _oracle_forward(pcA, pcB, W, k=3)
+    for n in ("pred_listAB", "pred_listBA"):
+        _check_pred(ps[n].cpu().numpy(), ref[n].numpy(), True)
+
+
+def test_large_batch_properties(dev):
+    """B=256 (Q = 32768 rows, 4x the bench size): finite, masked rows exactly zero, range [0,2], AB/BA symmetry under
+    swapping the clouds."""
+    pcA, pcB, _ = synth.s2_modelnet_shaped(256, 64, 7)
+    pcB[:, 3] = -1.0                                     # q = -1 sits on the open face: masked out
+    mod = _model(dev, "wide")
+    with torch.no_grad():
+        a = mod(_cu(pcA, dev), _cu(pcB, dev))
+        b = mod(_cu(pcB, dev), _cu(pcA, dev))
+    for n in ("pred_listAB", "pred_listBA"):
+        assert torch.isfinite(a[n]).all() and a[n].min().item() >= 0.0 and a[n].max().item() <= 2.0
+    assert a["pred_listAB"][:, 3].abs().max().item() == 0.0
+    assert torch.equal(a["pred_listAB"], b["pred_listBA"]) and torch.equal(a["pred_listBA"], b["pred_listAB"])
+
+
+def test_two_streams_are_independent(dev):
+    """The library is stream ordered and re-entrant: two streams with different inputs give the single-stream results."""
+    mod = _model(dev, "wide")
+    A1, B1 = (_cu(x, dev) for x in synth.s1_random_patches(8, 64, 1))
+    A2, B2 = (_cu(x, dev) for x in synth.s1_random_patches(8, 64, 2))
+    with torch.no_grad():
+        r1, r2 = mod(A1, B1), mod(A2, B2)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s1):
+            p1 = mod(A1, B1)
+        with torch.cuda.stream(s2):
+            p2 = mod(A2, B2)
+        torch.cuda.synchronize()
+    assert torch.equal(p1["pred_listAB"], r1["pred_listAB"]) and torch.equal(p2["pred_listBA"], r2["pred_listBA"])
