@@ -13,7 +13,8 @@ namespace dpd {
 
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
-             size_t ws_bytes, hipStream_t s, float* colsum = nullptr);
+             size_t ws_bytes, hipStream_t s, float* colsum = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
+             float* C2 = nullptr);
 
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
@@ -418,4 +419,18 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     DPD_LAUNCH(colsum_stage2, dim3((Nout + 255) / 256), dim3(256), 0, s, (const float*)part, Nout, db);
     DPD_CHECK_LAUNCH();
     return 0;
+}
+
+// dW of layers 2 and 3 in ONE grouped launch (identical shapes [H,H] = act^T g): 2 x 256 tiles fill the chip twice
+// as well as two 256-tile launches and pay one prologue/epilogue instead of two.
+extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
+                                            float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* stream) {
+    using namespace dpd;
+    if (!actA || !gA || !dWA || !actB || !gB || !dWB) return DPD_E_NULL;
+    if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
+    if (dtype != 0 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
+    int tile = g_plan_tile[OP_BWD_DW23];
+    if (tile < 4 || tile > 20) tile = 8;
+    return gemm_f32(1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, 1, tile, nullptr, 0,
+                    (hipStream_t)stream, nullptr, actB, gB, dWB);
 }

@@ -30,6 +30,9 @@ struct GemmArgs {
     const float* bias;
     const float* gate;
     float* colsum;    // optional [N]: += column sums of the stored values (atomics; caller zeroes it)
+    const float* A2;  // optional second problem of identical shape (grouped launch): blocks [per_z, 2*per_z)
+    const float* B2;
+    float* C2;
     int M, N, K;
     int lda, ldb, ldc;
     int epi;
@@ -356,12 +359,17 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
 
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int per_z = tilesM * tilesN;
-    const int sid = xcd_remap(blockIdx.x, per_z * g.split_k);
-    const int z = sid / per_z, t = sid % per_z;
+    const int ngrp = g.A2 ? 2 : 1;
+    const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
+    const int grp = sid / (per_z * g.split_k);            // grouped launch: second problem of identical shape
+    const int sid1 = sid % (per_z * g.split_k);
+    const int z = sid1 / per_z, t = sid1 % per_z;
     const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
     const int kbeg = z * g.k_chunk;
     const int kend = min(g.K, kbeg + g.k_chunk);
     const int nt = (kend - kbeg) / BK;
+    const float* gA = grp ? g.A2 : g.A;
+    const float* gB = grp ? g.B2 : g.B;
 
     // this wave's DMA pieces: piece p = wave + j*NW; p < PA -> A piece p, else B piece p-PA
     const float* src[PPW];
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         const bool isA = p < PA;
         const int c = isA ? p : p - PA;
         const bool kc = isA ? AK : BKC;
-        const float* base = isA ? g.A : g.B;
+        const float* base = isA ? gA : gB;
         const int ld = isA ? g.lda : g.ldb;
         const int mn0 = isA ? m0 : n0;
         const int MN = isA ? g.M : g.N;
@@ -520,10 +528,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         d[3] = (float)nt;
         return;
     }
+    GemmArgs gs = g;
+    if (grp) gs.C = g.C2;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) store_tile(g, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
+        for (int j = 0; j < TN; ++j) store_tile(gs, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
 }
 
 template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, int TM = 1, int TN = 1>
@@ -539,7 +549,7 @@ static int launch_dma(const GemmArgs& g, hipStream_t s) {
             done = true;
         }
     }
-    const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.split_k;
+    const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.split_k * (g.A2 ? 2 : 1);
     DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
     return (int)hipGetLastError();
 }
@@ -633,7 +643,7 @@ static double tile_eff(int M, int N, int BM, int BN, int split) {
 
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
-             size_t ws_bytes, hipStream_t s, float* colsum) {
+             size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2) {
     if (!A || !B || !C) return DPD_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || split_k < 1) return DPD_E_DIM;
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3)) return DPD_E_UNSUPPORTED;
@@ -656,6 +666,9 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.colsum = (split_k > 1) ? nullptr : colsum;
+    g.A2 = A2; g.B2 = B2; g.C2 = C2;
+    if (A2 && (!B2 || !C2 || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
+    if (A2 && !(tile >= 4 && tile <= 20)) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA kernels only
     if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.split_k = split_k;
@@ -726,12 +739,13 @@ extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
 
 extern "C" int dpd_gemm_f32_dbg(int M, int N, int K, const float* A, const float* B, float* Cout, float* dbg, int tile,
                                 void* stream) {
-    return dpd::gemm_f32(0, 0, M, N, K, A, K, B, N, Cout, N, nullptr, nullptr, 0, 1, tile, nullptr, 0, (hipStream_t)stream, dbg);
+    return dpd::gemm_f32(0, 0, M, N, K, A, K, B, N, Cout, N, nullptr, nullptr, 0, 1, tile, nullptr, 0, (hipStream_t)stream, dbg,
+                         nullptr, nullptr, nullptr);
 }
 
 extern "C" int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* Cout, int ldc, const float* bias, const float* gate, int epilogue,
                             int split_k, int tile, void* ws, size_t ws_bytes, void* stream) {
     return dpd::gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, Cout, ldc, bias, gate, epilogue, split_k, tile, ws,
-                         ws_bytes, (hipStream_t)stream, nullptr);
+                         ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
 }

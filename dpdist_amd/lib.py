@@ -41,6 +41,7 @@ SIGNATURES = {
     "dpd_stack_clouds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpd_l1_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "dpd_adam_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,

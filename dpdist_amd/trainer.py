@@ -95,8 +95,13 @@ class DPDistTrainer:
         dw(1, self.X, self.g1, d[0])
         if self.reducer:
             self.reducer.reduce_async(0)      # bucket 0 = dW1p + db1 (db1 was finished by the data chain)
-        dw(2, self.h1, self.g2, d[2])
-        dw(3, self.h2, self.g3, d[4])
+        if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
+            L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
+                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, 0, L.cur_stream()),
+                    "dpd_decoder_bwd_weights_pair")
+        else:
+            dw(2, self.h1, self.g2, d[2])
+            dw(3, self.h2, self.g3, d[4])
         if self.reducer:
             self.reducer.reduce_async(1)
 

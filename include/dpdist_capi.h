@@ -119,6 +119,11 @@ int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, 
 int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
                             int dtype, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
 
+/* dW of two layers of identical shape (layers 2 and 3: dW = act^T g, [Kin,Nout]) in ONE grouped launch; no bias
+ * gradients (they come from dpd_decoder_bwd_data).  Qb must be a multiple of 32.                          */
+int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
+                                 float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* stream);
+
 /* Scratch needed by dpd_decoder_bwd_weights / dpd_gemm_f32 (split-K slabs) for the given sizes. */
 size_t dpd_workspace_bytes(int Q, int KP, int H);
 
