@@ -16,6 +16,12 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
              size_t ws_bytes, hipStream_t s, float* colsum = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
              float* C2 = nullptr);
 
+int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
+            int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
+            hipStream_t s, float* colsum);
+int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
+                 long r8_plane, hipStream_t s);
+
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
 enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 = 4, OP_BWD_DW23 = 5, OP_COUNT = 6 };
@@ -27,6 +33,46 @@ enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 =
 //  gemm_f32 falls back to the register-staged 64x64 kernel otherwise.)
 static int g_plan_tile[OP_COUNT] = {9, 9, 8, 8, 8, 8};
 static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 2, 1};
+
+// Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
+//   0  exact fp32 on the fp32 MFMA (gemm_f32.hip)
+//   1  fp32-equivalent on the bf16 MFMA: operands split into 3 bf16 planes, 6 MFMA terms (gemm_x3.hip)
+//   2  bf16 operands, fp32 accumulation and fp32 outputs (mixed-precision training, BASELINE config 3)
+// For 1 and 2 each GEMM first writes the planes of its two operands into `scr` (unfused producers).
+struct Scratch {
+    char* p;
+    size_t bytes;
+};
+static size_t plane_bytes(int dtype, int Q, int KP, int H) {
+    if (dtype == 0) return 0;
+    const size_t np = dtype == 1 ? 3 : 1;
+    const size_t big = (size_t)(KP > H ? KP : H);
+    return np * 2 * ((size_t)Q * big + big * H) + 256;
+}
+
+static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                   int ldb, float* C, int ldc, const float* bias, const float* gate, int epilogue, void* ws, size_t ws_bytes,
+                   Scratch scr, hipStream_t s, float* colsum = nullptr) {
+    const int ra = transA ? K : M, ca = transA ? M : K;   // stored shape of A, B
+    const int rb = transB ? N : K, cb = transB ? K : N;
+    const bool planes_ok = dtype != 0 && !(K % 32) && !(ra & 7) && !(ca & 7) && !(rb & 7) && !(cb & 7) && !(transA && transB);
+    if (!planes_ok) {   // exact fp32 (also for shapes the plane kernels do not take)
+        const int split = (dtype == 0) ? g_plan_split[op] : 1;
+        return gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, gate, epilogue, colsum ? 1 : split,
+                        g_plan_tile[op], ws, ws_bytes, s, colsum);
+    }
+    const int np = dtype == 1 ? 3 : 1;
+    const size_t ae = (size_t)M * K, be = (size_t)K * N;
+    if (!scr.p || scr.bytes < (size_t)np * 2 * (ae + be)) return DPD_E_WORKSPACE;
+    uint16_t* Ap = (uint16_t*)scr.p;
+    uint16_t* Bp = Ap + (size_t)np * ae;
+    if (int rc = split_planes(A, ra, ca, lda, np, transA ? nullptr : Ap, ca, (long)ae, transA ? Ap : nullptr, (long)ae, s)) return rc;
+    if (int rc = split_planes(B, rb, cb, ldb, np, transB ? Bp : nullptr, cb, (long)be, transB ? nullptr : Bp, (long)be, s)) return rc;
+    // largest tile that still gives the 256 CUs at least ~200 workgroups
+    auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    const int tile = blocks(128, 128) >= 200 ? 2 : (blocks(64, 128) >= 200 ? 3 : 5);
+    return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum);
+}
 
 // ---- output layer: y = h3 W4 + b4 ; pred = clip(y,0,6)/3 * mask.  One wave per row. ----------------------
 __global__ __launch_bounds__(256) void out_fwd_kernel(const float* __restrict__ h3, const float* __restrict__ W4,
@@ -308,26 +354,37 @@ extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
     return 0;
 }
 
-extern "C" size_t dpd_workspace_bytes(int Q, int KP, int H) {
-    (void)Q;
+static size_t base_ws_bytes(int KP, int H) {
     const size_t slabs = (size_t)8 * (size_t)(KP > H ? KP : H) * H * sizeof(float);   // split-K <= 8 of the largest dW
     const size_t cols = dpd::colsum_ws_floats(H, 3) * sizeof(float);
-    return slabs + cols + 256;
+    return (slabs + cols + 255) / 256 * 256;
+}
+// plane scratch = the tail of the workspace
+static dpd::Scratch scratch_of(void* ws, size_t ws_bytes, int KP, int H) {
+    const size_t base = base_ws_bytes(KP, H);
+    if (!ws || ws_bytes <= base) return dpd::Scratch{nullptr, 0};
+    return dpd::Scratch{(char*)ws + base, ws_bytes - base};
+}
+
+extern "C" size_t dpd_workspace_bytes(int Q, int KP, int H, int dtype) {
+    return base_ws_bytes(KP, H) + dpd::plane_bytes(dtype, Q, KP, H);
 }
 
 extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
-                               int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* stream) {
+                               int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
+                               void* stream) {
     using namespace dpd;
     if (!X || !mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
     if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
     if (Q <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
-    if ((H & 63) || (KP & 3) || dtype != 0) return DPD_E_UNSUPPORTED;
+    if ((H & 63) || (KP & 3) || dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    const Scratch scr = scratch_of(ws, ws_bytes, KP, H);
+    if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
     // layer 1..3: h = relu(in W + b)   (tf_util.conv2d: conv2d + bias_add + relu, utils/tf_util.py:213-227)
-    if (int rc = gemm_f32(0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, 1, g_plan_tile[OP_FWD_L1],
-                          nullptr, 0, s)) return rc;
-    if (int rc = gemm_f32(0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, 1, g_plan_tile[OP_FWD_L23], nullptr, 0, s)) return rc;
-    if (int rc = gemm_f32(0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, 1, g_plan_tile[OP_FWD_L23], nullptr, 0, s)) return rc;
+    if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
+    if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
+    if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
     DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
     DPD_CHECK_LAUNCH();
     return 0;
@@ -336,13 +393,15 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
 extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1,
                                     const float* h2, const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p,
                                     int dtype, float* dy, float* g3, float* g2, float* g1, float* dX,
-                                    const dpd_small_grads* sg, void* stream) {
+                                    const dpd_small_grads* sg, void* ws, size_t ws_bytes, void* stream) {
     using namespace dpd;
     if (!dpred || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
-    if ((H & 63) || (KP & 3) || dtype != 0) return DPD_E_UNSUPPORTED;
+    if ((H & 63) || (KP & 3) || dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    const Scratch scr = scratch_of(ws, ws_bytes, KP, H);
+    if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
     float* db1 = sg ? sg->db1 : nullptr;
     float* db2 = sg ? sg->db2 : nullptr;
     float* db3 = sg ? sg->db3 : nullptr;
@@ -374,10 +433,10 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         }
     }
     // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0];  db2 / db1 = column sums, fused into the epilogue
-    if (int rc = gemm_f32(0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s, db2)) return rc;
-    if (int rc = gemm_f32(0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, 1, g_plan_tile[OP_BWD_DH], nullptr, 0, s, db1)) return rc;
+    if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2)) return rc;
+    if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1)) return rc;
     if (dX) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
-        if (int rc = gemm_f32(0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, 1, g_plan_tile[OP_BWD_DX], nullptr, 0, s)) return rc;
+        if (int rc = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s)) return rc;
     }
     return 0;
 }
@@ -388,7 +447,7 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     if (!act || !g || !dW) return DPD_E_NULL;
     if (layer == 4 && !db) return DPD_E_NULL;
     if (layer < 1 || layer > 4 || Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
-    if (dtype != 0) return DPD_E_UNSUPPORTED;
+    if (dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (layer == 4) {
         if (Nout != 3) return DPD_E_DIM;
@@ -404,13 +463,15 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     }
     if ((Nout & 3) || (Kin & 3) || (lda & 3)) return DPD_E_UNSUPPORTED;
     const int op = (layer == 1) ? OP_BWD_DW1 : OP_BWD_DW23;
-    const int split = g_plan_split[op];
+    const int split = dtype == 0 ? g_plan_split[op] : 1;
     const size_t slab_bytes = (split > 1) ? (size_t)split * Kin * Nout * sizeof(float) : 0;
     const size_t col_bytes = db ? colsum_ws_floats(Nout, 0) * sizeof(float) : 0;
     if ((slab_bytes + col_bytes) && (!ws || ws_bytes < slab_bytes + col_bytes)) return DPD_E_WORKSPACE;
+    const Scratch scr = scratch_of(ws, ws_bytes, Kin > Nout ? Kin : Nout, Nout);
+    if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
     // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout]
-    if (int rc = gemm_f32(1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, split, g_plan_tile[op], ws,
-                          slab_bytes, s)) return rc;
+    if (int rc = gemm_dt(dtype, op, 1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, ws, slab_bytes, scr, s))
+        return rc;
     if (!db) return 0;   // bias gradient already produced by dpd_decoder_bwd_data (fused)
     float* part = (float*)((char*)ws + slab_bytes);
     DPD_LAUNCH(colsum_stage1<0>, dim3((Nout + 63) / 64, kColChunks), dim3(256), 0, s, g, Nout, (const float*)nullptr,
@@ -424,11 +485,20 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
 // dW of layers 2 and 3 in ONE grouped launch (identical shapes [H,H] = act^T g): 2 x 256 tiles fill the chip twice
 // as well as two 256-tile launches and pay one prologue/epilogue instead of two.
 extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
-                                            float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* stream) {
+                                            float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws,
+                                            size_t ws_bytes, void* stream) {
     using namespace dpd;
     if (!actA || !gA || !dWA || !actB || !gB || !dWB) return DPD_E_NULL;
     if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
-    if (dtype != 0 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
+    if (dtype < 0 || dtype > 2 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
+    if (dtype != 0) {   // plane path: two launches (the planes of one GEMM at a time live in the scratch)
+        const Scratch scr = scratch_of(ws, ws_bytes, Kin > Nout ? Kin : Nout, Nout);
+        if (!scr.p) return DPD_E_WORKSPACE;
+        if (int rc = gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, nullptr, 0,
+                             scr, (hipStream_t)stream)) return rc;
+        return gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actB, lda, gB, Nout, dWB, Nout, nullptr, nullptr, 0, nullptr, 0, scr,
+                       (hipStream_t)stream);
+    }
     int tile = g_plan_tile[OP_BWD_DW23];
     if (tile < 4 || tile > 20) tile = 8;
     return gemm_f32(1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, 1, tile, nullptr, 0,

@@ -15,31 +15,9 @@
 //   * optional split-K into fp32 slabs + a fused reduce/epilogue kernel (deterministic, no atomics).
 //
 // Roofline: MFMA-bound.  Algorithmic flops = 2*M*N*K; bytes/flop of a 128x128 tile = 1/32 -> 8 B/clk/CU from L2.
-#include "common.h"
+#include "gemm_shared.h"
 
 namespace dpd {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_GATE = 3 };
-
-struct GemmArgs {
-    const float* A;
-    const float* B;
-    float* C;
-    const float* bias;
-    const float* gate;
-    float* colsum;    // optional [N]: += column sums of the stored values (atomics; caller zeroes it)
-    const float* A2;  // optional second problem of identical shape (grouped launch): blocks [per_z, 2*per_z)
-    const float* B2;
-    float* C2;
-    int M, N, K;
-    int lda, ldb, ldc;
-    int epi;
-    int split_k;      // >= 1
-    int k_chunk;      // K range per split (multiple of BK)
-    long slab_stride; // floats between split-K slabs (0 when split_k == 1)
-};
 
 // Loads a [BMN x BK] operand tile into registers and later stores it K-major into LDS.
 //   KCONTIG = true : element (mn,k) at p[mn*ld + k]   (transposed on the LDS write)
@@ -101,41 +79,6 @@ struct TileStage {
         }
     }
 };
-
-// Epilogue of one 32x32 MFMA tile: acc[r] is C[row0 + (r&3) + 8*(r>>2) + 4*half][col].  The gate / bias values are
-// fetched up front with clamped (always valid) addresses so that the 16 loads are in flight together instead of
-// one dependent L2 round trip per row.
-__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col_in, int half) {
-    const bool col_ok = col_in < g.N;
-    const int col = col_ok ? col_in : g.N - 1;      // clamp instead of returning: all 64 lanes reach the shuffle
-    float* Cz = g.C + (size_t)z * g.slab_stride;
-    const int epi = g.epi;
-    const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
-    float gv[16];
-    if (epi == EPI_GATE) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
-            gv[r] = g.gate[(size_t)row * g.ldc + col];
-        }
-    }
-    float cs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[r] + bv;
-        if (epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (epi == EPI_GATE) v = (gv[r] > 0.f) ? v : 0.f;
-        if (row < g.M && col_ok) {
-            Cz[(size_t)row * g.ldc + col] = v;
-            cs += v;
-        }
-    }
-    if (g.colsum) {   // bias gradient fused into the dH GEMM: 32-row partial per wave, one atomic per column
-        cs += __shfl_xor(cs, 32, 64);
-        if (half == 0 && col_ok) atomicAdd(g.colsum + col, cs);
-    }
-}
 
 // ABL: ablation switches for tools/gemm_bench.py (results are WRONG when != 0): bit0 = no global loads after the
 // first K-tile, bit1 = no LDS refill + no barrier in the loop.
@@ -290,40 +233,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //   * WR x WC = 4x4 (1024 threads, 128x128, 32 flop per L2 byte, one block per CU with 4 waves per SIMD),
 //     4x2 (128x64) and 2x2 (64x64) cover the smaller grids.
 // =========================================================================================================
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// One 1-KiB LDS-DMA piece: LDS[dst + lane*16] <- 16 bytes at this lane's source address.
-// Inline asm on purpose: with the builtin, hipcc knows an LDS write is pending and drains vmcnt(0) before the next
-// ds_read, which serialises the ring.  Here the pieces are invisible to its waitcnt bookkeeping and are retired by the
-// counted s_waitcnt vmcnt(N) in the K-loop (every piece is one VM_CNT event).  M0 is written in the same statement
-// that uses it and restored afterwards.
-__device__ __forceinline__ void dma_piece(const float* src, unsigned dst_bytes) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src), "s"(dst_bytes)
-        : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // MFMA operand fragments of one 8-deep k-block kb for the 32 rows/cols starting at mn0w (wave offset in the tile)
 template <bool KCONTIG, int BMN>
 __device__ __forceinline__ void load_frag(const float* img, int mn0w, int l31, int half, int kb, float (&f)[4]) {
@@ -566,6 +475,18 @@ struct GemmProf {
 };
 static GemmProf g_prof;
 
+bool prof_begin(hipStream_t s) {
+    const bool on = g_prof.on && g_prof.n < GemmProf::kMax;
+    if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+    return on;
+}
+void prof_end(bool on, hipStream_t s, double flops) {
+    if (!on) return;
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
+    g_prof.flops[g_prof.n] = flops;
+    ++g_prof.n;
+}
+
 template <int BM, int BN, int BK, bool AK, bool BKC, int ABL = 0>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     using StA = TileStage<BM, BK, AK>;
@@ -680,17 +601,10 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         g.k_chunk = (K + 31) / 32 * 32; g.C = C; g.ldc = ldc; g.slab_stride = 0; g.epi = epilogue;
     }
     // profiler bracket: the GEMM kernel AND, with split-K, its reduce kernel (both belong to this GEMM)
-    const bool prof = g_prof.on && g_prof.n < GemmProf::kMax;
-    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-    struct ProfEnd {
+    struct ProfScope {
         bool on; hipStream_t s; double fl;
-        ~ProfEnd() {
-            if (!on) return;
-            (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
-            g_prof.flops[g_prof.n] = fl;
-            ++g_prof.n;
-        }
-    } prof_end{prof, s, 2.0 * M * N * K};
+        ~ProfScope() { prof_end(on, s, fl); }
+    } prof_scope{prof_begin(s), s, 2.0 * M * N * K};
     int rc;
     if (!transA && !transB) rc = launch_tile<true, false>(tile, g, s);       // NN: A[M,K], B[K,N]
     else if (!transA && transB) rc = launch_tile<true, true>(tile, g, s);    // NT: A[M,K], B[N,K]

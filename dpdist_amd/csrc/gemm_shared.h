@@ -1,0 +1,103 @@
+// Pieces shared by the fp32 MFMA GEMM (gemm_f32.hip) and the split-bf16 MFMA GEMM (gemm_x3.hip).
+#pragma once
+#include "common.h"
+
+namespace dpd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_GATE = 3 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* gate;
+    float* colsum;    // optional [N]: += column sums of the stored values (atomics; caller zeroes it)
+    const float* A2;  // optional second problem of identical shape (grouped launch): blocks [per_z, 2*per_z)
+    const float* B2;
+    float* C2;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int epi;
+    int split_k;      // >= 1
+    int k_chunk;      // K range per split (multiple of BK)
+    long slab_stride; // floats between split-K slabs (0 when split_k == 1)
+};
+
+// Epilogue of one 32x32 MFMA tile: acc[r] is C[row0 + (r&3) + 8*(r>>2) + 4*half][col].  The gate / bias values are
+// fetched up front with clamped (always valid) addresses so that the 16 loads are in flight together instead of
+// one dependent L2 round trip per row.
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col_in, int half) {
+    const bool col_ok = col_in < g.N;
+    const int col = col_ok ? col_in : g.N - 1;      // clamp instead of returning: all 64 lanes reach the shuffle
+    float* Cz = g.C + (size_t)z * g.slab_stride;
+    const int epi = g.epi;
+    const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
+    float gv[16];
+    if (epi == EPI_GATE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
+            gv[r] = g.gate[(size_t)row * g.ldc + col];
+        }
+    }
+    float cs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r] + bv;
+        if (epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (epi == EPI_GATE) v = (gv[r] > 0.f) ? v : 0.f;
+        if (row < g.M && col_ok) {
+            Cz[(size_t)row * g.ldc + col] = v;
+            cs += v;
+        }
+    }
+    if (g.colsum) {   // bias gradient fused into the dH GEMM: 32-row partial per wave, one atomic per column
+        cs += __shfl_xor(cs, 32, 64);
+        if (half == 0 && col_ok) atomicAdd(g.colsum + col, cs);
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// One 1-KiB LDS-DMA piece: LDS[dst + lane*16] <- 16 bytes at this lane's source address.
+// Inline asm on purpose: with the builtin, hipcc knows an LDS write is pending and drains vmcnt(0) before the next
+// ds_read, which serialises the ring.  Here the pieces are invisible to its waitcnt bookkeeping and are retired by the
+// counted s_waitcnt vmcnt(N) in the K-loop (every piece is one VM_CNT event).  M0 is written in the same statement
+// that uses it and restored afterwards.
+__device__ __forceinline__ void dma_piece(const void* src, unsigned dst_bytes) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst_bytes)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+
+// in-stream GEMM profiler (gemm_f32.hip): event pair around one GEMM (kernel + split-K reduce)
+bool prof_begin(hipStream_t s);
+void prof_end(bool on, hipStream_t s, double flops);
+
+}  // namespace dpd

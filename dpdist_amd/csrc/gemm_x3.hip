@@ -1,0 +1,381 @@
+// fp32-accurate GEMM on the bf16 matrix cores (gfx950 / CDNA4): split-bf16 ("bf16x3") MFMA.
+//
+// gfx950 has no reduced-precision fast path for fp32 inputs (no xf32) and its fp32 MFMA runs at 1/16 of the bf16
+// rate (157 vs 2500 TFLOP/s).  An fp32 value is therefore carried as THREE bf16 planes
+//      a = hi + mid + lo,   hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid)     (|a - hi - mid - lo| <= 2^-27 |a|)
+// and a product a*b is evaluated with the six bf16 MFMAs whose weight is >= 2^-16:
+//      lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi          (dropped: mid*lo, lo*mid, lo*lo <= 3 * 2^-25 |a b|)
+// Each bf16 product is exact in fp32 and the matrix core accumulates in fp32, so the result has fp32-class error
+// (measured against fp64 in tests/test_gpu_parity.py next to the exact-fp32 MFMA kernel of gemm_f32.hip) at 6/16 of
+// the fp32 instruction time: 419 TFLOP/s of fp32-equivalent peak.  NP = 1 runs the same kernel on a single bf16 plane
+// (the plain bf16 training path, BASELINE config 3).
+//
+// Operand planes live in HBM in one of two chunked layouts (chunk = 8 bf16 = 16 B = one lane's MFMA operand):
+//      RC  (k = column index):  plane[r][c]            -> chunk (o = r, kg = c/8) at (r*ld + 8*kg)
+//      R8  (k = row index):     plane[r/8][c][r%8]     -> chunk (o = c, kg = r/8) at (kg*ld + c)*8
+// so every fragment is ONE ds_read_b128 whichever way the GEMM contracts, and every LDS image is lane-linear for the
+// LDS-DMA (global_load_lds_dwordx4): RC images are [rows][BK/8 slots] with the slot XOR-swizzled on the source address,
+// R8 images are [BK/8][rows] dense.  Producers (split_planes_kernel here, later the fused epilogues) write the planes.
+//
+// Kernel structure = gemm_f32.hip's LDS-DMA ring: NS stages, pieces issued NS-1 K-tiles ahead, one raw s_barrier per
+// K-tile, counted vmcnt, fragments requested one k16-step ahead of their MFMAs.
+#include <type_traits>
+
+#include "gemm_shared.h"
+
+namespace dpd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct X3Args {
+    GemmArgs e;           // epilogue view: C, bias, gate, colsum, M, N, K, ldc, epi, split (A/B/lda/ldb unused)
+    const uint16_t* A;    // plane 0 of A
+    const uint16_t* B;
+    long a_plane, b_plane;   // elements between planes
+    int lda, ldb;            // RC: row stride (elements); R8: entries per k-group row
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// chunk index inside an operand-plane image
+template <bool KC, int BO, int CPR>
+__device__ __forceinline__ int chunk_of(int o, int kg) {
+    return KC ? o * CPR + (kg ^ ((o / (16 / CPR)) & (CPR - 1))) : kg * BO + o;
+}
+
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
+    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
+    constexpr int CPR = BK / 8, KB = BK / 16;               // chunks per row, k16 steps per K-tile
+    constexpr int A_IMG = BM * CPR, B_IMG = BN * CPR;       // chunks per plane image
+    constexpr int PL = A_IMG + B_IMG, STAGE = NP * PL;      // chunks
+    constexpr int PA = A_IMG / 64, PB = B_IMG / 64;         // 1-KiB pieces per plane
+    constexpr int PPW = NP * (PA + PB) / NW;                // pieces per wave per K-tile
+    static_assert((NP * (PA + PB)) % NW == 0, "piece split");
+    static_assert(AK || BM % 64 == 0, "R8 images need 64-row pieces");
+    static_assert(BKC || BN % 64 == 0, "R8 images need 64-row pieces");
+    constexpr int NT = NP == 3 ? 6 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave / WC) * 32 * TM, wn0 = (wave % WC) * 32 * TN;
+
+    const int M = g.e.M, N = g.e.N;
+    const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
+    const int per_z = tilesM * tilesN;
+    const int sid = xcd_remap(blockIdx.x, per_z * g.e.split_k);
+    const int z = sid / per_z, t = sid % per_z;
+    const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
+    const int kbeg = z * g.e.k_chunk;
+    const int kend = min(g.e.K, kbeg + g.e.k_chunk);
+    const int nt = (kend - kbeg) / BK;
+
+    // this wave's DMA pieces: piece p = wave + j*NW -> (plane, operand, 1-KiB piece c of that plane image)
+    const uint16_t* src[PPW];
+    long step[PPW];
+    unsigned dst[PPW];
+    bool pieceA[PPW];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem_x3;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int p = wave + j * NW;
+        const int plane = p / (PA + PB), w = p % (PA + PB);
+        const bool isA = w < PA;
+        const int c = isA ? w : w - PA;
+        const bool kc = isA ? AK : BKC;
+        const uint16_t* base = isA ? g.A + plane * g.a_plane : g.B + plane * g.b_plane;
+        const int ld = isA ? g.lda : g.ldb;
+        const int o0 = isA ? m0 : n0;
+        const int O = isA ? M : N;
+        const int BO = isA ? BM : BN;
+        pieceA[j] = isA;
+        dst[j] = lds_base + (unsigned)(plane * PL + (isA ? 0 : A_IMG) + c * 64) * 16u;
+        if (kc) {
+            const int row = c * (64 / CPR) + lane / CPR, slot = lane % CPR;
+            const int kg = slot ^ ((row / (16 / CPR)) & (CPR - 1));
+            src[j] = base + (size_t)min(o0 + row, O - 1) * ld + kbeg + 8 * kg;
+            step[j] = BK;
+        } else {
+            const int lin = c * 64 + lane;
+            const int kg = lin / BO, o = lin % BO;
+            src[j] = base + ((size_t)(kbeg / 8 + kg) * ld + min(o0 + o, O - 1)) * 8;
+            step[j] = (long)CPR * ld * 8;
+        }
+    }
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            if (!((ABL & 32) && !pieceA[j]) && !((ABL & 64) && pieceA[j])) dma_piece(src[j], dst[j] + (unsigned)(stage * STAGE) * 16u);
+            src[j] += step[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: K-tiles 0 .. NS-2 in flight; wait for tile 0
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nt) issue(p);
+    static_assert((NS - 2) * PPW <= 63, "vmcnt range");
+    auto wait_later = [&](int later) {   // leave `later` whole K-tiles of this wave's pieces in flight
+        if (later >= 6) wait_vm<(NS >= 8 ? 6 : 0) * PPW>();
+        else if (later == 5) wait_vm<(NS >= 7 ? 5 : 0) * PPW>();
+        else if (later == 4) wait_vm<(NS >= 6 ? 4 : 0) * PPW>();
+        else if (later == 3) wait_vm<(NS >= 5 ? 3 : 0) * PPW>();
+        else if (later == 2) wait_vm<(NS >= 4 ? 2 : 0) * PPW>();
+        else if (later == 1) wait_vm<PPW>();
+        else wait_vm<0>();
+    };
+    wait_later(min(NS - 2, nt - 1));
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 fa[2][NP][TM], fb[2][NP][TN];
+    auto frags = [&](int stage, int kb, int buf) {
+        const char* st = smem_x3 + (size_t)stage * STAGE * 16;
+        const int kg = 2 * kb + half;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[buf][p][i] = *reinterpret_cast<const bf16x8*>(st + (p * PL + chunk_of<AK, BM, CPR>(wm0 + 32 * i + l31, kg)) * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[buf][p][j] =
+                    *reinterpret_cast<const bf16x8*>(st + (p * PL + A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
+        }
+    };
+    frags(0, 0, 0);
+
+    // one k16 step; CUR (compile time) = fragment buffer holding this step's operands
+    auto do_step = [&](int it, int kb, auto curc) {
+        constexpr int cur = decltype(curc)::value;
+        if (kb == KB - 1) {
+            // my pieces of K-tile it+1 have landed once only tiles it+2 .. it+NS-2 may be outstanding
+            if (!(ABL & 2)) {
+                wait_later(min(NS - 3, nt - 2 - it));
+                __builtin_amdgcn_s_barrier();
+            }
+            // everybody is past K-tile it-1: refill its stage with K-tile it+NS-1
+            if (!(ABL & 1) && it + NS - 1 < nt) issue((it + NS - 1) % NS);
+            if (it + 1 < nt) frags((it + 1) % NS, 0, cur ^ 1);
+        } else {
+            frags(it % NS, kb + 1, cur ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL & 16) {   // timing-only ablation: data path without the MFMA work
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][NP - 1][TM - 1], fb[cur][NP - 1][TN - 1], acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][0], fb[cur][0][0], acc[0][0], 0, 0, 0);
+        } else if (NP == 3) {
+            constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ta[q]][i], fb[cur][tb[q]][j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][i], fb[cur][0][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    if (KB == 2) {
+        for (int it = 0; it < nt; ++it) {
+            do_step(it, 0, C0{});
+            do_step(it, 1, C1{});
+        }
+    } else {
+        for (int it = 0; it < nt; it += 2) {
+            do_step(it, 0, C0{});
+            if (it + 1 < nt) do_step(it + 1, 0, C1{});
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) store_tile(g.e, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
+}
+
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
+static int launch_x3(const X3Args& g, hipStream_t s) {
+    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
+    constexpr size_t lds = (size_t)NS * NP * (BM + BN) * BK * 2;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK, ABL>;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            done = true;
+        }
+    }
+    const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * g.e.split_k;
+    DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
+    return (int)hipGetLastError();
+}
+
+// tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 128x128 (8 waves of 64x32), 3 = 64x128, 4 = 128x64, 5 = 64x64
+template <int NP, bool AK, bool BKC>
+static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32>(g, s);
+        case 2: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32>(g, s);
+        case 3: return launch_x3<NP, AK, BKC, 2, 2, 1, 2, 4, 32>(g, s);
+        case 4: return launch_x3<NP, AK, BKC, 2, 2, 2, 1, 4, 32>(g, s);
+        case 5: return launch_x3<NP, AK, BKC, 2, 2, 1, 1, 4, 32>(g, s);
+        case 6: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, 6, 16>(g, s);   // BK = 16: finer, deeper ring
+        case 7: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16>(g, s);
+        case 102: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 1>(g, s);    // ablations of tile 2 (wrong results)
+        case 202: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 3>(g, s);
+        case 1602: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 16>(g, s);
+        case 3202: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 32>(g, s);   // A pieces only
+        case 6402: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 64>(g, s);   // B pieces only
+        case 3209: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 4, 16, 32>(g, s);
+        case 107: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16, 1>(g, s);
+        case 1607: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16, 16>(g, s);
+        case 8: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 5, 16>(g, s);
+        case 9: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 4, 16>(g, s);
+        case 101: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 1>(g, s);
+        case 201: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 3>(g, s);
+        case 1601: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 16>(g, s);
+        default: return DPD_E_UNSUPPORTED;
+    }
+}
+
+// C[M,N] (fp32) = epi( op(A) op(B) ) from bf16 planes.  a_fmt/b_fmt: 0 = RC (k contiguous), 1 = R8 (k = row index).
+int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
+            int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
+            hipStream_t s, float* colsum) {
+    if (!A || !B || !C) return DPD_E_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
+    if (np != 1 && np != 3) return DPD_E_UNSUPPORTED;
+    if ((K % 32) || (N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return DPD_E_UNSUPPORTED;
+    if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) && !bias) return DPD_E_NULL;
+    if (epilogue == EPI_GATE && !gate) return DPD_E_NULL;
+    if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;
+    if (a_fmt && b_fmt == 0) return DPD_E_UNSUPPORTED;   // (R8, RC) never occurs in the decoder
+    X3Args g{};
+    g.e.C = C; g.e.bias = bias; g.e.gate = gate; g.e.colsum = colsum;
+    g.e.M = M; g.e.N = N; g.e.K = K; g.e.ldc = ldc; g.e.epi = epilogue;
+    g.e.split_k = 1; g.e.k_chunk = K; g.e.slab_stride = 0;
+    g.A = A; g.B = B; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
+    if (tile == 0) tile = 1;
+    struct ProfScope {
+        bool on; hipStream_t s; double fl;
+        ~ProfScope() { prof_end(on, s, fl); }
+    } prof_scope{prof_begin(s), s, 2.0 * M * N * K};
+    if (np == 3) {
+        if (!a_fmt && b_fmt) return launch_x3_tile<3, true, false>(tile, g, s);     // NN
+        if (!a_fmt && !b_fmt) return launch_x3_tile<3, true, true>(tile, g, s);     // NT
+        return launch_x3_tile<3, false, false>(tile, g, s);                          // TN
+    }
+    if (!a_fmt && b_fmt) return launch_x3_tile<1, true, false>(tile, g, s);
+    if (!a_fmt && !b_fmt) return launch_x3_tile<1, true, true>(tile, g, s);
+    return launch_x3_tile<1, false, false>(tile, g, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 [R, C] (row stride ld) -> np bf16 planes in RC and/or R8 layout.  R % 8 == 0, C % 8 == 0.
+// Block = 256 threads over an 8-row x 256-column strip; HBM-bound (4 B read, 2*np B written per layout).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void split3(float a, unsigned (&p)[3]) {
+    p[0] = bf16_rne(a);
+    const float hi = __uint_as_float(p[0] << 16);
+    const bool fin = (__float_as_uint(a) & 0x7f800000u) != 0x7f800000u;   // inf/NaN live in the hi plane only
+    const float r1 = fin ? a - hi : 0.f;
+    p[1] = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(p[1] << 16);
+    p[2] = bf16_rne(r2);
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int C, int ld, int np,
+                                                           uint16_t* __restrict__ rc, int ld_rc, long rc_plane,
+                                                           uint16_t* __restrict__ r8, long r8_plane) {
+    const int strips = (C + 255) / 256;
+    const int rg = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 256;
+    const int tid = threadIdx.x;
+    if (r8) {   // thread = one column: 8 rows -> one 16-B chunk per plane
+        const int c = c0 + tid;
+        if (c < C) {
+            unsigned w[3][4] = {};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned p[3];
+                split3(src[(size_t)(8 * rg + j) * ld + c], p);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) w[q][j >> 1] |= p[q] << (16 * (j & 1));
+            }
+            for (int q = 0; q < np; ++q)
+                *reinterpret_cast<uint4*>(r8 + q * r8_plane + ((size_t)rg * C + c) * 8) = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
+        }
+    }
+    if (rc) {   // thread = 8 consecutive columns of one row
+        const int r = 8 * rg + tid / 32, c = c0 + (tid % 32) * 8;
+        if (c < C) {
+            const float4 x0 = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+            const float4 x1 = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c + 4);
+            const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            unsigned w[3][4] = {};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned p[3];
+                split3(v[j], p);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) w[q][j >> 1] |= p[q] << (16 * (j & 1));
+            }
+            for (int q = 0; q < np; ++q)
+                *reinterpret_cast<uint4*>(rc + q * rc_plane + (size_t)r * ld_rc + c) = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
+        }
+    }
+}
+
+int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
+                 long r8_plane, hipStream_t s) {
+    if (!src || (!rc && !r8)) return DPD_E_NULL;
+    if (R <= 0 || C <= 0 || (R & 7) || (C & 7) || (ld & 3) || (np != 1 && np != 3)) return DPD_E_UNSUPPORTED;
+    const int strips = (C + 255) / 256;
+    DPD_LAUNCH(split_planes_kernel, dim3((R / 8) * strips), dim3(256), 0, s, src, R, C, ld, np, rc, ld_rc, rc_plane, r8,
+               r8_plane);
+    return (int)hipGetLastError();
+}
+
+}  // namespace dpd
+
+// ---- C ABI (building blocks; the decoder entry points use them when dtype != 0) -----------------------------
+extern "C" int dpd_split_planes(const float* src, int R, int C, int ld, int np, void* rc, int ld_rc, long rc_plane, void* r8,
+                                long r8_plane, void* stream) {
+    return dpd::split_planes(src, R, C, ld, np, (uint16_t*)rc, ld_rc, rc_plane, (uint16_t*)r8, r8_plane, (hipStream_t)stream);
+}
+
+extern "C" int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const void* A, int lda, long a_plane,
+                               const void* B, int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate,
+                               int epilogue, int tile, void* stream) {
+    return dpd::gemm_x3(np, a_fmt, b_fmt, M, N, K, (const uint16_t*)A, lda, a_plane, (const uint16_t*)B, ldb, b_plane, C, ldc,
+                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr);
+}

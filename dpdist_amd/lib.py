@@ -6,7 +6,7 @@ pointers + the current HIP stream.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import c_long, POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdpdist_hip.so")
@@ -34,15 +34,18 @@ SIGNATURES = {
     "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p]),
     "dpd_decoder_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_int, c_void_p,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dpd_decoder_bwd_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      POINTER(DecoderParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     POINTER(SmallGrads), c_void_p]),
+                                     POINTER(SmallGrads), c_void_p, c_size_t, c_void_p]),
     "dpd_stack_clouds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
-    "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dpd_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p]),
+    "dpd_gemm_planes": (c_int, [c_int] * 6 + [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_int, c_void_p,
+                                c_void_p, c_int, c_int, c_void_p]),
     "dpd_l1_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "dpd_adam_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                             c_float, c_void_p]),
@@ -74,6 +77,9 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+DTYPES = {"f32": 0, "f32x3": 1, "bf16": 2, 0: 0, 1: 1, 2: 2}   # include/dpdist_capi.h: enum dpd_dtype
 
 
 def check(rc, what):

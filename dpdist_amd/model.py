@@ -44,8 +44,11 @@ class DPDistParams(nn.Module):
     bucket 0 = layer 1 (10.3 MB), bucket 1 = the rest (8.4 MB).
     """
 
-    def __init__(self, k=5, mlp=(1024, 1024, 1024), device="cuda", init="xavier_tf"):
+    def __init__(self, k=5, mlp=(1024, 1024, 1024), device="cuda", init="xavier_tf", compute_dtype="f32"):
         super().__init__()
+        # compute type of the three wide layers (include/dpdist_capi.h: enum dpd_dtype): "f32" exact fp32 MFMA,
+        # "f32x3" fp32-equivalent split-bf16 MFMA, "bf16" mixed precision (bf16 operands, fp32 accumulate)
+        self.compute_dtype = compute_dtype
         self.k = int(k)
         self.mlp = tuple(int(h) for h in mlp)
         if len(set(self.mlp)) != 1 or self.mlp[0] % 64:
@@ -136,7 +139,7 @@ class _DPDistFn(torch.autograd.Function):
         fv = ops.mfv3d_fwd(pts, m, sigma)
         X, mask, vox = ops.patch_rows_fwd(q, fv, m, k, P.KP)
         params = P.views(flat)
-        h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H)
+        h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype)
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
         ctx.has_noise = noise is not None
         ctx.set_materialize_grads(False)
@@ -161,12 +164,14 @@ class _DPDistFn(torch.autograd.Function):
             dflat = torch.zeros_like(flat)
             d = P.views(dflat)
             small = (d[1], d[3], d[5], d[6], d[7])     # db1, db2, db3, dW4, db4 come out of the data chain (fused)
-        dy, g3, g2, g1, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, P.KP, need_in, small_grads=small)
+        dt = P.compute_dtype
+        ws = ops.workspace(Q, P.KP, P.H, flat.device, dt) if (need_w or dt) else None
+        dy, g3, g2, g1, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, P.KP, need_in, small_grads=small, dtype=dt,
+                                                  ws=ws)
         if need_w:
-            ws = ops.workspace(Q, P.KP, P.H, flat.device)
-            ops.decoder_bwd_weights(1, X, g1, Q, d[0], None, ws)
-            ops.decoder_bwd_weights(2, h1, g2, Q, d[2], None, ws)
-            ops.decoder_bwd_weights(3, h2, g3, Q, d[4], None, ws)
+            ops.decoder_bwd_weights(1, X, g1, Q, d[0], None, ws, dt)
+            ops.decoder_bwd_weights(2, h1, g2, Q, d[2], None, ws, dt)
+            ops.decoder_bwd_weights(3, h2, g3, Q, d[4], None, ws, dt)
         gA = gB = gN = None
         if need_in:
             dq, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k)

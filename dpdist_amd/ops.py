@@ -58,7 +58,11 @@ def patch_rows_bwd(dX, vox, C, N, m, k, want_dq=True, want_dfv=True):
     return dq, dfv
 
 
-def decoder_fwd(X, mask, params, H, bufs=None):
+def _ws_args(ws):
+    return (L.ptr(ws), ws.numel() * ws.element_size()) if ws is not None else (None, 0)
+
+
+def decoder_fwd(X, mask, params, H, bufs=None, dtype=0, ws=None):
     """X [Q,KP] -> (h1,h2,h3 [Q,H], y [Q,3], pred [Q,3])   (:513-544, :691, :695-698)"""
     L.req(X, name="X"), L.req(mask, name="mask")
     Q, KP = X.shape
@@ -69,8 +73,11 @@ def decoder_fwd(X, mask, params, H, bufs=None):
     else:
         h1, h2, h3, y, pred = bufs
     p = L.make_params(*params)
-    L.check(L.load().dpd_decoder_fwd(L.ptr(X), L.ptr(mask), Q, KP, H, p, 0, L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(y),
-                                     L.ptr(pred), L.cur_stream()), "dpd_decoder_fwd")
+    dtype = L.DTYPES[dtype]
+    if dtype and ws is None:
+        ws = workspace(Q, KP, H, X.device, dtype)
+    L.check(L.load().dpd_decoder_fwd(L.ptr(X), L.ptr(mask), Q, KP, H, p, dtype, L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(y),
+                                     L.ptr(pred), *_ws_args(ws), L.cur_stream()), "dpd_decoder_fwd")
     return h1, h2, h3, y, pred
 
 
@@ -87,7 +94,7 @@ def stack_clouds(pcA, pcB, noise=None):
     return pts, q
 
 
-def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None, small_grads=None):
+def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None, small_grads=None, dtype=0, ws=None):
     """dpred [Qb,3] (first Qb rows) -> dy [Qb,3], g3,g2,g1 [Qb,H], dX [Qb,KP] or None.
     small_grads = (db1, db2, db3, dW4, db4) tensors (or None each) to be filled by the fused epilogues."""
     L.req(dpred, name="dpred")
@@ -102,21 +109,24 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None,
         dy, g3, g2, g1, dX = bufs
     p = L.make_params(*params)
     sg = L.make_small_grads(*small_grads) if small_grads is not None else None
+    dtype = L.DTYPES[dtype]
+    if dtype and ws is None:
+        ws = workspace(Qb, KP, H, dev, dtype)
     L.check(L.load().dpd_decoder_bwd_data(L.ptr(dpred), L.ptr(mask), L.ptr(y), L.ptr(h1), L.ptr(h2), L.ptr(h3), Qb, KP, H,
-                                          p, 0, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), sg, L.cur_stream()),
-            "dpd_decoder_bwd_data")
+                                          p, dtype, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), sg, *_ws_args(ws),
+                                          L.cur_stream()), "dpd_decoder_bwd_data")
     return dy, g3, g2, g1, dX
 
 
-def workspace(Q, KP, H, device):
-    n = L.load().dpd_workspace_bytes(Q, KP, H)
+def workspace(Q, KP, H, device, dtype=0):
+    n = L.load().dpd_workspace_bytes(Q, KP, H, L.DTYPES[dtype])
     return torch.empty((n + 3) // 4, device=device, dtype=torch.float32)
 
 
-def decoder_bwd_weights(layer, act, g, Qb, dW, db, ws):
+def decoder_bwd_weights(layer, act, g, Qb, dW, db, ws, dtype=0):
     """dW/db of one layer from its input activation `act` [>=Qb, Kin] and output gradient `g` [Qb, Nout]."""
     Kin, Nout = dW.shape
-    L.check(L.load().dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), Qb, Kin, Nout, 0, L.ptr(dW),
+    L.check(L.load().dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), Qb, Kin, Nout, L.DTYPES[dtype], L.ptr(dW),
                                              L.ptr(db), L.ptr(ws), ws.numel() * 4, L.cur_stream()),
             "dpd_decoder_bwd_weights(layer=%d)" % layer)
 

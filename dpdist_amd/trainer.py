@@ -28,8 +28,10 @@ def learning_rate(step, base=1e-4, decay_step=300 * 512, decay_rate=0.5, floor=1
 
 class DPDistTrainer:
     def __init__(self, params: DPDistParams, batch_size, num_point=64, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4,
-                 decay_step=300 * 512, decay_rate=0.5, beta1=0.9, beta2=0.999, eps=1e-8, group=None, distributed=None):
+                 decay_step=300 * 512, decay_rate=0.5, beta1=0.9, beta2=0.999, eps=1e-8, group=None, distributed=None,
+                 compute_dtype=None):
         self.P = params
+        self.dt = L.DTYPES[params.compute_dtype if compute_dtype is None else compute_dtype]
         dev = params.flat.device
         self.B, self.N = int(batch_size), int(num_point)
         self.m = int(math.ceil(Embedding_Size ** (1 / 3) - 1e-9))
@@ -51,7 +53,7 @@ class DPDistTrainer:
         self.grad = torch.zeros(params.numel, device=dev, dtype=torch.float32)
         self.m_state = torch.zeros_like(self.grad)
         self.v_state = torch.zeros_like(self.grad)
-        self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H) + 3) // 4, device=dev, dtype=torch.float32)
+        self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H, self.dt) + 3) // 4, device=dev, dtype=torch.float32)
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
         import os
@@ -74,8 +76,9 @@ class DPDistTrainer:
         L.check(lib.dpd_mfv3d_fwd(L.ptr(self.pts), C, N, self.m, self.sigma, L.ptr(self.fv), s), "dpd_mfv3d_fwd")
         L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP, L.ptr(self.X),
                                        L.ptr(self.mask), L.ptr(self.vox), s), "dpd_patch_rows_fwd")
-        L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, 0, L.ptr(self.h1),
-                                    L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), s), "dpd_decoder_fwd")
+        L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
+                                    L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
+                                    self.ws.numel() * 4, s), "dpd_decoder_fwd")
 
     def backward(self, labels):
         lib, s, P = L.load(), L.cur_stream(), self.P
@@ -83,12 +86,13 @@ class DPDistTrainer:
         L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
         # data chain; db1..db3, dW4, db4 fall out of it (fused epilogues / one small kernel)
         L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
-                                         L.ptr(self.h3), BN, P.KP, P.H, self._cparams, 0, L.ptr(self.dy), L.ptr(self.g3),
-                                         L.ptr(self.g2), L.ptr(self.g1), None, self._csmall, s), "dpd_decoder_bwd_data")
+                                         L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
+                                         L.ptr(self.g2), L.ptr(self.g1), None, self._csmall, L.ptr(self.ws),
+                                         self.ws.numel() * 4, s), "dpd_decoder_bwd_data")
         d, wsb = self._gviews, self.ws.numel() * 4
 
         def dw(layer, act, g, dW):
-            L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], 0,
+            L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
                                                 L.ptr(dW), None, L.ptr(self.ws), wsb, L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
@@ -97,7 +101,7 @@ class DPDistTrainer:
             self.reducer.reduce_async(0)      # bucket 0 = dW1p + db1 (db1 was finished by the data chain)
         if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
             L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
-                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, 0, L.cur_stream()),
+                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, L.cur_stream()),
                     "dpd_decoder_bwd_weights_pair")
         else:
             dw(2, self.h1, self.g2, d[2])

@@ -93,7 +93,19 @@ typedef struct dpd_decoder_params {
 } dpd_decoder_params;
 
 int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
-                    int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* stream);
+                    int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* `dtype` of the decoder entry points = compute type of the three wide layers (inputs/outputs are always fp32):
+ *   DPD_F32     exact fp32 on the fp32 matrix-core instruction (bitwise an fmaf chain), no workspace needed in
+ *               dpd_decoder_fwd / dpd_decoder_bwd_data (ws may be NULL);
+ *   DPD_F32_X3  fp32-equivalent on the bf16 matrix cores: every operand is split into three bf16 planes
+ *               (hi+mid+lo, exact to 2^-27) and each product is the sum of the six bf16 MFMA terms of weight
+ *               >= 2^-16, accumulated in fp32 (error vs fp64 <= the DPD_F32 path's, tests/test_gpu_parity.py);
+ *   DPD_BF16    operands rounded to bf16, fp32 accumulation (mixed-precision training, tolerance ~1e-2 relative).
+ * DPD_F32_X3 / DPD_BF16 need ws = dpd_workspace_bytes(Q, KP, H, dtype) bytes (operand planes).  Shapes the plane
+ * kernels do not take (contraction length not a multiple of 32, dims not multiples of 8) run as DPD_F32.       */
+enum dpd_dtype { DPD_F32 = 0, DPD_F32_X3 = 1, DPD_BF16 = 2 };
 
 /* Backward, data chain: dpred [Qb,3] for the FIRST Qb rows (training mode: Qb = Q/2, only the AB half
  * carries gradient, train_multi_gpu_pc_compare_dist.py:274-277; as-loss mode: Qb = Q).
@@ -109,7 +121,7 @@ typedef struct dpd_small_grads {
 int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,
                          const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p, int dtype,
                          float* dy, float* g3, float* g2, float* g1, float* dX, const dpd_small_grads* sg,
-                         void* stream);
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* Backward, weight gradients of ONE layer (1..4) from the buffers above:
  *   layer 1: dW [KP,H] = X^T g1, db = colsum(g1);  2: h1^T g2;  3: h2^T g3;  4: dW [H,3] = h3^T dy.
@@ -122,10 +134,12 @@ int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g
 /* dW of two layers of identical shape (layers 2 and 3: dW = act^T g, [Kin,Nout]) in ONE grouped launch; no bias
  * gradients (they come from dpd_decoder_bwd_data).  Qb must be a multiple of 32.                          */
 int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
-                                 float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* stream);
+                                 float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws, size_t ws_bytes,
+                                 void* stream);
 
-/* Scratch needed by dpd_decoder_bwd_weights / dpd_gemm_f32 (split-K slabs) for the given sizes. */
-size_t dpd_workspace_bytes(int Q, int KP, int H);
+/* Scratch needed by the decoder entry points for the given sizes and compute type (split-K slabs, column-sum
+ * partials and, for dtype != DPD_F32, the bf16 operand planes of one GEMM at a time).                   */
+size_t dpd_workspace_bytes(int Q, int KP, int H, int dtype);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses.  Replaces utils/dpdist_util.py:962-980.  pred [2*BN,3] (AB rows first), labels [BN].
@@ -154,6 +168,21 @@ int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr
 int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* Cout, int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile,
                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bf16-plane building blocks (gemm_x3.hip).  A plane tensor holds np (1 or 3) bf16 planes of an fp32 matrix in
+ * 16-byte chunks of 8 contraction elements:
+ *   RC layout (contraction index = column):  plane[r][c],           leading dimension ld_rc (elements)
+ *   R8 layout (contraction index = row):     plane[r/8][c][r%8]
+ * dpd_split_planes writes either or both (rc / r8 may be NULL) from src [R,C] (row stride ld; R, C multiples of 8).
+ * dpd_gemm_planes: C [M,N] fp32 = epi(A B), A/B given as planes; a_fmt/b_fmt: 0 = RC (A stored [M,K], B stored
+ * [N,K]), 1 = R8 (A stored [K,M], B stored [K,N]); lda/ldb = row stride for RC, M resp. N for R8; K % 32 == 0;
+ * epilogue/bias/gate as in dpd_gemm_f32; tile 0 = default.                                                  */
+int dpd_split_planes(const float* src, int R, int C, int ld, int np, void* rc, int ld_rc, long rc_plane, void* r8,
+                     long r8_plane, void* stream);
+int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const void* A, int lda, long a_plane,
+                    const void* B, int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate,
+                    int epilogue, int tile, void* stream);
 
 /* Tuning knob (the library's only process-wide state; never needed for correctness): GEMM tile / split-K per
  * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3.

@@ -38,7 +38,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_host_only_entry_points(lib):
     assert lib.dpd_version().decode().startswith("dpdist_hip")
     assert lib.dpd_padded_width(5) == 2528 and lib.dpd_padded_width(3) == 544
-    assert lib.dpd_workspace_bytes(4096, 2528, 1024) >= 2 * 2528 * 1024 * 4
+    assert lib.dpd_workspace_bytes(4096, 2528, 1024, 0) >= 2 * 2528 * 1024 * 4
+    assert lib.dpd_workspace_bytes(4096, 2528, 1024, 1) >= lib.dpd_workspace_bytes(4096, 2528, 1024, 0) + 3 * 2 * 4096 * 2528
     assert lib.dpd_set_gemm_plan(99, 0, 1) < 0          # argument errors are negative codes
     assert lib.dpd_set_gemm_plan(4, 0, 2) == 0
 

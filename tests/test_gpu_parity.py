@@ -446,3 +446,172 @@ def test_two_streams_are_independent(dev):
             p2 = mod(A2, B2)
         torch.cuda.synchronize()
     assert torch.equal(p1["pred_listAB"], r1["pred_listAB"]) and torch.equal(p2["pred_listBA"], r2["pred_listBA"])
+
+
+# ------------------------------------------------------------------------------------------------ bf16 matrix-core paths
+def _planes(x, np_, want_rc, want_r8):
+    from dpdist_amd import lib as L
+    R, C = x.shape
+    rc = torch.empty(np_, R, C, device=x.device, dtype=torch.int16) if want_rc else None
+    r8 = torch.empty(np_, R // 8, C, 8, device=x.device, dtype=torch.int16) if want_r8 else None
+    L.check(L.load().dpd_split_planes(L.ptr(x), R, C, x.stride(0), np_, L.ptr(rc), C, R * C, L.ptr(r8), R * C,
+                                      L.cur_stream()), "dpd_split_planes")
+    return rc, r8
+
+
+def test_split_planes_reconstruct_exactly(dev):
+    """hi + mid + lo reproduces the fp32 value to 2^-27 relative (both layouts agree); NaN/inf stay in the hi plane."""
+    x = torch.randn(64, 256, device=dev) * torch.logspace(-20, 20, 256, device=dev)
+    x[3, 7] = float("inf")
+    x[5, 9] = float("nan")
+    rc, r8 = _planes(x, 3, True, True)
+    back = (rc.to(torch.int32) << 16).view(torch.float32).double().sum(0)
+    fin = torch.isfinite(x)
+    assert ((back - x.double()).abs()[fin] <= x.double().abs()[fin] * 2.0 ** -26).all()
+    assert torch.isinf(back[3, 7]) and torch.isnan(back[5, 9])
+    r8_as_rc = r8.permute(0, 1, 3, 2).reshape(3, 64, 256)     # [p][r/8][c][r%8] -> [p][r][c]
+    assert torch.equal(r8_as_rc, rc)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
+@pytest.mark.parametrize("np_", [3, 1])
+def test_gemm_planes(dev, np_, mode, tile):
+    """Split-bf16 GEMM against fp64: the 3-plane / 6-term form must be at least as accurate as the exact-fp32 MFMA
+    GEMM on the same operands (fp32-equivalent); the 1-plane form is a plain bf16 GEMM (2^-8 operand rounding)."""
+    from dpdist_amd import lib as L, ops
+    M, N, K = 200, 328, 544                  # ragged M (clamped rows), N % 8 == 0, K % 32 == 0
+    g = torch.Generator().manual_seed(tile * 10 + np_)
+    A = torch.randn(M, K, generator=g).to(dev)
+    B = torch.randn(K, N, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = torch.relu(A.double() @ B.double() + bias.double())
+    lib = L.load()
+    C = torch.empty(M, N, device=dev)
+    if mode == "NN":
+        a, _ = _planes(A, np_, True, False); _, b = _planes(B, np_, False, True)
+        args = (np_, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N)
+        c32 = ops.gemm_f32(A, B, bias=bias, epilogue=2, tile=8)
+    elif mode == "NT":
+        Bt = B.t().contiguous()
+        a, _ = _planes(A, np_, True, False); b, _ = _planes(Bt, np_, True, False)
+        args = (np_, 0, 0, M, N, K, L.ptr(a), K, M * K, L.ptr(b), K, N * K)
+        c32 = ops.gemm_f32(A, Bt, transB=True, bias=bias, epilogue=2, tile=8)
+    else:
+        At = A.t().contiguous()
+        _, a = _planes(At, np_, False, True); _, b = _planes(B, np_, False, True)
+        args = (np_, 1, 1, M, N, K, L.ptr(a), M, K * M, L.ptr(b), N, K * N)
+        c32 = ops.gemm_f32(At, B, transA=True, bias=bias, epilogue=2, tile=8)
+    L.check(lib.dpd_gemm_planes(*args, L.ptr(C), N, L.ptr(bias), None, 2, tile, L.cur_stream()), "dpd_gemm_planes")
+    err = (C.double() - ref).abs().max().item()
+    err32 = (c32.double() - ref).abs().max().item()
+    if np_ == 3:
+        assert err <= max(1.5 * err32, 2e-5), (err, err32)
+    else:
+        assert err <= 0.02 * K ** 0.5, err          # ~2^-8 per operand, random signs
+
+
+@pytest.mark.parametrize("case", ["s1", "boundary"])
+@pytest.mark.parametrize("wk", ["xavier_tf", "wide"])
+def test_forward_golden_f32x3(dev, golden_dir, case, wk):
+    """The fp32-equivalent bf16-matrix-core path meets the SAME bar as the exact-fp32 path."""
+    d = _g(golden_dir, "path_fwd_%s_%s.npz" % (case, wk))
+    mod = _model(dev, wk)
+    mod.params_.compute_dtype = "f32x3"
+    with torch.no_grad():
+        ps = mod(_cu(d["pcA"], dev), _cu(d["pcB"], dev))
+    for n in ("pred_listAB", "pred_listBA"):
+        _check_pred(ps[n].cpu().numpy(), d[n + "_f64"], wk == "wide")
+        _check_pred(ps[n].cpu().numpy(), d[n + "_f32"], wk == "wide")
+
+
+def test_forward_f32x3_is_as_accurate_as_f32(dev):
+    """B=32 (config 2): error of both fp32 paths against the float64 oracle, side by side."""
+    from oracle import restate as R
+    pcA, pcB = synth.s1_random_patches(32, 64, 0)
+    W = synth.make_weights("wide")
+    ref, _ = R.get_model(torch.tensor(pcA, dtype=torch.float64), torch.tensor(pcB, dtype=torch.float64),
+                         {n: torch.tensor(a, dtype=torch.float64) for n, a in W.items()})
+    errs = {}
+    for dt in ("f32", "f32x3"):
+        mod = _model(dev, "wide")
+        mod.params_.compute_dtype = dt
+        with torch.no_grad():
+            ps = mod(_cu(pcA, dev), _cu(pcB, dev))
+        errs[dt] = max(np.abs(ps[n].cpu().numpy() - ref[n].numpy()).max() for n in ("pred_listAB", "pred_listBA"))
+    assert errs["f32x3"] <= ABS_TOL and errs["f32x3"] <= 2.0 * errs["f32"] + 2e-6, errs
+
+
+def test_forward_bf16_tolerance(dev, golden_dir):
+    """BASELINE config 3 compute type: bf16 operands, fp32 accumulation.  Stated tolerance: 3e-2 absolute on the
+    predicted distances of the `wide` set (outputs in [0,2]; three chained bf16 GEMMs of K=2503/1024/1024)."""
+    d = _g(golden_dir, "path_fwd_s1_wide.npz")
+    mod = _model(dev, "wide")
+    mod.params_.compute_dtype = "bf16"
+    with torch.no_grad():
+        ps = mod(_cu(d["pcA"], dev), _cu(d["pcB"], dev))
+    for n in ("pred_listAB", "pred_listBA"):
+        err = np.abs(ps[n].cpu().numpy() - d[n + "_f64"])
+        assert err.max() <= 3e-2 and err.mean() <= 5e-3, (err.max(), err.mean())
+
+
+@pytest.mark.parametrize("dt", ["f32x3", "bf16"])
+def test_gradients_golden_plane_paths(dev, golden_dir, dt):
+    """Weight and input gradients through the plane GEMMs: f32x3 at the fp32 bars, bf16 at 3e-2 relative (norms)."""
+    from dpdist_amd import model as M
+    d = _g(golden_dir, "path_bwd_s2_wide.npz")
+    mod = _model(dev, "wide")
+    mod.params_.compute_dtype = dt
+    pcA = _cu(d["pcA"], dev).requires_grad_(True)
+    pcB = _cu(d["pcB"], dev).requires_grad_(True)
+    noise = _cu(d["noise"], dev).requires_grad_(True)
+    M.reset_default_graph()
+    ps = mod(pcA, pcB, add_noise=noise)
+    _, lp = M.get_loss(ps, {}, _cu(d["labels"], dev))
+    ls = M.get_collection("loss_samples")[0]
+    rel = 2e-4 if dt == "f32x3" else 3e-2
+    assert abs(ls.item() - float(d["loss_samples_f64"])) <= (2e-5 if dt == "f32x3" else 5e-3)
+    (gflat,) = torch.autograd.grad(ls, [mod.params_.flat], retain_graph=True)
+    gsd = mod.params_.tf_state_dict(gflat)
+    for n, g in gsd.items():
+        short = n.split("/")[-2][-1] + ("w" if n.endswith("weights") else "b")
+        g2 = g.reshape(-1, g.shape[-1]) if g.ndim == 4 else g
+        nrm = float(d["g%s_norm_f64" % short])
+        assert abs(np.sqrt((g2.astype(np.float64) ** 2).sum()) - nrm) <= rel * max(1.0, nrm), n
+        if g.ndim == 4:
+            assert np.abs(g2[:16, :16] - d["g%s_corner_f64" % short]).max() <= rel * max(1.0, nrm), n
+    gA, gB, gN = torch.autograd.grad(lp, [pcA, pcB, noise])
+    for g, n in ((gA, "d_pcA"), (gB, "d_pcB"), (gN, "d_noise")):
+        ref = d[n + "_f64"]
+        if dt == "f32x3":
+            bar = max(4.0 * np.abs(d[n + "_f32"] - ref).max(), 2e-4 * max(1.0, np.abs(ref).max()))
+        else:
+            bar = 5e-2 * max(1.0, np.abs(ref).max())
+        assert np.abs(g.cpu().numpy() - ref).max() <= bar, (n, np.abs(g.cpu().numpy() - ref).max(), bar)
+
+
+@pytest.mark.parametrize("dt", ["f32x3", "bf16"])
+def test_trainer_plane_paths(dev, dt):
+    """Training steps on the bf16 matrix cores: f32x3 tracks the fp32 trainer to fp32 round-off; bf16 (mixed precision:
+    fp32 master weights, fp32 Adam) tracks it to bf16 round-off and the loss decreases."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 8
+    pcA, pcB, lab = synth.s2_modelnet_shaped(B, 64, 100)
+    W0 = synth.make_weights("wide")
+    out = {}
+    for name in ("f32", dt):
+        P = DPDistParams(device=dev, compute_dtype=name)
+        P.load_tf_state_dict(W0)
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        losses = [tr.step(_cu(pcA, dev), _cu(pcB, dev), _cu(lab, dev)).cpu().numpy().copy() for _ in range(4)]
+        out[name] = (np.array(losses), P.flat.detach().cpu().numpy().copy())
+    l32, w32 = out["f32"]
+    lx, wx = out[dt]
+    if dt == "f32x3":
+        assert np.abs(lx - l32).max() <= 5e-5
+        # Adam's first steps move every weight by ~lr whatever the gradient size: tiny gradients may flip sign in round-off
+        assert np.abs(wx - w32).max() <= 2.5e-3 * 4 and np.abs(wx - w32).mean() <= 1e-5
+    else:
+        assert np.abs(lx - l32).max() <= 2e-2
+    assert lx[-1, 0] < lx[0, 0]
