@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
@@ -92,6 +93,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"],
+                    help="compute type of the three wide decoder layers (include/dpdist_capi.h: enum dpd_dtype)")
     ap.add_argument("--plan", default="", help="GEMM plan overrides for tuning, e.g. '0:10,1:9:1' = op:tile[:split_k]")
     a = ap.parse_args()
 
@@ -123,7 +126,7 @@ def main():
         f = [int(x) for x in item.split(":")]
         lib.check(L.dpd_set_gemm_plan(f[0], f[1], f[2] if len(f) > 2 else 1), "dpd_set_gemm_plan")
     B, N = a.batch, 64
-    P = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev)
+    P = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev, compute_dtype=a.dtype)
     g = torch.Generator().manual_seed(1234)            # same random-init weights on every rank (replicated variables)
     P.reset_parameters_tf(generator=g)
     tr = DPDistTrainer(P, B, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4)
@@ -170,9 +173,13 @@ def main():
             if n > 0 and ms.value > 0:
                 launches = n
                 ach = alg * a.steps / (ms.value * 1e-3) / 1e12
-                roof = {"bound": "mfma", "kernel": "gemm_dma_kernel<WR,WC,NS,...> (fp32 v_mfma_f32_32x32x2, LDS-DMA ring)",
-                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                # executed matrix-core flops per algorithmic flop: 1 on the fp32 MFMA, 6 bf16 terms in the split form
+                mult, peak, kern = {"f32": (1, PEAK_FP32_MFMA_TFLOPS, "gemm_dma_kernel<WR,WC,NS,...> (fp32 v_mfma_f32_32x32x2, LDS-DMA ring)"),
+                                    "f32x3": (6, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<3,...> (6 x v_mfma_f32_32x32x16_bf16 per product, LDS-DMA ring)"),
+                                    "bf16": (1, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<1,...> (v_mfma_f32_32x32x16_bf16, LDS-DMA ring)")}[a.dtype]
+                roof = {"bound": "mfma", "kernel": kern,
+                        "achieved": round(ach * mult, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach * mult / peak, 4), "traffic": None, "algorithmic_tflops": round(ach, 2),
                         "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
                         "alg_gflop_per_launch": round(alg / per_step / 1e9, 3),
                         "gemm_ms_per_step": round(ms.value / a.steps, 4)}
@@ -183,7 +190,7 @@ def main():
         qps = 2.0 * B * N * world * a.steps / el
         out = {"metric": "query-points/sec (DPDist fwd+bwd)", "value": round(qps, 1), "unit": "query-points/sec",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "DPDist training step (3DmFV 8^3 + 5^3-window decoder 2503-1024-1024-1024-3, "
                                       "fwd both directions + bwd AB half + Adam), S2 ModelNet-shaped clouds",
                           "pairs_per_gpu": B, "global_batch": B * world, "num_point": N, "query_points_per_step": 2 * B * N * world,

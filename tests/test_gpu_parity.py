@@ -615,3 +615,22 @@ def test_trainer_plane_paths(dev, dt):
     else:
         assert np.abs(lx - l32).max() <= 2e-2
     assert lx[-1, 0] < lx[0, 0]
+
+
+def test_bf16_training_tracks_fp32_over_50_steps(dev):
+    """B=64, bf16 MFMA with fp32 accumulate; the loss curve must track fp32 within 1 %
+    over 50 steps (the fp32 trainer is itself pinned to the oracle by test_trainer_steps_vs_oracle)."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 64
+    pcA, pcB, lab = synth.s2_modelnet_shaped(B, 64, 100)
+    W0 = synth.make_weights("wide")
+    curves = {}
+    for name in ("f32", "bf16"):
+        P = DPDistParams(device=dev, compute_dtype=name)
+        P.load_tf_state_dict(W0)
+        tr = DPDistTrainer(P, B, base_lr=1e-4, distributed=False)
+        curves[name] = np.array([tr.step(_cu(pcA, dev), _cu(pcB, dev), _cu(lab, dev))[0].item() for _ in range(50)])
+    rel = np.abs(curves["bf16"] - curves["f32"]) / curves["f32"]
+    assert rel.max() <= 0.01, rel.max()
+    assert curves["bf16"][-1] < 0.9 * curves["bf16"][0]
