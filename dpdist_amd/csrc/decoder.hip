@@ -7,7 +7,7 @@
 // the 3-wide output layer and the bias gradients are small HBM-bound kernels in this file.
 // Algorithmic work per query row (H = 1024): 4 663 296 MAC forward.  Activations h1,h2,h3 [Q,H] stay in HBM
 // (16.8 MB each at Q = 4096, resident in the 256 MiB Infinity Cache) for the backward pass.
-#include "common.h"
+#include "gemm_shared.h"
 
 namespace dpd {
 
@@ -18,7 +18,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
-            hipStream_t s, float* colsum);
+            hipStream_t s, float* colsum, const X3Out* out = nullptr);
 int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
                  long r8_plane, hipStream_t s);
 

@@ -28,11 +28,9 @@ struct GemmArgs {
 
 // Epilogue of one 32x32 MFMA tile: acc[r] is C[row0 + (r&3) + 8*(r>>2) + 4*half][col].  The gate / bias values are
 // fetched up front with clamped (always valid) addresses so that the 16 loads are in flight together instead of
-// one dependent L2 round trip per row.
-__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col_in, int half) {
-    const bool col_ok = col_in < g.N;
-    const int col = col_ok ? col_in : g.N - 1;      // clamp instead of returning: all 64 lanes reach the shuffle
-    float* Cz = g.C + (size_t)z * g.slab_stride;
+// one dependent L2 round trip per row.  tile_values() applies bias / ReLU / gate, put_tile() stores fp32 + column sums.
+__device__ __forceinline__ void tile_values(const GemmArgs& g, const f32x16& acc, int row0, int col_in, int half, float (&v)[16]) {
+    const int col = col_in < g.N ? col_in : g.N - 1;      // clamp instead of returning: all 64 lanes stay converged
     const int epi = g.epi;
     const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
     float gv[16];
@@ -43,22 +41,38 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc,
             gv[r] = g.gate[(size_t)row * g.ldc + col];
         }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float x = acc[r] + bv;
+        if (epi == EPI_BIAS_RELU) x = fmaxf(x, 0.f);
+        if (epi == EPI_GATE) x = (gv[r] > 0.f) ? x : 0.f;
+        v[r] = x;
+    }
+}
+
+__device__ __forceinline__ void put_tile(const GemmArgs& g, const float (&v)[16], int z, int row0, int col_in, int half) {
+    const bool col_ok = col_in < g.N;
+    const int col = col_ok ? col_in : g.N - 1;
+    float* Cz = g.C ? g.C + (size_t)z * g.slab_stride : nullptr;
     float cs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[r] + bv;
-        if (epi == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (epi == EPI_GATE) v = (gv[r] > 0.f) ? v : 0.f;
         if (row < g.M && col_ok) {
-            Cz[(size_t)row * g.ldc + col] = v;
-            cs += v;
+            if (Cz) Cz[(size_t)row * g.ldc + col] = v[r];
+            cs += v[r];
         }
     }
     if (g.colsum) {   // bias gradient fused into the dH GEMM: 32-row partial per wave, one atomic per column
         cs += __shfl_xor(cs, 32, 64);
         if (half == 0 && col_ok) atomicAdd(g.colsum + col, cs);
     }
+}
+
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col_in, int half) {
+    float v[16];
+    tile_values(g, acc, row0, col_in, half, v);
+    put_tile(g, v, z, row0, col_in, half);
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -95,6 +109,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// optional bf16-plane outputs of a gemm_x3 result (gemm_x3.hip): RC planes [np][M][ld_rc], R8 planes
+// [np][r8_rows/8][N][8] for the rows < r8_rows
+struct X3Out {
+    uint16_t* rc = nullptr;
+    uint16_t* r8 = nullptr;
+    long rc_plane = 0, r8_plane = 0;
+    int ld_rc = 0, r8_rows = 0, np = 0;
+};
 
 // in-stream GEMM profiler (gemm_f32.hip): event pair around one GEMM (kernel + split-K reduce)
 bool prof_begin(hipStream_t s);

@@ -33,7 +33,42 @@ struct X3Args {
     const uint16_t* B;
     long a_plane, b_plane;   // elements between planes
     int lda, ldb;            // RC: row stride (elements); R8: entries per k-group row
+    // optional plane outputs of C (np_out planes each), written by the LDS-staged epilogue:
+    uint16_t* out_rc;        // RC planes [np_out][M][ld_rc]   (C is the k-contiguous operand of the next GEMM)
+    uint16_t* out_r8;        // R8 planes [np_out][r8_rows/8][N][8], rows < r8_rows only (C as a k = row operand)
+    long rc_plane, r8_plane;
+    int ld_rc, r8_rows, np_out;
 };
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void split3(float a, unsigned (&p)[3]) {
+    p[0] = bf16_rne(a);
+    const float hi = __uint_as_float(p[0] << 16);
+    const bool fin = (__float_as_uint(a) & 0x7f800000u) != 0x7f800000u;   // inf/NaN live in the hi plane only
+    const float r1 = fin ? a - hi : 0.f;
+    p[1] = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(p[1] << 16);
+    p[2] = bf16_rne(r2);
+}
+
+// 8 fp32 values -> one 16-byte chunk per plane
+__device__ __forceinline__ void split_chunk(const float (&v)[8], uint4 (&w)[3]) {
+    unsigned u[3][4] = {};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned p[3];
+        split3(v[j], p);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) u[q][j >> 1] |= p[q] << (16 * (j & 1));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) w[q] = make_uint4(u[q][0], u[q][1], u[q][2], u[q][3]);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -209,16 +244,69 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
             if (it + 1 < nt) do_step(it + 1, 0, C1{});
         }
     }
+    if (!g.out_rc && !g.out_r8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) store_tile(g.e, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
+        return;
+    }
+    // Plane outputs: the finished tile is staged through the (now idle) LDS ring as fp32 [BM][BN+4] and re-read in
+    // the two chunk orientations, so that the next GEMMs find their operands as bf16 planes (no separate split pass).
+    constexpr int LDW = BN + 4;
+    float* st = reinterpret_cast<float*>(smem_x3);
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the ring (all DMA pieces were waited for above)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) store_tile(g.e, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
+        for (int j = 0; j < TN; ++j) {
+            float v[16];
+            const int row0 = wm0 + 32 * i, col = wn0 + 32 * j + l31;
+            tile_values(g.e, acc[i][j], m0 + row0, n0 + col, half, v);
+            put_tile(g.e, v, z, m0 + row0, n0 + col, half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[(row0 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDW + col] = v[r];
+        }
+    __syncthreads();
+    constexpr int NTHR = 64 * NW;
+    const int npo = g.np_out;
+    if (g.out_rc) {
+        for (int t2 = tid; t2 < BM * (BN / 8); t2 += NTHR) {
+            const int row = t2 / (BN / 8), cg = t2 % (BN / 8);
+            const int grow = m0 + row, gcol = n0 + 8 * cg;
+            if (grow < M && gcol < N) {
+                const float4 x0 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg);
+                const float4 x1 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg + 4);
+                const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                uint4 w[3];
+                split_chunk(v, w);
+                for (int q = 0; q < npo; ++q)
+                    *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
+            }
+        }
+    }
+    if (g.out_r8 && m0 < g.r8_rows) {
+        for (int t2 = tid; t2 < (BM / 8) * BN; t2 += NTHR) {
+            const int rg = t2 / BN, col = t2 % BN;
+            const int grow = m0 + 8 * rg, gcol = n0 + col;
+            if (grow < g.r8_rows && gcol < N) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = st[(8 * rg + j) * LDW + col];
+                uint4 w[3];
+                split_chunk(v, w);
+                for (int q = 0; q < npo; ++q)
+                    *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
+            }
+        }
+    }
 }
 
 template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
 static int launch_x3(const X3Args& g, hipStream_t s) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
-    constexpr size_t lds = (size_t)NS * NP * (BM + BN) * BK * 2;
+    constexpr size_t ring = (size_t)NS * NP * (BM + BN) * BK * 2, stage = (size_t)BM * (BN + 4) * 4;
+    constexpr size_t lds = ring > stage ? ring : stage;   // the plane epilogue stages the fp32 tile in the ring's LDS
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK, ABL>;
     if (lds > 64 * 1024) {
@@ -265,8 +353,11 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
 // C[M,N] (fp32) = epi( op(A) op(B) ) from bf16 planes.  a_fmt/b_fmt: 0 = RC (k contiguous), 1 = R8 (k = row index).
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
-            hipStream_t s, float* colsum) {
-    if (!A || !B || !C) return DPD_E_NULL;
+            hipStream_t s, float* colsum, const X3Out* out) {
+    const bool planes_out = out && (out->rc || out->r8);
+    if (!A || !B || (!C && !planes_out)) return DPD_E_NULL;
+    if (planes_out && ((out->np != 1 && out->np != 3) || (M & 7) || (N & 7) || (out->r8_rows & 7) || (out->rc && (out->ld_rc & 7))))
+        return DPD_E_UNSUPPORTED;
     if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
     if (np != 1 && np != 3) return DPD_E_UNSUPPORTED;
     if ((K % 32) || (N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return DPD_E_UNSUPPORTED;
@@ -279,6 +370,10 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     g.e.M = M; g.e.N = N; g.e.K = K; g.e.ldc = ldc; g.e.epi = epilogue;
     g.e.split_k = 1; g.e.k_chunk = K; g.e.slab_stride = 0;
     g.A = A; g.B = B; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
+    if (planes_out) {
+        g.out_rc = out->rc; g.out_r8 = out->r8; g.rc_plane = out->rc_plane; g.r8_plane = out->r8_plane;
+        g.ld_rc = out->ld_rc; g.r8_rows = out->r8_rows; g.np_out = out->np;
+    }
     if (tile == 0) tile = 1;
     struct ProfScope {
         bool on; hipStream_t s; double fl;
@@ -298,22 +393,6 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
 // fp32 [R, C] (row stride ld) -> np bf16 planes in RC and/or R8 layout.  R % 8 == 0, C % 8 == 0.
 // Block = 256 threads over an 8-row x 256-column strip; HBM-bound (4 B read, 2*np B written per layout).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-    unsigned u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
-__device__ __forceinline__ void split3(float a, unsigned (&p)[3]) {
-    p[0] = bf16_rne(a);
-    const float hi = __uint_as_float(p[0] << 16);
-    const bool fin = (__float_as_uint(a) & 0x7f800000u) != 0x7f800000u;   // inf/NaN live in the hi plane only
-    const float r1 = fin ? a - hi : 0.f;
-    p[1] = bf16_rne(r1);
-    const float r2 = r1 - __uint_as_float(p[1] << 16);
-    p[2] = bf16_rne(r2);
-}
-
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int C, int ld, int np,
                                                            uint16_t* __restrict__ rc, int ld_rc, long rc_plane,
                                                            uint16_t* __restrict__ r8, long r8_plane) {
@@ -375,7 +454,10 @@ extern "C" int dpd_split_planes(const float* src, int R, int C, int ld, int np, 
 
 extern "C" int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const void* A, int lda, long a_plane,
                                const void* B, int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate,
-                               int epilogue, int tile, void* stream) {
+                               int epilogue, int tile, void* out_rc, void* out_r8, int r8_rows, void* stream) {
+    dpd::X3Out o;
+    o.rc = (uint16_t*)out_rc; o.r8 = (uint16_t*)out_r8; o.np = np; o.ld_rc = N; o.r8_rows = r8_rows;
+    o.rc_plane = (long)M * N; o.r8_plane = (long)r8_rows * N;
     return dpd::gemm_x3(np, a_fmt, b_fmt, M, N, K, (const uint16_t*)A, lda, a_plane, (const uint16_t*)B, ldb, b_plane, C, ldc,
-                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr);
+                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr);
 }

@@ -45,7 +45,7 @@ SIGNATURES = {
     "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dpd_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p]),
     "dpd_gemm_planes": (c_int, [c_int] * 6 + [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_int, c_void_p,
-                                c_void_p, c_int, c_int, c_void_p]),
+                                c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dpd_l1_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "dpd_adam_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                             c_float, c_void_p]),

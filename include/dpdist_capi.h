@@ -177,12 +177,14 @@ int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, in
  * dpd_split_planes writes either or both (rc / r8 may be NULL) from src [R,C] (row stride ld; R, C multiples of 8).
  * dpd_gemm_planes: C [M,N] fp32 = epi(A B), A/B given as planes; a_fmt/b_fmt: 0 = RC (A stored [M,K], B stored
  * [N,K]), 1 = R8 (A stored [K,M], B stored [K,N]); lda/ldb = row stride for RC, M resp. N for R8; K % 32 == 0;
- * epilogue/bias/gate as in dpd_gemm_f32; tile 0 = default.                                                  */
+ * epilogue/bias/gate as in dpd_gemm_f32; tile 0 = default.  out_rc / out_r8 (may be NULL): the result is ALSO
+ * written as np planes, RC [np][M][N] and/or R8 [np][r8_rows/8][N][8] (rows < r8_rows), ready to be an operand of
+ * the next GEMM; C may then be NULL.                                                                       */
 int dpd_split_planes(const float* src, int R, int C, int ld, int np, void* rc, int ld_rc, long rc_plane, void* r8,
                      long r8_plane, void* stream);
 int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const void* A, int lda, long a_plane,
                     const void* B, int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate,
-                    int epilogue, int tile, void* stream);
+                    int epilogue, int tile, void* out_rc, void* out_r8, int r8_rows, void* stream);
 
 /* Tuning knob (the library's only process-wide state; never needed for correctness): GEMM tile / split-K per
  * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3.

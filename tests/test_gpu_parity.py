@@ -502,7 +502,7 @@ def test_gemm_planes(dev, np_, mode, tile):
         _, a = _planes(At, np_, False, True); _, b = _planes(B, np_, False, True)
         args = (np_, 1, 1, M, N, K, L.ptr(a), M, K * M, L.ptr(b), N, K * N)
         c32 = ops.gemm_f32(At, B, transA=True, bias=bias, epilogue=2, tile=8)
-    L.check(lib.dpd_gemm_planes(*args, L.ptr(C), N, L.ptr(bias), None, 2, tile, L.cur_stream()), "dpd_gemm_planes")
+    L.check(lib.dpd_gemm_planes(*args, L.ptr(C), N, L.ptr(bias), None, 2, tile, None, None, 0, L.cur_stream()), "dpd_gemm_planes")
     err = (C.double() - ref).abs().max().item()
     err32 = (c32.double() - ref).abs().max().item()
     if np_ == 3:
@@ -634,3 +634,30 @@ def test_bf16_training_tracks_fp32_over_50_steps(dev):
     rel = np.abs(curves["bf16"] - curves["f32"]) / curves["f32"]
     assert rel.max() <= 0.01, rel.max()
     assert curves["bf16"][-1] < 0.9 * curves["bf16"][0]
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 5])
+@pytest.mark.parametrize("np_", [3, 1])
+def test_gemm_planes_fused_outputs(dev, np_, tile):
+    """The LDS-staged epilogue writes the result as operand planes: bit-identical to splitting the fp32 result."""
+    from dpdist_amd import lib as L
+    M, N, K, R8 = 320, 264, 96, 192
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(dev)
+    B = torch.randn(K, N, generator=g).to(dev)
+    a, _ = _planes(A, np_, True, False)
+    _, b = _planes(B, np_, False, True)
+    C = torch.empty(M, N, device=dev)
+    rc = torch.zeros(np_, M, N, device=dev, dtype=torch.int16)
+    r8 = torch.zeros(np_, R8 // 8, N, 8, device=dev, dtype=torch.int16)
+    L.check(L.load().dpd_gemm_planes(np_, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N, L.ptr(C), N, None, None, 0,
+                                     tile, L.ptr(rc), L.ptr(r8), R8, L.cur_stream()), "dpd_gemm_planes")
+    want_rc, _ = _planes(C, np_, True, False)
+    _, want_r8 = _planes(C[:R8].contiguous(), np_, False, True)
+    assert torch.equal(rc, want_rc)
+    assert torch.equal(r8, want_r8)
+    # planes only (C == NULL)
+    rc2 = torch.zeros_like(rc)
+    L.check(L.load().dpd_gemm_planes(np_, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N, None, N, None, None, 0,
+                                     tile, L.ptr(rc2), None, 0, L.cur_stream()), "dpd_gemm_planes")
+    assert torch.equal(rc2, want_rc)

@@ -10,8 +10,8 @@ from dpdist_amd import lib as L, ops  # noqa: E402
 
 lib = L.load()
 P, I, LG = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
-lib.dpd_split_planes.argtypes = [P, I, I, I, I, P, I, LG, P, LG, P]
-lib.dpd_gemm_planes.argtypes = [I, I, I, I, I, I, P, I, LG, P, I, LG, P, I, P, P, I, I, P]
+
+
 dev = "cuda"
 
 
@@ -45,7 +45,7 @@ def run(mode, M, N, K, np_, tile, iters=20):
         args = (np_, 1, 1, M, N, K, L.ptr(a_r8), M, K * M, L.ptr(b_r8), N, K * N)
         f32 = lambda: ops.gemm_f32(A, B, transA=True, tile=8)
     C = torch.empty(M, N, device=dev)
-    call = lambda: lib.dpd_gemm_planes(*args, L.ptr(C), N, None, None, 0, tile, L.cur_stream())
+    call = lambda: lib.dpd_gemm_planes(*args, L.ptr(C), N, None, None, 0, tile, None, None, 0, L.cur_stream())
     rc = call()
     if rc != 0:
         print(f"{mode} tile {tile}: rc={rc}"); return
