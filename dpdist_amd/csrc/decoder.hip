@@ -21,6 +21,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
             hipStream_t s, float* colsum, const X3Out* out = nullptr);
 int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
                  long r8_plane, hipStream_t s);
+int split_planes_multi(SplitJobs jobs, hipStream_t s);
 
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
@@ -50,28 +51,63 @@ static size_t plane_bytes(int dtype, int Q, int KP, int H) {
     return np * 2 * ((size_t)Q * big + big * H) + 256;
 }
 
+// Apl / Bpl: operand planes that already exist (else the fp32 operand is split into `scr`); out: plane outputs.
 static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                    int ldb, float* C, int ldc, const float* bias, const float* gate, int epilogue, void* ws, size_t ws_bytes,
-                   Scratch scr, hipStream_t s, float* colsum = nullptr) {
+                   Scratch scr, hipStream_t s, float* colsum = nullptr, const void* Apl = nullptr, const void* Bpl = nullptr,
+                   const X3Out* out = nullptr) {
     const int ra = transA ? K : M, ca = transA ? M : K;   // stored shape of A, B
     const int rb = transB ? N : K, cb = transB ? K : N;
     const bool planes_ok = dtype != 0 && !(K % 32) && !(ra & 7) && !(ca & 7) && !(rb & 7) && !(cb & 7) && !(transA && transB);
     if (!planes_ok) {   // exact fp32 (also for shapes the plane kernels do not take)
+        if (Apl || Bpl || out) return DPD_E_UNSUPPORTED;   // callers only pass planes for shapes planes_shape_ok() accepts
         const int split = (dtype == 0) ? g_plan_split[op] : 1;
         return gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, gate, epilogue, colsum ? 1 : split,
                         g_plan_tile[op], ws, ws_bytes, s, colsum);
     }
     const int np = dtype == 1 ? 3 : 1;
     const size_t ae = (size_t)M * K, be = (size_t)K * N;
-    if (!scr.p || scr.bytes < (size_t)np * 2 * (ae + be)) return DPD_E_WORKSPACE;
-    uint16_t* Ap = (uint16_t*)scr.p;
-    uint16_t* Bp = Ap + (size_t)np * ae;
-    if (int rc = split_planes(A, ra, ca, lda, np, transA ? nullptr : Ap, ca, (long)ae, transA ? Ap : nullptr, (long)ae, s)) return rc;
-    if (int rc = split_planes(B, rb, cb, ldb, np, transB ? Bp : nullptr, cb, (long)be, transB ? nullptr : Bp, (long)be, s)) return rc;
+    const size_t need = (size_t)np * 2 * ((Apl ? 0 : ae) + (Bpl ? 0 : be));
+    if (need && (!scr.p || scr.bytes < need)) return DPD_E_WORKSPACE;
+    const uint16_t* Ap = (const uint16_t*)Apl;
+    const uint16_t* Bp = (const uint16_t*)Bpl;
+    uint16_t* cursor = (uint16_t*)scr.p;
+    if (!Ap) {
+        if (!A) return DPD_E_NULL;
+        if (int rc = split_planes(A, ra, ca, lda, np, transA ? nullptr : cursor, ca, (long)ae, transA ? cursor : nullptr, (long)ae, s))
+            return rc;
+        Ap = cursor;
+        cursor += (size_t)np * ae;
+    }
+    if (!Bp) {
+        if (!B) return DPD_E_NULL;
+        if (int rc = split_planes(B, rb, cb, ldb, np, transB ? cursor : nullptr, cb, (long)be, transB ? nullptr : cursor, (long)be, s))
+            return rc;
+        Bp = cursor;
+    }
     // largest tile that still gives the 256 CUs at least ~200 workgroups
     auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     const int tile = blocks(128, 128) >= 200 ? 2 : (blocks(64, 128) >= 200 ? 3 : 5);
-    return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum);
+    return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
+                   out);
+}
+
+// `pl` is honoured only for these shapes (everything the fused producers and the plane GEMMs assume)
+static const dpd_planes* usable_planes(const dpd_planes* pl, int dtype, int Q, int Qb, int KP, int H) {
+    if (!pl || dtype == 0) return nullptr;
+    if ((Q & 7) || (Qb & 31) || (KP & 31) || (H & 63)) return nullptr;
+    return pl;
+}
+static int check_planes(const dpd_planes* pl, int dtype) {
+    if (!pl) return 0;
+    if (pl->np != (dtype == 1 ? 3 : 1)) return DPD_E_DIM;
+    return 0;
+}
+static X3Out make_out(const dpd_planes* pl, void* rc, int rc_rows, void* r8, int r8_rows, int cols) {
+    X3Out o;
+    o.rc = (uint16_t*)rc; o.r8 = (uint16_t*)r8; o.np = pl->np; o.ld_rc = cols; o.r8_rows = r8_rows;
+    o.rc_plane = (long)rc_rows * cols; o.r8_plane = (long)r8_rows * cols;
+    return o;
 }
 
 // ---- output layer: y = h3 W4 + b4 ; pred = clip(y,0,6)/3 * mask.  One wave per row. ----------------------
@@ -370,21 +406,93 @@ extern "C" size_t dpd_workspace_bytes(int Q, int KP, int H, int dtype) {
     return base_ws_bytes(KP, H) + dpd::plane_bytes(dtype, Q, KP, H);
 }
 
+namespace {
+struct PlaneSizes {
+    size_t X_rc, X_r8, h_rc, h_r8, g, W1, W23;
+};
+PlaneSizes plane_sizes(int Q, int Qb, int KP, int H, int np) {
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    PlaneSizes z;
+    z.X_rc = al((size_t)np * 2 * Q * KP); z.X_r8 = al((size_t)np * 2 * Qb * KP);
+    z.h_rc = al((size_t)np * 2 * Q * H);  z.h_r8 = al((size_t)np * 2 * Qb * H);
+    z.g = al((size_t)np * 2 * Qb * H);
+    z.W1 = al((size_t)np * 2 * KP * H);   z.W23 = al((size_t)np * 2 * H * H);
+    return z;
+}
+}  // namespace
+
+extern "C" size_t dpd_planes_bytes(int Q, int Qb, int KP, int H, int dtype, int with_dx) {
+    if (dtype != 1 && dtype != 2) return 0;
+    const PlaneSizes z = plane_sizes(Q, Qb, KP, H, dtype == 1 ? 3 : 1);
+    return z.X_rc + z.X_r8 + 2 * (z.h_rc + z.h_r8) + (with_dx ? 6 : 5) * z.g + (with_dx ? 2 : 1) * z.W1 + 4 * z.W23;
+}
+
+extern "C" int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, int H, int dtype, int with_dx, dpd_planes* out) {
+    if (!mem || !out) return DPD_E_NULL;
+    if (dtype != 1 && dtype != 2) return DPD_E_UNSUPPORTED;
+    if (Q <= 0 || Qb <= 0 || Qb > Q || KP <= 0 || H <= 0) return DPD_E_DIM;
+    if (bytes < dpd_planes_bytes(Q, Qb, KP, H, dtype, with_dx)) return DPD_E_WORKSPACE;
+    const int np = dtype == 1 ? 3 : 1;
+    const PlaneSizes z = plane_sizes(Q, Qb, KP, H, np);
+    char* c = (char*)mem;
+    auto take = [&](size_t n) { void* r = c; c += n; return r; };
+    *out = dpd_planes{};
+    out->np = np; out->Q = Q; out->Qb = Qb;
+    out->X_rc = take(z.X_rc); out->X_r8 = take(z.X_r8);
+    out->h1_rc = take(z.h_rc); out->h1_r8 = take(z.h_r8); out->h2_rc = take(z.h_rc); out->h2_r8 = take(z.h_r8);
+    out->g3_rc = take(z.g); out->g3_r8 = take(z.g); out->g2_rc = take(z.g); out->g2_r8 = take(z.g); out->g1_r8 = take(z.g);
+    out->g1_rc = with_dx ? take(z.g) : nullptr;
+    out->W1_r8 = take(z.W1); out->W2_r8 = take(z.W23); out->W3_r8 = take(z.W23);
+    out->W2_rc = take(z.W23); out->W3_rc = take(z.W23);
+    out->W1_rc = with_dx ? take(z.W1) : nullptr;
+    return 0;
+}
+
+extern "C" int dpd_weights_to_planes(const dpd_decoder_params* p, int KP, int H, const dpd_planes* pl, void* stream) {
+    using namespace dpd;
+    if (!p || !pl || !p->W1p || !p->W2 || !p->W3) return DPD_E_NULL;
+    if (KP <= 0 || H <= 0 || (KP & 7) || (H & 7) || (pl->np != 1 && pl->np != 3)) return DPD_E_UNSUPPORTED;
+    SplitJobs jobs{};
+    auto add = [&](const float* src, int R, void* rc, void* r8) {
+        if (!rc && !r8) return;
+        jobs.j[jobs.n++] = SplitJob{src, (uint16_t*)rc, (uint16_t*)r8, (long)R * H, (long)R * H, R, H, H, H, pl->np, 0};
+    };
+    add(p->W1p, KP, pl->W1_rc, pl->W1_r8);
+    add(p->W2, H, pl->W2_rc, pl->W2_r8);
+    add(p->W3, H, pl->W3_rc, pl->W3_r8);
+    if (!jobs.n) return 0;
+    return split_planes_multi(jobs, (hipStream_t)stream);
+}
+
 extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
                                int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
-                               void* stream) {
+                               const dpd_planes* pl, void* stream) {
     using namespace dpd;
-    if (!X || !mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
+    pl = dpd::usable_planes(pl, dtype, Q, pl ? pl->Qb : 0, KP, H);
+    if ((!X && !(pl && pl->X_rc)) || !mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
+    if (pl && (pl->Q != Q || pl->Qb > Q)) return DPD_E_DIM;
+    if (int rc = dpd::check_planes(pl, dtype)) return rc;
     if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
     if (Q <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
     if ((H & 63) || (KP & 3) || dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const Scratch scr = scratch_of(ws, ws_bytes, KP, H);
-    if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
     // layer 1..3: h = relu(in W + b)   (tf_util.conv2d: conv2d + bias_add + relu, utils/tf_util.py:213-227)
-    if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
-    if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
-    if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
+    if (pl) {   // operands from / results to the persistent planes (no conversion passes)
+        X3Out o1 = make_out(pl, pl->h1_rc, Q, pl->h1_r8, pl->Qb, H), o2 = make_out(pl, pl->h2_rc, Q, pl->h2_r8, pl->Qb, H);
+        const bool w1 = o1.rc || o1.r8, w2 = o2.rc || o2.r8;
+        if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s, nullptr,
+                             pl->X_rc, pl->W1_r8, w1 ? &o1 : nullptr)) return rc;
+        if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s, nullptr,
+                             pl->h1_rc, pl->W2_r8, w2 ? &o2 : nullptr)) return rc;
+        if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s, nullptr,
+                             pl->h2_rc, pl->W3_r8, nullptr)) return rc;
+    } else {
+        if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
+        if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
+        if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
+        if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
+    }
     DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
     DPD_CHECK_LAUNCH();
     return 0;
@@ -393,7 +501,7 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
 extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1,
                                     const float* h2, const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p,
                                     int dtype, float* dy, float* g3, float* g2, float* g1, float* dX,
-                                    const dpd_small_grads* sg, void* ws, size_t ws_bytes, void* stream) {
+                                    const dpd_small_grads* sg, void* ws, size_t ws_bytes, const dpd_planes* pl, void* stream) {
     using namespace dpd;
     if (!dpred || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
@@ -401,7 +509,10 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     if ((H & 63) || (KP & 3) || dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const Scratch scr = scratch_of(ws, ws_bytes, KP, H);
-    if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
+    pl = usable_planes(pl, dtype, pl ? pl->Q : 0, Qb, KP, H);
+    if (pl && pl->Qb != Qb) return DPD_E_DIM;
+    if (int rc = check_planes(pl, dtype)) return rc;
+    if (dtype != 0 && !pl && !scr.p) return DPD_E_WORKSPACE;
     float* db1 = sg ? sg->db1 : nullptr;
     float* db2 = sg ? sg->db2 : nullptr;
     float* db3 = sg ? sg->db3 : nullptr;
@@ -433,6 +544,23 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         }
     }
     // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0];  db2 / db1 = column sums, fused into the epilogue
+    if (pl) {
+        if (pl->g3_rc || pl->g3_r8) {   // g3 comes from the small fused kernel above: one conversion launch for both layouts
+            if (int rc = split_planes(g3, Qb, H, H, pl->np, (uint16_t*)pl->g3_rc, H, (long)Qb * H, (uint16_t*)pl->g3_r8, (long)Qb * H, s))
+                return rc;
+        }
+        X3Out o2 = make_out(pl, pl->g2_rc, Qb, pl->g2_r8, Qb, H), o1 = make_out(pl, dX ? pl->g1_rc : nullptr, Qb, pl->g1_r8, Qb, H);
+        const bool w2 = o2.rc || o2.r8, w1 = o1.rc || o1.r8;
+        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2, pl->g3_rc,
+                             pl->W3_rc, w2 ? &o2 : nullptr)) return rc;
+        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1, pl->g2_rc,
+                             pl->W2_rc, w1 ? &o1 : nullptr)) return rc;
+        if (dX) {
+            if (int rc = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s, nullptr,
+                                 pl->g1_rc, pl->W1_rc, nullptr)) return rc;
+        }
+        return 0;
+    }
     if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2)) return rc;
     if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1)) return rc;
     if (dX) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
@@ -442,7 +570,8 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
 }
 
 extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
-                                       int dtype, float* dW, float* db, void* ws, size_t ws_bytes, void* stream) {
+                                       int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
+                                       void* stream) {
     using namespace dpd;
     if (!act || !g || !dW) return DPD_E_NULL;
     if (layer == 4 && !db) return DPD_E_NULL;
@@ -468,9 +597,15 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     const size_t col_bytes = db ? colsum_ws_floats(Nout, 0) * sizeof(float) : 0;
     if ((slab_bytes + col_bytes) && (!ws || ws_bytes < slab_bytes + col_bytes)) return DPD_E_WORKSPACE;
     const Scratch scr = scratch_of(ws, ws_bytes, Kin > Nout ? Kin : Nout, Nout);
-    if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
+    pl = usable_planes(pl, dtype, pl ? pl->Q : 0, Qb, layer == 1 ? Kin : 32, Nout);
+    if (pl && pl->Qb != Qb) return DPD_E_DIM;
+    if (int rc = check_planes(pl, dtype)) return rc;
+    const void* apl = !pl ? nullptr : (layer == 1 ? pl->X_r8 : (layer == 2 ? pl->h1_r8 : pl->h2_r8));
+    const void* gpl = !pl ? nullptr : (layer == 1 ? pl->g1_r8 : (layer == 2 ? pl->g2_r8 : pl->g3_r8));
+    if (dtype != 0 && !(apl && gpl) && !scr.p) return DPD_E_WORKSPACE;
     // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout]
-    if (int rc = gemm_dt(dtype, op, 1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, ws, slab_bytes, scr, s))
+    if (int rc = gemm_dt(dtype, op, 1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, ws, slab_bytes, scr, s, nullptr,
+                         apl, gpl, nullptr))
         return rc;
     if (!db) return 0;   // bias gradient already produced by dpd_decoder_bwd_data (fused)
     float* part = (float*)((char*)ws + slab_bytes);
@@ -486,18 +621,22 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
 // as well as two 256-tile launches and pay one prologue/epilogue instead of two.
 extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
                                             float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws,
-                                            size_t ws_bytes, void* stream) {
+                                            size_t ws_bytes, const dpd_planes* pl, void* stream) {
     using namespace dpd;
     if (!actA || !gA || !dWA || !actB || !gB || !dWB) return DPD_E_NULL;
     if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
     if (dtype != 0) {   // plane path: two launches (the planes of one GEMM at a time live in the scratch)
         const Scratch scr = scratch_of(ws, ws_bytes, Kin > Nout ? Kin : Nout, Nout);
-        if (!scr.p) return DPD_E_WORKSPACE;
+        pl = usable_planes(pl, dtype, pl ? pl->Q : 0, Qb, 32, Nout);
+        if (pl && pl->Qb != Qb) return DPD_E_DIM;
+        if (int rc = check_planes(pl, dtype)) return rc;
+        const bool have = pl && pl->h1_r8 && pl->g2_r8 && pl->h2_r8 && pl->g3_r8;   // pair = (layer 2, layer 3)
+        if (!have && !scr.p) return DPD_E_WORKSPACE;
         if (int rc = gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, nullptr, 0,
-                             scr, (hipStream_t)stream)) return rc;
+                             scr, (hipStream_t)stream, nullptr, have ? pl->h1_r8 : nullptr, have ? pl->g2_r8 : nullptr, nullptr)) return rc;
         return gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actB, lda, gB, Nout, dWB, Nout, nullptr, nullptr, 0, nullptr, 0, scr,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, nullptr, have ? pl->h2_r8 : nullptr, have ? pl->g3_r8 : nullptr, nullptr);
     }
     int tile = g_plan_tile[OP_BWD_DW23];
     if (tile < 4 || tile > 20) tile = 8;

@@ -110,6 +110,37 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
+// ---- fp32 -> bf16 planes (hi, mid, lo): shared by gemm_x3.hip and the producers that write planes directly ----
+// hipcc lowers the float -> __bf16 cast to the gfx950 hardware conversion (round to nearest even, NaN stays NaN)
+__device__ __forceinline__ unsigned bf16_bits(float x) {
+    const __bf16 h = (__bf16)x;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+
+__device__ __forceinline__ void split3(float a, unsigned (&p)[3]) {
+    p[0] = bf16_bits(a);
+    const float hi = __uint_as_float(p[0] << 16);
+    const bool fin = (__float_as_uint(a) & 0x7f800000u) != 0x7f800000u;   // inf/NaN live in the hi plane only
+    const float r1 = fin ? a - hi : 0.f;
+    p[1] = bf16_bits(r1);
+    const float r2 = r1 - __uint_as_float(p[1] << 16);
+    p[2] = bf16_bits(r2);
+}
+
+// 8 fp32 values -> one 16-byte chunk per plane
+__device__ __forceinline__ void split_chunk(const float (&v)[8], uint4 (&w)[3]) {
+    unsigned u[3][4] = {};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned p[3];
+        split3(v[j], p);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) u[q][j >> 1] |= p[q] << (16 * (j & 1));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) w[q] = make_uint4(u[q][0], u[q][1], u[q][2], u[q][3]);
+}
+
 // optional bf16-plane outputs of a gemm_x3 result (gemm_x3.hip): RC planes [np][M][ld_rc], R8 planes
 // [np][r8_rows/8][N][8] for the rows < r8_rows
 struct X3Out {
@@ -118,6 +149,19 @@ struct X3Out {
     long rc_plane = 0, r8_plane = 0;
     int ld_rc = 0, r8_rows = 0, np = 0;
 };
+
+struct SplitJob {
+    const float* src;
+    uint16_t* rc;
+    uint16_t* r8;
+    long rc_plane, r8_plane;
+    int R, C, ld, ld_rc, np, blk0;   // blk0 = first block of this job in a multi-job launch
+};
+struct SplitJobs {
+    int n;
+    SplitJob j[8];
+};
+
 
 // in-stream GEMM profiler (gemm_f32.hip): event pair around one GEMM (kernel + split-K reduce)
 bool prof_begin(hipStream_t s);

@@ -40,36 +40,6 @@ struct X3Args {
     int ld_rc, r8_rows, np_out;
 };
 
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-    unsigned u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
-__device__ __forceinline__ void split3(float a, unsigned (&p)[3]) {
-    p[0] = bf16_rne(a);
-    const float hi = __uint_as_float(p[0] << 16);
-    const bool fin = (__float_as_uint(a) & 0x7f800000u) != 0x7f800000u;   // inf/NaN live in the hi plane only
-    const float r1 = fin ? a - hi : 0.f;
-    p[1] = bf16_rne(r1);
-    const float r2 = r1 - __uint_as_float(p[1] << 16);
-    p[2] = bf16_rne(r2);
-}
-
-// 8 fp32 values -> one 16-byte chunk per plane
-__device__ __forceinline__ void split_chunk(const float (&v)[8], uint4 (&w)[3]) {
-    unsigned u[3][4] = {};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        unsigned p[3];
-        split3(v[j], p);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) u[q][j >> 1] |= p[q] << (16 * (j & 1));
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) w[q] = make_uint4(u[q][0], u[q][1], u[q][2], u[q][3]);
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -280,8 +250,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
                 const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                 uint4 w[3];
                 split_chunk(v, w);
-                for (int q = 0; q < npo; ++q)
-                    *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)   // compile-time plane index: w[] stays in registers
+                    if (q < npo) *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
             }
         }
     }
@@ -295,8 +266,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
                 for (int j = 0; j < 8; ++j) v[j] = st[(8 * rg + j) * LDW + col];
                 uint4 w[3];
                 split_chunk(v, w);
-                for (int q = 0; q < npo; ++q)
-                    *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < npo) *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
             }
         }
     }
@@ -393,55 +365,68 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
 // fp32 [R, C] (row stride ld) -> np bf16 planes in RC and/or R8 layout.  R % 8 == 0, C % 8 == 0.
 // Block = 256 threads over an 8-row x 256-column strip; HBM-bound (4 B read, 2*np B written per layout).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int R, int C, int ld, int np,
-                                                           uint16_t* __restrict__ rc, int ld_rc, long rc_plane,
-                                                           uint16_t* __restrict__ r8, long r8_plane) {
+__global__ __launch_bounds__(256) void split_planes_kernel(SplitJobs jobs) {
+    int ji = 0;
+    for (int t = 1; t < jobs.n; ++t)
+        if ((int)blockIdx.x >= jobs.j[t].blk0) ji = t;
+    const SplitJob& jb = jobs.j[ji];
+    const int C = jb.C, ld = jb.ld, np = jb.np;
+    const float* __restrict__ src = jb.src;
+    const int blk = blockIdx.x - jb.blk0;
     const int strips = (C + 255) / 256;
-    const int rg = blockIdx.x / strips, c0 = (blockIdx.x % strips) * 256;
+    const int rg = blk / strips, c0 = (blk % strips) * 256;
     const int tid = threadIdx.x;
-    if (r8) {   // thread = one column: 8 rows -> one 16-B chunk per plane
+    if (jb.r8) {   // thread = one column: 8 rows -> one 16-B chunk per plane
         const int c = c0 + tid;
         if (c < C) {
-            unsigned w[3][4] = {};
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                unsigned p[3];
-                split3(src[(size_t)(8 * rg + j) * ld + c], p);
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(8 * rg + j) * ld + c];
+            uint4 w[3];
+            split_chunk(v, w);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) w[q][j >> 1] |= p[q] << (16 * (j & 1));
-            }
-            for (int q = 0; q < np; ++q)
-                *reinterpret_cast<uint4*>(r8 + q * r8_plane + ((size_t)rg * C + c) * 8) = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
+            for (int q = 0; q < 3; ++q)
+                if (q < np) *reinterpret_cast<uint4*>(jb.r8 + q * jb.r8_plane + ((size_t)rg * C + c) * 8) = w[q];
         }
     }
-    if (rc) {   // thread = 8 consecutive columns of one row
+    if (jb.rc) {   // thread = 8 consecutive columns of one row
         const int r = 8 * rg + tid / 32, c = c0 + (tid % 32) * 8;
         if (c < C) {
             const float4 x0 = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
             const float4 x1 = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c + 4);
             const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            unsigned w[3][4] = {};
+            uint4 w[3];
+            split_chunk(v, w);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                unsigned p[3];
-                split3(v[j], p);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) w[q][j >> 1] |= p[q] << (16 * (j & 1));
-            }
-            for (int q = 0; q < np; ++q)
-                *reinterpret_cast<uint4*>(rc + q * rc_plane + (size_t)r * ld_rc + c) = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
+            for (int q = 0; q < 3; ++q)
+                if (q < np) *reinterpret_cast<uint4*>(jb.rc + q * jb.rc_plane + (size_t)r * jb.ld_rc + c) = w[q];
         }
     }
 }
 
+static bool split_job_ok(const SplitJob& j) {
+    return j.src && (j.rc || j.r8) && j.R > 0 && j.C > 0 && !(j.R & 7) && !(j.C & 7) && !(j.ld & 3) && (j.np == 1 || j.np == 3);
+}
+
+// up to 8 independent split jobs in ONE launch (the weight planes of a step)
+int split_planes_multi(SplitJobs jobs, hipStream_t s) {
+    if (jobs.n < 1 || jobs.n > 8) return DPD_E_DIM;
+    int total = 0;
+    for (int t = 0; t < jobs.n; ++t) {
+        if (!split_job_ok(jobs.j[t])) return jobs.j[t].src ? DPD_E_UNSUPPORTED : DPD_E_NULL;
+        jobs.j[t].blk0 = total;
+        total += (jobs.j[t].R / 8) * ((jobs.j[t].C + 255) / 256);
+    }
+    DPD_LAUNCH(split_planes_kernel, dim3(total), dim3(256), 0, s, jobs);
+    return (int)hipGetLastError();
+}
+
 int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
                  long r8_plane, hipStream_t s) {
-    if (!src || (!rc && !r8)) return DPD_E_NULL;
-    if (R <= 0 || C <= 0 || (R & 7) || (C & 7) || (ld & 3) || (np != 1 && np != 3)) return DPD_E_UNSUPPORTED;
-    const int strips = (C + 255) / 256;
-    DPD_LAUNCH(split_planes_kernel, dim3((R / 8) * strips), dim3(256), 0, s, src, R, C, ld, np, rc, ld_rc, rc_plane, r8,
-               r8_plane);
-    return (int)hipGetLastError();
+    SplitJobs jobs{};
+    jobs.n = 1;
+    jobs.j[0] = SplitJob{src, rc, r8, rc_plane, r8_plane, R, C, ld, ld_rc, np, 0};
+    return split_planes_multi(jobs, s);
 }
 
 }  // namespace dpd

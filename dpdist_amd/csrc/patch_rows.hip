@@ -9,7 +9,7 @@
 // (d_axis0, d_axis1, d_axis2) like extract_volume_patches) | q - centre (3) | zero pad ].  Everything is float4
 // aligned (20 channels = 5 float4; KP*4 bytes is a multiple of 16).  HBM-bound: algorithmic bytes per query row
 // = KP*4 written (+ 12 read; fv[c] = 40 KB per cloud is L2 resident and shared by the cloud's 64 rows).
-#include "common.h"
+#include "gemm_shared.h"
 
 namespace dpd {
 
@@ -56,6 +56,89 @@ __global__ __launch_bounds__(128) void patch_rows_fwd_kernel(const float* __rest
         for (int e = E + 3; e < KP; ++e) xr[e] = 0.f;
         mask[r] = valid ? 1.f : 0.f;
         vox[r] = (iy * m + ix) * m + iz;
+    }
+}
+
+// Forward with operand-plane outputs for the bf16-matrix-core decoder (gemm_x3.hip): block = 8 consecutive rows x one
+// half of the float4 column units.  A thread gathers the same float4 unit of the 8 rows, splits the 32 values once and
+// writes them in both chunk orientations: RC (8 bytes = half a chunk per row and plane) and, for the rows that carry
+// gradient (< r8_rows), R8 (4 chunks of 8 rows, 64 contiguous bytes per plane); fp32 X only if requested.
+struct RowInfo {
+    int ix, iy, iz, cloud;
+    float dx, dy, dz;
+};
+
+__global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __restrict__ q, const float* __restrict__ fv,
+                                                                float* __restrict__ X, float* __restrict__ mask,
+                                                                int32_t* __restrict__ vox, int Q, int N, int m, int k, int KP,
+                                                                GridAxis ax, int np, uint16_t* __restrict__ rc, long rc_plane,
+                                                                uint16_t* __restrict__ r8, long r8_plane, int r8_rows) {
+    __shared__ RowInfo s_row[8];
+    const int rg = blockIdx.x >> 1, part2 = blockIdx.x & 1, tid = threadIdx.x;
+    const int G = m * m * m, h = (k - 1) / 2;
+    if (tid < 8) {
+        const int r = 8 * rg + tid;
+        const float qx = q[(size_t)r * 3], qy = q[(size_t)r * 3 + 1], qz = q[(size_t)r * 3 + 2];
+        int ix = cell_of(ax, m, qx), iy = cell_of(ax, m, qy), iz = cell_of(ax, m, qz);
+        const bool valid = (ix >= 0) && (iy >= 0) && (iz >= 0);
+        if (!valid) { ix = 0; iy = 0; iz = 0; }
+        s_row[tid] = RowInfo{ix, iy, iz, r / N, qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz]};
+        if (part2 == 0) {
+            mask[r] = valid ? 1.f : 0.f;
+            vox[r] = (iy * m + ix) * m + iz;
+        }
+    }
+    __syncthreads();
+    const int E4 = k * k * k * (kF / 4), E = E4 * 4, U = KP / 4;
+    const int ubeg = part2 ? (U / 2) : 0, uend = part2 ? U : (U / 2);
+    const bool want_r8 = r8 && (8 * rg < r8_rows);
+    for (int j = ubeg + tid; j < uend; j += 256) {
+        float4 v[8];
+        if (j < E4) {
+            const int nb = j / 5, part = j % 5;
+            const int d0 = nb / (k * k) - h, d1 = (nb / k) % k - h, d2 = nb % k - h;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const RowInfo ri = s_row[rr];
+                const int g0 = ri.iy + d0, g1 = ri.ix + d1, g2 = ri.iz + d2;   // grid axes are (y, x, z), slowest first
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m)
+                    x = *reinterpret_cast<const float4*>(fv + ((size_t)ri.cloud * G + (size_t)((g0 * m + g1) * m + g2)) * kF + part * 4);
+                v[rr] = x;
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const RowInfo ri = s_row[rr];
+                v[rr] = (j == E4) ? make_float4(ri.dx, ri.dy, ri.dz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        (void)E;
+        unsigned pl[8][4][3];   // [row][element][plane]
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const float e[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) split3(e[t], pl[rr][t]);
+            if (X) *reinterpret_cast<float4*>(X + (size_t)(8 * rg + rr) * KP + 4 * j) = v[rr];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {   // compile-time plane index: pl[] stays in registers
+            if (p >= np) break;
+            if (rc) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    *reinterpret_cast<uint2*>(rc + p * rc_plane + (size_t)(8 * rg + rr) * KP + 4 * j) =
+                        make_uint2(pl[rr][0][p] | (pl[rr][1][p] << 16), pl[rr][2][p] | (pl[rr][3][p] << 16));
+            }
+            if (want_r8) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    *reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + 4 * j + t) * 8) =
+                        make_uint4(pl[0][t][p] | (pl[1][t][p] << 16), pl[2][t][p] | (pl[3][t][p] << 16),
+                                   pl[4][t][p] | (pl[5][t][p] << 16), pl[6][t][p] | (pl[7][t][p] << 16));
+            }
+        }
     }
 }
 
@@ -125,12 +208,21 @@ extern "C" int dpd_stack_clouds(const float* pcA, const float* pcB, const float*
 extern "C" int dpd_padded_width(int k) { return (k * k * k * DPD_FV_CHANNELS + 3 + 31) / 32 * 32; }
 
 extern "C" int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
-                                  float* mask, int32_t* vox, void* stream) {
+                                  float* mask, int32_t* vox, const dpd_planes* pl, void* stream) {
     using namespace dpd;
-    if (!q || !fv || !X || !mask || !vox) return DPD_E_NULL;
+    const int Q = C * N;
+    const bool planes = pl && (pl->X_rc || pl->X_r8) && !(Q & 7) && !(pl->Qb & 31) && !(KP & 31);
+    if (!q || !fv || (!X && !planes) || !mask || !vox) return DPD_E_NULL;
     if (C <= 0 || N <= 0) return DPD_E_DIM;
     if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
     if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
+    if (planes) {
+        if ((pl->np != 1 && pl->np != 3) || pl->Q != Q || pl->Qb > Q || pl->Qb < 0) return DPD_E_DIM;
+        DPD_LAUNCH(patch_rows_planes_kernel, dim3((Q / 8) * 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
+                   KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb);
+        DPD_CHECK_LAUNCH();
+        return 0;
+    }
     DPD_LAUNCH(patch_rows_fwd_kernel, dim3(C * N), dim3(128), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
                        KP, make_axis(m));
     DPD_CHECK_LAUNCH();

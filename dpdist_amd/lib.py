@@ -23,6 +23,12 @@ class SmallGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("db1", "db2", "db3", "dW4", "db4")]
 
 
+class Planes(Structure):     # include/dpdist_capi.h: dpd_planes
+    _fields_ = [("np", c_int), ("Q", c_int), ("Qb", c_int)] + [(n, c_void_p) for n in (
+        "X_rc", "X_r8", "h1_rc", "h1_r8", "h2_rc", "h2_r8", "g3_rc", "g3_r8", "g2_rc", "g2_r8", "g1_rc", "g1_r8",
+        "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc")]
+
+
 # name -> (restype, argtypes); mirrors include/dpdist_capi.h one to one
 SIGNATURES = {
     "dpd_version": (c_char_p, []),
@@ -30,18 +36,21 @@ SIGNATURES = {
     "dpd_mfv3d_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "dpd_mfv3d_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "dpd_patch_rows_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                   c_void_p, c_void_p]),
+                                   c_void_p, POINTER(Planes), c_void_p]),
     "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p]),
     "dpd_decoder_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_int, c_void_p,
-                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_decoder_bwd_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      POINTER(DecoderParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     POINTER(SmallGrads), c_void_p, c_size_t, c_void_p]),
+                                     POINTER(SmallGrads), c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_stack_clouds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                        c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
+    "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p]),
+    "dpd_planes_bytes": (c_size_t, [c_int] * 6),
+    "dpd_planes_carve": (c_int, [c_void_p, c_size_t] + [c_int] * 6 + [POINTER(Planes)]),
+    "dpd_weights_to_planes": (c_int, [POINTER(DecoderParams), c_int, c_int, POINTER(Planes), c_void_p]),
     "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dpd_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p]),
     "dpd_gemm_planes": (c_int, [c_int] * 6 + [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_int, c_void_p,

@@ -44,7 +44,7 @@ def patch_rows_fwd(q, fv, m, k, KP=None, out=None):
     else:
         X, mask, vox = out
     L.check(L.load().dpd_patch_rows_fwd(L.ptr(q), L.ptr(fv), C, N, m, k, KP, L.ptr(X), L.ptr(mask), L.ptr(vox),
-                                        L.cur_stream()), "dpd_patch_rows_fwd")
+                                        None, L.cur_stream()), "dpd_patch_rows_fwd")
     return X, mask, vox
 
 
@@ -77,7 +77,7 @@ def decoder_fwd(X, mask, params, H, bufs=None, dtype=0, ws=None):
     if dtype and ws is None:
         ws = workspace(Q, KP, H, X.device, dtype)
     L.check(L.load().dpd_decoder_fwd(L.ptr(X), L.ptr(mask), Q, KP, H, p, dtype, L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(y),
-                                     L.ptr(pred), *_ws_args(ws), L.cur_stream()), "dpd_decoder_fwd")
+                                     L.ptr(pred), *_ws_args(ws), None, L.cur_stream()), "dpd_decoder_fwd")
     return h1, h2, h3, y, pred
 
 
@@ -114,7 +114,7 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None,
         ws = workspace(Qb, KP, H, dev, dtype)
     L.check(L.load().dpd_decoder_bwd_data(L.ptr(dpred), L.ptr(mask), L.ptr(y), L.ptr(h1), L.ptr(h2), L.ptr(h3), Qb, KP, H,
                                           p, dtype, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), sg, *_ws_args(ws),
-                                          L.cur_stream()), "dpd_decoder_bwd_data")
+                                          None, L.cur_stream()), "dpd_decoder_bwd_data")
     return dy, g3, g2, g1, dX
 
 
@@ -127,7 +127,7 @@ def decoder_bwd_weights(layer, act, g, Qb, dW, db, ws, dtype=0):
     """dW/db of one layer from its input activation `act` [>=Qb, Kin] and output gradient `g` [Qb, Nout]."""
     Kin, Nout = dW.shape
     L.check(L.load().dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), Qb, Kin, Nout, L.DTYPES[dtype], L.ptr(dW),
-                                             L.ptr(db), L.ptr(ws), ws.numel() * 4, L.cur_stream()),
+                                             L.ptr(db), L.ptr(ws), ws.numel() * 4, None, L.cur_stream()),
             "dpd_decoder_bwd_weights(layer=%d)" % layer)
 
 

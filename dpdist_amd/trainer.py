@@ -54,6 +54,14 @@ class DPDistTrainer:
         self.m_state = torch.zeros_like(self.grad)
         self.v_state = torch.zeros_like(self.grad)
         self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H, self.dt) + 3) // 4, device=dev, dtype=torch.float32)
+        # bf16-matrix-core compute types: operand planes persist between the kernels (no conversion passes)
+        self._planes = None
+        if self.dt and Q % 8 == 0 and BN % 32 == 0 and KP % 32 == 0:
+            lib = L.load()
+            nbytes = lib.dpd_planes_bytes(Q, BN, KP, H, self.dt, 0)
+            self._plane_mem = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            self._planes = L.Planes()
+            L.check(lib.dpd_planes_carve(L.ptr(self._plane_mem), nbytes, Q, BN, KP, H, self.dt, 0, self._planes), "dpd_planes_carve")
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
         import os
@@ -63,6 +71,13 @@ class DPDistTrainer:
         self._gviews = params.views(self.grad)
         gv = self._gviews
         self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7])
+        self.refresh_weight_planes()
+
+    def refresh_weight_planes(self):
+        """Call after changing the weights from outside (load_tf_state_dict): re-derives the bf16 weight planes."""
+        if self._planes is not None:
+            L.check(L.load().dpd_weights_to_planes(self._cparams, self.P.KP, self.P.H, self._planes, L.cur_stream()),
+                    "dpd_weights_to_planes")
 
     # -- pieces (each enqueues kernels on the current stream; no host sync, no allocation) -----------------
     def _load_batch(self, pcA, pcB, noise):
@@ -74,11 +89,12 @@ class DPDistTrainer:
         lib, s, P = L.load(), L.cur_stream(), self.P
         C, N, Q = 2 * self.B, self.N, 2 * self.B * self.N
         L.check(lib.dpd_mfv3d_fwd(L.ptr(self.pts), C, N, self.m, self.sigma, L.ptr(self.fv), s), "dpd_mfv3d_fwd")
-        L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP, L.ptr(self.X),
-                                       L.ptr(self.mask), L.ptr(self.vox), s), "dpd_patch_rows_fwd")
+        L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP,
+                                       None if self._planes is not None else L.ptr(self.X), L.ptr(self.mask), L.ptr(self.vox),
+                                       self._planes, s), "dpd_patch_rows_fwd")
         L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
                                     L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
-                                    self.ws.numel() * 4, s), "dpd_decoder_fwd")
+                                    self.ws.numel() * 4, self._planes, s), "dpd_decoder_fwd")
 
     def backward(self, labels):
         lib, s, P = L.load(), L.cur_stream(), self.P
@@ -88,12 +104,12 @@ class DPDistTrainer:
         L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
                                          L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
                                          L.ptr(self.g2), L.ptr(self.g1), None, self._csmall, L.ptr(self.ws),
-                                         self.ws.numel() * 4, s), "dpd_decoder_bwd_data")
+                                         self.ws.numel() * 4, self._planes, s), "dpd_decoder_bwd_data")
         d, wsb = self._gviews, self.ws.numel() * 4
 
         def dw(layer, act, g, dW):
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
-                                                L.ptr(dW), None, L.ptr(self.ws), wsb, L.cur_stream()),
+                                                L.ptr(dW), None, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
         dw(1, self.X, self.g1, d[0])
@@ -101,7 +117,7 @@ class DPDistTrainer:
             self.reducer.reduce_async(0)      # bucket 0 = dW1p + db1 (db1 was finished by the data chain)
         if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
             L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
-                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, L.cur_stream()),
+                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
                     "dpd_decoder_bwd_weights_pair")
         else:
             dw(2, self.h1, self.g2, d[2])
@@ -120,6 +136,7 @@ class DPDistTrainer:
             gscale = self.reducer.grad_scale
         L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                      self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
+        self.refresh_weight_planes()
 
     @torch.no_grad()
     def step(self, pcA, pcB, labels, noise=None):

@@ -71,8 +71,11 @@ int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, int m, float
  * get_pc_grid_binary_mask_from_centers (:459-492) and get_emb_and_concat (:434-457) WITHOUT
  * materialising the [C,m^3,k^3*20] window tensor.
  *   q [C,N,3], fv [C,m^3,20] -> X [Q,KP] rows, mask [Q] (1/0), vox [Q] (voxel id, 0 if outside). */
+struct dpd_planes;   /* bf16 operand planes that persist between entry points; defined with the decoder below */
+/* `pl` (may be NULL): also write X as operand planes pl->X_rc (all rows) and pl->X_r8 (rows < pl->Qb), so that
+ * the decoder GEMMs of a bf16-matrix-core compute type need no separate conversion pass; X may then be NULL.  */
 int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
-                       float* mask, int32_t* vox, void* stream);
+                       float* mask, int32_t* vox, const struct dpd_planes* pl, void* stream);
 
 /* Backward of the gather: dX [Q,KP] -> dq [C,N,3] (overwritten; = dX[:,E:E+3]) and
  * dfv [C,m^3,20] (overwritten; scatter-add of the window columns).  Either output may be NULL.  */
@@ -94,7 +97,7 @@ typedef struct dpd_decoder_params {
 
 int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
                     int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
-                    void* stream);
+                    const dpd_planes* pl, void* stream);
 
 /* `dtype` of the decoder entry points = compute type of the three wide layers (inputs/outputs are always fp32):
  *   DPD_F32     exact fp32 on the fp32 matrix-core instruction (bitwise an fmaf chain), no workspace needed in
@@ -106,6 +109,32 @@ int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, con
  * DPD_F32_X3 / DPD_BF16 need ws = dpd_workspace_bytes(Q, KP, H, dtype) bytes (operand planes).  Shapes the plane
  * kernels do not take (contraction length not a multiple of 32, dims not multiples of 8) run as DPD_F32.       */
 enum dpd_dtype { DPD_F32 = 0, DPD_F32_X3 = 1, DPD_BF16 = 2 };
+
+/* Operand planes that persist between entry points (caller-owned memory; see dpd_planes_bytes / dpd_planes_carve).
+ * Layouts as in dpd_split_planes: RC = [np][rows][cols] bf16, R8 = [np][rows/8][cols][8].  A NULL member means
+ * "not kept": its producer skips it and its consumers convert from the fp32 tensor into `ws` instead.  A non-NULL
+ * member handed to a CONSUMER must hold what its producer wrote for the current tensors:
+ *   producer                         members
+ *   dpd_patch_rows_fwd               X_rc [Q,KP], X_r8 (rows < Qb)
+ *   dpd_decoder_fwd                  h1_rc, h2_rc [Q,H]; h1_r8, h2_r8 (rows < Qb)          consumes X_rc, W*_r8
+ *   dpd_decoder_bwd_data             g3_rc, g3_r8, g2_rc, g2_r8, g1_rc, g1_r8 [Qb,H]       consumes W*_rc
+ *   dpd_weights_to_planes            W1_r8, W2_r8, W3_r8 (forward), W1_rc, W2_rc, W3_rc (backward dH / dX)
+ *   dpd_decoder_bwd_weights[_pair]   -                                                     consumes X_r8/h*_r8, g*_r8
+ * Planes are only used when Q % 8 == 0, Qb % 32 == 0, KP % 32 == 0 (otherwise `pl` is ignored).              */
+typedef struct dpd_planes {
+    int np;       /* 3 for DPD_F32_X3, 1 for DPD_BF16 */
+    int Q, Qb;    /* rows of X/h1/h2 planes; rows that carry gradient (R8 planes of X/h*, all g planes) */
+    void *X_rc, *X_r8, *h1_rc, *h1_r8, *h2_rc, *h2_r8;
+    void *g3_rc, *g3_r8, *g2_rc, *g2_r8, *g1_rc, *g1_r8;
+    void *W1_r8, *W2_r8, *W3_r8, *W1_rc, *W2_rc, *W3_rc;
+} dpd_planes;
+
+/* Bytes for ALL members (with_dx: also g1_rc and W1_rc, needed only when dX is requested), and the carve-up of one
+ * caller buffer of that size into the members (host-side pointer arithmetic only).                          */
+size_t dpd_planes_bytes(int Q, int Qb, int KP, int H, int dtype, int with_dx);
+int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, int H, int dtype, int with_dx, dpd_planes* out);
+/* Weight planes from the fp32 variables (one launch): call after loading weights and after every optimizer step. */
+int dpd_weights_to_planes(const dpd_decoder_params* p, int KP, int H, const dpd_planes* pl, void* stream);
 
 /* Backward, data chain: dpred [Qb,3] for the FIRST Qb rows (training mode: Qb = Q/2, only the AB half
  * carries gradient, train_multi_gpu_pc_compare_dist.py:274-277; as-loss mode: Qb = Q).
@@ -121,7 +150,7 @@ typedef struct dpd_small_grads {
 int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,
                          const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p, int dtype,
                          float* dy, float* g3, float* g2, float* g1, float* dX, const dpd_small_grads* sg,
-                         void* ws, size_t ws_bytes, void* stream);
+                         void* ws, size_t ws_bytes, const dpd_planes* pl, void* stream);
 
 /* Backward, weight gradients of ONE layer (1..4) from the buffers above:
  *   layer 1: dW [KP,H] = X^T g1, db = colsum(g1);  2: h1^T g2;  3: h2^T g3;  4: dW [H,3] = h3^T dy.
@@ -129,13 +158,14 @@ int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, 
  * pre-activation output gradient.  dW/db are overwritten; db may be NULL for layers 1-3 when it was already
  * produced by dpd_decoder_bwd_data.  ws: dpd_workspace_bytes() bytes.                              */
 int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
-                            int dtype, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+                            int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
+                            void* stream);
 
 /* dW of two layers of identical shape (layers 2 and 3: dW = act^T g, [Kin,Nout]) in ONE grouped launch; no bias
  * gradients (they come from dpd_decoder_bwd_data).  Qb must be a multiple of 32.                          */
 int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
                                  float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws, size_t ws_bytes,
-                                 void* stream);
+                                 const dpd_planes* pl, void* stream);
 
 /* Scratch needed by the decoder entry points for the given sizes and compute type (split-K slabs, column-sum
  * partials and, for dtype != DPD_F32, the bf16 operand planes of one GEMM at a time).                   */

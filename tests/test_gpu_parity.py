@@ -661,3 +661,33 @@ def test_gemm_planes_fused_outputs(dev, np_, tile):
     L.check(L.load().dpd_gemm_planes(np_, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N, None, N, None, None, 0,
                                      tile, L.ptr(rc2), None, 0, L.cur_stream()), "dpd_gemm_planes")
     assert torch.equal(rc2, want_rc)
+
+
+@pytest.mark.parametrize("np_", [3, 1])
+def test_patch_rows_planes_match_split(dev, np_):
+    """The window gather writes X directly as operand planes: bit-identical to converting the fp32 rows."""
+    from dpdist_amd import lib as L, ops
+    B, N, m, k = 4, 64, 8, 5
+    pcA, pcB = synth.s1_random_patches(B, N, 3)
+    pts, q = ops.stack_clouds(_cu(pcA, dev), _cu(pcB, dev))
+    fv = ops.mfv3d_fwd(pts, m, 0.125)
+    X, mask, vox = ops.patch_rows_fwd(q, fv, m, k)
+    Q, KP, Qb = X.shape[0], X.shape[1], X.shape[0] // 2
+    lib = L.load()
+    dt = 1 if np_ == 3 else 2
+    nbytes = lib.dpd_planes_bytes(Q, Qb, KP, 1024, dt, 0)
+    mem = torch.zeros(nbytes, device=dev, dtype=torch.uint8)
+    pl = L.Planes()
+    L.check(lib.dpd_planes_carve(L.ptr(mem), nbytes, Q, Qb, KP, 1024, dt, 0, pl), "carve")
+    X2, mask2, vox2 = torch.zeros_like(X), torch.zeros_like(mask), torch.zeros_like(vox)
+    L.check(lib.dpd_patch_rows_fwd(L.ptr(q), L.ptr(fv), 2 * B, N, m, k, KP, L.ptr(X2), L.ptr(mask2), L.ptr(vox2), pl,
+                                   L.cur_stream()), "dpd_patch_rows_fwd")
+    assert torch.equal(X2, X) and torch.equal(mask2, mask) and torch.equal(vox2, vox)
+    want_rc, _ = _planes(X, np_, True, False)
+    _, want_r8 = _planes(X[:Qb].contiguous(), np_, False, True)
+    off = pl.X_rc - mem.data_ptr()
+    got_rc = mem[off:off + np_ * Q * KP * 2].view(torch.int16).view(np_, Q, KP)
+    off = pl.X_r8 - mem.data_ptr()
+    got_r8 = mem[off:off + np_ * Qb * KP * 2].view(torch.int16).view(np_, Qb // 8, KP, 8)
+    assert torch.equal(got_rc, want_rc)
+    assert torch.equal(got_r8, want_r8)

@@ -45,7 +45,12 @@ def run(mode, M, N, K, np_, tile, iters=20):
         args = (np_, 1, 1, M, N, K, L.ptr(a_r8), M, K * M, L.ptr(b_r8), N, K * N)
         f32 = lambda: ops.gemm_f32(A, B, transA=True, tile=8)
     C = torch.empty(M, N, device=dev)
-    call = lambda: lib.dpd_gemm_planes(*args, L.ptr(C), N, None, None, 0, tile, None, None, 0, L.cur_stream())
+    import os
+    outs = os.environ.get("OUTS", "")
+    o_rc = torch.empty(np_, M, N, device=dev, dtype=torch.int16) if "rc" in outs else None
+    o_r8 = torch.empty(np_, M // 8, N, 8, device=dev, dtype=torch.int16) if "r8" in outs else None
+    call = lambda: lib.dpd_gemm_planes(*args, L.ptr(C) if "noc" not in outs else None, N, None, None, 0, tile, L.ptr(o_rc), L.ptr(o_r8),
+                                       M if o_r8 is not None else 0, L.cur_stream())
     rc = call()
     if rc != 0:
         print(f"{mode} tile {tile}: rc={rc}"); return
