@@ -18,7 +18,8 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
-            hipStream_t s, float* colsum, const X3Out* out = nullptr);
+            hipStream_t s, float* colsum, const X3Out* out = nullptr, const uint16_t* A2 = nullptr, const uint16_t* B2 = nullptr,
+            float* C2 = nullptr);
 int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
                  long r8_plane, hipStream_t s);
 int split_planes_multi(SplitJobs jobs, hipStream_t s);
@@ -87,7 +88,9 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     }
     // largest tile that still gives the 256 CUs at least ~200 workgroups
     auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    const int tile = blocks(128, 128) >= 200 ? 2 : (blocks(64, 128) >= 200 ? 3 : 5);
+    // (measured, tools/x3_bench.py: 160 blocks of 128x128 beat 320 of 64x128 on the 2528x1024 dW1; 64x64 only when even
+    //  64x128 leaves most CUs idle)
+    const int tile = blocks(128, 128) >= 150 ? 2 : (blocks(64, 128) >= 100 ? 3 : 5);
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
                    out);
 }
@@ -633,6 +636,12 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
         if (int rc = check_planes(pl, dtype)) return rc;
         const bool have = pl && pl->h1_r8 && pl->g2_r8 && pl->h2_r8 && pl->g3_r8;   // pair = (layer 2, layer 3)
         if (!have && !scr.p) return DPD_E_WORKSPACE;
+        if (have) {   // both GEMMs in ONE grouped launch of 64x128 tiles: 2 x 128 workgroups fill the chip in one round
+            const long pe = (long)Kin * Qb, ge = (long)Qb * Nout;
+            return gemm_x3(pl->np, 1, 1, Kin, Nout, Qb, (const uint16_t*)pl->h1_r8, Kin, pe, (const uint16_t*)pl->g2_r8, Nout, ge, dWA, Nout,
+                           nullptr, nullptr, 0, 3, (hipStream_t)stream, nullptr, nullptr, (const uint16_t*)pl->h2_r8,
+                           (const uint16_t*)pl->g3_r8, dWB);
+        }
         if (int rc = gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, nullptr, 0,
                              scr, (hipStream_t)stream, nullptr, have ? pl->h1_r8 : nullptr, have ? pl->g2_r8 : nullptr, nullptr)) return rc;
         return gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actB, lda, gB, Nout, dWB, Nout, nullptr, nullptr, 0, nullptr, 0, scr,

@@ -38,6 +38,10 @@ struct X3Args {
     uint16_t* out_r8;        // R8 planes [np_out][r8_rows/8][N][8], rows < r8_rows only (C as a k = row operand)
     long rc_plane, r8_plane;
     int ld_rc, r8_rows, np_out;
+    // optional second problem of identical shape and layout (grouped launch): blocks [per_z, 2*per_z)
+    const uint16_t* A2;
+    const uint16_t* B2;
+    float* C2;
 };
 
 template <int N>
@@ -74,8 +78,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     const int M = g.e.M, N = g.e.N;
     const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
     const int per_z = tilesM * tilesN;
-    const int sid = xcd_remap(blockIdx.x, per_z * g.e.split_k);
+    const int sid0 = xcd_remap(blockIdx.x, per_z * g.e.split_k * (g.A2 ? 2 : 1));
+    const int grp = sid0 / (per_z * g.e.split_k);
+    const int sid = sid0 % (per_z * g.e.split_k);
     const int z = sid / per_z, t = sid % per_z;
+    const uint16_t* gA = grp ? g.A2 : g.A;
+    const uint16_t* gB = grp ? g.B2 : g.B;
     const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
     const int kbeg = z * g.e.k_chunk;
     const int kend = min(g.e.K, kbeg + g.e.k_chunk);
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         const bool isA = w < PA;
         const int c = isA ? w : w - PA;
         const bool kc = isA ? AK : BKC;
-        const uint16_t* base = isA ? g.A + plane * g.a_plane : g.B + plane * g.b_plane;
+        const uint16_t* base = isA ? gA + plane * g.a_plane : gB + plane * g.b_plane;
         const int ld = isA ? g.lda : g.ldb;
         const int o0 = isA ? m0 : n0;
         const int O = isA ? M : N;
@@ -215,10 +223,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         }
     }
     if (!g.out_rc && !g.out_r8) {
+        GemmArgs ge = g.e;
+        if (grp) ge.C = g.C2;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) store_tile(g.e, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
+            for (int j = 0; j < TN; ++j) store_tile(ge, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
         return;
     }
     // Plane outputs: the finished tile is staged through the (now idle) LDS ring as fp32 [BM][BN+4] and re-read in
@@ -289,7 +299,7 @@ static int launch_x3(const X3Args& g, hipStream_t s) {
             done = true;
         }
     }
-    const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * g.e.split_k;
+    const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * g.e.split_k * (g.A2 ? 2 : 1);
     DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
     return (int)hipGetLastError();
 }
@@ -325,7 +335,8 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
 // C[M,N] (fp32) = epi( op(A) op(B) ) from bf16 planes.  a_fmt/b_fmt: 0 = RC (k contiguous), 1 = R8 (k = row index).
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
-            hipStream_t s, float* colsum, const X3Out* out) {
+            hipStream_t s, float* colsum, const X3Out* out, const uint16_t* A2, const uint16_t* B2, float* C2) {
+    if (A2 && (!B2 || !C2 || out || colsum || epilogue != EPI_NONE)) return DPD_E_UNSUPPORTED;
     const bool planes_out = out && (out->rc || out->r8);
     if (!A || !B || (!C && !planes_out)) return DPD_E_NULL;
     if (planes_out && ((out->np != 1 && out->np != 3) || (M & 7) || (N & 7) || (out->r8_rows & 7) || (out->rc && (out->ld_rc & 7))))
@@ -342,6 +353,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     g.e.M = M; g.e.N = N; g.e.K = K; g.e.ldc = ldc; g.e.epi = epilogue;
     g.e.split_k = 1; g.e.k_chunk = K; g.e.slab_stride = 0;
     g.A = A; g.B = B; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
+    g.A2 = A2; g.B2 = B2; g.C2 = C2;
     if (planes_out) {
         g.out_rc = out->rc; g.out_r8 = out->r8; g.rc_plane = out->rc_plane; g.r8_plane = out->r8_plane;
         g.ld_rc = out->ld_rc; g.r8_rows = out->r8_rows; g.np_out = out->np;
@@ -350,7 +362,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     struct ProfScope {
         bool on; hipStream_t s; double fl;
         ~ProfScope() { prof_end(on, s, fl); }
-    } prof_scope{prof_begin(s), s, 2.0 * M * N * K};
+    } prof_scope{prof_begin(s), s, 2.0 * M * N * K * (A2 ? 2 : 1)};
     if (np == 3) {
         if (!a_fmt && b_fmt) return launch_x3_tile<3, true, false>(tile, g, s);     // NN
         if (!a_fmt && !b_fmt) return launch_x3_tile<3, true, true>(tile, g, s);     // NT
@@ -444,5 +456,5 @@ extern "C" int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K
     o.rc = (uint16_t*)out_rc; o.r8 = (uint16_t*)out_r8; o.np = np; o.ld_rc = N; o.r8_rows = r8_rows;
     o.rc_plane = (long)M * N; o.r8_plane = (long)r8_rows * N;
     return dpd::gemm_x3(np, a_fmt, b_fmt, M, N, K, (const uint16_t*)A, lda, a_plane, (const uint16_t*)B, ldb, b_plane, C, ldc,
-                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr);
+                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr, nullptr, nullptr, nullptr);
 }
