@@ -248,6 +248,93 @@ __global__ __launch_bounds__(256) void out_bwd_fused_kernel(const float* __restr
     for (int i = threadIdx.x; i < 4 * H + 3; i += 256) out[i] = s_acc[i];
 }
 
+// Same contract as out_bwd_fused_kernel for H % 256 == 0, H <= 1024: a lane owns 4 consecutive columns in each
+// 256-column group (float4 loads/stores, both rows of a wave in flight together) and the four waves' partials are
+// combined with ONE barrier (each wave has its own LDS slab).  LDS: 4 * (4H + 4) floats.
+__global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __restrict__ dpred, const float* __restrict__ mask,
+                                                              const float* __restrict__ y, const float* __restrict__ h3,
+                                                              const float* __restrict__ W4, float* __restrict__ dy,
+                                                              float* __restrict__ g3, int Qb, int H, ZeroList zl,
+                                                              float* __restrict__ scratch) {
+    extern __shared__ float s_acc[];   // [4 waves][4H + 4]
+    if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
+        for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ng = H / 256;            // column groups (<= 4)
+    const int P = 4 * H + 4;
+    constexpr int RW = kOBRows / 4;    // rows per wave
+    float w4[4][4][3], s3[4][4], a4[4][4][3];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s3[jj][e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a4[jj][e][c] = 0.f;
+                w4[jj][e][c] = (jj < ng) ? W4[(256 * jj + 4 * lane + e) * 3 + c] : 0.f;
+            }
+        }
+    float dsum[3] = {0.f, 0.f, 0.f};
+    float d[RW][3];
+    float4 hv[RW][4];
+    const int row0 = blockIdx.x * kOBRows + wave * RW;
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int row = min(row0 + rr, Qb - 1);
+        const bool live = row0 + rr < Qb;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float yv = y[(size_t)row * 3 + c];
+            d[rr][c] = (live && yv > 0.f && yv < 6.f) ? dpred[(size_t)row * 3 + c] * mask[row] / 3.0f : 0.f;   // relu6' = 1 on (0,6)
+            dsum[c] += d[rr][c];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (jj < ng) hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int row = row0 + rr;
+        if (row >= Qb) break;
+        if (lane < 3) dy[(size_t)row * 3 + lane] = d[rr][lane];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (jj < ng) {
+                const float hh[4] = {hv[rr][jj].x, hv[rr][jj].y, hv[rr][jj].z, hv[rr][jj].w};
+                float gg[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = d[rr][0] * w4[jj][e][0] + d[rr][1] * w4[jj][e][1] + d[rr][2] * w4[jj][e][2];
+                    gg[e] = (hh[e] > 0.f) ? v : 0.f;
+                    s3[jj][e] += gg[e];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) a4[jj][e][c] += hh[e] * d[rr][c];
+                }
+                *reinterpret_cast<float4*>(g3 + (size_t)row * H + 256 * jj + 4 * lane) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+            }
+        }
+    }
+    float* mine = s_acc + wave * P;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (jj < ng) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 256 * jj + 4 * lane + e;
+                mine[k] = s3[jj][e];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mine[H + k * 3 + c] = a4[jj][e][c];
+            }
+        }
+    }
+    if (lane < 3) mine[4 * H + lane] = (lane == 0) ? dsum[0] : ((lane == 1) ? dsum[1] : dsum[2]);
+    __syncthreads();
+    float* out = scratch + (size_t)blockIdx.x * P;
+    for (int i = threadIdx.x; i < 4 * H + 3; i += 256) out[i] = ((s_acc[i] + s_acc[P + i]) + s_acc[2 * P + i]) + s_acc[3 * P + i];
+}
+
 // out[i] = sum_b scratch[b][i] in a fixed order: 16 outputs x 16 block-slices per workgroup, LDS tree at the end
 __global__ __launch_bounds__(256) void small_grads_reduce(const float* __restrict__ scratch, int nblk, int H,
                                                            float* __restrict__ db3, float* __restrict__ dW4,
@@ -526,8 +613,20 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     if (fused) {
         // one pass over h3: dy, g3 and block partials of db3 / dW4 / db4 (g2 is free until the first dH GEMM: scratch)
         ZeroList zl{{db1, db2, nullptr, nullptr, nullptr}, {H, H, 0, 0, 0}};
-        DPD_LAUNCH(out_bwd_fused_kernel, dim3(nblk), dim3(256), (size_t)(4 * H + 4) * sizeof(float), s, dpred, mask, y, h3,
-                   p->W4, dy, g3, Qb, H, zl, g2);
+        if (H % 256 == 0 && H <= 1024) {
+            const size_t lds = (size_t)4 * (4 * H + 4) * sizeof(float);
+            if (lds > 64 * 1024) {
+                static bool done = false;
+                if (!done) {
+                    DPD_HIP(hipFuncSetAttribute((const void*)out_bwd_fused4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    done = true;
+                }
+            }
+            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, g2);
+        } else {
+            DPD_LAUNCH(out_bwd_fused_kernel, dim3(nblk), dim3(256), (size_t)(4 * H + 4) * sizeof(float), s, dpred, mask, y, h3,
+                       p->W4, dy, g3, Qb, H, zl, g2);
+        }
         DPD_CHECK_LAUNCH();
         DPD_LAUNCH(small_grads_reduce, dim3((4 * H + 3 + 15) / 16), dim3(256), 0, s, (const float*)g2, nblk, H, db3, dW4, db4);
         DPD_CHECK_LAUNCH();

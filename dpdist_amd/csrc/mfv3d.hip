@@ -55,7 +55,8 @@ __device__ __forceinline__ float pnorm(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Forward kernel: one workgroup of 1024 threads (16 waves = 4 per SIMD) per cloud.
+// Forward: kSlices workgroups of 1024 threads per cloud (each owns a contiguous slice of the Gaussians), then a
+// small normalisation kernel.  64 clouds alone would occupy 64 of the 256 CUs; sliced, the chip is full at B = 32.
 //
 // The Gaussians have diagonal covariance on a product grid, so the responsibility factorises exactly:
 //     Q_ng = w p_ng / sum_g' w p_ng' = (ex[n][j]/Sx[n]) * (ey[n][i]/Sy[n]) * (ez[n][t]/Sz[n]),
@@ -65,27 +66,27 @@ __device__ __forceinline__ float pnorm(float x) {
 // if w*p_ng underflows to 0 for EVERY Gaussian of some point (0/0 at :74) the whole descriptor is NaN.
 //
 //   tables  zq[a][n][i] = { z = (p[n][a]-l_i)/sigma , q = e/S }  (float2, one ds_read_b64 per axis per pair)
-//   pass 2  wave <-> 32 Gaussians; lane&31 <-> Gaussian, lane>>5 <-> half of the points; 20 running statistics in
-//           registers; the two halves are merged with one __shfl_xor(.,32) per statistic
-//   norm    power-1/2, per-channel L2 over the Gaussian axis (shuffle within the wave, LDS across the 16 waves)
-//   store   staged through LDS [G][21] (conflict free), coalesced float4 stores
-// dynamic LDS (floats): zq[3*N*m*2] | S[3*N] | minz2[3*N] | stage[G*21] | chred[16*20] | scale[20] | flag
+//   pass 2  lane&7 <-> Gaussian (8 per wave), lane>>3 <-> one eighth of the points; 20 running statistics in registers;
+//           the eight point groups are merged with three __shfl_xor per statistic
+//   store   power-1/2 values staged through LDS [slice][21] (conflict free), coalesced float4 stores (NaN if 0/0)
+//   norm    mfv3d_norm_kernel: per-channel L2 over the Gaussian axis (:124-126), fixed summation order
+// dynamic LDS (floats): zq[3*N*m*2] | S[3*N] | minz2[3*N] | stage[slice*21] | flag
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kFwdThreads = 1024;
+constexpr int kSlices = 4;
 
 __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __restrict__ pts, float* __restrict__ fv,
-                                                                 MfvConst k) {
+                                                                 MfvConst k, int gslice) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = k.N, G = k.G, m = k.m;
     float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][N][m]
     float* s_S = sm + 6 * N * m;                    // [3][N]
     float* s_mz = s_S + 3 * N;                      // [3][N] min_i z^2
-    float* s_stage = s_mz + 3 * N;                  // [G][21]
-    float* s_chred = s_stage + G * kFP;             // [16][20]
-    float* s_scale = s_chred + 16 * kF;             // [20]
-    int* s_bad = reinterpret_cast<int*>(s_scale + kF);
+    float* s_stage = s_mz + 3 * N;                  // [gslice][21]
+    int* s_bad = reinterpret_cast<int*>(s_stage + gslice * kFP);
 
-    const int tid = threadIdx.x, c = blockIdx.x;
+    const int tid = threadIdx.x, c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
+    const int g0 = sl * gslice, gcount = max(0, min(G, g0 + gslice) - g0);
     const int lane = tid & 63, wave = tid >> 6;
     const float* p = pts + (size_t)c * N * 3;
     if (tid == 0) *s_bad = 0;
@@ -119,23 +120,20 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
     const float2* zqz = s_zq + 2 * N * m;
 
     // ---- per-Gaussian statistics over the points ---------------------------------------------------------------
-    float chsq[kF];
-#pragma unroll
-    for (int f = 0; f < kF; ++f) chsq[f] = 0.f;
     const float invN = 1.0f / (float)N;
     const float inv_dpi = 1.0f / k.dpi_den;
-    const int hpts = (N + 1) / 2;
-    const int half = lane >> 5;
-    for (int gbase = wave * 32; gbase < G; gbase += 16 * 32) {
-        const int g = gbase + (lane & 31);
-        const bool live = g < G;
-        const int gg = live ? g : 0;
+    const int npg = (N + 7) / 8;
+    const int grp = lane >> 3;
+    for (int gbase = wave * 8; gbase < gcount; gbase += 16 * 8) {
+        const int gl = gbase + (lane & 7);
+        const bool live = gl < gcount;
+        const int gg = live ? g0 + gl : 0;
         const int i = gg / (m * m), j = (gg / m) % m, t = gg % m;   // centre (x,y,z) = (l[j], l[i], l[t])  (:47-48)
         float pi_s = 0.f, pi_mx = -INFINITY;
         float mu_s[3] = {0.f, 0.f, 0.f}, mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
         float sg_s[3] = {0.f, 0.f, 0.f}, sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
-        const int n1 = min(N, (half + 1) * hpts);
-        for (int n = half * hpts; n < n1; ++n) {
+        const int n1 = min(N, (grp + 1) * npg);
+        for (int n = grp * npg; n < n1; ++n) {
             const float2 vx = zqx[n * m + j], vy = zqy[n * m + i], vz = zqz[n * m + t];
             const float z[3] = {vx.x, vy.x, vz.x};
             const float Q = (vx.y * vy.y) * vz.y;                              // :73-74, factorised
@@ -150,19 +148,22 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
                 sg_s[d] += b; sg_mx[d] = fmaxf(sg_mx[d], b); sg_mn[d] = fminf(sg_mn[d], b);
             }
         }
-        // merge the two point halves (lanes l and l^32 hold the same Gaussian)
-        pi_s += __shfl_xor(pi_s, 32, 64);
-        pi_mx = fmaxf(pi_mx, __shfl_xor(pi_mx, 32, 64));
+        // merge the eight point groups (lanes l, l^8, l^16, l^32 ... hold the same Gaussian)
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            mu_s[d] += __shfl_xor(mu_s[d], 32, 64);
-            sg_s[d] += __shfl_xor(sg_s[d], 32, 64);
-            mu_mx[d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], 32, 64));
-            mu_mn[d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], 32, 64));
-            sg_mx[d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], 32, 64));
-            sg_mn[d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], 32, 64));
+        for (int o = 8; o < 64; o <<= 1) {
+            pi_s += __shfl_xor(pi_s, o, 64);
+            pi_mx = fmaxf(pi_mx, __shfl_xor(pi_mx, o, 64));
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                mu_s[d] += __shfl_xor(mu_s[d], o, 64);
+                sg_s[d] += __shfl_xor(sg_s[d], o, 64);
+                mu_mx[d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], o, 64));
+                mu_mn[d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], o, 64));
+                sg_mx[d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], o, 64));
+                sg_mn[d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], o, 64));
+            }
         }
-        if (live && half == 0) {
+        if (live && grp == 0) {
             float v[kF];
             v[0] = pi_s * invN;                                                 // :81 reduce_mean
             v[1] = pi_mx;                                                       // :80
@@ -176,42 +177,54 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
                 v[17 + d] = sg_mn[d] * k.sig_scale;
             }
 #pragma unroll
-            for (int f = 0; f < kF; ++f) {
-                const float s = pnorm(v[f]);
-                s_stage[g * kFP + f] = s;
-                chsq[f] += s * s;
-            }
+            for (int f = 0; f < kF; ++f) s_stage[gl * kFP + f] = pnorm(v[f]);   // power-1/2 (:119-121)
         }
     }
+    __syncthreads();
 
-    // ---- L2 normalisation over the Gaussian axis, per channel (:124-126) ---------------------------------------
-#pragma unroll
-    for (int f = 0; f < kF; ++f) {
-        const float s = wave_sum(chsq[f]);
-        if (lane == 0) s_chred[wave * kF + f] = s;
+    // ---- coalesced store of the slice: fv[c][g0 + g][f], 4 consecutive f of one g per thread --------------------
+    float* out = fv + ((size_t)c * G + g0) * kF;
+    const bool bad = *s_bad != 0;
+    const float qnan = __int_as_float(0x7fc00000);
+    for (int i4 = tid; i4 < gcount * kF / 4; i4 += kFwdThreads) {
+        const int e = i4 * 4, g = e / kF, f = e % kF;
+        float4 o = make_float4(s_stage[g * kFP + f], s_stage[g * kFP + f + 1], s_stage[g * kFP + f + 2], s_stage[g * kFP + f + 3]);
+        if (bad) o = make_float4(qnan, qnan, qnan, qnan);   // 0/0 at :74 poisons every statistic of the cloud
+        *reinterpret_cast<float4*>(out + e) = o;
+    }
+}
+
+// L2 normalisation over the Gaussian axis, per channel (:124-126), in place.  One 256-thread block per cloud; thread
+// t owns the float4 channel group t % 5 of the Gaussians t/5, t/5 + 51, ... -> 20 per-channel sums in a fixed order.
+__global__ __launch_bounds__(256) void mfv3d_norm_kernel(float* __restrict__ fv, int G) {
+    __shared__ float s_part[51][kF];
+    __shared__ float s_scale[kF];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    float4* base = reinterpret_cast<float4*>(fv + (size_t)c * G * kF);
+    const int part = tid % 5, row = tid / 5;    // 255 working threads = 51 rows x 5 channel groups
+    float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 255) {
+        for (int g = row; g < G; g += 51) {
+            const float4 v = base[g * 5 + part];
+            sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+        }
+        s_part[row][part * 4 + 0] = sq.x; s_part[row][part * 4 + 1] = sq.y;
+        s_part[row][part * 4 + 2] = sq.z; s_part[row][part * 4 + 3] = sq.w;
     }
     __syncthreads();
     if (tid < kF) {
         float ss = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) ss += s_chred[w * kF + tid];
-        s_scale[tid] = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        for (int r = 0; r < 51; ++r) ss += s_part[r][tid];
+        s_scale[tid] = 1.0f / sqrtf(fmaxf(ss, 1e-12f));      // l2_normalize: x * rsqrt(max(sum x^2, eps))
     }
     __syncthreads();
-
-    // ---- coalesced store: fv[c][g][f], 4 consecutive f of one g per thread ---------------------------------------
-    float* out = fv + (size_t)c * G * kF;
-    const bool bad = *s_bad != 0;
-    const float qnan = __int_as_float(0x7fc00000);
-    for (int i4 = tid; i4 < G * kF / 4; i4 += kFwdThreads) {
-        const int e = i4 * 4, g = e / kF, f = e % kF;
-        float4 o;
-        o.x = s_stage[g * kFP + f] * s_scale[f];
-        o.y = s_stage[g * kFP + f + 1] * s_scale[f + 1];
-        o.z = s_stage[g * kFP + f + 2] * s_scale[f + 2];
-        o.w = s_stage[g * kFP + f + 3] * s_scale[f + 3];
-        if (bad) o = make_float4(qnan, qnan, qnan, qnan);   // 0/0 at :74 poisons every statistic of the cloud
-        *reinterpret_cast<float4*>(out + e) = o;
+    if (tid < 255) {
+        const float4 sc = make_float4(s_scale[part * 4], s_scale[part * 4 + 1], s_scale[part * 4 + 2], s_scale[part * 4 + 3]);
+        for (int g = row; g < G; g += 51) {
+            float4 v = base[g * 5 + part];
+            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+            base[g * 5 + part] = v;
+        }
     }
 }
 
@@ -231,8 +244,8 @@ static int make_const(int N, int m, float sigma, MfvConst& k) {
     return 0;
 }
 
-static size_t fwd_lds_bytes(int N, int m, int G) {
-    return (size_t)(6 * N * m + 6 * N + G * kFP + 16 * kF + kF + 4) * sizeof(float);
+static size_t fwd_lds_bytes(int N, int m, int gslice) {
+    return (size_t)(6 * N * m + 6 * N + gslice * kFP + 4) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -480,9 +493,12 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     if (C <= 0) return DPD_E_DIM;
     MfvConst k{};
     if (int rc = make_const(N, m, sigma, k)) return rc;
-    const size_t lds = fwd_lds_bytes(N, m, k.G);
+    const int gslice = (k.G + kSlices - 1) / kSlices;
+    const size_t lds = fwd_lds_bytes(N, m, gslice);
     if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
-    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k);
+    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k, gslice);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, fv, k.G);
     DPD_CHECK_LAUNCH();
     return 0;
 }
