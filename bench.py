@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"],
                     help="compute type of the three wide decoder layers (include/dpdist_capi.h: enum dpd_dtype)")
+    ap.add_argument("--prefetch", action="store_true", help="side-stream input pipeline (DPDistTrainer.step(prefetch=...))")
     ap.add_argument("--plan", default="", help="GEMM plan overrides for tuning, e.g. '0:10,1:9:1' = op:tile[:split_k]")
     a = ap.parse_args()
 
@@ -139,12 +140,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # --prefetch: every step also runs the NEXT batch's encoder + gather on a side stream (each timed step still executes
+    # exactly one front end).  Measured SLOWER than plain stream order on MI355X (0.73 vs 0.67 ms: the cross-stream event
+    # waits cost more than the ~35 us of front end they hide), so it is off by default.
+    nxt = (pcA, pcB, None) if a.prefetch else None
     for _ in range(a.warmup):
-        tr.step(pcA, pcB, lab)
+        tr.step(pcA, pcB, lab, prefetch=nxt)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr.step(pcA, pcB, lab)
+        tr.step(pcA, pcB, lab, prefetch=nxt)
     sync()
     el = time.perf_counter() - t0
     if use_dist:

@@ -189,8 +189,7 @@ def train(argv=None):
     lo, hi = shard_range(F.batch_size, rank, world)
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)       # noqa: E731
 
-    def run_epoch(ds, training):
-        sums, n = torch.zeros(2, device=dev), 0
+    def batches(ds, training):
         while ds.has_next_batch():
             data, label = ds.next_batch(augment=training)
             if len(data) < F.batch_size:                           # static shapes like the reference: pad the last batch
@@ -201,10 +200,25 @@ def train(argv=None):
             noise = None
             if F.add_noise > 0.0:                                  # :768-771
                 noise = cu((np.random.randn(F.batch_size, N, 3) * F.add_noise).astype(np.float32)[lo:hi])
-            a, b, l = cu(pcA[lo:hi]), cu(pcB[lo:hi]), cu(lab[lo:hi])
-            loss = tr.step(a, b, l, noise) if training else tr.evaluate(a, b, l, noise)[0]
+            yield cu(pcA[lo:hi]), cu(pcB[lo:hi]), cu(lab[lo:hi]), noise
+
+    def run_epoch(ds, training):
+        sums, n = torch.zeros(2, device=dev), 0
+        it = batches(ds, training)
+        cur = next(it, None)
+        while cur is not None:
+            nxt = next(it, None)                                   # composed one batch ahead (host work overlaps the GPU step)
+            a, b, l, noise = cur
+            if training:
+                # trainer-side prefetch (encoder + gather of the next batch on a side stream) measured slower than plain
+                # stream order on MI355X, see bench.py --prefetch; opt in with DPD_PREFETCH=1
+                pf = (nxt[0], nxt[1], nxt[3]) if (nxt is not None and os.environ.get("DPD_PREFETCH") == "1") else None
+                loss = tr.step(a, b, l, noise, prefetch=pf)
+            else:
+                loss = tr.evaluate(a, b, l, noise)[0]
             sums += loss
             n += 1
+            cur = nxt
         ds.reset()
         if world > 1:
             dist.all_reduce(sums)

@@ -9,6 +9,10 @@ One `step(pcA, pcB, labels, noise)` = what `train_multi_gpu_pc_compare_dist.py:7
 Only the AB half of the rows carries gradient (loss_samples reads pred_listAB only), so the backward GEMMs run on
 B*N rows while the forward runs on 2*B*N.
 
+Input pipeline: `step(..., prefetch=(pcA', pcB', noise'))` runs the NEXT batch's front end (stacking, 3DmFV encoder, window
+gather -- none of which depends on the weights) on a side stream while this step's backward and Adam occupy the main
+stream; the next `step` on those tensors then starts at the decoder.  Without `prefetch` everything is in stream order.
+
 Backward schedule (chosen for overlap, not for autodiff order): dH chain g3 -> g2 -> g1, then dW1 (largest bucket,
 all-reduce launched immediately), then dW2, dW3, dW4 (second bucket), then one fused Adam over the flat buffer.
 """
@@ -79,19 +83,50 @@ class DPDistTrainer:
             L.check(L.load().dpd_weights_to_planes(self._cparams, self.P.KP, self.P.H, self._planes, L.cur_stream()),
                     "dpd_weights_to_planes")
 
+        self._after_dw1 = None
+        self._side = None          # side stream of the prefetch pipeline (created on first use)
+        self._pref_key = None      # identity of the batch whose front end is (being) computed on the side stream
+        self._ev_front = self._ev_xfree = self._ev_fwd = None
+
     # -- pieces (each enqueues kernels on the current stream; no host sync, no allocation) -----------------
+    @staticmethod
+    def _key(pcA, pcB, noise):
+        return (pcA.data_ptr(), pcB.data_ptr(), None if noise is None else noise.data_ptr(), pcA._version, pcB._version)
+
+    def _front(self, pcA, pcB, noise, gate=None):
+        """stacking + encoder + window gather of one batch on the CURRENT stream; `gate`: event to wait for before the
+        gather overwrites X / mask / vox (their last reader of the previous step)."""
+        self._load_batch(pcA, pcB, noise)
+        self._encode()
+        if gate is not None:
+            torch.cuda.current_stream().wait_event(gate)
+        self._gather()
+
     def _load_batch(self, pcA, pcB, noise):
         L.check(L.load().dpd_stack_clouds(L.ptr(L.req(pcA, name="pcA")), L.ptr(L.req(pcB, name="pcB")),
                                           None if noise is None else L.ptr(L.req(noise, name="add_noise")), self.B, self.N,
                                           L.ptr(self.pts), L.ptr(self.q), L.cur_stream()), "dpd_stack_clouds")
 
-    def forward(self):
+    def _encode(self):
+        L.check(L.load().dpd_mfv3d_fwd(L.ptr(self.pts), 2 * self.B, self.N, self.m, self.sigma, L.ptr(self.fv), L.cur_stream()),
+                "dpd_mfv3d_fwd")
+
+    def _gather(self):
         lib, s, P = L.load(), L.cur_stream(), self.P
-        C, N, Q = 2 * self.B, self.N, 2 * self.B * self.N
-        L.check(lib.dpd_mfv3d_fwd(L.ptr(self.pts), C, N, self.m, self.sigma, L.ptr(self.fv), s), "dpd_mfv3d_fwd")
+        C, N = 2 * self.B, self.N
         L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP,
                                        None if self._planes is not None else L.ptr(self.X), L.ptr(self.mask), L.ptr(self.vox),
                                        self._planes, s), "dpd_patch_rows_fwd")
+
+    def forward(self):
+        """encoder + gather + decoder of the batch loaded by _load_batch (stream order)."""
+        self._encode()
+        self._gather()
+        self._decode()
+
+    def _decode(self):
+        lib, s, P = L.load(), L.cur_stream(), self.P
+        Q = 2 * self.B * self.N
         L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
                                     L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
                                     self.ws.numel() * 4, self._planes, s), "dpd_decoder_fwd")
@@ -113,6 +148,8 @@ class DPDistTrainer:
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
         dw(1, self.X, self.g1, d[0])
+        if self._after_dw1 is not None:
+            self._after_dw1()             # X / mask are free from here on: the prefetch pipeline hooks in
         if self.reducer:
             self.reducer.reduce_async(0)      # bucket 0 = dW1p + db1 (db1 was finished by the data chain)
         if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
@@ -138,20 +175,51 @@ class DPDistTrainer:
                                      self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
         self.refresh_weight_planes()
 
+    def _take_front(self, pcA, pcB, noise):
+        """Make the front-end buffers (pts, q, fv, X, mask, vox) hold this batch on the current stream."""
+        main = torch.cuda.current_stream()
+        if self._pref_key is not None:
+            main.wait_event(self._ev_front)            # whatever the side stream was doing with the buffers is ordered first
+            hit = self._pref_key == self._key(pcA, pcB, noise)
+            self._pref_key = None
+            if hit:
+                return
+        self._front(pcA, pcB, noise)
+
     @torch.no_grad()
-    def step(self, pcA, pcB, labels, noise=None):
-        """One training step.  Returns the device tensor [loss_samples, loss_pred] of THIS rank's shard (no host sync)."""
-        self._load_batch(pcA, pcB, noise)
-        self.forward()
-        self.backward(labels.reshape(-1))
+    def step(self, pcA, pcB, labels, noise=None, prefetch=None):
+        """One training step.  Returns the device tensor [loss_samples, loss_pred] of THIS rank's shard (no host sync).
+        prefetch = (pcA', pcB', noise' or None): the NEXT step's inputs (already complete on the current stream); their
+        front end runs on a side stream under this step's backward and optimizer."""
+        self._take_front(pcA, pcB, noise)
+        self._decode()
+        if prefetch is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.P.flat.device)
+                self._ev_front, self._ev_xfree, self._ev_fwd = (torch.cuda.Event() for _ in range(3))
+            main = torch.cuda.current_stream()
+            self._ev_fwd.record(main)                  # inputs complete + this step's gather/decoder ordered before the side work
+
+            def launch_front():
+                self._ev_xfree.record(main)            # recorded right after dW1, the last reader of X / mask
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(self._ev_fwd)
+                    self._front(*prefetch, gate=self._ev_xfree)
+                    self._ev_front.record(self._side)
+                self._pref_key = self._key(*prefetch)
+            self._after_dw1 = launch_front
+        try:
+            self.backward(labels.reshape(-1))
+        finally:
+            self._after_dw1 = None
         self.apply_gradients()
         return self.loss
 
     @torch.no_grad()
     def evaluate(self, pcA, pcB, labels, noise=None):
         """Forward only (eval_one_epoch_3d, train_multi_gpu...:809-873): returns [loss_samples, loss_pred] and pred_AB[...,0]."""
-        self._load_batch(pcA, pcB, noise)
-        self.forward()
+        self._take_front(pcA, pcB, noise)
+        self._decode()
         BN = self.B * self.N
         L.check(L.load().dpd_l1_loss(L.ptr(self.pred), L.ptr(labels.reshape(-1)), BN, 0, 1.0, L.ptr(self.loss), None,
                                      L.cur_stream()), "dpd_l1_loss")
