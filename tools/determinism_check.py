@@ -4,7 +4,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dpdist_amd import synth  # noqa: E402
 from dpdist_amd.model import DPDistParams  # noqa: E402
 from dpdist_amd.trainer import DPDistTrainer  # noqa: E402

@@ -1,0 +1,71 @@
+"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh on the GPU box) into the tracked profiles/<tag>_* files.
+
+    python tools/summarize_profiles.py r01
+"""
+import csv
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def mine(name):
+    return name.startswith("dpd::") or name.startswith("void dpd::")
+
+
+def copy(a, b):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (tag, b)))
+
+
+for a, b in (("bench.json", "bench.json"), ("bench_f32x3.json", "bench_f32x3.json"), ("bench_bf16.json", "bench_bf16.json"),
+             ("bench_bf16_b64.json", "bench_bf16_b64.json"), ("bench_f32_b64.json", "bench_f32_b64.json"),
+             ("x3_bench.txt", "x3_bench.txt"), ("gemm_bench.txt", "gemm_bench.txt")):
+    copy(a, b)
+
+# per-kernel stats (our kernels only), one file per compute type
+for sub, out in (("stats", "kernel_stats.csv"), ("stats_f32x3", "kernel_stats_f32x3.csv"), ("stats_bf16", "kernel_stats_bf16.csv")):
+    f = os.path.join(src, sub, "%s_kernel_stats.csv" % tag)
+    if not os.path.exists(f):
+        continue
+    rows = [r for r in csv.DictReader(open(f)) if mine(r["Name"])]
+    with open(os.path.join(dst, "%s_%s" % (tag, out)), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], "%.1f" % (float(r["TotalDurationNs"]) / 1e3), "%.2f" % (float(r["AverageNs"]) / 1e3),
+                        "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3), r["Percentage"]])
+
+# PMC summary: FETCH_SIZE / WRITE_SIZE (KiB per launch) and MFMA-busy fraction per kernel
+acc = defaultdict(lambda: defaultdict(list))
+for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_MFMA"):
+    f = os.path.join(src, sub, "p_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        if mine(r["Kernel_Name"]):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+stats = {}
+f = os.path.join(src, "stats", "%s_kernel_stats.csv" % tag)
+if os.path.exists(f):
+    stats = {r["Name"]: r for r in csv.DictReader(open(f))}
+with open(os.path.join(dst, "%s_pmc_summary.csv" % tag), "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["kernel", "calls_in_stats", "avg_us", "FETCH_SIZE_KB_per_launch(raw)", "fabric_read_MB_per_launch(x2 gfx950 correction)",
+                "WRITE_SIZE_KB_per_launch", "MFMA_busy_frac(under PMC collection)"])
+    mean = lambda v: sum(v) / len(v) if v else None   # noqa: E731
+    for k, c in sorted(acc.items(), key=lambda kv: -float(stats.get(kv[0], {}).get("TotalDurationNs", 0))):
+        fe, wr = mean(c.get("FETCH_SIZE", [])), mean(c.get("WRITE_SIZE", []))
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+        busy, act = mean(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])), mean(c.get("GRBM_GUI_ACTIVE", []))
+        act = act / 8.0 * 1024.0 if act else act
+        st = stats.get(k, {})
+        w.writerow([k, st.get("Calls", ""), "%.2f" % (float(st["AverageNs"]) / 1e3) if st else "",
+                    "%.0f" % fe if fe is not None else "", "%.1f" % (2 * fe * 1024 / 1e6) if fe is not None else "",
+                    "%.0f" % wr if wr is not None else "", "%.3f" % (busy / act) if busy and act else ""])
+print("wrote", sorted(x for x in os.listdir(dst) if x.startswith(tag)))

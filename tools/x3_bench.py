@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dpdist_amd import lib as L, ops  # noqa: E402
 
 lib = L.load()
