@@ -591,12 +591,14 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
 extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1,
                                     const float* h2, const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p,
                                     int dtype, float* dy, float* g3, float* g2, float* g1, float* dX,
-                                    const dpd_small_grads* sg, void* ws, size_t ws_bytes, const dpd_planes* pl, void* stream) {
+                                    const dpd_small_grads* sg, void* ws, size_t ws_bytes, const dpd_planes* pl, int phases,
+                                    void* stream) {
     using namespace dpd;
     if (!dpred || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
     if ((H & 63) || (KP & 3) || dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
+    if (phases <= 0 || phases > 7) return DPD_E_DIM;
     hipStream_t s = (hipStream_t)stream;
     const Scratch scr = scratch_of(ws, ws_bytes, KP, H);
     pl = usable_planes(pl, dtype, pl ? pl->Q : 0, Qb, KP, H);
@@ -610,7 +612,9 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     float* db4 = sg ? sg->db4 : nullptr;
     const int nblk = (Qb + kOBRows - 1) / kOBRows;
     const bool fused = (db3 || dW4 || db4) && H <= 64 * kOBMaxJ && (size_t)nblk * (4 * H + 4) <= (size_t)Qb * H;
-    if (fused) {
+    if (!(phases & 1)) {
+        // output layer already done by an earlier call
+    } else if (fused) {
         // one pass over h3: dy, g3 and block partials of db3 / dW4 / db4 (g2 is free until the first dH GEMM: scratch)
         ZeroList zl{{db1, db2, nullptr, nullptr, nullptr}, {H, H, 0, 0, 0}};
         if (H % 256 == 0 && H <= 1024) {
@@ -647,25 +651,29 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     }
     // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0];  db2 / db1 = column sums, fused into the epilogue
     if (pl) {
-        if (pl->g3_rc || pl->g3_r8) {   // g3 comes from the small fused kernel above: one conversion launch for both layouts
+        if ((phases & 1) && (pl->g3_rc || pl->g3_r8)) {   // g3 comes from the small fused kernel above: one conversion launch for both layouts
             if (int rc = split_planes(g3, Qb, H, H, pl->np, (uint16_t*)pl->g3_rc, H, (long)Qb * H, (uint16_t*)pl->g3_r8, (long)Qb * H, s))
                 return rc;
         }
         X3Out o2 = make_out(pl, pl->g2_rc, Qb, pl->g2_r8, Qb, H), o1 = make_out(pl, dX ? pl->g1_rc : nullptr, Qb, pl->g1_r8, Qb, H);
         const bool w2 = o2.rc || o2.r8, w1 = o1.rc || o1.r8;
-        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2, pl->g3_rc,
-                             pl->W3_rc, w2 ? &o2 : nullptr)) return rc;
-        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1, pl->g2_rc,
-                             pl->W2_rc, w1 ? &o1 : nullptr)) return rc;
-        if (dX) {
+        if (phases & 2)
+            if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2, pl->g3_rc,
+                                 pl->W3_rc, w2 ? &o2 : nullptr)) return rc;
+        if (phases & 4)
+            if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1, pl->g2_rc,
+                                 pl->W2_rc, w1 ? &o1 : nullptr)) return rc;
+        if (dX && (phases & 4)) {
             if (int rc = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s, nullptr,
                                  pl->g1_rc, pl->W1_rc, nullptr)) return rc;
         }
         return 0;
     }
-    if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2)) return rc;
-    if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1)) return rc;
-    if (dX) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
+    if (phases & 2)
+        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2)) return rc;
+    if (phases & 4)
+        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1)) return rc;
+    if (dX && (phases & 4)) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
         if (int rc = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s)) return rc;
     }
     return 0;

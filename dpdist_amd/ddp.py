@@ -3,12 +3,14 @@
 Replaces the reference's in-graph towers (`train_multi_gpu_pc_compare_dist.py:237-302`) and its CPU-side
 `average_gradients` (`:936-974`: stack + reduce_mean of 8 variables = 18.67 MB per tower per step over PCIe).
 
-Design for MI355X: weights and Adam state are replicated on every GPU; the flat gradient buffer is cut into two
-buckets in reverse-availability order -- bucket 0 = layer 1 (dW1p+db1, 10.3 MB, produced FIRST by the backward
-schedule of trainer.py), bucket 1 = layers 2-4 (8.4 MB) -- and each bucket's all-reduce(sum) is enqueued on a side
-stream the moment its producer kernels are enqueued, so the 10.3 MB transfer overlaps the dW2/dW3/dW4 GEMMs.  The
-1/world scale is folded into the Adam kernel (`gscale`).  xGMI is point-to-point, so two large messages beat the
-reference's eight small ones.
+Design for MI355X: weights and Adam state are replicated on every GPU; the flat gradient buffer is cut into three
+buckets -- bucket 0 = layer 1 (dW1p+db1, 10.3 MB), bucket 1 = layer 2 (4.2 MB), bucket 2 = layers 3-4 (4.2 MB).  The
+data-parallel backward of trainer.py produces every weight gradient as soon as its inputs exist (dW3 right after the
+output layer, dW2 after g2, dW1 last) and enqueues each bucket's all-reduce(sum) on a side stream the moment its
+producer kernels are enqueued: the collectives are serial on the RCCL stream, so what matters is how early the first one
+starts -- here ~250 us of backward GEMMs before the end, and only the tail of the last bucket is exposed.  The 1/world
+scale is folded into the Adam kernel (`gscale`).  xGMI is point-to-point (ring all-reduce is per-link bound), so three
+messages of 4-10 MB beat the reference's eight small ones.
 
 `shard_range` gives rank r the pairs [r*B/P, (r+1)*B/P) like `tf.slice` at `:241-251`.
 """

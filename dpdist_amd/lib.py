@@ -43,7 +43,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_decoder_bwd_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      POINTER(DecoderParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     POINTER(SmallGrads), c_void_p, c_size_t, POINTER(Planes), c_void_p]),
+                                     POINTER(SmallGrads), c_void_p, c_size_t, POINTER(Planes), c_int, c_void_p]),
     "dpd_stack_clouds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),

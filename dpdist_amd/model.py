@@ -66,7 +66,9 @@ class DPDistParams(nn.Module):
             self._segments[n] = (off, cnt, shp)
             off += _align4(cnt)
         self.numel = off
-        self.bucket_bounds = [0, self._segments["W2"][0], off]   # [layer 1 | layers 2-4]
+        # gradient buckets in flat order [layer 1 | layer 2 | layers 3-4]; the data-parallel backward of trainer.py
+        # produces (and all-reduces) them in the order 2, 1, 0
+        self.bucket_bounds = [0, self._segments["W2"][0], self._segments["W3"][0], off]
         self.flat = nn.Parameter(torch.zeros(off, device=device, dtype=torch.float32))
         if init == "xavier_tf":
             self.reset_parameters_tf()

@@ -114,7 +114,7 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None,
         ws = workspace(Qb, KP, H, dev, dtype)
     L.check(L.load().dpd_decoder_bwd_data(L.ptr(dpred), L.ptr(mask), L.ptr(y), L.ptr(h1), L.ptr(h2), L.ptr(h3), Qb, KP, H,
                                           p, dtype, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), sg, *_ws_args(ws),
-                                          None, L.cur_stream()), "dpd_decoder_bwd_data")
+                                          None, 7, L.cur_stream()), "dpd_decoder_bwd_data")
     return dy, g3, g2, g1, dX
 
 

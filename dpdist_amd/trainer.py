@@ -17,6 +17,7 @@ Backward schedule (chosen for overlap, not for autodiff order): dH chain g3 -> g
 all-reduce launched immediately), then dW2, dW3, dW4 (second bucket), then one fused Adam over the flat buffer.
 """
 import math
+import os
 
 import torch
 
@@ -135,23 +136,41 @@ class DPDistTrainer:
         lib, s, P = L.load(), L.cur_stream(), self.P
         BN = self.B * self.N
         L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
-        # data chain; db1..db3, dW4, db4 fall out of it (fused epilogues / one small kernel)
-        L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
-                                         L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
-                                         L.ptr(self.g2), L.ptr(self.g1), None, self._csmall, L.ptr(self.ws),
-                                         self.ws.numel() * 4, self._planes, s), "dpd_decoder_bwd_data")
         d, wsb = self._gviews, self.ws.numel() * 4
+
+        def data(phases):   # db1..db3, dW4, db4 fall out of the data chain (fused epilogues / one small kernel)
+            L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
+                                             L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
+                                             L.ptr(self.g2), L.ptr(self.g1), None, self._csmall, L.ptr(self.ws), wsb, self._planes,
+                                             phases, s), "dpd_decoder_bwd_data")
 
         def dw(layer, act, g, dW):
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
                                                 L.ptr(dW), None, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
+        if self.reducer and os.environ.get("DPD_DP_SCHEDULE", "early") == "early":
+            # Data-parallel schedule: every weight gradient is produced as early as its inputs exist, smallest bucket first,
+            # so that the all-reduces (serial on the RCCL stream) start ~250 us before the backward ends instead of after dW1:
+            #   output layer -> dW3 -> [bucket 2: W3,b3,W4,b4] -> g2 -> dW2 -> [bucket 1: W2,b2] -> g1 -> dW1 -> [bucket 0]
+            data(1)
+            dw(3, self.h2, self.g3, d[4])
+            self.reducer.reduce_async(2)
+            data(2)
+            dw(2, self.h1, self.g2, d[2])
+            self.reducer.reduce_async(1)
+            data(4)
+            dw(1, self.X, self.g1, d[0])
+            if self._after_dw1 is not None:
+                self._after_dw1()
+            self.reducer.reduce_async(0)
+            return
+        data(7)
         dw(1, self.X, self.g1, d[0])
         if self._after_dw1 is not None:
             self._after_dw1()             # X / mask are free from here on: the prefetch pipeline hooks in
         if self.reducer:
-            self.reducer.reduce_async(0)      # bucket 0 = dW1p + db1 (db1 was finished by the data chain)
+            self.reducer.reduce_async(0)
         if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
             L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
                                                      L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
@@ -159,8 +178,9 @@ class DPDistTrainer:
         else:
             dw(2, self.h1, self.g2, d[2])
             dw(3, self.h2, self.g3, d[4])
-        if self.reducer:
+        if self.reducer:      # DPD_DP_SCHEDULE=late (A/B reference): plain order, all-reduces start after dW1
             self.reducer.reduce_async(1)
+            self.reducer.reduce_async(2)
 
     def apply_gradients(self):
         base_lr, decay_step, decay_rate, b1, b2, eps = self.hp

@@ -142,7 +142,10 @@ int dpd_weights_to_planes(const dpd_decoder_params* p, int KP, int H, const dpd_
  * dX [Qb,KP] = g1 * W1p^T (as-loss mode, TF autodiff through :516).
  * `sg` (may be NULL) lists the small gradients that fall out of this chain for free and are then written here
  * (overwritten): db3/db2/db1 [H] = column sums of g3/g2/g1 (fused into the dH GEMM epilogues, fp32 atomics),
- * dW4 [H,3] = h3^T dy, db4 [3].  Any member may be NULL.                                          */
+ * dW4 [H,3] = h3^T dy, db4 [3].  Any member may be NULL.
+ * `phases` selects the parts of the chain to run, so that a data-parallel caller can interleave the weight-gradient
+ * GEMMs (and start their all-reduce) between them: 1 = output layer (dy, g3, db3, dW4, db4; clears db1/db2),
+ * 2 = g2 (+db2), 4 = g1 (+db1) and dX; 7 = everything.  The same buffers must be passed to every call.     */
 typedef struct dpd_small_grads {
     float* db1; float* db2; float* db3; float* dW4; float* db4;
 } dpd_small_grads;
@@ -150,7 +153,7 @@ typedef struct dpd_small_grads {
 int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,
                          const float* h3, int Qb, int KP, int H, const dpd_decoder_params* p, int dtype,
                          float* dy, float* g3, float* g2, float* g1, float* dX, const dpd_small_grads* sg,
-                         void* ws, size_t ws_bytes, const dpd_planes* pl, void* stream);
+                         void* ws, size_t ws_bytes, const dpd_planes* pl, int phases, void* stream);
 
 /* Backward, weight gradients of ONE layer (1..4) from the buffers above:
  *   layer 1: dW [KP,H] = X^T g1, db = colsum(g1);  2: h1^T g2;  3: h2^T g3;  4: dW [H,3] = h3^T dy.

@@ -46,8 +46,9 @@ def _worker(rank, world, port, out):
     P = DPDistParams(k=5, mlp=mlp, device="cpu", init=None)
     flat = _flat_grad(P, pcA[lo:hi], pcB[lo:hi], lab[lo:hi], mlp).float()
     red = BucketReducer(flat, P.bucket_bounds)
-    red.reduce_async(0)          # layer-1 bucket first, as in trainer.backward
-    red.reduce_async(1)
+    assert len(P.bucket_bounds) == 4
+    for b in (2, 1, 0):          # layers 3-4, layer 2, layer 1: the order trainer.backward produces them in
+        red.reduce_async(b)
     red.wait()
     flat *= red.grad_scale
     if rank == 0:

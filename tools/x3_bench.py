@@ -77,6 +77,15 @@ if __name__ == "__main__":
     tiles = [int(t) for t in sys.argv[1:]] or [1, 2, 6, 7]
     import os
     quick = os.environ.get("QUICK")
+    if os.environ.get("B64"):
+        for np_ in (1, 3):
+            for tile in tiles:
+                run("NN", 8192, 1024, 2528, np_, tile)
+                run("NN", 8192, 1024, 1024, np_, tile)
+                run("NT", 4096, 1024, 1024, np_, tile)
+                run("TN", 2560, 1024, 4096, np_, tile)
+                run("TN", 1024, 1024, 4096, np_, tile)
+        sys.exit(0)
     if os.environ.get("MODES"):
         for tile in tiles:
             for mode in ("NN", "NT", "TN"):
