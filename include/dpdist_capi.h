@@ -184,6 +184,17 @@ int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float 
                 float* dpred, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Chamfer distance (baseline loss of the AUE task).  Replaces pairwise_diff + chmafer_dist
+ * (train_multi_gpu_pc_compare_dist.py:891-916): a [B,N,3] (pc), b [B,M,3] (rec_pc),
+ *   loss[0] = ( mean_bi min_j |b_bi - a_bj|^2 + mean_bj min_i |a_bj - b_bi|^2 ) / 2     (squared distances).
+ * min_a/arg_a [B,N], min_b/arg_b [B,M] receive the per-point minima and their indices (kept for the backward).
+ * dpd_chamfer_bwd: da, db (either may be NULL) = gscale * d loss / d a, d loss / d b (overwritten).        */
+int dpd_chamfer_fwd(const float* a, const float* b, int B, int N, int M, float* min_a, int32_t* arg_a, float* min_b,
+                    int32_t* arg_b, float* loss, void* stream);
+int dpd_chamfer_bwd(const float* a, const float* b, int B, int N, int M, const int32_t* arg_a, const int32_t* arg_b,
+                    float gscale, float* da, float* db, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * tf.train.AdamOptimizer step (epsilon-hat form), train_multi_gpu_pc_compare_dist.py:216,301:
  *   g' = g * gscale;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr_t m / (sqrt(v)+eps)
  * with lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller.  n elements (any n).              */
