@@ -63,8 +63,13 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     if (!planes_ok) {   // exact fp32 (also for shapes the plane kernels do not take)
         if (Apl || Bpl || out) return DPD_E_UNSUPPORTED;   // callers only pass planes for shapes planes_shape_ok() accepts
         const int split = (dtype == 0) ? g_plan_split[op] : 1;
-        return gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, gate, epilogue, colsum ? 1 : split,
-                        g_plan_tile[op], ws, ws_bytes, s, colsum);
+        int tile = g_plan_tile[op];
+        // the 128x128 one-workgroup-per-CU kernels need >= ~200 tiles to fill the chip (B = 32 forward); smaller batches
+        // (as-loss mode at the PCRNet batch of 16: M = 2048 -> 128 tiles) run the 64x64 kernel, 3 workgroups per CU
+        const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        if ((tile == 9 || tile == 5 || tile == 10) && tiles128 < 200) tile = 8;
+        return gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, gate, epilogue, colsum ? 1 : split, tile, ws, ws_bytes,
+                        s, colsum);
     }
     const int np = dtype == 1 ? 3 : 1;
     const size_t ae = (size_t)M * K, be = (size_t)K * N;

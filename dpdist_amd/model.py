@@ -186,6 +186,42 @@ class _DPDistFn(torch.autograd.Function):
         return gA, gB, gN, dflat, None, None, None, None
 
 
+class _AsLossFn(torch.autograd.Function):
+    """DPDist as a frozen loss in ONE autograd node (pcrnet-registration/iterative_PCRNet_ours.py:229-257, AUE splice
+    train_multi_gpu...:417-431):  loss_pred = (mean(output1[...,0]) + mean(output2[...,0])) / 2 of (pcA, pcB), gradients to
+    the two clouds only.  Same kernels as _DPDistFn + _L1LossFn, without the slicing / mean / add glue in between."""
+
+    @staticmethod
+    def forward(ctx, pcA, pcB, flat, P, m, k, sigma):
+        B, N, _ = pcA.shape
+        pts, q = ops.stack_clouds(pcA, pcB, None)
+        fv = ops.mfv3d_fwd(pts, m, sigma)
+        X, mask, vox = ops.patch_rows_fwd(q, fv, m, k, P.KP)
+        params = P.views(flat)
+        h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype)
+        loss, _ = ops.l1_loss(pred, mask[:B * N], mode=0)          # labels only enter loss_samples, which is not used here
+        ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
+        ctx.save_for_backward(pts, flat, mask, vox, h1, h2, h3, y, pred)
+        return loss[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        P = ctx.P
+        B, N, m, k, sigma = ctx.cfg
+        pts, flat, mask, vox, h1, h2, h3, y, pred = ctx.saved_tensors
+        Q = 2 * B * N
+        _, dpred = ops.l1_loss(pred, mask[:B * N], mode=2)          # d loss_pred / d pred, [Q,3]
+        dpred.mul_(g)                                               # upstream gradient (device scalar, no host sync)
+        dt = P.compute_dtype
+        ws = ops.workspace(Q, P.KP, P.H, flat.device, dt) if dt else None
+        _, _, _, _, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, P.views(flat), P.KP, True, dtype=dt, ws=ws)
+        dq, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k)
+        dpts = ops.mfv3d_bwd(pts, dfv, m, sigma)
+        gA = dpts[:B] + dq[B:]      # encoder route + query route (BA half queries pcA)
+        gB = dpts[B:] + dq[:B]
+        return gA, gB, None, None, None, None, None
+
+
 class _L1LossFn(torch.autograd.Function):
     """utils/dpdist_util.py:962-980 on the HIP loss kernel: pred [2BN,3], labels [BN] -> [loss_samples, loss_pred]."""
 
@@ -336,5 +372,7 @@ class DPDistLoss(nn.Module):
             p.requires_grad_(False)
 
     def forward(self, source, template):
-        ps = self.model(source, template)
-        return (ps["pred_listAB"][..., 0].mean() + ps["pred_listBA"][..., 0].mean()) / 2
+        mod = self.model
+        m = int(math.ceil(mod.Embedding_Size ** (1 / 3) - 1e-9))
+        return _AsLossFn.apply(source.contiguous(), template.contiguous(), mod.params_.flat, mod.params_, m, mod.k,
+                               float(mod.sigma))

@@ -766,3 +766,24 @@ def test_data_parallel_schedule_matches_plain_backward(dev):
             assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item()), n
         else:                      # dW2/dW3 come from different launches (grouped vs single): same tiles, same k order
             assert torch.equal(a, b), n
+
+
+def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
+    """DPDistLoss (one fused autograd node) == get_model + get_loss['loss_pred'] of the module contract, value and
+    input gradients, and both match the golden float64 gradients."""
+    from dpdist_amd import model as M
+    d = _g(golden_dir, "path_bwd_s2_wide.npz")
+    mod = _model(dev, "wide")
+    a1 = _cu(d["pcA"], dev).requires_grad_(True)
+    b1 = _cu(d["pcB"], dev).requires_grad_(True)
+    loss1 = M.DPDistLoss(mod)(a1, b1)
+    gA1, gB1 = torch.autograd.grad(loss1 * 2.0, [a1, b1])
+    a2 = _cu(d["pcA"], dev).requires_grad_(True)
+    b2 = _cu(d["pcB"], dev).requires_grad_(True)
+    M.reset_default_graph()
+    ps = mod(a2, b2)
+    _, lp = M.get_loss(ps, {}, _cu(d["labels"], dev))
+    gA2, gB2 = torch.autograd.grad(lp * 2.0, [a2, b2])
+    assert abs(loss1.item() - lp.item()) <= 1e-7
+    assert (gA1 - gA2).abs().max().item() <= 1e-6 * max(1.0, gA2.abs().max().item())
+    assert (gB1 - gB2).abs().max().item() <= 1e-6 * max(1.0, gB2.abs().max().item())

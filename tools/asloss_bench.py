@@ -22,10 +22,12 @@ def main():
     ap.add_argument("--batch", type=int, default=16)     # run_train_and_eval_PCRNet.bash:18,72
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = DPDistModel(device=dev)
     model.load_tf_state_dict(synth.make_weights("wide"))
+    model.params_.compute_dtype = a.dtype
     loss_fn = DPDistLoss(model)
     pcA, pcB, _ = synth.s2_modelnet_shaped(a.batch, 64, 100)
     src = torch.tensor(pcA, device=dev, requires_grad=True)
@@ -45,7 +47,7 @@ def main():
         l = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"mode": "as-loss (fwd + bwd to inputs)", "batch": a.batch, "ms_per_step": round(el / a.steps * 1e3, 4),
+    print(json.dumps({"mode": "as-loss (fwd + bwd to inputs)", "batch": a.batch, "dtype": a.dtype, "ms_per_step": round(el / a.steps * 1e3, 4),
                       "query_points_per_sec": round(2 * a.batch * 64 * a.steps / el, 1), "loss_pred": round(float(l), 6),
                       "grad_norm": round(float(src.grad.norm()), 6)}))
 
