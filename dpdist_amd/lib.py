@@ -48,6 +48,7 @@ SIGNATURES = {
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p]),
+    "dpd_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "dpd_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "dpd_planes_bytes": (c_size_t, [c_int] * 6),

@@ -48,6 +48,7 @@ def build_parser():
     p.add_argument("--test_shapes", type=int, default=100, help="synthetic stand-in for the 100 test chairs")
     p.add_argument("--eval_every", type=int, default=10)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--restore", default="", help="TF V2 checkpoint prefix (model.ckpt) or .npz to start from")
     return p
 
 
@@ -152,6 +153,7 @@ def train(argv=None):
     import torch.distributed as dist
     from .ddp import shard_range
     from .model import DPDistParams
+    from .tf_checkpoint import read_checkpoint, write_checkpoint
     from .trainer import DPDistTrainer
 
     F = build_parser().parse_args(argv)
@@ -184,6 +186,8 @@ def train(argv=None):
     test_ds = SyntheticDistanceDataset(F.test_shapes, 2 * N, F.batch_size, "test", F.seed)
     params = DPDistParams(k=K, mlp=(1024, 1024, 1024), device=dev)
     params.reset_parameters_tf(generator=torch.Generator().manual_seed(F.seed))               # replicated variables
+    if F.restore:                                                                            # saver.restore (:443-453)
+        params.load_tf_state_dict(dict(np.load(F.restore)) if F.restore.endswith(".npz") else read_checkpoint(F.restore))
     tr = DPDistTrainer(params, dev_bs, num_point=N, Embedding_Size=F.embedding_size, sigma3dmfv=sigma,
                        base_lr=F.learning_rate_dpdist, decay_step=F.decay_step, decay_rate=F.decay_rate)
     lo, hi = shard_range(F.batch_size, rank, world)
@@ -233,7 +237,9 @@ def train(argv=None):
             es, ep = run_epoch(test_ds, False)
             log_string("eval mean loss: %f" % es)
             if rank == 0:
-                np.savez(os.path.join(F.log_dir, "model.ckpt.npz"), **params.tf_state_dict())   # TF variable names/layouts
+                sd = params.tf_state_dict()                                                    # TF variable names/layouts
+                np.savez(os.path.join(F.log_dir, "model.ckpt.npz"), **sd)
+                write_checkpoint(os.path.join(F.log_dir, "model.ckpt"), sd)                    # saver.save(...) (:354-357)
                 with open(os.path.join(F.log_dir, "metrics.jsonl"), "a") as f:
                     f.write(json.dumps({"epoch": epoch + 1, "step": tr.t, "train_loss_samples": ls, "eval_loss_samples": es}) + "\n")
     if world > 1:

@@ -183,6 +183,10 @@ size_t dpd_workspace_bytes(int Q, int KP, int H, int dtype);
 int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float gscale, float* loss,
                 float* dpred, void* stream);
 
+/* Host utility: CRC32C (Castagnoli, reflected, init/xorout ~0) of n bytes continuing from `crc` (0 to start); used
+ * by the TensorFlow-checkpoint interchange of dpdist_amd/tf_checkpoint.py.  No device work.                 */
+uint32_t dpd_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* ---------------------------------------------------------------------------------------------
  * Chamfer distance (baseline loss of the AUE task).  Replaces pairwise_diff + chmafer_dist
  * (train_multi_gpu_pc_compare_dist.py:891-916): a [B,N,3] (pc), b [B,M,3] (rec_pc),
