@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"],
                     help="compute type of the three wide decoder layers (include/dpdist_capi.h: enum dpd_dtype)")
+    ap.add_argument("--no-other-dtypes", action="store_true",
+                    help="skip the extra single-GPU timing of the same step in the other compute types")
     ap.add_argument("--prefetch", action="store_true", help="side-stream input pipeline (DPDistTrainer.step(prefetch=...))")
     ap.add_argument("--plan", default="", help="GEMM plan overrides for tuning, e.g. '0:10,1:9:1' = op:tile[:split_k]")
     a = ap.parse_args()
@@ -201,6 +203,34 @@ def main():
                           "pairs_per_gpu": B, "global_batch": B * world, "num_point": N, "query_points_per_step": 2 * B * N * world,
                           "parallelism": "dp%d" % world, "loss_samples_last": round(float(loss[0]), 6)},
                "roofline": roof}
+        if world == 1 and not use_dist and not a.no_other_dtypes:
+            # Same step, same batch, same K steps in the other compute types of the decoder GEMMs (include/dpdist_capi.h:
+            # enum dpd_dtype).  Reported next to `value`, never as `value`: f32x3 is fp32-equivalent (tests prove it at
+            # least as accurate as the exact-fp32 MFMA path), bf16 is the mixed-precision type of BASELINE configs 3-4.
+            others = {}
+            for dt in os.environ.get("DPD_BENCH_OTHERS", "f32,f32x3,bf16").split(","):
+                if dt == a.dtype:
+                    continue
+                try:
+                    P2 = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev, compute_dtype=dt)
+                    P2.reset_parameters_tf(generator=torch.Generator().manual_seed(1234))
+                    tr2 = DPDistTrainer(P2, B, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4, distributed=False)
+                    for _ in range(a.warmup):
+                        tr2.step(pcA, pcB, lab)
+                    e2 = float("inf")
+                    for _rep in range(2):      # best of two: late in a long process the host occasionally stalls a whole loop
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(a.steps):
+                            tr2.step(pcA, pcB, lab)
+                        torch.cuda.synchronize()
+                        e2 = min(e2, time.perf_counter() - t1)
+                    others[dt] = {"ms_per_step": round(e2 / a.steps * 1e3, 4), "value": round(2.0 * B * N * a.steps / e2, 1),
+                                  "loss_samples_last": round(float(tr2.loss.cpu()[0]), 6)}
+                    del tr2, P2
+                except Exception as e:   # never take the headline number down
+                    others[dt] = {"error": repr(e)}
+            out["other_compute_types"] = others
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(B, N)

@@ -471,14 +471,21 @@ struct GemmProf {
     static constexpr int kMax = 8192;
     hipEvent_t ev[2 * kMax];
     double flops[kMax];
-    bool have_events = false;
+    int created = 0;   // events [0, created) exist
 };
 static GemmProf g_prof;
 
+// Events are created on demand and destroyed by dpd_prof_enable(0): thousands of live timing events slow every
+// later kernel launch of the process down (host side; measured as sporadic 3x slower steps after a profiled pass).
 bool prof_begin(hipStream_t s) {
-    const bool on = g_prof.on && g_prof.n < GemmProf::kMax;
-    if (on) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
-    return on;
+    if (!(g_prof.on && g_prof.n < GemmProf::kMax)) return false;
+    for (int i = 2 * g_prof.n; i < 2 * g_prof.n + 2; ++i)
+        if (i >= g_prof.created) {
+            if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return false;
+            g_prof.created = i + 1;
+        }
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
+    return true;
 }
 void prof_end(bool on, hipStream_t s, double flops) {
     if (!on) return;
@@ -625,12 +632,14 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 // ---- profiler C ABI -------------------------------------------------------------------------------------
 extern "C" int dpd_prof_enable(int on) {
     using dpd::g_prof;
-    if (on && !g_prof.have_events) {
-        for (int i = 0; i < 2 * dpd::GemmProf::kMax; ++i) DPD_HIP(hipEventCreate(&g_prof.ev[i]));
-        g_prof.have_events = true;
-    }
     g_prof.on = on != 0;
-    if (on) g_prof.n = 0;
+    if (on) {
+        g_prof.n = 0;
+    } else {   // release the events (dpd_prof_collect must have been called before)
+        for (int i = 0; i < g_prof.created; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        g_prof.created = 0;
+        g_prof.n = 0;
+    }
     return 0;
 }
 
