@@ -471,6 +471,259 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Backward, sliced over the POINTS: kSlices workgroups per cloud (a single workgroup per cloud leaves 3/4 of the chip idle
+// at the as-loss batch sizes: 32 clouds at B = 16).  Everything that is a sum over Gaussians for a fixed point (T_n, dx_n)
+// is local to the point's slice; the only cross-slice quantity is the per-Gaussian statistic record (7 sums, 7 maxima,
+// 6 minima over the points + how many points attain each extreme), exchanged through `part`:
+//   mfv3d_bwd_stats_kernel   slice -> part[c][s][33][G]    (sum / max / min over the slice's points, local tie counts)
+//   mfv3d_bwd_apply_kernel   combines the kSlices records (ties: counts of the slices whose extreme equals the global
+//                            one), then runs P2-P4 of mfv3d_bwd_kernel for its own points and writes their dpts.
+// Same per-(point, Gaussian) expressions as the monolithic kernel -> identical tie tests; sums differ by association.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRec = 33;   // 20 statistics + 13 tie counts
+
+__device__ __forceinline__ void build_tables(const float* p, int n0, int np_, const MfvConst& k, float2* s_zq, float* s_S, int tid) {
+    const int m = k.m;
+    for (int e = tid; e < 3 * np_ * m; e += kFwdThreads) {
+        const int a = e / (np_ * m), ln = (e / m) % np_, i = e % m;
+        const float z = (p[(n0 + ln) * 3 + a] - k.ax.c[i]) / k.sigma;
+        s_zq[e] = make_float2(z, expf(-0.5f * (z * z)));
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * np_; e += kFwdThreads) {
+        float S = 0.f;
+        for (int i = 0; i < m; ++i) S += s_zq[e * m + i].y;
+        s_S[e] = S;
+    }
+    __syncthreads();
+    for (int e = tid; e < 3 * np_ * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[e / m];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const float* __restrict__ pts, float* __restrict__ part,
+                                                                       MfvConst k, int nslice) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = k.N, G = k.G, m = k.m;
+    const int c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
+    const int n0 = min(N, sl * nslice), np_ = min(N, n0 + nslice) - n0;
+    float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][np_][m]
+    float* s_S = sm + 6 * nslice * m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    build_tables(pts + (size_t)c * N * 3, n0, np_, k, s_zq, s_S, tid);
+    const float2* zqx = s_zq;
+    const float2* zqy = s_zq + np_ * m;
+    const float2* zqz = s_zq + 2 * np_ * m;
+    const int g = wave * 32 + (lane & 31);
+    const bool live = g < G;
+    const int gg = live ? g : 0;
+    const int gi = gg / (m * m), gj = (gg / m) % m, gt = gg % m;
+    const float inv_dpi = 1.0f / k.dpi_den;
+    const int hpts = (np_ + 1) / 2;
+    const int nbeg = half * hpts, nend = min(np_, (half + 1) * hpts);
+    float rec[kRec];
+    {
+        float pi_s = 0.f, pi_mx = -INFINITY;
+        float mu_s[3] = {0.f, 0.f, 0.f}, mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
+        float sg_s[3] = {0.f, 0.f, 0.f}, sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
+        for (int n = nbeg; n < nend; ++n) {
+            const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+            pi_s += q.dpi; pi_mx = fmaxf(pi_mx, q.dpi);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                mu_s[d] += q.a[d]; mu_mx[d] = fmaxf(mu_mx[d], q.a[d]); mu_mn[d] = fminf(mu_mn[d], q.a[d]);
+                sg_s[d] += q.b[d]; sg_mx[d] = fmaxf(sg_mx[d], q.b[d]); sg_mn[d] = fminf(sg_mn[d], q.b[d]);
+            }
+        }
+        rec[0] = pi_s + __shfl_xor(pi_s, 32, 64);            // SUMS here (the mean's 1/N is applied after the combine)
+        rec[1] = fmaxf(pi_mx, __shfl_xor(pi_mx, 32, 64));
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            rec[2 + d] = mu_s[d] + __shfl_xor(mu_s[d], 32, 64);
+            rec[5 + d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], 32, 64));
+            rec[8 + d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], 32, 64));
+            rec[11 + d] = sg_s[d] + __shfl_xor(sg_s[d], 32, 64);
+            rec[14 + d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], 32, 64));
+            rec[17 + d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], 32, 64));
+        }
+    }
+    {
+        float cnt[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) cnt[i] = 0.f;
+        for (int n = nbeg; n < nend; ++n) {
+            const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+            cnt[0] += (q.dpi == rec[1]) ? 1.f : 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                cnt[1 + d] += (q.a[d] == rec[5 + d]) ? 1.f : 0.f;
+                cnt[4 + d] += (q.a[d] == rec[8 + d]) ? 1.f : 0.f;
+                cnt[7 + d] += (q.b[d] == rec[14 + d]) ? 1.f : 0.f;
+                cnt[10 + d] += (q.b[d] == rec[17 + d]) ? 1.f : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) rec[20 + i] = cnt[i] + __shfl_xor(cnt[i], 32, 64);
+    }
+    if (live && half == 0) {
+        float* out = part + ((size_t)(c * kSlices + sl) * kRec) * G + g;
+#pragma unroll
+        for (int i = 0; i < kRec; ++i) out[(size_t)i * G] = rec[i];
+    }
+}
+
+__global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const float* __restrict__ pts, const float* __restrict__ dfv,
+                                                                       const float* __restrict__ part, float* __restrict__ dpts,
+                                                                       MfvConst k, int nslice) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = k.N, G = k.G, m = k.m;
+    const int c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
+    const int n0 = min(N, sl * nslice), np_ = min(N, n0 + nslice) - n0;
+    float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][np_][m]
+    float* s_S = sm + 6 * nslice * m;               // [3][nslice]
+    float* s_chred = s_S + 3 * nslice;              // [16][40]
+    float* s_ch = s_chred + 16 * 2 * kF;            // [40]
+    float* s_T = s_ch + 2 * kF;                     // [nslice]
+    float* s_part = s_T + nslice;                   // [16][nslice][3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    build_tables(pts + (size_t)c * N * 3, n0, np_, k, s_zq, s_S, tid);
+    const float2* zqx = s_zq;
+    const float2* zqy = s_zq + np_ * m;
+    const float2* zqz = s_zq + 2 * np_ * m;
+    const int g = wave * 32 + (lane & 31);
+    const bool live = g < G;
+    const int gg = live ? g : 0;
+    const int gi = gg / (m * m), gj = (gg / m) % m, gt = gg % m;
+    const float invN = 1.0f / (float)N, inv_dpi = 1.0f / k.dpi_den;
+    const int hpts = (np_ + 1) / 2;
+    const int nbeg = half * hpts, nend = min(np_, (half + 1) * hpts);
+
+    // ---- combine the slices' records (fixed order) ------------------------------------------------------------
+    float raw[kF], cnt[13];
+    {
+        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
+        float r[kSlices][kRec];
+#pragma unroll
+        for (int s2 = 0; s2 < kSlices; ++s2)
+#pragma unroll
+            for (int i = 0; i < kRec; ++i) r[s2][i] = part[((size_t)(c * kSlices + s2) * kRec + i) * G + gg];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) {
+            const bool is_sum = (f == 0) || (f >= 2 && f < 5) || (f >= 11 && f < 14);
+            const bool is_max = (f == 1) || (f >= 5 && f < 8) || (f >= 14 && f < 17);
+            float v = r[0][f];
+#pragma unroll
+            for (int s2 = 1; s2 < kSlices; ++s2) v = is_sum ? v + r[s2][f] : (is_max ? fmaxf(v, r[s2][f]) : fminf(v, r[s2][f]));
+            raw[f] = is_sum ? v * invN : v;
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < kSlices; ++s2) t += (r[s2][mm[i]] == raw[mm[i]]) ? r[s2][20 + i] : 0.f;
+            cnt[i] = t;
+        }
+    }
+    // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv (every slice recomputes them: all G are in the block) ----
+    const float* df = dfv + ((size_t)c * G + gg) * kF;
+    float dr[kF];
+    {
+        const bool mine = live && half == 0;
+#pragma unroll
+        for (int f = 0; f < kF; ++f) {
+            const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
+            const float sv = pnorm(raw[f] * cst);
+            const float dy = mine ? df[f] : 0.f;
+            const float a = wave_sum(mine ? sv * sv : 0.f), b = wave_sum(sv * dy);
+            if (lane == 0) { s_chred[wave * 2 * kF + f] = a; s_chred[wave * 2 * kF + kF + f] = b; }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * kF) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_chred[w * 2 * kF + tid];
+        s_ch[tid] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < kF; ++f) {
+        const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
+        const float v = raw[f] * cst;
+        const float sv = pnorm(v);
+        const float ss = s_ch[f], dot = s_ch[kF + f];
+        const float dy = live ? df[f] : 0.f;
+        float ds;
+        if (ss >= 1e-12f) {
+            const float rs = 1.0f / sqrtf(ss);
+            ds = rs * dy - sv * dot * rs * rs * rs;
+        } else {
+            ds = dy * 1e6f;
+        }
+        float dv = 0.f;
+        if (fabsf(v) >= 1e-12f) dv = ds * 0.5f / sqrtf(fabsf(v));
+        float d = dv * cst;
+        if (f == 0 || (f >= 2 && f < 5) || (f >= 11 && f < 14)) d *= invN;
+        dr[f] = live ? d : 0.f;
+    }
+    {
+        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
+#pragma unroll
+        for (int i = 0; i < 13; ++i) dr[mm[i]] = dr[mm[i]] / fmaxf(cnt[i], 1.f);
+    }
+    // ---- T_n and dz for the slice's own points (as P3 / P4 of mfv3d_bwd_kernel) ----------------------------------
+    for (int n = nbeg; n < nend; ++n) {
+        const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+        float dQ = (dr[0] + ((q.dpi == raw[1]) ? dr[1] : 0.f)) * inv_dpi;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float ga = dr[2 + d] + ((q.a[d] == raw[5 + d]) ? dr[5 + d] : 0.f) + ((q.a[d] == raw[8 + d]) ? dr[8 + d] : 0.f);
+            const float gb = dr[11 + d] + ((q.b[d] == raw[14 + d]) ? dr[14 + d] : 0.f) + ((q.b[d] == raw[17 + d]) ? dr[17 + d] : 0.f);
+            dQ += ga * q.z[d] + gb * (q.z[d] * q.z[d] - 1.0f);
+        }
+        const float t = half_sum32(live ? dQ * q.Q : 0.f);
+        if ((lane & 31) == 0) s_part[wave * nslice + n] = t;
+    }
+    __syncthreads();
+    for (int n = tid; n < np_; n += kFwdThreads) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_part[w * nslice + n];
+        s_T[n] = t;
+    }
+    __syncthreads();
+    for (int n = nbeg; n < nend; ++n) {
+        const PQ q = eval_pq(zqx[n * m + gj], zqy[n * m + gi], zqz[n * m + gt], k.w, inv_dpi);
+        float dQ = (dr[0] + ((q.dpi == raw[1]) ? dr[1] : 0.f)) * inv_dpi;
+        float ga[3], gb[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ga[d] = dr[2 + d] + ((q.a[d] == raw[5 + d]) ? dr[5 + d] : 0.f) + ((q.a[d] == raw[8 + d]) ? dr[8 + d] : 0.f);
+            gb[d] = dr[11 + d] + ((q.b[d] == raw[14 + d]) ? dr[14 + d] : 0.f) + ((q.b[d] == raw[17 + d]) ? dr[17 + d] : 0.f);
+            dQ += ga[d] * q.z[d] + gb[d] * (q.z[d] * q.z[d] - 1.0f);
+        }
+        const float u = dQ - s_T[n];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float dz = live ? q.Q * (ga[d] + 2.0f * gb[d] * q.z[d]) - q.z[d] * q.Q * u : 0.f;
+            const float t = half_sum32(dz);
+            if ((lane & 31) == 0) s_part[(wave * nslice + n) * 3 + d] = t;
+        }
+    }
+    __syncthreads();
+    float* out = dpts + ((size_t)c * N + n0) * 3;
+    for (int i = tid; i < np_ * 3; i += kFwdThreads) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_part[w * nslice * 3 + i];
+        out[i] = t / k.sigma;
+    }
+}
+
+static size_t bwd_sliced_lds_bytes(int nslice, int m) {
+    return (size_t)(6 * nslice * m + 3 * nslice + 16 * 2 * kF + 2 * kF + nslice + 16 * nslice * 3 + 4) * sizeof(float);
+}
+
 static size_t bwd_lds_bytes(int N, int m) {
     return (size_t)(6 * N * m + 3 * N + 16 * 2 * kF + 2 * kF + N + 16 * N * 3 + 4) * sizeof(float);
 }
@@ -503,14 +756,31 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     return 0;
 }
 
-extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, int m, float sigma, float* dpts,
-                             void* stream) {
+extern "C" size_t dpd_mfv3d_bwd_workspace_bytes(int C, int m) {
+    return (size_t)(C > 0 ? C : 0) * dpd::kSlices * dpd::kRec * (size_t)(m * m * m) * sizeof(float);
+}
+
+extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, int m, float sigma, float* dpts, void* ws,
+                             size_t ws_bytes, void* stream) {
     using namespace dpd;
     if (!pts || !dfv || !dpts) return DPD_E_NULL;
     if (C <= 0) return DPD_E_DIM;
     MfvConst k{};
     if (int rc = make_const(N, m, sigma, k)) return rc;
     if (k.G > 512) return DPD_E_UNSUPPORTED;   // per-Gaussian gradient record lives in registers: one Gaussian per lane pair
+    if (ws && ws_bytes >= dpd_mfv3d_bwd_workspace_bytes(C, m) && N >= 2 * kSlices) {
+        // sliced over the points: kSlices workgroups per cloud, per-Gaussian statistic records exchanged through `ws`
+        const int nslice = (N + kSlices - 1) / kSlices;
+        const size_t l1 = (size_t)(6 * nslice * m + 3 * nslice + 4) * sizeof(float), l2 = bwd_sliced_lds_bytes(nslice, m);
+        if (int rc = set_lds(mfv3d_bwd_stats_kernel, l1)) return rc;
+        if (int rc = set_lds(mfv3d_bwd_apply_kernel, l2)) return rc;
+        DPD_LAUNCH(mfv3d_bwd_stats_kernel, dim3(C * kSlices), dim3(kFwdThreads), l1, (hipStream_t)stream, pts, (float*)ws, k, nslice);
+        DPD_CHECK_LAUNCH();
+        DPD_LAUNCH(mfv3d_bwd_apply_kernel, dim3(C * kSlices), dim3(kFwdThreads), l2, (hipStream_t)stream, pts, dfv, (const float*)ws,
+                   dpts, k, nslice);
+        DPD_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = bwd_lds_bytes(N, m);
     if (int rc = set_lds(mfv3d_bwd_kernel, lds)) return rc;
     DPD_LAUNCH(mfv3d_bwd_kernel, dim3(C), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, dfv, dpts, k);

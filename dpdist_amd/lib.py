@@ -34,7 +34,8 @@ SIGNATURES = {
     "dpd_version": (c_char_p, []),
     "dpd_padded_width": (c_int, [c_int]),
     "dpd_mfv3d_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
-    "dpd_mfv3d_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "dpd_mfv3d_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dpd_mfv3d_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dpd_patch_rows_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, POINTER(Planes), c_void_p]),
     "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

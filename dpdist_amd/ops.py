@@ -23,12 +23,15 @@ def mfv3d_fwd(pts, m, sigma):
     return fv
 
 
-def mfv3d_bwd(pts, dfv, m, sigma):
+def mfv3d_bwd(pts, dfv, m, sigma, sliced=True):
+    """dfv [C,m^3,20] -> dpts [C,N,3]; sliced: 4 workgroups per cloud through a small workspace (default)."""
     L.req(pts, name="pts"), L.req(dfv, name="dfv")
     C, N, _ = pts.shape
     dpts = torch.empty_like(pts)
-    L.check(L.load().dpd_mfv3d_bwd(L.ptr(pts), L.ptr(dfv), C, N, m, float(sigma), L.ptr(dpts), L.cur_stream()),
-            "dpd_mfv3d_bwd")
+    lib = L.load()
+    ws = torch.empty(lib.dpd_mfv3d_bwd_workspace_bytes(C, m) // 4, device=pts.device, dtype=torch.float32) if sliced else None
+    L.check(lib.dpd_mfv3d_bwd(L.ptr(pts), L.ptr(dfv), C, N, m, float(sigma), L.ptr(dpts), L.ptr(ws),
+                              ws.numel() * 4 if ws is not None else 0, L.cur_stream()), "dpd_mfv3d_bwd")
     return dpts
 
 

@@ -63,8 +63,11 @@ int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma, float* fv,
 
 /* Backward of the encoder (TF autodiff of :69-126): dfv [C,m^3,20] -> dpts [C,N,3] (overwritten).
  * Max/min gradients are split evenly among ties, like tf.reduce_max/min.                        */
-int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, int m, float sigma, float* dpts,
-                  void* stream);
+int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, int m, float sigma, float* dpts, void* ws,
+                  size_t ws_bytes, void* stream);
+/* ws (optional): dpd_mfv3d_bwd_workspace_bytes(C, m) bytes let the backward run as 4 workgroups per cloud (sliced over
+ * the points, two launches) instead of one -- 2-3x faster at the as-loss batch sizes; NULL keeps the one-launch form. */
+size_t dpd_mfv3d_bwd_workspace_bytes(int C, int m);
 
 /* ---------------------------------------------------------------------------------------------
  * Query -> voxel lookup + local-window gather.  Replaces local_z_3d (utils/dpdist_util.py:911-930),
