@@ -44,6 +44,16 @@ def gemm_flops_per_step(B, N, E3, H):
     return fwd + bwd, 3 + 2 + 3
 
 
+def gemm_bytes_per_step(B, N, KP, H):
+    """Algorithmic HBM bytes of the same GEMMs (fp32; every operand read once, every result written once; the dH GEMMs
+    also read their ReLU gate)."""
+    Q, BN = 2 * B * N, B * N
+    fwd = 4.0 * ((Q * KP + KP * H + Q * H) + 2 * (Q * H + H * H + Q * H))
+    dh = 4.0 * 2 * (BN * H + H * H + BN * H + BN * H)
+    dw = 4.0 * ((BN * KP + BN * H + KP * H) + 2 * (BN * H + BN * H + H * H))
+    return fwd + dh + dw
+
+
 def cpu_baseline(B, N, budget_s=24.0):
     """Oracle fwd+bwd (training mode) on the host cores; bounded sample, reported in query-points/sec.
     torch-CPU collapses when given every hardware thread of a large box, so a few intra-op thread counts are tried
@@ -83,6 +93,26 @@ def cpu_baseline(B, N, budget_s=24.0):
     return {"value": round(qps, 1), "unit": "query-points/sec", "cores": nt, "kind": "port",
             "sample": "%d fwd+bwd steps of the torch-CPU oracle at B=%d (same S2 workload) in %.1f s with %d threads "
                       "(best of %s threads; host has %d hardware threads)" % (n, B, el, nt, cands, ncpu)}
+
+
+def pmc_traffic(kernel_substr):
+    """Fabric-side bytes per launch of the dominant kernel family from the COMMITTED PMC summary of the same command
+    (profiles/rNN_pmc_summary.csv: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md section HBM).  bench.py cannot collect counters itself; None when no summary is in the tree."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return None, None
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_substr in r["kernel"] and r["calls_in_stats"] and r["fabric_read_MB_per_launch(x2 gfx950 correction)"]:
+            calls = int(r["calls_in_stats"])
+            rd = float(r["fabric_read_MB_per_launch(x2 gfx950 correction)"]) * 1e6
+            wr = float(r["WRITE_SIZE_KB_per_launch"] or 0) * 1024.0
+            tot += calls * (rd + wr)
+            n += calls
+    return (tot / n if n else None), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -184,11 +214,18 @@ def main():
                 mult, peak, kern = {"f32": (1, PEAK_FP32_MFMA_TFLOPS, "gemm_dma_kernel<WR,WC,NS,...> (fp32 v_mfma_f32_32x32x2, LDS-DMA ring)"),
                                     "f32x3": (6, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<3,...> (6 x v_mfma_f32_32x32x16_bf16 per product, LDS-DMA ring)"),
                                     "bf16": (1, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<1,...> (v_mfma_f32_32x32x16_bf16, LDS-DMA ring)")}[a.dtype]
+                traffic, tsrc = pmc_traffic("gemm_dma_kernel") if a.dtype == "f32" else (None, None)
                 roof = {"bound": "mfma", "kernel": kern,
                         "achieved": round(ach * mult, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach * mult / peak, 4), "traffic": None, "algorithmic_tflops": round(ach, 2),
+                        "frac": round(ach * mult / peak, 4),
+                        "traffic": round(traffic) if traffic else None,
+                        "traffic_note": ("bytes per launch at the L2's fabric side (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits "
+                                         "included), launch-weighted over the family, from %s" % tsrc) if traffic else
+                                        "PMC passes are separate rocprofv3 runs: profiles/",
+                        "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(B, N, 2528, 1024) / (launches / a.steps)),
+                        "algorithmic_tflops": round(ach, 2),
                         "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
-                        "alg_gflop_per_launch": round(alg / per_step / 1e9, 3),
+                        "alg_gflop_per_launch": round(alg / (launches / a.steps) / 1e9, 3),
                         "gemm_ms_per_step": round(ms.value / a.steps, 4)}
     if use_dist:
         dist.barrier()
