@@ -738,7 +738,8 @@ def test_prefetch_pipeline_is_bitwise_equivalent(dev):
     assert (tr2.evaluate(*batches[2])[0] - l2).abs().max().item() <= 1e-7
 
 
-def test_data_parallel_schedule_matches_plain_backward(dev):
+@pytest.mark.parametrize("dt", ["f32", "f32x3"])
+def test_data_parallel_schedule_matches_plain_backward(dev, dt):
     """The interleaved data-parallel backward (phased data chain, dW3 -> dW2 -> dW1, three buckets all-reduced on the RCCL
     stream; exercised here with a single-rank process group) produces the same gradients as the plain schedule."""
     import torch.distributed as dist
@@ -756,7 +757,7 @@ def test_data_parallel_schedule_matches_plain_backward(dev):
     try:
         for mode in ("plain", "dp"):
             os.environ["DPD_FORCE_DIST"] = "1" if mode == "dp" else "0"
-            P = DPDistParams(device=dev)
+            P = DPDistParams(device=dev, compute_dtype=dt)
             P.load_tf_state_dict(W0)
             tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=(mode == "dp"))
             assert (tr.reducer is not None and tr.reducer.active) == (mode == "dp")
@@ -774,8 +775,10 @@ def test_data_parallel_schedule_matches_plain_backward(dev):
         a, b = g0[off:off + cnt], g1[off:off + cnt]
         if n in ("b1", "b2"):      # fp32 atomics in the dH epilogues: order-dependent round-off
             assert (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item()), n
-        else:                      # dW2/dW3 come from different launches (grouped vs single): same tiles, same k order
+        elif dt == "f32":          # dW2/dW3 come from different launches (grouped vs single): same tiles, same k order
             assert torch.equal(a, b), n
+        else:                      # plane path: grouped 64x128 tiles vs single 64x64 tiles -> different accumulation order
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item()), n
 
 
 def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
