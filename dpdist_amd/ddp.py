@@ -26,17 +26,19 @@ def shard_range(global_batch, rank, world):
 
 
 class BucketReducer:
-    """All-reduce slices of one flat gradient buffer, asynchronously with respect to the compute stream."""
+    """All-reduce slices of one flat gradient buffer, asynchronously with respect to the compute stream.
+
+    The collective is issued with async_op=True from the compute stream: ProcessGroupNCCL orders its internal RCCL stream
+    after everything already enqueued on the current stream (the producers of the bucket) and `Work.wait()` later makes
+    the current stream -- not the host -- wait for it, so one event hop each way is all the synchronisation there is."""
 
     def __init__(self, flat_grad, bounds, group=None, force=False):
         self.flat = flat_grad
         self.bounds = list(bounds)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.cuda = flat_grad.is_cuda
         # force=True issues the collectives even for a single rank (exercises the RCCL/stream plumbing on one GPU)
         self.active = dist.is_initialized() and (self.world > 1 or force)
-        self.comm_stream = torch.cuda.Stream() if (self.cuda and self.active) else None
         self._pending = []
 
     def reduce_async(self, bucket):
@@ -44,26 +46,12 @@ class BucketReducer:
         if not self.active:
             return
         lo, hi = self.bounds[bucket], self.bounds[bucket + 1]
-        view = self.flat[lo:hi]
-        if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                done = torch.cuda.Event()
-                done.record(self.comm_stream)
-            self._pending.append(done)
-        else:   # gloo / CPU tensors (tests)
-            self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
         """Make the current stream (or the host, for CPU tensors) wait for every outstanding bucket."""
         for h in self._pending:
-            if self.cuda:
-                torch.cuda.current_stream().wait_event(h)
-            else:
-                h.wait()
+            h.wait()
         self._pending = []
 
     @property
