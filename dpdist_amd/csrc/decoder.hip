@@ -14,7 +14,7 @@ namespace dpd {
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
              size_t ws_bytes, hipStream_t s, float* colsum = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
-             float* C2 = nullptr);
+             float* C2 = nullptr, const int* M_dev = nullptr, const int* K_dev = nullptr);
 
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
@@ -564,7 +564,8 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
                                const dpd_planes* pl, void* stream) {
     using namespace dpd;
     pl = dpd::usable_planes(pl, dtype, Q, pl ? pl->Qb : 0, KP, H);
-    if ((!X && !(pl && pl->X_rc)) || !mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
+    const bool skip1 = !X && !(pl && pl->X_rc);   // layer 1 already evaluated into h1 (dpd_layer1_fwd_unique)
+    if (!mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
     if (pl && (pl->Q != Q || pl->Qb > Q)) return DPD_E_DIM;
     if (int rc = dpd::check_planes(pl, dtype)) return rc;
     if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
@@ -576,6 +577,7 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     if (pl) {   // operands from / results to the persistent planes (no conversion passes)
         X3Out o1 = make_out(pl, pl->h1_rc, Q, pl->h1_r8, pl->Qb, H), o2 = make_out(pl, pl->h2_rc, Q, pl->h2_r8, pl->Qb, H);
         const bool w1 = o1.rc || o1.r8, w2 = o2.rc || o2.r8;
+        if (skip1) return DPD_E_UNSUPPORTED;   // the unique-row layer 1 exists for DPD_F32 only
         if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s, nullptr,
                              pl->X_rc, pl->W1_r8, w1 ? &o1 : nullptr)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s, nullptr,
@@ -584,7 +586,8 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
                              pl->h2_rc, pl->W3_r8, nullptr)) return rc;
     } else {
         if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
-        if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
+        if (!skip1)
+            if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
     }

@@ -266,17 +266,23 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm0 = (wave / WC) * 32 * TM, wn0 = (wave % WC) * 32 * TN;
 
-    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    // data-dependent row count (row de-duplication): the grid is sized for g.M, the tile space -- and with it the XCD remap,
+    // so that the live tiles spread over all eight XCDs -- for the actual count; surplus workgroups exit
+    const int Mlim = g.M_dev ? min(g.M, *g.M_dev) : g.M;
+    const int tilesM = (Mlim + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int per_z = tilesM * tilesN;
     const int ngrp = g.A2 ? 2 : 1;
+    if ((int)blockIdx.x >= per_z * g.split_k * ngrp) return;   // whole workgroup: uniform, before any barrier
     const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
     const int grp = sid / (per_z * g.split_k);            // grouped launch: second problem of identical shape
     const int sid1 = sid % (per_z * g.split_k);
     const int z = sid1 / per_z, t = sid1 % per_z;
     const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
-    const int kbeg = z * g.k_chunk;
-    const int kend = min(g.K, kbeg + g.k_chunk);
-    const int nt = (kend - kbeg) / BK;
+    const int Klim = g.K_dev ? min(g.K, *g.K_dev) : g.K;  // data-dependent contraction length (multiple of 32)
+    const int kchunk = g.K_dev ? (((Klim + g.split_k - 1) / g.split_k + 31) / 32 * 32) : g.k_chunk;
+    const int kbeg = z * kchunk;
+    const int kend = min(Klim, kbeg + kchunk);
+    const int nt = max(0, (kend - kbeg) / BK);
     const float* gA = grp ? g.A2 : g.A;
     const float* gB = grp ? g.B2 : g.B;
 
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         const float* base = isA ? gA : gB;
         const int ld = isA ? g.lda : g.ldb;
         const int mn0 = isA ? m0 : n0;
-        const int MN = isA ? g.M : g.N;
+        const int MN = isA ? Mlim : g.N;   // (M_dev is only accepted for row-major A, so Mlim == g.M in the TN form)
         const int BMN = isA ? BM : BN;
         dst[j] = lds_base + (unsigned)((isA ? 0 : A_IMG) + c * 256) * 4u;
         if (kc) {
@@ -439,6 +445,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     }
     GemmArgs gs = g;
     if (grp) gs.C = g.C2;
+    gs.M = Mlim;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -571,7 +578,8 @@ static double tile_eff(int M, int N, int BM, int BN, int split) {
 
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
-             size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2) {
+             size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2, const int* M_dev,
+             const int* K_dev) {
     if (!A || !B || !C) return DPD_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || split_k < 1) return DPD_E_DIM;
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3)) return DPD_E_UNSUPPORTED;
@@ -595,6 +603,9 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.colsum = (split_k > 1) ? nullptr : colsum;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
+    g.M_dev = M_dev; g.K_dev = K_dev;
+    if ((M_dev || K_dev) && !(tile >= 4 && tile <= 20)) return DPD_E_UNSUPPORTED;   // device-side extents: DMA kernels only
+    if (M_dev && transA) return DPD_E_UNSUPPORTED;
     if (A2 && (!B2 || !C2 || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
     if (A2 && !(tile >= 4 && tile <= 20)) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA kernels only
     if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
@@ -663,12 +674,12 @@ extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
 extern "C" int dpd_gemm_f32_dbg(int M, int N, int K, const float* A, const float* B, float* Cout, float* dbg, int tile,
                                 void* stream) {
     return dpd::gemm_f32(0, 0, M, N, K, A, K, B, N, Cout, N, nullptr, nullptr, 0, 1, tile, nullptr, 0, (hipStream_t)stream, dbg,
-                         nullptr, nullptr, nullptr);
+                         nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* Cout, int ldc, const float* bias, const float* gate, int epilogue,
                             int split_k, int tile, void* ws, size_t ws_bytes, void* stream) {
     return dpd::gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, Cout, ldc, bias, gate, epilogue, split_k, tile, ws,
-                         ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
+                         ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }

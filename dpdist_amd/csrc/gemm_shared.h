@@ -18,6 +18,10 @@ struct GemmArgs {
     const float* A2;  // optional second problem of identical shape (grouped launch): blocks [per_z, 2*per_z)
     const float* B2;
     float* C2;
+    // optional data-dependent extents read on the DEVICE (row de-duplication, decoder.hip): the grid is sized for M / K,
+    // tiles whose rows start at or beyond *M_dev exit, the contraction stops at *K_dev (a multiple of 32, <= K)
+    const int* M_dev;
+    const int* K_dev;
     int M, N, K;
     int lda, ldb, ldc;
     int epi;

@@ -49,6 +49,11 @@ SIGNATURES = {
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p]),
+    "dpd_dedupe_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
+    "dpd_patch_rows_fwd_unique": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 5),
+    "dpd_layer1_fwd_unique": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5),
+    "dpd_layer1_bwd_unique_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpd_layer1_bwd_weights_unique": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dpd_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "dpd_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),

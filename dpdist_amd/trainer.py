@@ -34,7 +34,7 @@ def learning_rate(step, base=1e-4, decay_step=300 * 512, decay_rate=0.5, floor=1
 class DPDistTrainer:
     def __init__(self, params: DPDistParams, batch_size, num_point=64, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4,
                  decay_step=300 * 512, decay_rate=0.5, beta1=0.9, beta2=0.999, eps=1e-8, group=None, distributed=None,
-                 compute_dtype=None):
+                 compute_dtype=None, dedupe=None):
         self.P = params
         self.dt = L.DTYPES[params.compute_dtype if compute_dtype is None else compute_dtype]
         dev = params.flat.device
@@ -59,6 +59,17 @@ class DPDistTrainer:
         self.m_state = torch.zeros_like(self.grad)
         self.v_state = torch.zeros_like(self.grad)
         self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H, self.dt) + 3) // 4, device=dev, dtype=torch.float32)
+        # Layer 1 on the UNIQUE (cloud, voxel) rows (csrc/dedupe.hip): exact-fp32 compute type only.  Experimental and off by
+        # default (slower at B = 32 until the layer-1 GEMM gets a stream-K decomposition, see the header of dedupe.hip)
+        if dedupe is None:
+            dedupe = os.environ.get("DPD_DEDUPE", "0") == "1"
+        self.dedupe = bool(dedupe) and self.dt == 0 and KP % 32 == 0 and Q * 3 * 4 <= 150 * 1024 and BN >= 32
+        if self.dedupe:
+            i32 = lambda n: torch.empty(n, device=dev, dtype=torch.int32)   # noqa: E731
+            self.u_of_q, self.rep_q, self.counts = i32(Q), i32(Q), torch.zeros(4, device=dev, dtype=torch.int32)
+            self.xyz, self.T = f(Q, 3), f(Q, H)
+            self.ws1 = torch.empty(L.load().dpd_layer1_bwd_unique_workspace_bytes(BN, KP, H) // 4 + 1, device=dev,
+                                   dtype=torch.float32)
         # bf16-matrix-core compute types: operand planes persist between the kernels (no conversion passes)
         self._planes = None
         if self.dt and Q % 8 == 0 and BN % 32 == 0 and KP % 32 == 0:
@@ -69,7 +80,6 @@ class DPDistTrainer:
             L.check(lib.dpd_planes_carve(L.ptr(self._plane_mem), nbytes, Q, BN, KP, H, self.dt, 0, self._planes), "dpd_planes_carve")
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
-        import os
         self.reducer = BucketReducer(self.grad, params.bucket_bounds, group,
                                      force=os.environ.get("DPD_FORCE_DIST") == "1") if use_dist else None
         self._cparams = L.make_params(*params.views())
@@ -115,6 +125,12 @@ class DPDistTrainer:
     def _gather(self):
         lib, s, P = L.load(), L.cur_stream(), self.P
         C, N = 2 * self.B, self.N
+        if self.dedupe:     # voxel lookup + unique-row numbering, then the window gather of the unique rows only
+            L.check(lib.dpd_dedupe_rows(L.ptr(self.q), C, N, self.m, self.B * N, L.ptr(self.u_of_q), L.ptr(self.rep_q),
+                                        L.ptr(self.counts), L.ptr(self.xyz), L.ptr(self.mask), L.ptr(self.vox), s), "dpd_dedupe_rows")
+            L.check(lib.dpd_patch_rows_fwd_unique(L.ptr(self.fv), C, N, self.m, self.k, P.KP, L.ptr(self.rep_q), L.ptr(self.vox),
+                                                  L.ptr(self.counts), L.ptr(self.X), s), "dpd_patch_rows_fwd_unique")
+            return
         L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP,
                                        None if self._planes is not None else L.ptr(self.X), L.ptr(self.mask), L.ptr(self.vox),
                                        self._planes, s), "dpd_patch_rows_fwd")
@@ -128,6 +144,14 @@ class DPDistTrainer:
     def _decode(self):
         lib, s, P = L.load(), L.cur_stream(), self.P
         Q = 2 * self.B * self.N
+        if self.dedupe:     # layer 1 on the unique rows, expanded to h1; the decoder entry point then starts at layer 2
+            v = P.views()
+            L.check(lib.dpd_layer1_fwd_unique(L.ptr(self.X), L.ptr(self.counts), L.ptr(self.u_of_q), L.ptr(self.xyz), Q, P.KP, P.H,
+                                              P.E, L.ptr(v[0]), L.ptr(v[1]), L.ptr(self.T), L.ptr(self.h1), s), "dpd_layer1_fwd_unique")
+            L.check(lib.dpd_decoder_fwd(None, L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
+                                        L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
+                                        self.ws.numel() * 4, None, s), "dpd_decoder_fwd")
+            return
         L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
                                     L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
                                     self.ws.numel() * 4, self._planes, s), "dpd_decoder_fwd")
@@ -145,6 +169,12 @@ class DPDistTrainer:
                                              phases, s), "dpd_decoder_bwd_data")
 
         def dw(layer, act, g, dW):
+            if layer == 1 and self.dedupe:
+                L.check(lib.dpd_layer1_bwd_weights_unique(L.ptr(self.X), L.ptr(self.g1), L.ptr(self.u_of_q), L.ptr(self.rep_q),
+                                                          L.ptr(self.xyz), L.ptr(self.counts), self.N, BN, P.KP, P.H, P.E, L.ptr(dW),
+                                                          L.ptr(self.ws1), self.ws1.numel() * 4, L.cur_stream()),
+                        "dpd_layer1_bwd_weights_unique")
+                return
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
                                                 L.ptr(dW), None, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)

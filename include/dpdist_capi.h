@@ -102,6 +102,8 @@ int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, con
                     int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
                     const dpd_planes* pl, void* stream);
 
+/* X may be NULL when layer 1 was already evaluated into h1 by dpd_layer1_fwd_unique (DPD_F32, no planes).          */
+
 /* `dtype` of the decoder entry points = compute type of the three wide layers (inputs/outputs are always fp32):
  *   DPD_F32     exact fp32 on the fp32 matrix-core instruction (bitwise an fmaf chain), no workspace needed in
  *               dpd_decoder_fwd / dpd_decoder_bwd_data (ws may be NULL);
@@ -185,6 +187,31 @@ size_t dpd_workspace_bytes(int Q, int KP, int H, int dtype);
  * mode 2 (as-loss): dpred [2*BN,3] = d loss_pred / d pred * gscale.                              */
 int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float gscale, float* loss,
                 float* dpred, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row de-duplication for layer 1 (DPD_F32) -- EXPERIMENTAL, not used by default (see csrc/dedupe.hip for the measured
+ * status).  The 2500 window columns of a decoder input row depend only on (cloud,
+ * voxel of the query) (get_emb_and_concat gathers the same embedding row, utils/dpdist_util.py:434-457; only the three
+ * centre-relative coordinates differ, :455), and surface-shaped clouds put 64 queries into ~35-45 voxels, so layer 1
+ * and its weight gradient can run on the UNIQUE rows.  Everything data dependent stays on the device:
+ *   counts[0] = U (unique rows, numbered in query order), [1] = U_ab (those of the first Qb queries), [2],[3] = both
+ *   rounded up to 32.
+ * dpd_dedupe_rows        q [C,N,3] -> u_of_q [Q], rep_q [Q] (first query of each unique row), counts [4],
+ *                        xyz [Q,3] (q - voxel centre), mask [Q], vox [Q]        (replaces that part of dpd_patch_rows_fwd)
+ * dpd_patch_rows_fwd_unique   X_u [Q,KP]: rows [0,U) = window | 0 0 0 | 0-pad; rows [U, round32(U)) zeroed
+ * dpd_layer1_fwd_unique  T [Q,H] (rows < U) = X_u W1p;  h1 [Q,H] = relu(T[u_of_q] + xyz W1p[E..E+2] + b1)
+ * dpd_layer1_bwd_weights_unique   dW1 [KP,H] = X_u^T (segment sums of g1 over each unique row) ; rows E..E+2 = xyz^T g1
+ * Same values as the row-by-row evaluation up to the association of the three xyz terms in the fp32 sum.          */
+int dpd_dedupe_rows(const float* q, int C, int N, int m, int Qb, int32_t* u_of_q, int32_t* rep_q, int32_t* counts,
+                    float* xyz, float* mask, int32_t* vox, void* stream);
+int dpd_patch_rows_fwd_unique(const float* fv, int C, int N, int m, int k, int KP, const int32_t* rep_q,
+                              const int32_t* vox, const int32_t* counts, float* X_u, void* stream);
+int dpd_layer1_fwd_unique(const float* X_u, const int32_t* counts, const int32_t* u_of_q, const float* xyz, int Q, int KP,
+                          int H, int E, const float* W1p, const float* b1, float* T, float* h1, void* stream);
+size_t dpd_layer1_bwd_unique_workspace_bytes(int Qb, int KP, int H);
+int dpd_layer1_bwd_weights_unique(const float* X_u, const float* g1, const int32_t* u_of_q, const int32_t* rep_q,
+                                  const float* xyz, const int32_t* counts, int N, int Qb, int KP, int H, int E, float* dW1,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* Host utility: CRC32C (Castagnoli, reflected, init/xorout ~0) of n bytes continuing from `crc` (0 to start); used
  * by the TensorFlow-checkpoint interchange of dpdist_amd/tf_checkpoint.py.  No device work.                 */
