@@ -852,3 +852,37 @@ def test_unique_row_layer1_matches_plain_path(dev, case):
     assert (a["loss"] - b["loss"]).abs().max().item() <= 1e-6
     scale = a["grad"].abs().max().item()
     assert (a["grad"] - b["grad"]).abs().max().item() <= 2e-5 * max(1.0, scale), ((a["grad"] - b["grad"]).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("N", [36, 100])
+@pytest.mark.parametrize("dt", ["f32x3", "bf16"])
+def test_plane_paths_on_shapes_the_plane_kernels_do_not_take(dev, dt, N):
+    """num_point 36 / 100 with B = 3: Q = 216 / 600 rows, contraction lengths that are not multiples of 32 in the backward --
+    the decoder entry points run those GEMMs on the exact-fp32 kernel instead (documented fallback), results stay in bar,
+    and both trainers (plane path off for these shapes) and the autograd path work."""
+    from dpdist_amd import model as M
+    from dpdist_amd.trainer import DPDistTrainer
+    rng = np.random.default_rng(N)
+    pcA = rng.uniform(-0.9, 0.9, (3, N, 3)).astype(np.float32)
+    pcB = rng.uniform(-0.9, 0.9, (3, N, 3)).astype(np.float32)
+    lab = np.abs(pcB[..., 0]).astype(np.float32)
+    W = synth.make_weights("wide")
+    ref = _oracle_forward(pcA, pcB, W)
+    mod = _model(dev, "wide")
+    mod.params_.compute_dtype = dt
+    a = _cu(pcA, dev).requires_grad_(True)
+    ps = mod(a, _cu(pcB, dev))
+    tol = 1e-4 if dt == "f32x3" else 3e-2
+    for n in ("pred_listAB", "pred_listBA"):
+        assert np.abs(ps[n].detach().cpu().numpy() - ref[n].numpy()).max() <= tol
+    loss = M.DPDistLoss(mod)(a, _cu(pcB, dev))
+    (ga,) = torch.autograd.grad(loss, [a])
+    assert torch.isfinite(ga).all() and ga.abs().max().item() > 0
+    curves = {}
+    for name in ("f32", dt):                       # the trainer on these shapes tracks the exact-fp32 trainer
+        P = M.DPDistParams(device=dev, compute_dtype=name)
+        P.load_tf_state_dict(W)
+        tr = DPDistTrainer(P, 3, num_point=N, base_lr=1e-4, distributed=False)
+        curves[name] = np.array([tr.step(_cu(pcA, dev), _cu(pcB, dev), _cu(lab, dev))[0].item() for _ in range(5)])
+    assert np.isfinite(curves[dt]).all()
+    assert np.abs(curves[dt] - curves["f32"]).max() <= (1e-4 if dt == "f32x3" else 2e-2)
