@@ -886,3 +886,25 @@ def test_plane_paths_on_shapes_the_plane_kernels_do_not_take(dev, dt, N):
         curves[name] = np.array([tr.step(_cu(pcA, dev), _cu(pcB, dev), _cu(lab, dev))[0].item() for _ in range(5)])
     assert np.isfinite(curves[dt]).all()
     assert np.abs(curves[dt] - curves["f32"]).max() <= (1e-4 if dt == "f32x3" else 2e-2)
+
+
+def test_integration_md_stub_runs_as_written(dev, golden_dir, monkeypatch):
+    """The ctypes stub printed in INTEGRATION.md section 2 is executed verbatim and must reproduce the golden forward."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch.*?)```", text, re.S).group(1)
+    monkeypatch.chdir(root)                       # the stub opens "dpdist_amd/libdpdist_hip.so" relative to the repo root
+    from dpdist_amd import lib as L
+    L.load()                                      # torch first, then the library (load order note of section 1)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    d = _g(golden_dir, "path_fwd_s1_wide.npz")
+    mod = _model(dev, "wide")
+    v = mod.params_.views()
+    params = ns["DecoderParams"](*[t.data_ptr() for t in v])
+    pcA, pcB = _cu(d["pcA"], dev), _cu(d["pcB"], dev)
+    out = ns["dpdist_forward"](pcA, pcB, torch.zeros_like(pcA), params)
+    torch.cuda.synchronize()
+    for n in ("pred_listAB", "pred_listBA"):
+        _check_pred(out[n].cpu().numpy(), d[n + "_f64"], True)
