@@ -27,3 +27,10 @@ python $R/bench.py --batch 64 --no-cpu-baseline > $OUT/bench_f32_b64.json 2>> $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32x3 -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype f32x3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16 -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype bf16 > /dev/null 2>&1
 python $R/tools/x3_bench.py 2 3 5 > $OUT/x3_bench.txt 2>&1
+# PMC passes for the plane compute types (same separate-pass rule)
+for dt in f32x3 bf16; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${dt}_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes --dtype $dt > /dev/null 2>&1
+  done
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_${dt}_MFMA -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes --dtype $dt > /dev/null 2>&1
+done

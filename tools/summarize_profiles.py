@@ -41,31 +41,39 @@ for sub, out in (("stats", "kernel_stats.csv"), ("stats_f32x3", "kernel_stats_f3
             w.writerow([r["Name"], r["Calls"], "%.1f" % (float(r["TotalDurationNs"]) / 1e3), "%.2f" % (float(r["AverageNs"]) / 1e3),
                         "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3), r["Percentage"]])
 
-# PMC summary: FETCH_SIZE / WRITE_SIZE (KiB per launch) and MFMA-busy fraction per kernel
-acc = defaultdict(lambda: defaultdict(list))
-for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_MFMA"):
-    f = os.path.join(src, sub, "p_counter_collection.csv")
-    if not os.path.exists(f):
-        continue
-    for r in csv.DictReader(open(f)):
-        if mine(r["Kernel_Name"]):
-            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-stats = {}
-f = os.path.join(src, "stats", "%s_kernel_stats.csv" % tag)
-if os.path.exists(f):
-    stats = {r["Name"]: r for r in csv.DictReader(open(f))}
-with open(os.path.join(dst, "%s_pmc_summary.csv" % tag), "w", newline="") as fh:
-    w = csv.writer(fh)
-    w.writerow(["kernel", "calls_in_stats", "avg_us", "FETCH_SIZE_KB_per_launch(raw)", "fabric_read_MB_per_launch(x2 gfx950 correction)",
-                "WRITE_SIZE_KB_per_launch", "MFMA_busy_frac(under PMC collection)"])
-    mean = lambda v: sum(v) / len(v) if v else None   # noqa: E731
-    for k, c in sorted(acc.items(), key=lambda kv: -float(stats.get(kv[0], {}).get("TotalDurationNs", 0))):
-        fe, wr = mean(c.get("FETCH_SIZE", [])), mean(c.get("WRITE_SIZE", []))
-        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
-        busy, act = mean(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])), mean(c.get("GRBM_GUI_ACTIVE", []))
-        act = act / 8.0 * 1024.0 if act else act
-        st = stats.get(k, {})
-        w.writerow([k, st.get("Calls", ""), "%.2f" % (float(st["AverageNs"]) / 1e3) if st else "",
-                    "%.0f" % fe if fe is not None else "", "%.1f" % (2 * fe * 1024 / 1e6) if fe is not None else "",
-                    "%.0f" % wr if wr is not None else "", "%.3f" % (busy / act) if busy and act else ""])
+# PMC summaries: FETCH_SIZE / WRITE_SIZE (KiB per launch) and MFMA-busy fraction per kernel, one file per compute type
+def pmc_summary(prefix, stats_sub, out_name):
+    acc = defaultdict(lambda: defaultdict(list))
+    for cname in ("FETCH_SIZE", "WRITE_SIZE", "MFMA"):
+        f = os.path.join(src, prefix + cname, "p_counter_collection.csv")
+        if not os.path.exists(f):
+            continue
+        for r in csv.DictReader(open(f)):
+            if mine(r["Kernel_Name"]):
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not acc:
+        return
+    stats = {}
+    f = os.path.join(src, stats_sub, "%s_kernel_stats.csv" % tag)
+    if os.path.exists(f):
+        stats = {r["Name"]: r for r in csv.DictReader(open(f))}
+    with open(os.path.join(dst, "%s_%s" % (tag, out_name)), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "calls_in_stats", "avg_us", "FETCH_SIZE_KB_per_launch(raw)", "fabric_read_MB_per_launch(x2 gfx950 correction)",
+                    "WRITE_SIZE_KB_per_launch", "MFMA_busy_frac(under PMC collection)"])
+        mean = lambda v: sum(v) / len(v) if v else None   # noqa: E731
+        for k, c in sorted(acc.items(), key=lambda kv: -float(stats.get(kv[0], {}).get("TotalDurationNs", 0))):
+            fe, wr = mean(c.get("FETCH_SIZE", [])), mean(c.get("WRITE_SIZE", []))
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+            busy, act = mean(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [])), mean(c.get("GRBM_GUI_ACTIVE", []))
+            act = act / 8.0 * 1024.0 if act else act
+            st = stats.get(k, {})
+            w.writerow([k, st.get("Calls", ""), "%.2f" % (float(st["AverageNs"]) / 1e3) if st else "",
+                        "%.0f" % fe if fe is not None else "", "%.1f" % (2 * fe * 1024 / 1e6) if fe is not None else "",
+                        "%.0f" % wr if wr is not None else "", "%.3f" % (busy / act) if busy and act else ""])
+
+
+pmc_summary("pmc_", "stats", "pmc_summary.csv")
+pmc_summary("pmc_f32x3_", "stats_f32x3", "pmc_summary_f32x3.csv")
+pmc_summary("pmc_bf16_", "stats_bf16", "pmc_summary_bf16.csv")
 print("wrote", sorted(x for x in os.listdir(dst) if x.startswith(tag)))
