@@ -24,7 +24,9 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, ablations=False):
+    """ablations=True also compiles the timing-only kernel variants behind DPD_ABLATIONS (tools/gemm_bench.py,
+    tools/x3_bench.py ablation tile codes); they double the build time and are not part of the product."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -33,7 +35,7 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-DDPD_ABLATIONS"] if ablations else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:
@@ -51,4 +53,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv or "--ablations" in sys.argv, ablations="--ablations" in sys.argv)

@@ -538,6 +538,7 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 19: return launch_dma<4, 4, 3, AK, BKC, 64>(g, s);    // 9 / 10 / 5 without the progress-based s_setprio
         case 20: return launch_dma<4, 4, 5, AK, BKC, 64>(g, s);
         case 15: return launch_dma<4, 4, 4, AK, BKC, 64>(g, s);
+#ifdef DPD_ABLATIONS   // timing-only / diagnostic variants for tools/gemm_bench.py and tools/gemm_dbg.py (python -m dpdist_amd.build --ablations)
         case 5129: return launch_dma<4, 4, 3, AK, BKC, 512>(g, s);   // fragments only ONE k-block ahead (A/B reference)
         case 5125: return launch_dma<4, 4, 4, AK, BKC, 512>(g, s);
         case 5128: return launch_dma<2, 2, 3, AK, BKC, 512>(g, s);
@@ -553,9 +554,11 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 45: return launch_dma<4, 4, 3, AK, BKC, 4>(g, s);
         case 85: return launch_dma<4, 4, 3, AK, BKC, 8>(g, s);
         case 95: return launch_dma<4, 4, 3, AK, BKC, 9>(g, s);
+#endif
         case 1: return launch_cfg<128, 128, 32, AK, BKC>(g, s);
         case 2: return launch_cfg<128, 64, 32, AK, BKC>(g, s);
         case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);
+#ifdef DPD_ABLATIONS
         case 43: return launch_cfg<64, 64, 32, AK, BKC, 4>(g, s);     // experiments (correct results)
         case 83: return launch_cfg<64, 64, 32, AK, BKC, 8>(g, s);
         case 123: return launch_cfg<64, 64, 32, AK, BKC, 12>(g, s);
@@ -565,6 +568,7 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 113: return launch_cfg<64, 64, 32, AK, BKC, 1>(g, s);
         case 23: return launch_cfg<64, 64, 32, AK, BKC, 2>(g, s);
         case 33: return launch_cfg<64, 64, 32, AK, BKC, 3>(g, s);
+#endif
         default: return DPD_E_UNSUPPORTED;
     }
 }

@@ -315,7 +315,8 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 5: return launch_x3<NP, AK, BKC, 2, 2, 1, 1, 4, 32>(g, s);
         case 6: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, 6, 16>(g, s);   // BK = 16: finer, deeper ring
         case 7: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16>(g, s);
-        case 102: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 1>(g, s);    // ablations of tile 2 (wrong results)
+#ifdef DPD_ABLATIONS   // timing-only ablations for tools/x3_bench.py (wrong results): python -m dpdist_amd.build --ablations
+        case 102: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 1>(g, s);    // ablations of tile 2
         case 202: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 3>(g, s);
         case 1602: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 16>(g, s);
         case 3202: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 32>(g, s);   // A pieces only
@@ -328,6 +329,7 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 101: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 1>(g, s);
         case 201: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 3>(g, s);
         case 1601: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 16>(g, s);
+#endif
         default: return DPD_E_UNSUPPORTED;
     }
 }

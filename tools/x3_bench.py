@@ -1,4 +1,5 @@
-"""Correctness (vs fp64) and speed of the split-bf16 MFMA GEMM (gemm_x3.hip) next to the exact-fp32 MFMA GEMM.
+"""(Ablation tile codes need a library built with `python -m dpdist_amd.build --ablations`.)
+Correctness (vs fp64) and speed of the split-bf16 MFMA GEMM (gemm_x3.hip) next to the exact-fp32 MFMA GEMM.
     python tools/x3_bench.py [tiles...]"""
 import ctypes
 import sys
