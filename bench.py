@@ -115,6 +115,49 @@ def pmc_traffic(kernel_substr):
     return (tot / n if n else None), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (the reference picks its towers with a
+    flag inside one process, train_multi_gpu_pc_compare_dist.py:122-126,237-302; here: one process per GPU over RCCL, the same
+    environment contract as `python -m torch.distributed.run --nproc-per-node N`).  Rank 0 prints the JSON line; the exit code
+    is the first non-zero rank exit code.  Children are stopped by PID, never by pattern."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+        sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible\n" % (n, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        return 2
+    return spawn_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+
+
+def spawn_ranks(n, cmd):
+    """Run `cmd` n times with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set (rendezvous on 127.0.0.1, free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        procs.append(subprocess.Popen(list(cmd), env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:        # one rank died: the others would hang in the next collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,9 +178,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (a.gpus, a.gpus))
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            raise SystemExit(self_launch(a.gpus))     # plain `python bench.py --gpus N`: spawn the N ranks ourselves
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DPDist path has no CPU fallback")

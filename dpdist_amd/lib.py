@@ -117,8 +117,14 @@ def cur_stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def req(t, dtype=None, name="tensor"):
+def req(t, dtype=None, name="tensor", shape=None, numel=None):
+    """Boundary check of a tensor handed to the C ABI (which only sees a raw pointer): device, dtype, contiguity and --
+    when given -- the exact shape / element count the entry point will read or write."""
     import torch
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+    if numel is not None and t.numel() != numel:
+        raise RuntimeError("%s must have %d elements, got %d" % (name, numel, t.numel()))
     if not t.is_cuda:
         raise RuntimeError("%s must live on the GPU (dpdist_amd has no CPU path)" % name)
     if dtype is None:

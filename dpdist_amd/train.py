@@ -147,6 +147,21 @@ def compose_batch(batch_data, batch_label, num_point):
     return pcA.astype(np.float32), pcB.astype(np.float32), labels.astype(np.float32)
 
 
+def iter_global_batches(ds, batch_size, num_point, training):
+    """Host side of train_one_epoch_3d / eval_one_epoch_3d (:737-766, :820-847): yields (pcA, pcB, labels_AB) of the STATIC
+    global batch shape.  Like the reference, the arrays are persistent per-epoch buffers that start at zero; a short last
+    batch overwrites rows [0, bsize) and the remaining rows keep the previous batch's content (the yielded arrays are
+    the buffers themselves: copy before the next iteration)."""
+    cur_A = np.zeros((batch_size, num_point, 3), np.float32)
+    cur_B = np.zeros((batch_size, num_point, 3), np.float32)
+    cur_lab = np.zeros((batch_size, num_point), np.float32)
+    while ds.has_next_batch():
+        data, label = ds.next_batch(augment=training)
+        bsize = len(data)
+        cur_A[:bsize], cur_B[:bsize], cur_lab[:bsize] = compose_batch(data, label, num_point)
+        yield cur_A, cur_B, cur_lab
+
+
 # --------------------------------------------------------------------------------------------------------------
 def train(argv=None):
     import torch
@@ -194,17 +209,11 @@ def train(argv=None):
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)       # noqa: E731
 
     def batches(ds, training):
-        while ds.has_next_batch():
-            data, label = ds.next_batch(augment=training)
-            if len(data) < F.batch_size:                           # static shapes like the reference: pad the last batch
-                pad = F.batch_size - len(data)
-                data = np.concatenate([data, data[:pad]])
-                label = np.concatenate([label, label[:pad]])
-            pcA, pcB, lab = compose_batch(data, label, N)
+        for pcA, pcB, lab in iter_global_batches(ds, F.batch_size, N, training):
             noise = None
             if F.add_noise > 0.0:                                  # :768-771
                 noise = cu((np.random.randn(F.batch_size, N, 3) * F.add_noise).astype(np.float32)[lo:hi])
-            yield cu(pcA[lo:hi]), cu(pcB[lo:hi]), cu(lab[lo:hi]), noise
+            yield cu(pcA[lo:hi].copy()), cu(pcB[lo:hi].copy()), cu(lab[lo:hi].copy()), noise
 
     def run_epoch(ds, training):
         sums, n = torch.zeros(2, device=dev), 0

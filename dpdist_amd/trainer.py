@@ -86,6 +86,12 @@ class DPDistTrainer:
         self._gviews = params.views(self.grad)
         gv = self._gviews
         self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7])
+        self._after_dw1 = None
+        self._side = None          # side stream of the prefetch pipeline (created on first use)
+        self._pref_key = None      # identity of the batch whose front end is (being) computed on the side stream
+        self._ev_front = self._ev_xfree = self._ev_fwd = None
+        self.front_launches = 0    # front ends (stack + encoder + gather) enqueued so far, on either stream
+        self.prefetch_hits = 0     # steps that found their front end already computed by the side stream
         self.refresh_weight_planes()
 
     def refresh_weight_planes(self):
@@ -93,11 +99,6 @@ class DPDistTrainer:
         if self._planes is not None:
             L.check(L.load().dpd_weights_to_planes(self._cparams, self.P.KP, self.P.H, self._planes, L.cur_stream()),
                     "dpd_weights_to_planes")
-
-        self._after_dw1 = None
-        self._side = None          # side stream of the prefetch pipeline (created on first use)
-        self._pref_key = None      # identity of the batch whose front end is (being) computed on the side stream
-        self._ev_front = self._ev_xfree = self._ev_fwd = None
 
     # -- pieces (each enqueues kernels on the current stream; no host sync, no allocation) -----------------
     @staticmethod
@@ -107,6 +108,7 @@ class DPDistTrainer:
     def _front(self, pcA, pcB, noise, gate=None):
         """stacking + encoder + window gather of one batch on the CURRENT stream; `gate`: event to wait for before the
         gather overwrites X / mask / vox (their last reader of the previous step)."""
+        self.front_launches += 1
         self._load_batch(pcA, pcB, noise)
         self._encode()
         if gate is not None:
@@ -114,8 +116,9 @@ class DPDistTrainer:
         self._gather()
 
     def _load_batch(self, pcA, pcB, noise):
-        L.check(L.load().dpd_stack_clouds(L.ptr(L.req(pcA, name="pcA")), L.ptr(L.req(pcB, name="pcB")),
-                                          None if noise is None else L.ptr(L.req(noise, name="add_noise")), self.B, self.N,
+        shp = (self.B, self.N, 3)
+        L.check(L.load().dpd_stack_clouds(L.ptr(L.req(pcA, name="pcA", shape=shp)), L.ptr(L.req(pcB, name="pcB", shape=shp)),
+                                          None if noise is None else L.ptr(L.req(noise, name="add_noise", shape=shp)), self.B, self.N,
                                           L.ptr(self.pts), L.ptr(self.q), L.cur_stream()), "dpd_stack_clouds")
 
     def _encode(self):
@@ -159,6 +162,7 @@ class DPDistTrainer:
     def backward(self, labels):
         lib, s, P = L.load(), L.cur_stream(), self.P
         BN = self.B * self.N
+        L.req(labels, name="labels", numel=BN)
         L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
         d, wsb = self._gviews, self.ws.numel() * 4
 
@@ -233,6 +237,7 @@ class DPDistTrainer:
             hit = self._pref_key == self._key(pcA, pcB, noise)
             self._pref_key = None
             if hit:
+                self.prefetch_hits += 1
                 return
         self._front(pcA, pcB, noise)
 
@@ -271,6 +276,7 @@ class DPDistTrainer:
         self._take_front(pcA, pcB, noise)
         self._decode()
         BN = self.B * self.N
+        L.req(labels, name="labels", numel=BN)
         L.check(L.load().dpd_l1_loss(L.ptr(self.pred), L.ptr(labels.reshape(-1)), BN, 0, 1.0, L.ptr(self.loss), None,
                                      L.cur_stream()), "dpd_l1_loss")
         return self.loss, self.pred[:BN, 0].view(self.B, self.N)

@@ -78,3 +78,28 @@ def test_shard_range():
     assert [shard_range(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+_RANK_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+t = torch.tensor([float(os.environ["LOCAL_RANK"]) + 1.0])
+dist.all_reduce(t)
+if dist.get_rank() == 0:
+    open(sys.argv[1], "w").write("%d %.1f" % (dist.get_world_size(), t.item()))
+dist.destroy_process_group()
+if os.environ["RANK"] == sys.argv[2]:
+    sys.exit(7)
+"""
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher: bench.spawn_ranks starts N processes with the torchrun environment
+    contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* on 127.0.0.1), waits for them and returns the first failure."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out = tmp_path / "r0.txt"
+    assert bench.spawn_ranks(2, [sys.executable, "-c", _RANK_SCRIPT, str(out), "-1"]) == 0
+    assert out.read_text() == "2 3.0"
+    assert bench.spawn_ranks(2, [sys.executable, "-c", _RANK_SCRIPT, str(out), "1"]) == 7

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from dpdist_amd import synth
-from dpdist_amd.train import SyntheticDistanceDataset, compose_batch
+from dpdist_amd.train import SyntheticDistanceDataset, compose_batch, iter_global_batches
 
 
 def test_compose_batch_follows_the_reference_recipe():
@@ -38,6 +38,28 @@ def test_dataset_item_format_and_interface():
     assert seen == 10
     ds.reset()
     assert ds.has_next_batch()
+
+
+def test_short_last_batch_keeps_the_static_shape():
+    """train_multi_gpu_pc_compare_dist.py:737-766: the batch buffers are persistent; a short last batch (here 4 of 16, i.e.
+    fewer than half -- the case a wrap-around pad of `data[:pad]` cannot fill) overwrites rows [0, bsize) only."""
+    N, Bg = 64, 16
+    ds = SyntheticDistanceDataset(36, 2 * N, Bg, "test", seed=3)
+    got = [(a.copy(), b.copy(), l.copy()) for a, b, l in iter_global_batches(ds, Bg, N, False)]
+    assert len(got) == 3
+    for a, b, l in got:
+        assert a.shape == b.shape == (Bg, N, 3) and l.shape == (Bg, N)
+    ds.reset()
+    ds.batch_idx = 2
+    d, lab = ds.next_batch()
+    assert len(d) == 4
+    # rows 0..3 = the 4 remaining shapes (up to the per-item point permutation: compare as sets of label values),
+    # rows 4..15 = the previous batch, untouched
+    assert np.array_equal(got[2][0][4:], got[1][0][4:]) and np.array_equal(got[2][2][4:], got[1][2][4:])
+    assert not np.array_equal(got[2][0][:4], got[1][0][:4])
+    # every shard of an 8-rank run has rows (the round-1 code handed 0-row tensors to ranks 4-7 here)
+    for r in range(8):
+        assert got[2][0][r * 2:(r + 1) * 2].shape == (2, N, 3)
 
 
 @pytest.mark.gpu
