@@ -33,8 +33,8 @@ enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 =
 //   bwd dW1 (2528x1024x2048)  64x64  3-stage, split-K 2    ~102            bwd dW2/3         64x64 3-stage    ~ 97
 // (run-to-run spread between boxes is ~10 %; the ranking inside one run is stable.  DMA kernels need K % 32 == 0;
 //  gemm_f32 falls back to the register-staged 64x64 kernel otherwise.)
-static int g_plan_tile[OP_COUNT] = {9, 9, 8, 8, 8, 8};
-static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 2, 1};
+static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33};
+static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1};
 
 // Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
 //   0  exact fp32 on the fp32 MFMA (gemm_f32.hip)
@@ -479,7 +479,7 @@ static size_t colsum_ws_floats(int ncols, int nw) { return (size_t)kColChunks * 
 }  // namespace dpd
 
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
-    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 20 || split_k < 1 || split_k > 8) return DPD_E_DIM;
+    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 1 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;
     return 0;
@@ -763,7 +763,7 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                        (hipStream_t)stream, nullptr, have ? pl->h2_r8 : nullptr, have ? pl->g3_r8 : nullptr, nullptr);
     }
     int tile = g_plan_tile[OP_BWD_DW23];
-    if (tile < 4 || tile > 20) tile = 8;
+    if (!((tile >= 4 && tile <= 20) || (tile >= 30 && tile <= 39))) tile = 8;
     return gemm_f32(1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, 1, tile, nullptr, 0,
                     (hipStream_t)stream, nullptr, actB, gB, dWB);
 }

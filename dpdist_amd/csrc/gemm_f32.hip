@@ -16,6 +16,7 @@
 //
 // Roofline: MFMA-bound.  Algorithmic flops = 2*M*N*K; bytes/flop of a 128x128 tile = 1/32 -> 8 B/clk/CU from L2.
 #include "gemm_shared.h"
+#include "gemm_rs.h"
 
 namespace dpd {
 
@@ -523,6 +524,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 
 template <bool AK, bool BKC>
 static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
+    if (tile >= 30 && tile <= 39) return launch_rs_tile<AK, BKC>(tile, g, s);   // register-streamed kernels (gemm_rs.h)
     switch (tile) {
         case 4: return launch_dma<2, 2, 4, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 64 KiB  (2 blocks/CU)
         case 5: return launch_dma<4, 4, 4, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 128 KiB (1 block/CU)
@@ -601,7 +603,8 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         (void)tile_eff;
         tile = 3;
     }
-    if (((tile >= 4 && tile <= 20) || tile > 2000) && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
+    const bool whole_tiles = (tile >= 4 && tile <= 20) || (tile >= 30 && tile <= 39);   // kernels that need whole 32-deep K-tiles
+    if ((whole_tiles || tile > 2000) && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
         tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
@@ -611,7 +614,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     if ((M_dev || K_dev) && !(tile >= 4 && tile <= 20)) return DPD_E_UNSUPPORTED;   // device-side extents: DMA kernels only
     if (M_dev && transA) return DPD_E_UNSUPPORTED;
     if (A2 && (!B2 || !C2 || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
-    if (A2 && !(tile >= 4 && tile <= 20)) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA kernels only
+    if (A2 && !whole_tiles) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA / register-streamed kernels only
     if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.split_k = split_k;

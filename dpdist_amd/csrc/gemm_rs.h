@@ -1,0 +1,181 @@
+// Register-streamed fp32 MFMA GEMM (gfx950 / CDNA4): no LDS, no barriers.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate (64 cycles per instruction per SIMD), so one wave needs only
+// ONE VGPR per operand per 64 cycles -- 16x less operand bandwidth per flop than a bf16 GEMM.  At that rate the L1/L2 path
+// can feed the MFMA operands straight into registers; what limited the LDS-ring kernel of gemm_f32.hip (73 % of the MFMA peak)
+// was not data but synchronisation: a workgroup barrier per K-tile plus the LDS-DMA refill cost it 22 % (ablations in
+// DESIGN.md section 3.1).  Here every wave is independent:
+//   * a wave owns a (32*TM) x (32*TN) output tile (TM*TN accumulators of 16 VGPRs) and streams its own operands with
+//     buffer loads, one K-tile (32 contraction steps) ahead of the MFMAs (double-buffered in VGPRs, counted vmcnt by hipcc);
+//   * lane (l31, half) of a 32x32x2 MFMA supplies A[l31][k] / B[k][l31] for k = the lane's half of the k pair.  Inside a
+//     32-deep K-tile the contraction index is assigned as  k = 32 t + 16 half + 4 b + s  (block b = 0..3, step s = 0..3):
+//       K-contiguous operand  -> the lane reads 64 contiguous bytes of its row as four dwordx4 (b = 0..3): the four loads
+//                                of a half-wave hit the same 32 x 128-B lines back to back (L1 hits after the first);
+//       MN-contiguous operand -> one dword per (b, s): 32 lanes read 128 contiguous bytes of row k (perfectly coalesced);
+//     A and B use the same assignment, which is all the contraction needs;
+//   * addresses: one buffer descriptor per operand, a loop-invariant per-lane voffset, the K progress in the SCALAR offset
+//     -> no vector address arithmetic in the loop; out-of-range rows/columns are clamped (never stored);
+//   * the workgroup (WR x WC waves, one per SIMD for 2x2) only exists to place waves that share operand rows/columns on
+//     one CU (L1 reuse) and to make the block -> tile map XCD-aware; waves never wait for each other, so ragged tiles
+//     simply retire early.
+// Results are bitwise identical to the LDS kernels (a k-ordered fmaf chain per output element; the permutation inside a
+// K-tile changes the ORDER of the chain, so "identical" holds between rs configurations, not against the ring kernels).
+#pragma once
+#include "gemm_shared.h"
+
+namespace dpd {
+
+typedef unsigned rs_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_rsrc(const void* p, size_t bytes) {
+    // raw (untyped, stride 0) buffer; word3 = 0x00020000 is the gfx9/CDNA data format for dword MUBUF accesses
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+}
+
+// One operand tile (32 rows/cols of the wave tile) of one K-tile: v[b][s] = operand value for block b, step s
+struct RsFrag {
+    float v[4][4];
+};
+
+// the loads of one operand tile that belong to step (b, s) of a K-tile (issued one pipeline depth ahead of their use)
+template <bool KC>
+__device__ __forceinline__ void rs_load_step(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned k0, unsigned ld, int b, int s, RsFrag& f) {
+    if (KC) {   // voff = (row*ld + 16*half)*4 ; soffset = k0*4 ; block b -> +16 B ; one dwordx4 carries the four steps
+        if (s == 0) {
+            const rs_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u * b, k0 * 4u, 0);
+            f.v[b][0] = __uint_as_float(x.x); f.v[b][1] = __uint_as_float(x.y);
+            f.v[b][2] = __uint_as_float(x.z); f.v[b][3] = __uint_as_float(x.w);
+        }
+    } else {    // voff = (16*half*ld + col)*4 ; soffset = (k0 + 4b + s)*ld*4
+        f.v[b][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (k0 + 4u * b + s) * ld * 4u, 0));
+    }
+}
+
+// D = pipeline depth in K-tiles (operand register sets): the loads of K-tile t+D-1 are issued, step by step, between the
+// MFMAs of K-tile t, so every operand has D-1 whole tile times ((TM*TN*16) MFMAs x 64 cycles each) to arrive.
+template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
+    constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int per_z = tilesM * tilesN;
+    const int ngrp = g.A2 ? 2 : 1;
+    const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
+    const int grp = sid / (per_z * g.split_k);
+    const int sid1 = sid % (per_z * g.split_k);
+    const int z = sid1 / per_z, t = sid1 % per_z;
+    const int m0 = (t / tilesN) * BM + (wave / WC) * 32 * TM, n0 = (t % tilesN) * BN + (wave % WC) * 32 * TN;
+    if (m0 >= g.M || n0 >= g.N) return;   // ragged edge: this wave has no output (no barriers anywhere, so it may leave)
+    const unsigned kbeg = z * g.k_chunk;
+    const unsigned kend = min(g.K, (int)kbeg + g.k_chunk);
+    const int nt = (int)(kend - kbeg) / 32;
+    const float* gA = grp ? g.A2 : g.A;
+    const float* gB = grp ? g.B2 : g.B;
+    const unsigned lda = g.lda, ldb = g.ldb;
+
+    const __amdgpu_buffer_rsrc_t ra = rs_rsrc(gA, AK ? ((size_t)(g.M - 1) * lda + g.K) * 4 : ((size_t)(g.K - 1) * lda + g.M) * 4);
+    const __amdgpu_buffer_rsrc_t rb = rs_rsrc(gB, BKC ? ((size_t)(g.N - 1) * ldb + g.K) * 4 : ((size_t)(g.K - 1) * ldb + g.N) * 4);
+    unsigned va[TM], vb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const unsigned r = min(m0 + 32 * i + l31, g.M - 1);
+        va[i] = AK ? (r * lda + 16u * half) * 4u : (16u * half * lda + r) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const unsigned c = min(n0 + 32 * j + l31, g.N - 1);
+        vb[j] = BKC ? (c * ldb + 16u * half) * 4u : (16u * half * ldb + c) * 4u;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    RsFrag fa[D][TM], fb[D][TN];
+    // all loads of K-tile kt (clamped to the last tile: a redundant reload instead of a branch) into register set d
+    auto load_step = [&](int kt, int d, int b, int s) {
+        const unsigned k0 = kbeg + 32u * min(kt, nt - 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rs_load_step<AK>(ra, va[i], k0, lda, b, s, fa[d][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rs_load_step<BKC>(rb, vb[j], k0, ldb, b, s, fb[d][j]);
+    };
+    // One K-tile: 16 steps of TM*TN MFMAs on register set `cur`; the loads of K-tile `kt_next` go into set `nxt` in the
+    // same (b, s) order in which they will be consumed.  sched_barrier pins [loads of the step | MFMAs of the step]: left
+    // alone, the machine scheduler sinks the loads to the end of the tile and halves the prefetch distance.
+    auto tile = [&](int cur, int nxt, int kt_next, bool do_load) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (do_load) load_step(kt_next, nxt, b, s);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].v[b][s], fb[cur][j].v[b][s], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    // prologue: K-tiles 0 .. D-2 in flight
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) load_step(d, d, b, s);
+    // The loop body is branch-free on purpose: with a conditional load hipcc's waitcnt pass must assume the not-taken path
+    // and waits for the loads it has just issued; a straight-line body gets the exact counted vmcnt.
+    int kt = 0;
+    for (; kt + D <= nt; kt += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) tile(j, (j + D - 1) % D, kt + j + D - 1, true);
+    }
+    // remainder (< D tiles): their operands are already in flight in sets 0 .. rem-1
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+        if (kt + j < nt) tile(j, 0, 0, false);
+
+    GemmArgs gs = g;
+    if (grp) gs.C = g.C2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) store_tile(gs, acc[i][j], z, m0 + 32 * i, n0 + 32 * j + l31, half);
+}
+
+template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D>
+static int launch_rs(const GemmArgs& g, hipStream_t s) {
+    constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
+    const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.split_k * (g.A2 ? 2 : 1);
+    DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);
+    return (int)hipGetLastError();
+}
+
+// tile codes 30..39: register-streamed kernels (wave tile, waves per workgroup, pipeline depth)
+template <bool AK, bool BKC>
+static int launch_rs_tile(int tile, const GemmArgs& g, hipStream_t s) {
+    switch (tile) {
+        case 30: return launch_rs<AK, BKC, 2, 2, 2, 2, 2>(g, s);   // 128x128 workgroup, 4 waves of 64x64, 2 operand sets
+        case 31: return launch_rs<AK, BKC, 2, 1, 2, 2, 2>(g, s);   // 128x64,  4 waves of 64x32
+        case 32: return launch_rs<AK, BKC, 1, 2, 2, 2, 2>(g, s);   //  64x128, 4 waves of 32x64
+        case 33: return launch_rs<AK, BKC, 1, 1, 2, 2, 2>(g, s);   //  64x64,  4 waves of 32x32
+        case 34: return launch_rs<AK, BKC, 2, 1, 2, 2, 3>(g, s);   // 128x64,  3 operand sets (two K-tiles ahead)
+        case 35: return launch_rs<AK, BKC, 1, 2, 2, 2, 3>(g, s);   //  64x128, 3 operand sets
+        case 36: return launch_rs<AK, BKC, 1, 1, 2, 2, 3>(g, s);   //  64x64,  3 operand sets
+        case 37: return launch_rs<AK, BKC, 2, 2, 2, 4, 2>(g, s);   // 128x256, 8 waves (2 per SIMD)
+        default: return DPD_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace dpd

@@ -160,7 +160,7 @@ def test_patch_rows_backward_is_transpose(dev):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM building block
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 34, 35, 36, 37])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
 def test_gemm_f32(dev, tile, mode):
     from dpdist_amd import ops
