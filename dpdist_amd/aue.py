@@ -12,6 +12,7 @@ Restates (relative to /root/reference):
                                                  gradients to the 'g2' (AE) variables only, Adam
     train_multi_gpu_pc_compare_dist.py:525-566   one step per batch with OPT_TYPE 'ours' (loss_p) or 'chamfer' (loss_c); both logged
 """
+import numpy as np
 import torch
 from torch import nn
 
@@ -42,9 +43,10 @@ class _ChamferFn(torch.autograd.Function):
         M = rec.shape[1]
         da = torch.empty_like(pc) if ctx.needs_input_grad[0] else None
         db = torch.empty_like(rec) if ctx.needs_input_grad[1] else None
-        L.check(L.load().dpd_chamfer_bwd(L.ptr(pc), L.ptr(rec), B, N, M, L.ptr(arg_a), L.ptr(arg_b), float(g), L.ptr(da), L.ptr(db),
+        L.check(L.load().dpd_chamfer_bwd(L.ptr(pc), L.ptr(rec), B, N, M, L.ptr(arg_a), L.ptr(arg_b), 1.0, L.ptr(da), L.ptr(db),
                                          L.cur_stream()), "dpd_chamfer_bwd")
-        return da, db
+        # the upstream gradient stays on the device (no host sync, any scalar-shaped g)
+        return (None if da is None else da.mul_(g)), (None if db is None else db.mul_(g))
 
 
 def chamfer_dist(pc, rec_pc):
@@ -70,6 +72,30 @@ class PointNetAE(nn.Module):
         self.point = nn.ModuleList([nn.Sequential(*block(dims[i], dims[i + 1], bn)) for i in range(5)])
         self.fc = nn.Sequential(*block(1024, 1024, bn), *block(1024, 1024, bn), nn.Linear(1024, num_point * 3))
         self.num_point = num_point
+
+    @torch.no_grad()
+    def load_tf_state_dict(self, sd):
+        """TF variables of get_model_aue_pn (scope 'aue'): <layer>/{weights, biases} and <layer>/bn/{beta, gamma, moving_mean,
+        moving_variance} for conv1..5, fc1, fc2; fc3 plain."""
+        get = lambda n: torch.as_tensor(np.asarray(sd[n]), dtype=torch.float32)   # noqa: E731
+
+        def put(block, scope, has_bn):
+            lin = block[0]
+            w = get(scope + "/weights")
+            lin.weight.copy_(w.reshape(-1, w.shape[-1]).t())
+            lin.bias.copy_(get(scope + "/biases"))
+            if has_bn and isinstance(block[1], nn.BatchNorm1d):
+                bn = block[1]
+                bn.bias.copy_(get(scope + "/bn/beta")); bn.weight.copy_(get(scope + "/bn/gamma"))
+                bn.running_mean.copy_(get(scope + "/bn/moving_mean")); bn.running_var.copy_(get(scope + "/bn/moving_variance"))
+
+        for i, blk in enumerate(self.point, 1):
+            put(blk, "aue/conv%d" % i, True)
+        mods = list(self.fc)
+        per = (len(mods) - 1) // 2
+        put(mods[:per], "aue/fc1", True)
+        put(mods[per:2 * per], "aue/fc2", True)
+        put(mods[2 * per:], "aue/fc3", False)
 
     def embed(self, pc):
         B, N, _ = pc.shape

@@ -26,15 +26,18 @@ int split_planes_multi(SplitJobs jobs, hipStream_t s);
 
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
-enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 = 4, OP_BWD_DW23 = 5, OP_COUNT = 6 };
+enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 = 4, OP_BWD_DW23 = 5, OP_BWD_DH_T = 6, OP_BWD_DX_T = 7,
+       OP_COUNT = 8 };   // _T: the same product with a transposed weight copy (NN form)
 // Defaults measured on MI355X at B=32 (tools/gemm_bench.py, profiles/): LDS-DMA ring kernels everywhere;
 //   fwd L1 (4096x1024x2528)  128x128 16-wave 3-stage ring  ~127 TFLOP/s    fwd L2/3 (K=1024) 128x128 3-stage  ~120
 //   bwd dH (2048x1024x1024)   64x64  3-stage               ~ 93..106       bwd dX            64x64 3-stage    ~103
 //   bwd dW1 (2528x1024x2048)  64x64  3-stage, split-K 2    ~102            bwd dW2/3         64x64 3-stage    ~ 97
 // (run-to-run spread between boxes is ~10 %; the ranking inside one run is stable.  DMA kernels need K % 32 == 0;
 //  gemm_f32 falls back to the register-staged 64x64 kernel otherwise.)
-static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33};
-static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1};
+static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32};
+static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1};
+static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
+static int g_x3_pair_tile = 0;
 
 // Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
 //   0  exact fp32 on the fp32 MFMA (gemm_f32.hip)
@@ -95,7 +98,8 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     // (measured, tools/x3_bench.py: 160 blocks of 128x128 beat 320 of 64x128 on the 2528x1024 dW1; 64x64 only when even
     //  64x128 leaves most CUs idle)
-    const int tile = blocks(128, 128) >= 150 ? 2 : (blocks(64, 128) >= 100 ? 3 : 5);
+    int tile = blocks(128, 128) >= 150 ? 2 : (blocks(64, 128) >= 100 ? 3 : 5);
+    if (np == 1 && g_x3_tile[op] && !(K % 64)) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..23)
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
                    out);
 }
@@ -476,9 +480,41 @@ __global__ __launch_bounds__(256) void dy_colsum_kernel(const float* __restrict_
 
 static size_t colsum_ws_floats(int ncols, int nw) { return (size_t)kColChunks * ncols * (nw ? nw : 1); }
 
+// out[c][r] = in[r][c] for up to three matrices in one launch (64x64 tiles through LDS, both sides coalesced)
+struct TransposeJobs {
+    const float* in[3];
+    float* out[3];
+    int R[3], C[3], blk0[4];
+    int n;
+};
+__global__ __launch_bounds__(256) void transpose_kernel(TransposeJobs J) {
+    __shared__ float t[64][65];
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.blk0[j + 1]) ++j;
+    const int R = J.R[j], C = J.C[j], tc = (C + 63) / 64;
+    const int b = blockIdx.x - J.blk0[j];
+    const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
+    const float* __restrict__ in = J.in[j];
+    float* __restrict__ out = J.out[j];
+    const int x = threadIdx.x & 63, y0 = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int y = y0 + 4 * i;
+        t[y][x] = (r0 + y < R && c0 + x < C) ? in[(size_t)(r0 + y) * C + c0 + x] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int y = y0 + 4 * i;
+        if (c0 + y < C && r0 + x < R) out[(size_t)(c0 + y) * R + r0 + x] = t[x][y];
+    }
+}
+
 }  // namespace dpd
 
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
+    if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 12) { dpd::g_x3_tile[op - 16] = tile; return 0; }
+    if (op == 32 && tile >= 0 && tile <= 12) { dpd::g_x3_pair_tile = tile; return 0; }
     if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 1 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;
@@ -557,6 +593,25 @@ extern "C" int dpd_weights_to_planes(const dpd_decoder_params* p, int KP, int H,
     add(p->W3, H, pl->W3_rc, pl->W3_r8);
     if (!jobs.n) return 0;
     return split_planes_multi(jobs, (hipStream_t)stream);
+}
+
+extern "C" int dpd_weights_transpose(const dpd_decoder_params* p, int KP, int H, float* W2T, float* W3T, float* W1pT, void* stream) {
+    using namespace dpd;
+    if (!p || !p->W2 || !p->W3 || !W2T || !W3T) return DPD_E_NULL;
+    if (W1pT && !p->W1p) return DPD_E_NULL;
+    if (KP <= 0 || H <= 0) return DPD_E_DIM;
+    TransposeJobs J{};
+    auto add = [&](const float* in, float* out, int R, int C) {
+        J.in[J.n] = in; J.out[J.n] = out; J.R[J.n] = R; J.C[J.n] = C;
+        J.blk0[J.n + 1] = J.blk0[J.n] + ((R + 63) / 64) * ((C + 63) / 64);
+        ++J.n;
+    };
+    add(p->W2, W2T, H, H);
+    add(p->W3, W3T, H, H);
+    if (W1pT) add(p->W1p, W1pT, KP, H);
+    DPD_LAUNCH(transpose_kernel, dim3(J.blk0[J.n]), dim3(256), 0, (hipStream_t)stream, J);
+    DPD_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
@@ -677,12 +732,17 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         }
         return 0;
     }
+    // exact-fp32 path with transposed weight copies: the NT products become NN (weights read row-coalesced)
+    const bool t3 = dtype == 0 && p->W3T, t2 = dtype == 0 && p->W2T, t1 = dtype == 0 && p->W1pT;
     if (phases & 2)
-        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2)) return rc;
+        if (int rc = gemm_dt(dtype, t3 ? OP_BWD_DH_T : OP_BWD_DH, 0, t3 ? 0 : 1, Qb, H, H, g3, H, t3 ? p->W3T : p->W3, H, g2, H, nullptr, h2, 3,
+                             nullptr, 0, scr, s, db2)) return rc;
     if (phases & 4)
-        if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1)) return rc;
+        if (int rc = gemm_dt(dtype, t2 ? OP_BWD_DH_T : OP_BWD_DH, 0, t2 ? 0 : 1, Qb, H, H, g2, H, t2 ? p->W2T : p->W2, H, g1, H, nullptr, h1, 3,
+                             nullptr, 0, scr, s, db1)) return rc;
     if (dX && (phases & 4)) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
-        if (int rc = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s)) return rc;
+        if (int rc = gemm_dt(dtype, t1 ? OP_BWD_DX_T : OP_BWD_DX, 0, t1 ? 0 : 1, Qb, KP, H, g1, H, t1 ? p->W1pT : p->W1p, t1 ? KP : H, dX, KP,
+                             nullptr, nullptr, 0, nullptr, 0, scr, s)) return rc;
     }
     return 0;
 }
@@ -753,8 +813,9 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
         if (!have && !scr.p) return DPD_E_WORKSPACE;
         if (have) {   // both GEMMs in ONE grouped launch of 64x128 tiles: 2 x 128 workgroups fill the chip in one round
             const long pe = (long)Kin * Qb, ge = (long)Qb * Nout;
+            const int ptile = (pl->np == 1 && g_x3_pair_tile && !(Qb % 64)) ? g_x3_pair_tile : 3;
             return gemm_x3(pl->np, 1, 1, Kin, Nout, Qb, (const uint16_t*)pl->h1_r8, Kin, pe, (const uint16_t*)pl->g2_r8, Nout, ge, dWA, Nout,
-                           nullptr, nullptr, 0, 3, (hipStream_t)stream, nullptr, nullptr, (const uint16_t*)pl->h2_r8,
+                           nullptr, nullptr, 0, ptile, (hipStream_t)stream, nullptr, nullptr, (const uint16_t*)pl->h2_r8,
                            (const uint16_t*)pl->g3_r8, dWB);
         }
         if (int rc = gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, nullptr, 0,

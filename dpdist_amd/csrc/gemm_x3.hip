@@ -211,7 +211,14 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    if (KB == 2) {
+    if (KB == 4) {          // BK = 64: four k16 steps per K-tile, one barrier per 4 * TM * TN MFMAs
+        for (int it = 0; it < nt; ++it) {
+            do_step(it, 0, C0{});
+            do_step(it, 1, C1{});
+            do_step(it, 2, C0{});
+            do_step(it, 3, C1{});
+        }
+    } else if (KB == 2) {
         for (int it = 0; it < nt; ++it) {
             do_step(it, 0, C0{});
             do_step(it, 1, C1{});
@@ -315,6 +322,12 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 5: return launch_x3<NP, AK, BKC, 2, 2, 1, 1, 4, 32>(g, s);
         case 6: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, 6, 16>(g, s);   // BK = 16: finer, deeper ring
         case 7: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16>(g, s);
+        // BK = 64 (one plane only: a 3-plane stage would not fit the LDS): 4x fewer barriers per MFMA
+        case 8: if (NP == 1) return launch_x3<1, AK, BKC, 4, 2, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64, 144 KiB
+        case 9: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 1, 4, 64>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 64x32, 128 KiB
+        case 10: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x128, 4 waves of 64x64
+        case 11: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x256, 8 waves of 64x64
+        case 12: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 1, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 64x128, 4 waves of 32x64
 #ifdef DPD_ABLATIONS   // timing-only ablations for tools/x3_bench.py (wrong results): python -m dpdist_amd.build --ablations
         case 102: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 1>(g, s);    // ablations of tile 2
         case 202: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 3>(g, s);
@@ -346,6 +359,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
     if (np != 1 && np != 3) return DPD_E_UNSUPPORTED;
     if ((K % 32) || (N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return DPD_E_UNSUPPORTED;
+    if (tile >= 8 && tile <= 12 && (K % 64)) return DPD_E_UNSUPPORTED;   // BK = 64 kernels take whole 64-deep K-tiles
     if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) && !bias) return DPD_E_NULL;
     if (epilogue == EPI_GATE && !gate) return DPD_E_NULL;
     if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;

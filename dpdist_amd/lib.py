@@ -16,7 +16,7 @@ _ERR = {-1: "DPD_E_NULL (null pointer)", -2: "DPD_E_DIM (bad dimension)",
 
 
 class DecoderParams(Structure):
-    _fields_ = [(n, c_void_p) for n in ("W1p", "b1", "W2", "b2", "W3", "b3", "W4", "b4")]
+    _fields_ = [(n, c_void_p) for n in ("W1p", "b1", "W2", "b2", "W3", "b3", "W4", "b4", "W2T", "W3T", "W1pT")]
 
 
 class SmallGrads(Structure):
@@ -60,6 +60,7 @@ SIGNATURES = {
     "dpd_planes_bytes": (c_size_t, [c_int] * 6),
     "dpd_planes_carve": (c_int, [c_void_p, c_size_t] + [c_int] * 6 + [POINTER(Planes)]),
     "dpd_weights_to_planes": (c_int, [POINTER(DecoderParams), c_int, c_int, POINTER(Planes), c_void_p]),
+    "dpd_weights_transpose": (c_int, [POINTER(DecoderParams), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dpd_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p]),
     "dpd_gemm_planes": (c_int, [c_int] * 6 + [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_int, c_void_p,
@@ -136,8 +137,8 @@ def req(t, dtype=None, name="tensor", shape=None, numel=None):
     return t
 
 
-def make_params(W1p, b1, W2, b2, W3, b3, W4, b4):
-    return DecoderParams(*[t.data_ptr() for t in (W1p, b1, W2, b2, W3, b3, W4, b4)])
+def make_params(W1p, b1, W2, b2, W3, b3, W4, b4, W2T=None, W3T=None, W1pT=None):
+    return DecoderParams(*[None if t is None else t.data_ptr() for t in (W1p, b1, W2, b2, W3, b3, W4, b4, W2T, W3T, W1pT)])
 
 
 def make_small_grads(db1, db2, db3, dW4, db4):

@@ -26,8 +26,10 @@ TF_NAME = "pc_compare/dpdist_local/mapper_conv%d/%s"
 F = 20
 
 
-def placeholder_inputs(batch_size, num_point, NUM_DIMS=3, device="cuda"):
-    """models/dpdist_and_aue.py:23-28: zero-filled stand-ins for input1, input2, labels12, labels21."""
+def placeholder_inputs(batch_size, num_point, NUM_DIMS=2, device="cuda"):
+    """models/dpdist_and_aue.py:23-28, same positional arguments and the same default NUM_DIMS=2 (the trainer always passes
+    NUM_DIMS=3, train_multi_gpu_pc_compare_dist.py:192): zero-filled float32 stand-ins for the placeholders input1, input2
+    [B,N,NUM_DIMS] and labels12, labels21 [B,N], in that order."""
     z = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)   # noqa: E731
     return z(batch_size, num_point, NUM_DIMS), z(batch_size, num_point, NUM_DIMS), z(batch_size, num_point), z(batch_size, num_point)
 
@@ -80,6 +82,22 @@ class DPDistParams(nn.Module):
 
     def views(self, flat=None):
         return [self.view(n, flat) for n in ("W1p", "b1", "W2", "b2", "W3", "b3", "W4", "b4")]
+
+    def transposed(self, flat=None):
+        """(W2T, W3T, W1pT): transposed copies for the fp32 backward data GEMMs (include/dpdist_capi.h:
+        dpd_weights_transpose), cached until the parameter buffer changes (frozen weights in as-loss mode: one launch)."""
+        from . import lib as L
+        src = self.flat if flat is None else flat
+        key = (src.data_ptr(), src._version)
+        if getattr(self, "_tr_key", None) != key:
+            H, KP = self.H, self.KP
+            dev = src.device
+            t = [torch.empty(H, H, device=dev), torch.empty(H, H, device=dev), torch.empty(H, KP, device=dev)]
+            cp = L.make_params(*self.views(src))
+            L.check(L.load().dpd_weights_transpose(cp, KP, H, L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.cur_stream()),
+                    "dpd_weights_transpose")
+            self._tr, self._tr_key = t, key
+        return self._tr
 
     # -- TF interchange -----------------------------------------------------------------------------
     def tf_shapes(self):
@@ -168,8 +186,9 @@ class _DPDistFn(torch.autograd.Function):
             small = (d[1], d[3], d[5], d[6], d[7])     # db1, db2, db3, dW4, db4 come out of the data chain (fused)
         dt = P.compute_dtype
         ws = ops.workspace(Q, P.KP, P.H, flat.device, dt) if (need_w or dt) else None
+        wT = P.transposed(flat) if dt in ("f32", 0) else None
         dy, g3, g2, g1, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, P.KP, need_in, small_grads=small, dtype=dt,
-                                                  ws=ws)
+                                                  ws=ws, transposed=wT)
         if need_w:
             ops.decoder_bwd_weights(1, X, g1, Q, d[0], None, ws, dt)
             ops.decoder_bwd_weights(2, h1, g2, Q, d[2], None, ws, dt)
@@ -214,7 +233,8 @@ class _AsLossFn(torch.autograd.Function):
         dpred.mul_(g)                                               # upstream gradient (device scalar, no host sync)
         dt = P.compute_dtype
         ws = ops.workspace(Q, P.KP, P.H, flat.device, dt) if dt else None
-        _, _, _, _, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, P.views(flat), P.KP, True, dtype=dt, ws=ws)
+        wT = P.transposed(flat) if dt in ("f32", 0) else None
+        _, _, _, _, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, P.views(flat), P.KP, True, dtype=dt, ws=ws, transposed=wT)
         dq, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k)
         dpts = ops.mfv3d_bwd(pts, dfv, m, sigma)
         gA = dpts[:B] + dq[B:]      # encoder route + query route (BA half queries pcA)

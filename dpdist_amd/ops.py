@@ -97,7 +97,8 @@ def stack_clouds(pcA, pcB, noise=None):
     return pts, q
 
 
-def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None, small_grads=None, dtype=0, ws=None):
+def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None, small_grads=None, dtype=0, ws=None,
+                     transposed=None):
     """dpred [Qb,3] (first Qb rows) -> dy [Qb,3], g3,g2,g1 [Qb,H], dX [Qb,KP] or None.
     small_grads = (db1, db2, db3, dW4, db4) tensors (or None each) to be filled by the fused epilogues."""
     L.req(dpred, name="dpred")
@@ -110,7 +111,7 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None,
         dX = torch.empty(Qb, KP, device=dev, dtype=torch.float32) if want_dX else None
     else:
         dy, g3, g2, g1, dX = bufs
-    p = L.make_params(*params)
+    p = L.make_params(*params, *(transposed if transposed is not None else ()))
     sg = L.make_small_grads(*small_grads) if small_grads is not None else None
     dtype = L.DTYPES[dtype]
     if dtype and ws is None:

@@ -14,6 +14,7 @@ Restates (relative to /root/reference/pcrnet-registration):
 """
 import math
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -52,6 +53,26 @@ class PoseNet(nn.Module):
                                   nn.Linear(512, 256), nn.ReLU(), nn.Dropout(p=0.3), nn.Linear(256, 7))
         self.lim_rot = lim_rot
 
+    @torch.no_grad()
+    def load_tf_state_dict(self, sd):
+        """TF variables of ipcr_model.pointnet / get_pose: conv{1..5}/{weights [1,kw,cin,cout], biases}, fc{1..4}/{weights
+        [in,out], biases} -> the Linear layers (a 1xW VALID conv on [B,N,W,1] / [B,N,1,C] is a per-point linear map)."""
+        lin = [m for m in self.point if isinstance(m, nn.Linear)]
+        for i, l in enumerate(lin, 1):
+            w = torch.as_tensor(np.asarray(sd["conv%d/weights" % i]), dtype=torch.float32)
+            l.weight.copy_(w.reshape(-1, w.shape[-1]).t())
+            l.bias.copy_(torch.as_tensor(np.asarray(sd["conv%d/biases" % i]), dtype=torch.float32))
+        lin = [m for m in self.head if isinstance(m, nn.Linear)]
+        for i, l in enumerate(lin, 1):
+            l.weight.copy_(torch.as_tensor(np.asarray(sd["fc%d/weights" % i]), dtype=torch.float32).t())
+            l.bias.copy_(torch.as_tensor(np.asarray(sd["fc%d/biases" % i]), dtype=torch.float32))
+
+    def features(self, source, template):
+        """ipcr_model.pointnet (:198-233): (source_global_feature, template_global_feature), each [B, out_features]."""
+        f = self.point(torch.cat([source, template], 0)).amax(1)
+        B = source.shape[0]
+        return f[:B], f[B:]
+
     def forward(self, source, template):
         f = self.point(torch.cat([source, template], 0)).amax(1)            # max pool over the points
         B = source.shape[0]
@@ -68,8 +89,65 @@ def compose(T, pose):
     return M @ T
 
 
-def find_errors(T_pred, R_gt, t_gt):
-    """results_itrPCRNet_no_stop.py:112-133 on matrices: translation L2 error and the rotation angle (deg) of
+def euler_to_mat(rx, ry, rz):
+    """transforms3d.euler.euler2mat(rz, ry, rx, 'szyx') as the reference calls it (helper.py:301,
+    results_itrPCRNet_no_stop.py:121-122): static frame, about z, then y, then x  ->  R = Rx(rx) Ry(ry) Rz(rz)."""
+    cx, sx, cy, sy, cz, sz = math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry), math.cos(rz), math.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def mat_to_euler(R):
+    """transforms3d.euler.mat2euler(R, 'szyx') re-ordered like helper.find_final_pose (:331-345): returns (rx, ry, rz)."""
+    cy = math.hypot(R[0, 0], R[0, 1])
+    if cy > 4 * np.finfo(float).eps:
+        return math.atan2(-R[1, 2], R[2, 2]), math.atan2(R[0, 2], cy), math.atan2(-R[0, 1], R[0, 0])
+    return math.atan2(R[2, 1], R[1, 1]), math.atan2(R[0, 2], cy), 0.0
+
+
+def find_errors(gt_pose, final_pose):
+    """results_itrPCRNet_no_stop.py:112-133, same signature: poses are 6-vectors (x, y, z, rx, ry, rz), angles in radians.
+    Returns (translation L2 error, |angle| in degrees of the axis-angle form of R_pred R_gt^-1)."""
+    gt_pose, final_pose = np.asarray(gt_pose, dtype=np.float64), np.asarray(final_pose, dtype=np.float64)
+    translation_error = float(np.sqrt(np.sum(np.square(gt_pose[0:3] - final_pose[0:3]))))
+    gt_mat = euler_to_mat(gt_pose[3], gt_pose[4], gt_pose[5])
+    pt_mat = euler_to_mat(final_pose[3], final_pose[4], final_pose[5])
+    error_mat = pt_mat @ np.linalg.inv(gt_mat)
+    # transforms3d.axangles.mat2axangle: angle = atan2(sin, cos) with cos = (trace - 1) / 2; its magnitude is acos(cos)
+    angle = math.acos(min(1.0, max(-1.0, (np.trace(error_mat) - 1.0) / 2.0)))
+    return translation_error, abs(angle * (180 / np.pi))
+
+
+def transformation_quat2mat(poses, TRANSFORMATIONS, templates_data):
+    """helper.py:309-329 (numpy, same argument order): compose the 4x4 transforms with the predicted (t, quaternion) poses
+    and move the clouds.  poses [..., B, 7]; TRANSFORMATIONS [B,4,4] and templates_data [B,N,3] are updated in place."""
+    poses = np.array(poses)
+    poses = poses.reshape(poses.shape[-2], poses.shape[-1])
+    for i in range(poses.shape[0]):
+        q = poses[i, 3:7] / max(np.linalg.norm(poses[i, 3:7]), np.finfo(float).eps)      # transforms3d.quat2mat normalises
+        rot = quat_to_mat(torch.tensor(q[None], dtype=torch.float64))[0].numpy()
+        M = np.zeros((4, 4))
+        M[3, 3] = 1
+        M[0:3, 0:3] = rot
+        M[0:3, 3] = poses[i, 0:3]
+        TRANSFORMATIONS[i] = M @ TRANSFORMATIONS[i]
+        templates_data[i] = (rot @ templates_data[i].T).T + poses[i, 0:3]
+    return TRANSFORMATIONS, templates_data
+
+
+def find_final_pose(TRANSFORMATIONS):
+    """helper.py:331-345: 4x4 transforms -> (x, y, z, rx, ry, rz)."""
+    out = np.zeros((TRANSFORMATIONS.shape[0], 6))
+    for i in range(TRANSFORMATIONS.shape[0]):
+        out[i, 3:6] = mat_to_euler(TRANSFORMATIONS[i, 0:3, 0:3])
+        out[i, 0:3] = TRANSFORMATIONS[i, 0:3, 3]
+    return out
+
+
+def pose_errors(T_pred, R_gt, t_gt):
+    """find_errors on matrices (batched torch): translation L2 error and the rotation angle (deg) of
     R_pred R_gt^-1, for T_pred mapping the source onto the template and (R_gt, t_gt) the pose that created the source."""
     # template = R_gt^-1 (source - t_gt)  ->  ideal prediction R = R_gt^T, t = -R_gt^T t_gt
     R_id = R_gt.transpose(1, 2)

@@ -161,3 +161,63 @@ def s2_modelnet_shaped(B=64, N=64, seed=100):
         pcA[b] = (surfA @ R.T + shift).astype(np.float32)
         pcB[b] = (B_local @ R.T + shift).astype(np.float32)
     return pcA, pcB, lab
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# weights of the consumers' small networks by seed (fixtures store seeds, never weight blobs)
+# ----------------------------------------------------------------------------------------------------------------
+def make_named_weights(spec, seed, scale=1.0):
+    """spec: ordered list of (tf variable name, shape).  Kernels ('weights'): N(0, 2/fan_in) * scale; 'biases' / 'beta':
+    N(0, 0.05); 'gamma': 1 + N(0, 0.1); 'moving_mean': N(0, 0.1); 'moving_variance': U(0.5, 1.5)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in spec:
+        leaf = name.split("/")[-1]
+        if leaf == "weights":
+            fan_in = int(np.prod(shape[:-1]))
+            w = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in) * scale
+        elif leaf in ("biases", "beta"):
+            w = rng.standard_normal(shape) * 0.05
+        elif leaf == "gamma":
+            w = 1.0 + rng.standard_normal(shape) * 0.1
+        elif leaf == "moving_mean":
+            w = rng.standard_normal(shape) * 0.1
+        elif leaf == "moving_variance":
+            w = rng.uniform(0.5, 1.5, shape)
+        else:
+            raise ValueError(name)
+        out[name] = w.astype(np.float32)
+    return out
+
+
+def pose_net_spec(out_features=1024):
+    """Variables of pcrnet-registration/models/ipcr_model.py: pointnet (:198-233, conv1..5) + get_pose (:273-284, fc1..4)."""
+    dims = [3, 64, 64, 64, 128, out_features]
+    spec = []
+    for i in range(5):
+        spec += [("conv%d/weights" % (i + 1), (1, 3 if i == 0 else 1, 1 if i == 0 else dims[i], dims[i + 1])),
+                 ("conv%d/biases" % (i + 1), (dims[i + 1],))]
+    fdims = [2 * out_features, 1024, 512, 256, 7]
+    for i in range(4):
+        spec += [("fc%d/weights" % (i + 1), (fdims[i], fdims[i + 1])), ("fc%d/biases" % (i + 1), (fdims[i + 1],))]
+    return spec
+
+
+def aue_pn_spec(num_point=64):
+    """Variables of models/dpdist_and_aue.py:get_model_aue_pn (:88-145) under scope 'aue': conv1..5 + fc1, fc2 with batch norm
+    (beta, gamma, moving_mean, moving_variance in '<layer>/bn'), fc3 plain."""
+    dims = [3, 64, 64, 64, 128, 1024]
+    spec = []
+
+    def bn(scope, c):
+        return [("%s/bn/%s" % (scope, n), (c,)) for n in ("beta", "gamma", "moving_mean", "moving_variance")]
+
+    for i in range(5):
+        sc = "aue/conv%d" % (i + 1)
+        spec += [(sc + "/weights", (1, 3 if i == 0 else 1, 1 if i == 0 else dims[i], dims[i + 1])), (sc + "/biases", (dims[i + 1],))]
+        spec += bn(sc, dims[i + 1])
+    for i, (a, b) in enumerate(((1024, 1024), (1024, 1024))):
+        sc = "aue/fc%d" % (i + 1)
+        spec += [(sc + "/weights", (a, b)), (sc + "/biases", (b,))] + bn(sc, b)
+    spec += [("aue/fc3/weights", (1024, num_point * 3)), ("aue/fc3/biases", (num_point * 3,))]
+    return spec

@@ -82,7 +82,12 @@ class DPDistTrainer:
         use_dist = dist.is_initialized() if distributed is None else distributed
         self.reducer = BucketReducer(self.grad, params.bucket_bounds, group,
                                      force=os.environ.get("DPD_FORCE_DIST") == "1") if use_dist else None
-        self._cparams = L.make_params(*params.views())
+        # exact-fp32 compute type: transposed copies of W2 / W3 so that the backward data GEMMs (g W^T) read the weights
+        # row-coalesced (register-streamed kernel, csrc/gemm_rs.h); refreshed after every optimizer step
+        self.W2T = self.W3T = None
+        if self.dt == 0:
+            self.W2T, self.W3T = f(H, H), f(H, H)
+        self._cparams = L.make_params(*params.views(), self.W2T, self.W3T, None)
         self._gviews = params.views(self.grad)
         gv = self._gviews
         self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7])
@@ -95,10 +100,14 @@ class DPDistTrainer:
         self.refresh_weight_planes()
 
     def refresh_weight_planes(self):
-        """Call after changing the weights from outside (load_tf_state_dict): re-derives the bf16 weight planes."""
+        """Call after changing the weights from outside (load_tf_state_dict): re-derives the bf16 weight planes / the
+        transposed fp32 copies."""
         if self._planes is not None:
             L.check(L.load().dpd_weights_to_planes(self._cparams, self.P.KP, self.P.H, self._planes, L.cur_stream()),
                     "dpd_weights_to_planes")
+        if self.W2T is not None:
+            L.check(L.load().dpd_weights_transpose(self._cparams, self.P.KP, self.P.H, L.ptr(self.W2T), L.ptr(self.W3T), None,
+                                                   L.cur_stream()), "dpd_weights_transpose")
 
     # -- pieces (each enqueues kernels on the current stream; no host sync, no allocation) -----------------
     @staticmethod

@@ -96,7 +96,15 @@ typedef struct dpd_decoder_params {
     const float* W2;  const float* b2;
     const float* W3;  const float* b3;
     const float* W4;  const float* b4;
+    /* optional (NULL = absent) transposed copies written by dpd_weights_transpose: W2T, W3T [H,H], W1pT [H,KP].  With them
+     * the backward data GEMMs g2 = g3 W3^T, g1 = g2 W2^T, dX = g1 W1p^T read their weight operand row-coalesced (the
+     * register-streamed fp32 kernel then runs them at the forward's rate); without them the LDS-ring kernel is used.  */
+    const float* W2T; const float* W3T; const float* W1pT;
 } dpd_decoder_params;
+
+/* Refresh the transposed weight copies (one launch): W2T, W3T [H,H] and, if W1pT != NULL, W1pT [H,KP].  Call after
+ * loading weights and after every optimizer step (training), once for frozen weights (as-loss mode).  DPD_F32 only.  */
+int dpd_weights_transpose(const dpd_decoder_params* p, int KP, int H, float* W2T, float* W3T, float* W1pT, void* stream);
 
 int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
                     int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,

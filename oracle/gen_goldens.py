@@ -177,18 +177,218 @@ def fx_small_mlp(tf, MODEL, out_dir):
         print("mlp64 m=%d AB mean %.4f" % (m, res["pred_listAB_f32"][..., 0].mean()))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# f-rows: the consumers of the boundary.  Functions that live in modules which cannot be imported (the
+# trainer and the evaluation script run argparse / dataset / log-directory code at import time and need h5py / trimesh)
+# are taken from the reference FILE by name with `ast` and executed unchanged in a namespace holding the stub.
+# ------------------------------------------------------------------------------------------------------------------
+def extract_functions(path, names, namespace):
+    import ast
+    src = open(path).read()
+    tree = ast.parse(src)
+    found = {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+            exec(code, namespace)
+            found[node.name] = namespace[node.name]
+    missing = set(names) - set(found)
+    assert not missing, missing
+    return found
+
+
+def load_registration(ref):
+    sys.path.insert(0, os.path.join(ref, "pcrnet-registration"))
+    sys.path.insert(0, os.path.join(ref, "pcrnet-registration", "models"))
+    import importlib
+    # the registration code has its OWN utils/tf_util.py: import it under the name the model expects
+    for m in ("tf_util",):
+        sys.modules.pop(m, None)
+    sys.path.insert(0, os.path.join(ref, "pcrnet-registration", "utils"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        helper = importlib.import_module("helper")
+        ipcr = importlib.import_module("ipcr_model")
+    assert os.path.realpath(helper.__file__).startswith(os.path.realpath(ref))
+    return helper, ipcr
+
+
+def fx_pose(tf, ref, out_dir):
+    """F-f2: quaternion transform, pose normalisation, the pose network (inference branch) and the error metric."""
+    helper, ipcr = load_registration(ref)
+    import numpy as _np
+    import transforms3d
+    import transforms3d.euler as t3d
+    ns = {"np": _np, "t3d": t3d, "transforms3d": transforms3d}
+    fe = extract_functions(os.path.join(ref, "pcrnet-registration", "results_itrPCRNet_no_stop.py"), ["find_errors"], ns)["find_errors"]
+    rng = np.random.default_rng(31)
+    B, N = 4, 64
+    data = rng.uniform(-0.8, 0.8, (B, N, 3)).astype(np.float32)
+    quat = rng.standard_normal((B, 4)).astype(np.float32)
+    quat[:2] /= np.linalg.norm(quat[:2], axis=1, keepdims=True)       # two unit quaternions, two un-normalised ones
+    trans = rng.uniform(-0.2, 0.2, (B, 3)).astype(np.float32)
+    raw7 = (rng.standard_normal((B, 7)) * 1.5).astype(np.float32)
+    src = rng.uniform(-0.8, 0.8, (B, N, 3)).astype(np.float32)
+    tmpl = rng.uniform(-0.8, 0.8, (B, N, 3)).astype(np.float32)
+    from dpdist_amd import synth
+    W = synth.make_named_weights(synth.pose_net_spec(1024), seed=41)
+    res = {"data": data, "quat": quat, "trans": trans, "raw7": raw7, "source": src, "template": tmpl, "weights_seed": np.array(41)}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        tf.set_real_dtype(dt)
+        tf.reset_default_graph()
+        tf.set_variable_overrides(W)
+        T = lambda a: tf.Tensor(torch.tensor(a, dtype=dt))   # noqa: E731
+        with contextlib.redirect_stdout(io.StringIO()):
+            res["transformed_" + tag] = helper.transformation_quat_tensor(T(data), T(quat), T(trans)).numpy()
+            res["quat_normalize45_" + tag] = ipcr.quat_normalize(T(raw7), rot_lim=45.0).numpy()
+            res["quat_normalize10_" + tag] = ipcr.quat_normalize(T(raw7), rot_lim=10.0).numpy()
+            is_training = tf.constant(False)
+            fs, ft = ipcr.get_model(T(src), T(tmpl), is_training, bn_decay=None, PN=True, POOL="max", out_features=1024)
+            res["feat_source_" + tag], res["feat_template_" + tag] = fs.numpy(), ft.numpy()
+            res["pose_raw_" + tag] = ipcr.get_pose(fs, ft, is_training, bn_decay=None, lim_rot=False).numpy()
+            tf.reset_default_graph()
+            tf.set_variable_overrides(W)
+            fs, ft = ipcr.get_model(T(src), T(tmpl), is_training, bn_decay=None, PN=True, POOL="max", out_features=1024)
+            res["pose_lim45_" + tag] = ipcr.get_pose(fs, ft, is_training, bn_decay=None, lim_rot=45.0).numpy()
+    # the evaluation metric (results_itrPCRNet_no_stop.py:112-133): poses are (x,y,z, rx,ry,rz) in radians
+    gt = np.concatenate([rng.uniform(-0.3, 0.3, (8, 3)), rng.uniform(-0.8, 0.8, (8, 3))], 1)
+    fin = gt + np.concatenate([rng.normal(0, 0.02, (8, 3)), rng.normal(0, 0.15, (8, 3))], 1)
+    errs = np.array([fe(gt[i], fin[i]) for i in range(8)])
+    res.update({"err_gt_pose": gt, "err_final_pose": fin, "err_translation": errs[:, 0], "err_rotation_deg": errs[:, 1]})
+    # helper.transformation_quat2mat (:309-329) and find_final_pose (:331-345): numpy + transforms3d
+    poses = np.concatenate([trans, quat], 1).astype(np.float64)
+    TR = np.tile(np.eye(4), (B, 1, 1))
+    TR, moved = helper.transformation_quat2mat(poses.reshape(1, B, 7), TR, data.astype(np.float64).copy())
+    res.update({"quat2mat_T": TR, "quat2mat_data": moved, "final_pose": helper.find_final_pose(TR)})
+    np.savez_compressed(os.path.join(out_dir, "pose_cases.npz"), **res)
+    print("pose_cases:", {k: np.asarray(v).shape for k, v in res.items()})
+
+
+def fx_chamfer(tf, ref, out_dir):
+    """F-f4: pairwise_diff / chmafer_dist of the trainer (train_multi_gpu_pc_compare_dist.py:891-916) + autograd gradients."""
+    ns = {"tf": tf, "np": np}
+    fns = extract_functions(os.path.join(ref, "train_multi_gpu_pc_compare_dist.py"), ["pairwise_diff", "chmafer_dist"], ns)
+    rng = np.random.default_rng(51)
+    pc = rng.uniform(-0.8, 0.8, (3, 64, 3)).astype(np.float32)
+    rec = (pc[:, :48] + rng.normal(0, 0.05, (3, 48, 3))).astype(np.float32)
+    rec[0, 5] = rec[0, 6]                         # duplicate points: ties in the minima
+    res = {"pc": pc, "rec_pc": rec}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        tf.set_real_dtype(dt)
+        a = tf.Tensor(torch.tensor(pc, dtype=dt, requires_grad=True))
+        b = tf.Tensor(torch.tensor(rec, dtype=dt, requires_grad=True))
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = fns["chmafer_dist"](a, b)
+            sq = fns["pairwise_diff"](b, a)
+        ga, gb = torch.autograd.grad(loss.v, [a.v, b.v])
+        res.update({"loss_" + tag: loss.numpy(), "d_pc_" + tag: ga.numpy(), "d_rec_" + tag: gb.numpy(),
+                    "sqdist_rec_pc_" + tag: sq.numpy()})
+    np.savez_compressed(os.path.join(out_dir, "chamfer_cases.npz"), **res)
+    print("chamfer_cases: loss %.6f" % res["loss_f32"])
+
+
+def fx_aue_pn(tf, MODEL, out_dir):
+    """F-f4: the PointNet autoencoder get_model_aue_pn (models/dpdist_and_aue.py:88-145), training and inference branches of
+    its batch norm, weights by seed (synth.aue_pn_spec)."""
+    from dpdist_amd import synth
+    rng = np.random.default_rng(61)
+    pts = rng.uniform(-0.8, 0.8, (4, 64, 3)).astype(np.float32)
+    W = synth.make_named_weights(synth.aue_pn_spec(64), seed=62, scale=1.0)
+    res = {"points": pts, "weights_seed": np.array(62)}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        for train in (False, True):
+            tf.set_real_dtype(dt)
+            tf.reset_default_graph()
+            tf.set_variable_overrides(W)
+            x = tf.Tensor(torch.tensor(pts, dtype=dt, requires_grad=True))
+            with contextlib.redirect_stdout(io.StringIO()):
+                out = MODEL.get_model_aue_pn(x, tf.constant(train), bn_decay=0.9)
+            key = "train" if train else "eval"
+            res["out_%s_%s" % (key, tag)] = out.numpy()
+            if train:   # moving statistics after ONE training-mode forward (updates_collections=None: updated in place)
+                v = tf.stub_variables()
+                res["mm_conv1_" + tag] = v["aue/conv1/bn/moving_mean"].numpy()
+                res["mv_conv1_" + tag] = v["aue/conv1/bn/moving_variance"].numpy()
+                res["mm_fc2_" + tag] = v["aue/fc2/bn/moving_mean"].numpy()
+                res["mv_fc2_" + tag] = v["aue/fc2/bn/moving_variance"].numpy()
+                g, = torch.autograd.grad(out.v.sum(), [x.v])
+                res["d_points_train_" + tag] = g.numpy()
+    res["var_names"] = np.array(sorted(tf.stub_variables()))
+    np.savez_compressed(os.path.join(out_dir, "aue_pn_cases.npz"), **res)
+    print("aue_pn_cases: |out| %.4f, %d variables" % (np.abs(res["out_eval_f32"]).mean(), len(res["var_names"])))
+
+
+def fx_step(tf, MODEL, ref, out_dir):
+    """F4: 3 optimizer steps with the trainer's own assembly -- two towers on batch slices, compute_gradients per
+    tower, average_gradients (:936-974), get_learning_rate (:976-990: staircase decay + floor), AdamOptimizer.apply_gradients
+    with the global step (:216,301) -- on a fixed batch, decoder 64-64-64 so that whole weight tensors fit the fixture."""
+    mlp = (64, 64, 64)
+    GB, towers = 4, 2
+    pcA, pcB, lab = synth.s2_modelnet_shaped(GB, 64, seed=100)
+    W0 = synth.make_weights("wide", mlp=mlp)
+    consts = {"BASE_LEARNING_RATE": 1e-3, "DECAY_STEP": 2, "DECAY_RATE": 0.5}     # decays after step 2: the staircase is exercised
+    res = {"pcA": pcA, "pcB": pcB, "labels": lab, "base_lr": np.array(1e-3), "decay_step": np.array(2), "decay_rate": np.array(0.5)}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        ns = {"tf": tf, "np": np, **consts}
+        fns = extract_functions(os.path.join(ref, "train_multi_gpu_pc_compare_dist.py"), ["average_gradients", "get_learning_rate"], ns)
+        tf.set_real_dtype(dt)
+        tf.reset_default_graph()
+        W = {k: v.copy() for k, v in W0.items()}
+        batch = tf.Tensor(torch.zeros((), dtype=torch.float64), name="batch")                  # global step (:205-207)
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = tf.train.AdamOptimizer(lambda: fns["get_learning_rate"](batch, consts["BASE_LEARNING_RATE"]))
+        losses, lrs = [], []
+        for step in range(3):
+            tf.reset_default_graph()
+            tf.set_variable_overrides(W)
+            tower_grads, tower_loss = [], []
+            per = GB // towers
+            for t in range(towers):                                                        # tf.slice per tower (:241-251)
+                sl = slice(t * per, (t + 1) * per)
+                with tf.variable_scope(tf.get_variable_scope(), reuse=(t > 0) or None):
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        pred, end_points, _ = MODEL.get_model(
+                            tf.Tensor(torch.tensor(pcA[sl], dtype=dt)), tf.Tensor(torch.tensor(pcB[sl], dtype=dt)), True, bn_decay=None,
+                            wd=0.0, bn=0, sig=False, Embedding_Size=512, pn="3dmfv", k=5, localSNmlp=list(mlp), overlap=True,
+                            full_fv=True, conv_version=1, sigma3dmfv=2.0 * 0.0625, add_noise=tf.Tensor(torch.zeros(per, 64, 3, dtype=dt)))
+                        MODEL.get_loss(pred, end_points, tf.Tensor(torch.tensor(lab[sl], dtype=dt)), loss_type="l1_dist")
+                loss_t = tf.get_collection("loss_samples")[-1]
+                names = sorted(tf.stub_variables())
+                tower_grads.append(opt.compute_gradients(loss_t, [tf.stub_variables()[n] for n in names]))
+                tower_loss.append(loss_t)
+            with contextlib.redirect_stdout(io.StringIO()):
+                grads = fns["average_gradients"](tower_grads)
+                lrs.append(float(fns["get_learning_rate"](batch, consts["BASE_LEARNING_RATE"]).numpy()))
+                opt.apply_gradients(grads, global_step=batch)
+            losses.append(float(tf.reduce_mean(tower_loss).numpy()))
+            W = {n: tf.stub_variables()[n].numpy().copy() for n in names}
+        res["loss_samples_" + tag] = np.array(losses)
+        res["lr_" + tag] = np.array(lrs)
+        for n in sorted(W):
+            short = n.split("/")[-2][-1] + ("w" if n.endswith("weights") else "b")
+            res["final_%s_%s" % (short, tag)] = W[n]
+    np.savez_compressed(os.path.join(out_dir, "step_adam.npz"), **res)
+    print("step_adam: losses", res["loss_samples_f32"], "lr", res["lr_f32"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma list of fixtures: fv,path,bwd,mlp64,chamfer,aue,step,pose")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
     tf, MODEL, dpdist_util = load_reference(a.ref)
-    fx_fv(tf, dpdist_util, a.out)
-    fx_path(tf, MODEL, a.out)
-    fx_bwd(tf, MODEL, a.out)
-    fx_small_mlp(tf, MODEL, a.out)
+    todo = set(a.only.split(",")) if a.only else None
+    want = lambda n: todo is None or n in todo   # noqa: E731
+    if want("fv"): fx_fv(tf, dpdist_util, a.out)
+    if want("path"): fx_path(tf, MODEL, a.out)
+    if want("bwd"): fx_bwd(tf, MODEL, a.out)
+    if want("mlp64"): fx_small_mlp(tf, MODEL, a.out)
+    if want("chamfer"): fx_chamfer(tf, a.ref, a.out)
+    if want("aue"): fx_aue_pn(tf, MODEL, a.out)
+    if want("step"): fx_step(tf, MODEL, a.ref, a.out)
+    if want("pose"): fx_pose(tf, a.ref, a.out)      # last: it re-binds the module name `tf_util` to the registration code's copy
 
 
 if __name__ == "__main__":

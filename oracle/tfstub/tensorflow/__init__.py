@@ -10,6 +10,7 @@ eagerly on torch-CPU so that autograd also yields gradient goldens.
 Only the ~50 symbols the DPDist hot path touches are provided.  Nothing here is copied from
 TensorFlow or from the reference.
 """
+import builtins as _b
 import contextlib
 import math as _pymath
 
@@ -129,8 +130,8 @@ class Tensor:
     def __getitem__(self, idx):
         if not isinstance(idx, tuple):
             idx = (idx,)
-        idx = tuple(_unwrap(i) if not isinstance(i, slice) else
-                    slice(_unwrap(i.start), _unwrap(i.stop), _unwrap(i.step)) for i in idx)
+        idx = tuple(_unwrap(i) if not isinstance(i, _b.slice) else
+                    _b.slice(_unwrap(i.start), _unwrap(i.stop), _unwrap(i.step)) for i in idx)
         return Tensor(self.v[idx])
 
     # -- arithmetic
@@ -345,8 +346,49 @@ def stack(values, axis=0):
 
 def split(value, num_or_size_splits, axis=0):
     t = _t(value)
-    assert isinstance(num_or_size_splits, int)
-    return [Tensor(p) for p in torch.chunk(t, num_or_size_splits, dim=axis)]
+    if isinstance(num_or_size_splits, int):
+        return [Tensor(p) for p in torch.chunk(t, num_or_size_splits, dim=axis)]
+    return [Tensor(p) for p in torch.split(t, [int(_unwrap(n)) for n in num_or_size_splits], dim=axis)]   # sized form
+
+
+def slice(input_, begin, size, name=None):  # noqa: A001
+    """tf.slice: size -1 = to the end of that axis."""
+    t = _t(input_)
+    idx = []
+    for ax, (b, n) in enumerate(zip(begin, size)):
+        b, n = int(_unwrap(b)), int(_unwrap(n))
+        idx.append(_b.slice(b, t.shape[ax] if n == -1 else b + n))
+    return Tensor(t[tuple(idx)])
+
+
+def tensordot(a, b, axes, name=None):
+    a_ax, b_ax = axes
+    a_ax = [a_ax] if isinstance(a_ax, int) else list(a_ax)
+    b_ax = [b_ax] if isinstance(b_ax, int) else list(b_ax)
+    return Tensor(torch.tensordot(_t(a), _t(b), dims=(a_ax, b_ax)))
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+    x, y = _t(a), _t(b)
+    if transpose_a:
+        x = x.transpose(-1, -2)
+    if transpose_b:
+        y = y.transpose(-1, -2)
+    return Tensor(x @ y)
+
+
+def norm(tensor, ord="euclidean", axis=None, keepdims=None, name=None):  # noqa: A002
+    """tf.norm: ord 2 / 'euclidean' over `axis` = sqrt(sum x^2) (vector norm)."""
+    assert ord in (2, "euclidean")
+    t = _t(tensor)
+    kd = _b.bool(keepdims)
+    return Tensor(torch.sqrt((t * t).sum() if axis is None else (t * t).sum(dim=axis, keepdim=kd)))
+
+
+def cond(pred, true_fn=None, false_fn=None, name=None):
+    p = _unwrap(pred)
+    p = _b.bool(p.item()) if isinstance(p, torch.Tensor) else _b.bool(p)
+    return true_fn() if p else false_fn()
 
 
 def gather_nd(params, indices):
@@ -373,6 +415,12 @@ def add_n(xs, name=None):
     return Tensor(out)
 
 
+def add(a, b, name=None): return Tensor(_t(a)) + b
+def subtract(a, b, name=None): return Tensor(_t(a)) - b
+def divide(a, b, name=None): return Tensor(_t(a)) / b
+def tanh(x, name=None): return Tensor(torch.tanh(_t(x)))
+def sin(x, name=None): return Tensor(torch.sin(_t(x)))
+def cos(x, name=None): return Tensor(torch.cos(_t(x)))
 def sqrt(x): return Tensor(torch.sqrt(_t(x)))
 def abs(x): return Tensor(torch.abs(_t(x)))  # noqa: A001
 def sign(x): return Tensor(torch.sign(_t(x)))
@@ -489,6 +537,16 @@ class _NN:
     def bias_add(value, bias, data_format="NHWC", name=None):
         return Tensor(_t(value) + _t(bias))
 
+    @staticmethod
+    def max_pool(value, ksize, strides, padding, data_format="NHWC", name=None):
+        assert data_format == "NHWC" and padding == "VALID"
+        y = F.max_pool2d(_t(value).permute(0, 3, 1, 2), (int(ksize[1]), int(ksize[2])), (int(strides[1]), int(strides[2])))
+        return Tensor(y.permute(0, 2, 3, 1))
+
+    @staticmethod
+    def dropout(x, keep_prob, noise_shape=None, seed=None, name=None):
+        raise NotImplementedError("stub: dropout is only reachable with is_training=True; goldens use the inference branch")
+
 
 nn = _NN()
 
@@ -532,6 +590,43 @@ class _Layers:
         return Tensor(t.reshape(t.shape[0], -1))
 
 
+def _batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, is_training=True, updates_collections=None,
+                scope=None, data_format="NHWC", reuse=None, **kw):
+    """tf.contrib.layers.batch_norm (TF 1.14), the subset utils/tf_util.py:573-577 uses: variables <scope>/beta, gamma,
+    moving_mean, moving_variance; training = batch statistics over all axes but the last (biased variance in the
+    normalisation), moving averages updated in place with the UNBIASED variance (fused kernel, updates_collections=None);
+    inference = the moving statistics."""
+    assert data_format == "NHWC"
+    x = _t(inputs)
+    C = x.shape[-1]
+    train = _unwrap(is_training)
+    train = _b.bool(train.item()) if isinstance(train, torch.Tensor) else _b.bool(train)
+    with variable_scope(scope or "BatchNorm", reuse=reuse):
+        beta = get_variable("beta", [C], initializer=constant_initializer(0.0)) if center else None
+        gamma = get_variable("gamma", [C], initializer=constant_initializer(1.0)) if scale else None
+        mm = get_variable("moving_mean", [C], initializer=constant_initializer(0.0), trainable=False)
+        mv = get_variable("moving_variance", [C], initializer=constant_initializer(1.0), trainable=False)
+    axes = tuple(builtins_range(x.dim() - 1))
+    if train:
+        mean = x.mean(dim=axes)
+        var = ((x - mean) ** 2).mean(dim=axes)
+        n = x.numel() // C
+        with torch.no_grad():
+            mm.v.mul_(decay).add_(mean.detach() * (1 - decay))
+            mv.v.mul_(decay).add_(var.detach() * (n / max(n - 1, 1)) * (1 - decay))
+    else:
+        mean, var = mm.v, mv.v
+    y = (x - mean) * torch.rsqrt(var + epsilon)
+    if gamma is not None:
+        y = y * gamma.v
+    if beta is not None:
+        y = y + beta.v
+    return Tensor(y)
+
+
+_Layers.batch_norm = staticmethod(_batch_norm)
+
+
 class _Contrib:
     distributions = _Distributions()
     layers = _Layers()
@@ -551,3 +646,55 @@ class _Summary:
 
 
 summary = _Summary()
+
+
+# ---------------------------------------------------------------------------------------------
+# tf.train: what the trainer's optimizer assembly touches (train_multi_gpu_pc_compare_dist.py:216,274-277,301,976-990)
+# ---------------------------------------------------------------------------------------------
+class _AdamOptimizer:
+    """tf.train.AdamOptimizer (TF 1.14, 'epsilon hat' form):
+        lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= lr_t m / (sqrt(v) + eps)
+    `learning_rate` may be a python float or a callable evaluated at every apply (the stub has no graph, so a learning-rate
+    TENSOR that depends on the global step is passed as a thunk by the generator)."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, name="Adam"):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+        self.t = 0
+        self.m, self.v = {}, {}
+
+    def compute_gradients(self, loss, var_list=None):
+        vs = list(var_list)
+        gs = torch.autograd.grad(_t(loss), [v.v for v in vs], retain_graph=True, allow_unused=True)
+        return [(None if g is None else Tensor(g), v) for g, v in zip(gs, vs)]
+
+    def apply_gradients(self, grads_and_vars, global_step=None):
+        lr = self.lr() if callable(self.lr) else self.lr
+        lr = float(_t(lr)) if not isinstance(lr, float) else lr
+        self.t += 1
+        lr_t = lr * _pymath.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        with torch.no_grad():
+            for g, var in grads_and_vars:
+                if g is None:
+                    continue
+                g = _t(g).to(var.v.dtype)
+                m = self.m.setdefault(var.name, torch.zeros_like(var.v))
+                v = self.v.setdefault(var.name, torch.zeros_like(var.v))
+                m.mul_(self.b1).add_(g * (1 - self.b1))
+                v.mul_(self.b2).add_(g * g * (1 - self.b2))
+                var.v.sub_(lr_t * m / (v.sqrt() + self.eps))
+            if global_step is not None:
+                global_step.v.add_(1)
+
+
+class _Train:
+    AdamOptimizer = _AdamOptimizer
+
+    @staticmethod
+    def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, staircase=False, name=None):
+        p = _t(global_step).to(torch.float64) / float(_unwrap(decay_steps))
+        if staircase:
+            p = torch.floor(p)
+        return Tensor((float(learning_rate) * float(decay_rate) ** p).to(_REAL))
+
+
+train = _Train()

@@ -153,3 +153,32 @@ def test_nan_semantics_far_point():
     assert torch.isnan(R.mfv3d(pts)).any()
     pts[0, 0] = 1.2
     assert not torch.isnan(R.mfv3d(pts)).any()
+
+
+def test_restatement_reproduces_the_optimizer_steps_fixture(golden_dir):
+    """F4 (tests/golden/step_adam.npz): three steps of the trainer's own optimizer assembly -- two towers, compute_gradients,
+    average_gradients, get_learning_rate (staircase, decays after step 2), AdamOptimizer.apply_gradients
+    (train_multi_gpu_pc_compare_dist.py:216,241-251,274-277,301,936-990), run by oracle/gen_goldens.py:fx_step -- pin the
+    restatement's loss/gradient, adam_tf_step and learning_rate."""
+    import math
+    d = np.load(os.path.join(golden_dir, "step_adam.npz"))
+    mlp = (64, 64, 64)
+    W0 = synth.make_weights("wide", mlp=mlp)
+    Wt = {n: torch.tensor(a, dtype=torch.float64, requires_grad=True) for n, a in W0.items()}
+    ms = {n: np.zeros_like(a, dtype=np.float64) for n, a in W0.items()}
+    vs = {n: np.zeros_like(a, dtype=np.float64) for n, a in W0.items()}
+    pcA, pcB, lab = (torch.tensor(d[k], dtype=torch.float64) for k in ("pcA", "pcB", "labels"))
+    base, dstep, drate = float(d["base_lr"]), int(d["decay_step"]), float(d["decay_rate"])
+    for t in range(1, 4):
+        lr = R.learning_rate(t - 1, base, dstep, drate)
+        assert math.isclose(lr, float(d["lr_f64"][t - 1]), rel_tol=1e-12)
+        pred, _ = R.get_model(pcA, pcB, Wt)           # full batch: the mean of two equal tower means
+        ls, _ = R.get_loss(pred, lab)
+        assert abs(ls.item() - float(d["loss_samples_f64"][t - 1])) <= 1e-10
+        names = sorted(Wt)
+        gs = torch.autograd.grad(ls, [Wt[n] for n in names])
+        for n, g in zip(names, gs):
+            R.adam_tf_step(Wt[n].detach().numpy(), g.numpy(), ms[n], vs[n], t, lr)
+    for n in Wt:
+        short = n.split("/")[-2][-1] + ("w" if n.endswith("weights") else "b")
+        assert np.abs(Wt[n].detach().numpy() - d["final_%s_f64" % short]).max() <= 1e-9, n

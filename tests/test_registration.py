@@ -1,4 +1,8 @@
-"""Row f2 (registration harness): pose math against scipy (CPU); GPU: gradients reach the pose network through DPDist."""
+"""Row f2 (registration harness): the pose math, the pose network and the error metric against goldens produced by the
+reference's own functions (tests/golden/pose_cases.npz, oracle/gen_goldens.py:fx_pose runs helper.transformation_quat_tensor,
+ipcr_model.quat_normalize / get_model / get_pose, results_itrPCRNet_no_stop.find_errors, helper.transformation_quat2mat /
+find_final_pose under the stubs), plus scipy cross-checks; GPU: gradients reach the pose network through DPDist."""
+import os
 import math
 
 import numpy as np
@@ -6,8 +10,68 @@ import pytest
 import torch
 from scipy.spatial.transform import Rotation
 
-from dpdist_amd.registration import (PoseNet, compose, find_errors, quat_normalize, quat_to_mat,
-                                     transformation_quat_tensor)
+from dpdist_amd import synth
+from dpdist_amd.registration import (PoseNet, compose, find_errors, find_final_pose, pose_errors, quat_normalize, quat_to_mat,
+                                     transformation_quat2mat, transformation_quat_tensor)
+
+
+@pytest.fixture(scope="module")
+def pose(golden_dir):
+    return np.load(os.path.join(golden_dir, "pose_cases.npz"))
+
+
+def test_transformation_quat_tensor_golden(pose):
+    """helper.py:539-570 run by the generator; unit AND un-normalised quaternions (no normalisation inside)."""
+    for dt, tag, tol in ((torch.float32, "f32", 2e-6), (torch.float64, "f64", 1e-12)):
+        got = transformation_quat_tensor(torch.tensor(pose["data"], dtype=dt), torch.tensor(pose["quat"], dtype=dt),
+                                         torch.tensor(pose["trans"], dtype=dt)).numpy()
+        assert np.abs(got - pose["transformed_" + tag]).max() <= tol
+
+
+@pytest.mark.parametrize("lim", [45, 10])
+def test_quat_normalize_golden(pose, lim):
+    """models/ipcr_model.py:285-294."""
+    got = quat_normalize(torch.tensor(pose["raw7"], dtype=torch.float64), rot_lim=float(lim)).numpy()
+    assert np.abs(got - pose["quat_normalize%d_f64" % lim]).max() <= 1e-12
+    got32 = quat_normalize(torch.tensor(pose["raw7"]), rot_lim=float(lim)).numpy()
+    assert np.abs(got32 - pose["quat_normalize%d_f32" % lim]).max() <= 1e-6
+
+
+def test_pose_network_golden(pose):
+    """ipcr_model.pointnet + get_pose (inference branch of the dropout) with the seeded weights of synth.pose_net_spec."""
+    net = PoseNet(out_features=1024, lim_rot=0).double().eval()
+    net.load_tf_state_dict(synth.make_named_weights(synth.pose_net_spec(1024), seed=int(pose["weights_seed"])))
+    src, tmpl = torch.tensor(pose["source"], dtype=torch.float64), torch.tensor(pose["template"], dtype=torch.float64)
+    with torch.no_grad():
+        fs, ft = net.features(src, tmpl)
+        raw = net(src, tmpl)
+        net.lim_rot = 45.0
+        lim = net(src, tmpl)
+    assert np.abs(fs.numpy() - pose["feat_source_f64"]).max() <= 1e-10
+    assert np.abs(ft.numpy() - pose["feat_template_f64"]).max() <= 1e-10
+    assert np.abs(raw.numpy() - pose["pose_raw_f64"]).max() <= 1e-10
+    assert np.abs(lim.numpy() - pose["pose_lim45_f64"]).max() <= 1e-10
+    assert np.abs(raw.numpy() - pose["pose_raw_f32"]).max() <= 1e-4        # the float32 run of the same graph
+
+
+def test_find_errors_golden(pose):
+    """results_itrPCRNet_no_stop.py:112-133 (same signature) against its own output."""
+    for i in range(len(pose["err_gt_pose"])):
+        te, re = find_errors(pose["err_gt_pose"][i], pose["err_final_pose"][i])
+        assert abs(te - pose["err_translation"][i]) <= 1e-12
+        assert abs(re - pose["err_rotation_deg"][i]) <= 1e-8
+    te, re = find_errors(pose["err_gt_pose"][0], pose["err_gt_pose"][0])
+    assert te == 0.0 and re <= 1e-5
+
+
+def test_quat2mat_and_final_pose_golden(pose):
+    """helper.transformation_quat2mat (:309-329) and find_final_pose (:331-345)."""
+    B = pose["quat"].shape[0]
+    poses = np.concatenate([pose["trans"], pose["quat"]], 1).astype(np.float64)
+    T, moved = transformation_quat2mat(poses.reshape(1, B, 7), np.tile(np.eye(4), (B, 1, 1)), pose["data"].astype(np.float64).copy())
+    assert np.abs(T - pose["quat2mat_T"]).max() <= 1e-12
+    assert np.abs(moved - pose["quat2mat_data"]).max() <= 1e-12
+    assert np.abs(find_final_pose(T) - pose["final_pose"]).max() <= 1e-12
 
 
 def test_quat_to_mat_matches_scipy():
@@ -40,7 +104,8 @@ def test_quat_normalize_limits():
     assert (ang <= 45.0 + 1e-3).all()
 
 
-def test_find_errors():
+def test_pose_errors_on_matrices():
+    find_errors = pose_errors
     ang = math.radians(30.0)
     Rg = torch.tensor(Rotation.from_rotvec([0, 0, ang]).as_matrix())[None]
     tg = torch.tensor([[0.05, -0.02, 0.01]], dtype=torch.float64)

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 
 from dpdist_amd import synth  # noqa: E402
 from dpdist_amd.model import DPDistLoss, DPDistModel  # noqa: E402
-from dpdist_amd.registration import IterativeRegistration, PoseNet, find_errors, quat_to_mat  # noqa: E402
+from dpdist_amd.registration import IterativeRegistration, PoseNet, pose_errors as find_errors, quat_to_mat  # noqa: E402
 from dpdist_amd.trainer import DPDistTrainer  # noqa: E402
 
 
