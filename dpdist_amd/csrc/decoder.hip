@@ -20,6 +20,9 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
             hipStream_t s, float* colsum, const X3Out* out = nullptr, const uint16_t* A2 = nullptr, const uint16_t* B2 = nullptr,
             float* C2 = nullptr);
+int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
+                   const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
+                   hipStream_t s, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
 int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
                  long r8_plane, hipStream_t s);
 int split_planes_multi(SplitJobs jobs, hipStream_t s);
@@ -27,16 +30,16 @@ int split_planes_multi(SplitJobs jobs, hipStream_t s);
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
 enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 = 4, OP_BWD_DW23 = 5, OP_BWD_DH_T = 6, OP_BWD_DX_T = 7,
-       OP_COUNT = 8 };   // _T: the same product with a transposed weight copy (NN form)
+       OP_BWD_DW1_G = 8, OP_COUNT = 9 };   // _T: the same product with a transposed weight copy (NN form); _G: fused gather
 // Defaults measured on MI355X at B=32 (tools/gemm_bench.py, profiles/): LDS-DMA ring kernels everywhere;
 //   fwd L1 (4096x1024x2528)  128x128 16-wave 3-stage ring  ~127 TFLOP/s    fwd L2/3 (K=1024) 128x128 3-stage  ~120
 //   bwd dH (2048x1024x1024)   64x64  3-stage               ~ 93..106       bwd dX            64x64 3-stage    ~103
 //   bwd dW1 (2528x1024x2048)  64x64  3-stage, split-K 2    ~102            bwd dW2/3         64x64 3-stage    ~ 97
 // (run-to-run spread between boxes is ~10 %; the ranking inside one run is stable.  DMA kernels need K % 32 == 0;
 //  gemm_f32 falls back to the register-staged 64x64 kernel otherwise.)
-static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32};
-static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1};
-static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
+static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32, 30};
+static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 3};
+static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
 static int g_x3_pair_tile = 0;
 
 // Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
@@ -649,6 +652,55 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
     DPD_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- fused window gather (DPD_F32): layer 1 reads its input rows straight from the Fisher vectors --------------------
+static int check_gather(const dpd_gather* g, int rows, size_t* a_bytes, size_t* xyz_off) {
+    if (!g || !g->fv || !g->xyz || !g->rowinfo || !g->table) return DPD_E_NULL;
+    if (g->C <= 0 || g->G <= 0 || rows <= 0) return DPD_E_DIM;
+    // ONE buffer descriptor serves both: xyz must live behind fv in the same allocation, 32-bit offsets
+    if ((const char*)g->xyz < (const char*)g->fv) return DPD_E_UNSUPPORTED;
+    *xyz_off = (size_t)((const char*)g->xyz - (const char*)g->fv);
+    if (*xyz_off < (size_t)g->C * g->G * DPD_FV_CHANNELS * sizeof(float)) return DPD_E_DIM;
+    *a_bytes = *xyz_off + (size_t)rows * 16;
+    return 0;
+}
+
+extern "C" int dpd_decoder_fwd_gather(const dpd_gather* src, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
+                                      float* h1, float* h2, float* h3, float* y, float* pred, void* stream) {
+    using namespace dpd;
+    if (!mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
+    if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
+    if (Q <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
+    if ((H & 63) || (KP & 31)) return DPD_E_UNSUPPORTED;
+    size_t a_bytes = 0, xyz_off = 0;
+    if (int rc = check_gather(src, Q, &a_bytes, &xyz_off)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    int t1 = g_plan_tile[OP_FWD_L1];
+    if (t1 < 30 || t1 > 33) t1 = 32;
+    if (int rc = gemm_rs_gather(1, Q, H, KP, src->fv, a_bytes, xyz_off, (const uint2*)src->table, (const uint2*)src->rowinfo, p->W1p, H, h1,
+                                H, p->b1, EPI_BIAS_RELU, t1, s)) return rc;
+    const Scratch scr{nullptr, 0};
+    if (int rc = gemm_dt(0, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
+    if (int rc = gemm_dt(0, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
+    DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_decoder_bwd_weights_gather(const dpd_gather* src, const float* g1, int Qb, int KP, int H, float* dW1, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    using namespace dpd;
+    if (!g1 || !dW1) return DPD_E_NULL;
+    if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
+    if ((H & 63) || (KP & 31) || (Qb & 31)) return DPD_E_UNSUPPORTED;
+    size_t a_bytes = 0, xyz_off = 0;
+    if (int rc = check_gather(src, Qb, &a_bytes, &xyz_off)) return rc;
+    int t = g_plan_tile[OP_BWD_DW1_G], split = g_plan_split[OP_BWD_DW1_G];
+    if (t < 30 || t > 33) t = 33;
+    if (split > 1 && (!ws || (size_t)split * KP * H * sizeof(float) > ws_bytes)) split = 1;
+    return gemm_rs_gather(2, KP, H, Qb, src->fv, a_bytes, xyz_off, (const uint2*)src->table, (const uint2*)src->rowinfo, g1, H, dW1, H,
+                          nullptr, EPI_NONE, t, (hipStream_t)stream, split, ws, ws_bytes);
 }
 
 extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1,

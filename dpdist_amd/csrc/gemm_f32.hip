@@ -645,6 +645,43 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     return 0;
 }
 
+// Layer-1 GEMMs with the window gather fused into the A operand (gemm_rs.h, ASRC 1 / 2):
+//   which = 1: C [M = query rows, N] = epi( X W ),  X gathered;  K = KP (whole 32-deep K-tiles)
+//   which = 2: C [M = KP window columns, N] = X^T G,  X^T gathered, G [K = rows, N] row-major
+int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
+                   const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
+                   hipStream_t s, int split_k, void* ws, size_t ws_bytes) {
+    if (!fv || !ktab || !rowinfo || !B || !C) return DPD_E_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
+    if ((K % 32) || (N & 3) || (ldb & 3) || (ldc & 3) || (which == 2 && (M & 3))) return DPD_E_UNSUPPORTED;
+    if (a_bytes > 0xfffffff0ull || xyz_off > 0xfffffff0ull) return DPD_E_UNSUPPORTED;   // 32-bit buffer offsets
+    if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) && !bias) return DPD_E_NULL;
+    GemmArgs g{};
+    g.A = fv; g.B = B; g.C = C; g.bias = bias;
+    g.ktab = ktab; g.rowinfo = rowinfo; g.xyz_off = (unsigned)xyz_off; g.a_bytes = (unsigned)a_bytes;
+    g.M = M; g.N = N; g.K = K; g.lda = 0; g.ldb = ldb; g.ldc = ldc;
+    g.epi = epilogue; g.split_k = 1; g.k_chunk = K; g.slab_stride = 0;
+    if (split_k > 1) {       // deterministic slabs + the fused reduce kernel, as in gemm_f32()
+        const int chunk = (((K + split_k - 1) / split_k) + 31) / 32 * 32;
+        if (chunk * (split_k - 1) >= K) return DPD_E_UNSUPPORTED;
+        if (!ws || (size_t)split_k * M * N * sizeof(float) > ws_bytes) return DPD_E_WORKSPACE;
+        g.split_k = split_k; g.k_chunk = chunk; g.C = (float*)ws; g.ldc = N; g.slab_stride = (long)M * N; g.epi = EPI_NONE;
+    }
+    struct ProfScope {
+        bool on; hipStream_t s; double fl;
+        ~ProfScope() { prof_end(on, s, fl); }
+    } prof_scope{prof_begin(s), s, 2.0 * M * N * K};
+    if (int rc = which == 1 ? launch_rs_gather_fwd(tile, g, s) : launch_rs_gather_dw(tile, g, s)) return rc;
+    if (split_k > 1) {
+        const long total4 = (long)M * N / 4;
+        const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+        DPD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, split_k, (long)M * N, M, N, C, ldc, bias,
+                   (const float*)nullptr, epilogue);
+        return (int)hipGetLastError();
+    }
+    return 0;
+}
+
 }  // namespace dpd
 
 // ---- profiler C ABI -------------------------------------------------------------------------------------

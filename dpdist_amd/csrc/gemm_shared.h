@@ -22,6 +22,12 @@ struct GemmArgs {
     // tiles whose rows start at or beyond *M_dev exit, the contraction stops at *K_dev (a multiple of 32, <= K)
     const int* M_dev;
     const int* K_dev;
+    // optional fused window gather (gemm_rs.h, ASRC != 0): the A operand is not read from memory at A/lda but gathered from
+    // the Fisher vectors through the per-row / per-column tables of patch_rows.hip (A = fv base, ONE buffer with xyz behind it)
+    const uint2* ktab;      // [K/4 or M/4] per float4 window column: {byte offset of the neighbour's channels, required-validity bits}
+    const uint2* rowinfo;   // [rows] per query row: {byte offset (c*G + v)*80 of its voxel in fv, validity bits of its 3 x k neighbour offsets}
+    unsigned xyz_off;       // byte offset of xyz [rows,4] from the fv base (same allocation)
+    unsigned a_bytes;       // bytes covered by the A buffer descriptor (fv + xyz)
     int M, N, K;
     int lda, ldb, ldc;
     int epi;

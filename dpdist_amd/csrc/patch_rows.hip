@@ -193,7 +193,89 @@ __global__ __launch_bounds__(256) void stack_clouds_kernel(const float* __restri
     q[n + i] = a;
 }
 
+// Front end of the fused-gather path: input stacking (models/dpdist_and_aue.py:45,56-61,69) + the query lookup of
+// get_pc_grid_binary_mask_from_centers (:459-492) in ONE launch, one thread per query row r = c*N + n:
+//   pts  [2B,N,3] = [pcA + noise ; pcB]        encoder input
+//   mask [Q], vox [Q]                           as dpd_patch_rows_fwd
+//   xyz  [Q,4]  = (q - centre, 0)               the three centre-relative columns of the decoder input row (:455)
+//   rowinfo [Q] = { (c*G + vox)*80 bytes , validity bits } bit 8*a + d set <=> neighbour offset d of grid axis a (y, x, z) is inside the grid
+__global__ __launch_bounds__(256) void front_kernel(const float* __restrict__ pcA, const float* __restrict__ pcB,
+                                                     const float* __restrict__ noise, int B, int N, int m, int k, GridAxis ax,
+                                                     float* __restrict__ pts, float* __restrict__ q_out, float* __restrict__ mask,
+                                                     int32_t* __restrict__ vox, float4* __restrict__ xyz, uint2* __restrict__ rowinfo) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * B * N) return;
+    const int c = r / N, n = r % N, h = (k - 1) / 2;
+    const bool first = c < B;
+    const size_t ia = ((size_t)(first ? c : c - B) * N + n) * 3;
+    float a[3], b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a[d] = pcA[ia + d]; b[d] = pcB[ia + d]; }
+    // rows of the first half: encoder point = pcA + noise, query = pcB; second half: encoder point = pcB, query = pcA (un-noised)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float e = first ? (noise ? a[d] + noise[ia + d] : a[d]) : b[d];
+        pts[(size_t)r * 3 + d] = e;
+        if (q_out) q_out[(size_t)r * 3 + d] = first ? b[d] : a[d];
+    }
+    const float qx = first ? b[0] : a[0], qy = first ? b[1] : a[1], qz = first ? b[2] : a[2];
+    int ix = cell_of(ax, m, qx), iy = cell_of(ax, m, qy), iz = cell_of(ax, m, qz);
+    const bool valid = (ix >= 0) && (iy >= 0) && (iz >= 0);
+    if (!valid) { ix = 0; iy = 0; iz = 0; }
+    const int v = (iy * m + ix) * m + iz;
+    mask[r] = valid ? 1.f : 0.f;
+    vox[r] = v;
+    xyz[r] = make_float4(qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz], 0.f);
+    unsigned bits = 0;
+    const int i3[3] = {iy, ix, iz};      // grid axes are (y, x, z), slowest first
+#pragma unroll
+    for (int a3 = 0; a3 < 3; ++a3)
+        for (int d = 0; d < k; ++d)
+            if ((unsigned)(i3[a3] + d - h) < (unsigned)m) bits |= 1u << (8 * a3 + d);
+    rowinfo[r] = make_uint2((unsigned)(c * m * m * m + v) * (unsigned)(kF * sizeof(float)), bits);
+}
+
+// ktab[k4] for the float4 column k4 of a decoder input row: window columns -> {byte offset of that neighbour's 4 channels
+// relative to the row's own voxel, the validity bits it needs}; the q - centre float4 and the zero padding are marked.
+__global__ __launch_bounds__(256) void gather_table_kernel(uint2* __restrict__ tab, int n4, int m, int k) {
+    const int k4 = blockIdx.x * 256 + threadIdx.x;
+    if (k4 >= n4) return;
+    const int E4 = k * k * k * (kF / 4), h = (k - 1) / 2;
+    if (k4 < E4) {
+        const int nb = k4 / 5, part = k4 % 5;
+        const int d0 = nb / (k * k), d1 = (nb / k) % k, d2 = nb % k;
+        const int delta = ((((d0 - h) * m + (d1 - h)) * m + (d2 - h)) * kF + part * 4) * 4;
+        tab[k4] = make_uint2((unsigned)delta, (1u << d0) | (1u << (8 + d1)) | (1u << (16 + d2)));
+    } else {
+        tab[k4] = make_uint2(0u, k4 == E4 ? 0x40000000u : 0x80000000u);
+    }
+}
+
 }  // namespace dpd
+
+extern "C" int dpd_front(const float* pcA, const float* pcB, const float* noise, int B, int N, int m, int k, float* pts, float* q,
+                         float* mask, int32_t* vox, float* xyz, void* rowinfo, void* stream) {
+    using namespace dpd;
+    if (!pcA || !pcB || !pts || !mask || !vox || !xyz || !rowinfo) return DPD_E_NULL;
+    if (B <= 0 || N <= 0) return DPD_E_DIM;
+    if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
+    if (((uintptr_t)xyz & 15) || ((uintptr_t)rowinfo & 7)) return DPD_E_UNSUPPORTED;
+    const int Q = 2 * B * N;
+    DPD_LAUNCH(front_kernel, dim3((Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, pcA, pcB, noise, B, N, m, k, make_axis(m), pts, q,
+               mask, vox, (float4*)xyz, (uint2*)rowinfo);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_gather_table(int m, int k, int KP, void* table, void* stream) {
+    using namespace dpd;
+    if (!table) return DPD_E_NULL;
+    if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
+    if (KP < k * k * k * kF + 3 || (KP & 31) || ((uintptr_t)table & 7)) return DPD_E_DIM;
+    DPD_LAUNCH(gather_table_kernel, dim3((KP / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint2*)table, KP / 4, m, k);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int dpd_stack_clouds(const float* pcA, const float* pcB, const float* noise, int B, int N, float* pts, float* q,
                                 void* stream) {

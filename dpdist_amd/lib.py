@@ -23,6 +23,10 @@ class SmallGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("db1", "db2", "db3", "dW4", "db4")]
 
 
+class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
+    _fields_ = [("fv", c_void_p), ("xyz", c_void_p), ("rowinfo", c_void_p), ("table", c_void_p), ("C", c_int), ("G", c_int)]
+
+
 class Planes(Structure):     # include/dpdist_capi.h: dpd_planes
     _fields_ = [("np", c_int), ("Q", c_int), ("Qb", c_int)] + [(n, c_void_p) for n in (
         "X_rc", "X_r8", "h1_rc", "h1_r8", "h2_rc", "h2_r8", "g3_rc", "g3_r8", "g2_rc", "g2_r8", "g1_rc", "g1_r8",
@@ -46,6 +50,10 @@ SIGNATURES = {
                                      POINTER(DecoderParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      POINTER(SmallGrads), c_void_p, c_size_t, POINTER(Planes), c_int, c_void_p]),
     "dpd_stack_clouds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dpd_front": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
+    "dpd_gather_table": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpd_decoder_fwd_gather": (c_int, [POINTER(Gather), c_void_p, c_int, c_int, c_int, POINTER(DecoderParams)] + [c_void_p] * 6),
+    "dpd_decoder_bwd_weights_gather": (c_int, [POINTER(Gather), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p]),

@@ -47,9 +47,27 @@ class DPDistTrainer:
         C, Q, BN = 2 * B, 2 * B * N, B * N
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)   # noqa: E731
         self.pts, self.q = f(C, N, 3), f(C, N, 3)
-        self.fv = f(C, self.m ** 3, 20)
-        self.X, self.mask = f(Q, KP), f(Q)
+        # Exact-fp32 compute type, opt-in (DPD_FUSED_GATHER=1): the window gather fused into the layer-1 GEMMs (csrc/gemm_rs.h,
+        # SURVEY K2) -- X [Q,KP] (41 MB at B = 32, 82 MB at B = 64) is never materialised; bitwise the same results.  Measured
+        # SLOWER on MI355X at B = 32 (layer 1: 180 us against 147 + 13.5 us for gather kernel + plain GEMM; dW1: 152 against
+        # 91 us: the per-lane address arithmetic sits in the in-order issue stream of an MFMA-bound wave), so the default
+        # keeps X.  fv and the q - centre columns share ONE allocation either way (one buffer descriptor).
+        G = self.m ** 3
+        self.fused = (self.dt == 0 and KP % 32 == 0 and BN % 32 == 0 and not dedupe
+                      and os.environ.get("DPD_FUSED_GATHER", "0") == "1" and os.environ.get("DPD_DEDUPE", "0") != "1")
+        self._fvx = f(C * G * 20 + Q * 4)
+        self.fv = self._fvx[:C * G * 20].view(C, G, 20)
+        self.xyz = self._fvx[C * G * 20:].view(Q, 4)
+        self.mask = f(Q)
         self.vox = torch.empty(Q, device=dev, dtype=torch.int32)
+        if self.fused:
+            self.X = None
+            self.rowinfo = torch.empty(Q, 2, device=dev, dtype=torch.int32)
+            self.ktab = torch.empty(KP // 4, 2, device=dev, dtype=torch.int32)
+            L.check(L.load().dpd_gather_table(self.m, params.k, KP, L.ptr(self.ktab), L.cur_stream()), "dpd_gather_table")
+            self._gsrc = L.Gather(self.fv.data_ptr(), self.xyz.data_ptr(), self.rowinfo.data_ptr(), self.ktab.data_ptr(), C, G)
+        else:
+            self.X = f(Q, KP)
         self.h1, self.h2, self.h3 = f(Q, H), f(Q, H), f(Q, H)
         self.y, self.pred = f(Q, 3), f(Q, 3)
         self.dpred, self.dy = f(BN, 3), f(BN, 3)
@@ -126,6 +144,12 @@ class DPDistTrainer:
 
     def _load_batch(self, pcA, pcB, noise):
         shp = (self.B, self.N, 3)
+        if self.fused:      # stacking + query lookup in one launch (the gather itself happens inside the layer-1 GEMMs)
+            L.check(L.load().dpd_front(L.ptr(L.req(pcA, name="pcA", shape=shp)), L.ptr(L.req(pcB, name="pcB", shape=shp)),
+                                       None if noise is None else L.ptr(L.req(noise, name="add_noise", shape=shp)), self.B, self.N,
+                                       self.m, self.k, L.ptr(self.pts), None, L.ptr(self.mask), L.ptr(self.vox), L.ptr(self.xyz),
+                                       L.ptr(self.rowinfo), L.cur_stream()), "dpd_front")
+            return
         L.check(L.load().dpd_stack_clouds(L.ptr(L.req(pcA, name="pcA", shape=shp)), L.ptr(L.req(pcB, name="pcB", shape=shp)),
                                           None if noise is None else L.ptr(L.req(noise, name="add_noise", shape=shp)), self.B, self.N,
                                           L.ptr(self.pts), L.ptr(self.q), L.cur_stream()), "dpd_stack_clouds")
@@ -135,6 +159,8 @@ class DPDistTrainer:
                 "dpd_mfv3d_fwd")
 
     def _gather(self):
+        if self.fused:
+            return
         lib, s, P = L.load(), L.cur_stream(), self.P
         C, N = 2 * self.B, self.N
         if self.dedupe:     # voxel lookup + unique-row numbering, then the window gather of the unique rows only
@@ -156,6 +182,11 @@ class DPDistTrainer:
     def _decode(self):
         lib, s, P = L.load(), L.cur_stream(), self.P
         Q = 2 * self.B * self.N
+        if self.fused:
+            L.check(lib.dpd_decoder_fwd_gather(self._gsrc, L.ptr(self.mask), Q, P.KP, P.H, self._cparams, L.ptr(self.h1),
+                                               L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), s),
+                    "dpd_decoder_fwd_gather")
+            return
         if self.dedupe:     # layer 1 on the unique rows, expanded to h1; the decoder entry point then starts at layer 2
             v = P.views()
             L.check(lib.dpd_layer1_fwd_unique(L.ptr(self.X), L.ptr(self.counts), L.ptr(self.u_of_q), L.ptr(self.xyz), Q, P.KP, P.H,
@@ -182,6 +213,10 @@ class DPDistTrainer:
                                              phases, s), "dpd_decoder_bwd_data")
 
         def dw(layer, act, g, dW):
+            if layer == 1 and self.fused:
+                L.check(lib.dpd_decoder_bwd_weights_gather(self._gsrc, L.ptr(self.g1), BN, P.KP, P.H, L.ptr(dW), L.ptr(self.ws), wsb, L.cur_stream()),
+                        "dpd_decoder_bwd_weights_gather")
+                return
             if layer == 1 and self.dedupe:
                 L.check(lib.dpd_layer1_bwd_weights_unique(L.ptr(self.X), L.ptr(self.g1), L.ptr(self.u_of_q), L.ptr(self.rep_q),
                                                           L.ptr(self.xyz), L.ptr(self.counts), self.N, BN, P.KP, P.H, P.E, L.ptr(dW),

@@ -80,6 +80,27 @@ struct dpd_planes;   /* bf16 operand planes that persist between entry points; d
 int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
                        float* mask, int32_t* vox, const struct dpd_planes* pl, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused-gather path (DPD_F32): the decoder input rows X [Q,KP] are never materialised -- layer 1 and its weight gradient read
+ * them straight out of the Fisher vectors inside the GEMM (csrc/gemm_rs.h).
+ * dpd_front = dpd_stack_clouds + the lookup half of dpd_patch_rows_fwd in one launch:
+ *   pcA, pcB, noise [B,N,3] (noise may be NULL) -> pts [2B,N,3], q [2B,N,3] (may be NULL), mask [Q], vox [Q],
+ *   xyz [Q,4] = (q - centre, 0) (16-byte aligned), rowinfo [Q] x 8 bytes = {byte offset of fv row c*G + vox, neighbour-validity bits}.
+ * dpd_gather_table fills `table` [KP/4] x 8 bytes (per float4 column of a row: neighbour offset + the validity bits it needs;
+ *   depends on (m, k, KP) only: build once).
+ * dpd_gather names the sources; `xyz` MUST lie behind `fv` in the same allocation (one 32-bit-offset buffer descriptor
+ *   covers both): allocate [C*G*20 floats | Q*4 floats] and pass the two views.                                       */
+int dpd_front(const float* pcA, const float* pcB, const float* noise, int B, int N, int m, int k, float* pts, float* q,
+              float* mask, int32_t* vox, float* xyz, void* rowinfo, void* stream);
+int dpd_gather_table(int m, int k, int KP, void* table, void* stream);
+typedef struct dpd_gather {
+    const float* fv;        /* [C, G, 20] Fisher vectors (dpd_mfv3d_fwd)                       */
+    const float* xyz;       /* [Q, 4] from dpd_front, behind fv in the same allocation           */
+    const void* rowinfo;    /* [Q] x 8 bytes from dpd_front                                      */
+    const void* table;      /* [KP/4] x 8 bytes from dpd_gather_table                            */
+    int C, G;               /* clouds, Gaussians per cloud (m^3)                                 */
+} dpd_gather;
+
 /* Backward of the gather: dX [Q,KP] -> dq [C,N,3] (overwritten; = dX[:,E:E+3]) and
  * dfv [C,m^3,20] (overwritten; scatter-add of the window columns).  Either output may be NULL.  */
 int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, int N, int m, int k, int KP, float* dq,
@@ -111,6 +132,14 @@ int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, con
                     const dpd_planes* pl, void* stream);
 
 /* X may be NULL when layer 1 was already evaluated into h1 by dpd_layer1_fwd_unique (DPD_F32, no planes).          */
+
+/* dpd_decoder_fwd with layer 1 gathering its rows from `src` (DPD_F32; KP % 32 == 0), and the layer-1 weight gradient
+ * dW1 [KP,H] = X^T g1 over the first Qb rows gathered the same way (Qb % 32 == 0).  Bitwise identical to running the
+ * register-streamed kernels on a materialised X.                                                                  */
+int dpd_decoder_fwd_gather(const dpd_gather* src, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
+                           float* h1, float* h2, float* h3, float* y, float* pred, void* stream);
+int dpd_decoder_bwd_weights_gather(const dpd_gather* src, const float* g1, int Qb, int KP, int H, float* dW1, void* ws,
+                                   size_t ws_bytes, void* stream);   /* ws: dpd_workspace_bytes() (split-K slabs), may be NULL */
 
 /* `dtype` of the decoder entry points = compute type of the three wide layers (inputs/outputs are always fp32):
  *   DPD_F32     exact fp32 on the fp32 matrix-core instruction (bitwise an fmaf chain), no workspace needed in

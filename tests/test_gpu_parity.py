@@ -990,3 +990,86 @@ def test_integration_md_stub_runs_as_written(dev, golden_dir, monkeypatch):
     torch.cuda.synchronize()
     for n in ("pred_listAB", "pred_listBA"):
         _check_pred(out[n].cpu().numpy(), d[n + "_f64"], True)
+
+
+# ------------------------------------------------------------------------------------------------ fused window gather (K2)
+@pytest.mark.parametrize("m,k", [(8, 5), (5, 3)])
+def test_fused_gather_is_bitwise_the_materialised_rows(dev, m, k):
+    """Layer 1 and dW1 with the window gather fused into the GEMM's A operand (csrc/gemm_rs.h, ASRC 1 / 2) against the SAME
+    register-streamed kernels run on the materialised X [Q,KP] of dpd_patch_rows_fwd (itself bit-exact against the oracle,
+    test_patch_rows_bit_exact): identical contraction order -> identical bits.  Boundary clouds put queries on cell edges,
+    outside the cube (masked rows gather voxel 0) and next to the grid border (out-of-grid neighbours = zero padding)."""
+    from dpdist_amd import lib as L, ops
+    lib = L.load()
+    B, N, H = 4, 64, 128
+    pcA, pcB = synth.boundary_cloud(B, N, seed=7)
+    pcA2, pcB2 = synth.s1_random_patches(B, N, 3)
+    pcA = np.concatenate([pcA[:2], pcA2[:2]]); pcB = np.concatenate([pcB[:2], pcB2[:2]])
+    a, b = _cu(pcA, dev), _cu(pcB, dev)
+    C, Q, G = 2 * B, 2 * B * N, m ** 3
+    KP = ops.padded_width(k)
+    # unfused reference path
+    pts0, q0 = ops.stack_clouds(a, b, None)
+    fv0 = ops.mfv3d_fwd(pts0, m, 0.125)
+    X, mask0, vox0 = ops.patch_rows_fwd(q0, fv0, m, k, KP)
+    # fused sources
+    fvx = torch.empty(C * G * 20 + Q * 4, device=dev)
+    fv, xyz = fvx[:C * G * 20].view(C, G, 20), fvx[C * G * 20:].view(Q, 4)
+    pts, mask, vox = torch.empty(C, N, 3, device=dev), torch.empty(Q, device=dev), torch.empty(Q, device=dev, dtype=torch.int32)
+    rowinfo = torch.empty(Q, 2, device=dev, dtype=torch.int32)
+    ktab = torch.empty(KP // 4, 2, device=dev, dtype=torch.int32)
+    L.check(lib.dpd_gather_table(m, k, KP, L.ptr(ktab), L.cur_stream()), "dpd_gather_table")
+    L.check(lib.dpd_front(L.ptr(a), L.ptr(b), None, B, N, m, k, L.ptr(pts), None, L.ptr(mask), L.ptr(vox), L.ptr(xyz), L.ptr(rowinfo),
+                          L.cur_stream()), "dpd_front")
+    fv.copy_(ops.mfv3d_fwd(pts, m, 0.125))
+    assert torch.equal(pts, pts0) and torch.equal(mask, mask0) and torch.equal(vox, vox0)
+    E = k ** 3 * 20
+    assert torch.equal(xyz[:, :3], X[:, E:E + 3]) and not xyz[:, 3].any()
+    g = torch.Generator().manual_seed(3)
+    W = [(torch.randn(KP, H, generator=g) * 0.3).to(dev), (torch.randn(H, H, generator=g) * 0.1).to(dev),
+         (torch.randn(H, H, generator=g) * 0.1).to(dev), (torch.randn(H, 3, generator=g) * 0.3).to(dev)]
+    bs = [torch.randn(H, generator=g).to(dev) * 0.1 for _ in range(3)] + [torch.randn(3, generator=g).to(dev)]
+    params = (W[0], bs[0], W[1], bs[1], W[2], bs[2], W[3], bs[3])
+    gs = L.Gather(fv.data_ptr(), xyz.data_ptr(), rowinfo.data_ptr(), ktab.data_ptr(), C, G)
+    h = [torch.empty(Q, H, device=dev) for _ in range(3)]
+    y, pred = torch.empty(Q, 3, device=dev), torch.empty(Q, 3, device=dev)
+    L.check(lib.dpd_decoder_fwd_gather(gs, L.ptr(mask), Q, KP, H, L.make_params(*params), L.ptr(h[0]), L.ptr(h[1]), L.ptr(h[2]), L.ptr(y),
+                                       L.ptr(pred), L.cur_stream()), "dpd_decoder_fwd_gather")
+    ref1 = ops.gemm_f32(X, W[0], bias=bs[0], epilogue=2, tile=32)
+    assert torch.equal(h[0], ref1)
+    h1r, h2r, h3r, yr, predr = ops.decoder_fwd(X, mask0, params, H)
+    assert torch.equal(pred, predr) and torch.equal(h[2], h3r)
+    # dW1 = X^T g1 over the first Qb rows
+    Qb = Q // 2
+    g1 = torch.randn(Qb, H, generator=g).to(dev)
+    dW = torch.empty(KP, H, device=dev)
+    for op_tile, split in ((33, 1), (30, 1), (31, 2)):     # wave tiles 32x32 / 64x64 / 64x32, with and without split-K slabs
+        ops.set_gemm_plan(8, op_tile, split)
+        ws = torch.empty(max(split, 1) * KP * H, device=dev)
+        dW = torch.empty(KP, H, device=dev)
+        L.check(lib.dpd_decoder_bwd_weights_gather(gs, L.ptr(g1), Qb, KP, H, L.ptr(dW), L.ptr(ws), ws.numel() * 4, L.cur_stream()),
+                "dpd_decoder_bwd_weights_gather")
+        refd = ops.gemm_f32(X[:Qb], g1, transA=True, tile=33, split_k=split)
+        assert torch.equal(dW, refd), (op_tile, split)
+    ops.set_gemm_plan(8, 30, 3)
+    assert not dW[E + 3:].any()                       # zero-pad columns of X -> zero rows of dW1
+
+
+def test_fused_trainer_matches_unfused(dev, monkeypatch):
+    """The default f32 trainer (fused gather, no X buffer) and the DPD_FUSED_GATHER=0 trainer produce the same weights."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 4
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DPD_FUSED_GATHER", fused)
+        P = DPDistParams(device=dev)
+        P.load_tf_state_dict(synth.make_weights("wide"))
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        assert tr.fused == (fused == "1") and (tr.X is None) == tr.fused
+        losses = [tr.step(pcA, pcB, lab).clone() for _ in range(3)]
+        outs.append((torch.stack(losses), P.flat.detach().clone()))
+    assert torch.equal(outs[0][0][0], outs[1][0][0])                       # first step: same bits
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-6
+    assert (outs[0][1] - outs[1][1]).abs().mean().item() <= 1e-6         # later steps: db1/db2 atomics order only
