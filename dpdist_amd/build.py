@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdpdist_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_x3.hip", "mfv3d.hip", "patch_rows.hip", "decoder.hip", "loss_adam.hip", "chamfer.hip", "host_util.hip", "dedupe.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_x3.hip", "mfv3d.hip", "patch_rows.hip", "decoder.hip", "loss_adam.hip", "chamfer.hip", "host_util.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,9 +24,7 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, ablations=False):
-    """ablations=True also compiles the timing-only kernel variants behind DPD_ABLATIONS (tools/gemm_bench.py,
-    tools/x3_bench.py ablation tile codes); they double the build time and are not part of the product."""
+def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -35,7 +33,7 @@ def build(force=False, verbose=True, ablations=False):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + (["-DDPD_ABLATIONS"] if ablations else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:
@@ -53,4 +51,4 @@ def build(force=False, verbose=True, ablations=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv or "--ablations" in sys.argv, ablations="--ablations" in sys.argv)
+    build(force="--force" in sys.argv)

@@ -25,7 +25,29 @@
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
 
+#include <atomic>
+
 namespace dpd {
+
+// Opt a kernel into more than 64 KiB of dynamic LDS, once per (kernel, device): `slot` is a per-call-site static array of
+// flags indexed by the CURRENT device, so a process that drives several GPUs configures each of them (the attribute is
+// per device), and concurrent first calls are a benign repeat of an idempotent setting.
+struct LdsOptIn {
+    std::atomic<bool> done[64];
+};
+inline int ensure_dyn_lds(LdsOptIn& slot, const void* kern, size_t lds) {
+    if (lds <= 64 * 1024) return 0;
+    if (lds > 160 * 1024) return DPD_E_UNSUPPORTED;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    dev = (dev < 0 || dev >= 64) ? 63 : dev;
+    if (slot.done[dev].load(std::memory_order_acquire)) return 0;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    slot.done[dev].store(true, std::memory_order_release);
+    return 0;
+}
 
 constexpr int kWave = 64;   // CDNA wavefront
 constexpr int kNumXCD = 8;  // MI355X: 8 XCDs, block b runs on XCD b % 8 (speed only, never correctness)

@@ -14,7 +14,7 @@ namespace dpd {
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
              size_t ws_bytes, hipStream_t s, float* colsum = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
-             float* C2 = nullptr, const int* M_dev = nullptr, const int* K_dev = nullptr);
+             float* C2 = nullptr);
 
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
@@ -263,19 +263,30 @@ __global__ __launch_bounds__(256) void out_bwd_fused_kernel(const float* __restr
 // Same contract as out_bwd_fused_kernel for H % 256 == 0, H <= 1024: a lane owns 4 consecutive columns in each
 // 256-column group (float4 loads/stores, both rows of a wave in flight together) and the four waves' partials are
 // combined with ONE barrier (each wave has its own LDS slab).  LDS: 4 * (4H + 4) floats.
+// L1: optional fused loss (training mode, utils/dpdist_util.py:962-980): with l1.labels the kernel derives
+// d loss_samples / d pred_AB = sign(pred_AB[:,0] - labels) * gscale / Qb itself (dpred is not read) and adds the three loss sums
+// (sum |pred_AB - labels|, sum pred_AB, sum pred_BA over its rows) to the block record [4H+4 .. 4H+6].
+struct L1Fuse {
+    const float* pred;     // [2*Qb, 3]
+    const float* labels;   // [Qb]
+    float gscale;
+};
+constexpr int kOBRec = 8;   // record = 4H + 8 floats: db3 [H] | dW4 [3H] | db4 [3] | pad | loss sums [3] | pad
+
 __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __restrict__ dpred, const float* __restrict__ mask,
                                                               const float* __restrict__ y, const float* __restrict__ h3,
                                                               const float* __restrict__ W4, float* __restrict__ dy,
                                                               float* __restrict__ g3, int Qb, int H, ZeroList zl,
-                                                              float* __restrict__ scratch) {
-    extern __shared__ float s_acc[];   // [4 waves][4H + 4]
+                                                              float* __restrict__ scratch, L1Fuse l1) {
+    extern __shared__ float s_acc[];   // [4 waves][4H + 8]
     if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
         for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = H / 256;            // column groups (<= 4)
-    const int P = 4 * H + 4;
+    const int P = 4 * H + kOBRec;
     constexpr int RW = kOBRows / 4;    // rows per wave
+    float lsum[3] = {0.f, 0.f, 0.f};   // loss sums of this wave's rows (identical in every lane)
     float w4[4][4][3], s3[4][4], a4[4][4][3];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
@@ -296,10 +307,21 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
     for (int rr = 0; rr < RW; ++rr) {
         const int row = min(row0 + rr, Qb - 1);
         const bool live = row0 + rr < Qb;
+        float dp[3];
+        if (l1.labels) {           // d mean|pred_AB[:,0] - labels| / d pred_AB (tf.abs gradient = sign), channels 1, 2 get none
+            const float pab = l1.pred[(size_t)row * 3], pba = l1.pred[((size_t)Qb + row) * 3];
+            const float df = pab - l1.labels[row];
+            dp[0] = ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f)) * (1.0f / (float)Qb) * l1.gscale;
+            dp[1] = 0.f; dp[2] = 0.f;
+            if (live) { lsum[0] += fabsf(df); lsum[1] += pab; lsum[2] += pba; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dp[c] = dpred[(size_t)row * 3 + c];
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float yv = y[(size_t)row * 3 + c];
-            d[rr][c] = (live && yv > 0.f && yv < 6.f) ? dpred[(size_t)row * 3 + c] * mask[row] / 3.0f : 0.f;   // relu6' = 1 on (0,6)
+            d[rr][c] = (live && yv > 0.f && yv < 6.f) ? dp[c] * mask[row] / 3.0f : 0.f;   // relu6' = 1 on (0,6)
             dsum[c] += d[rr][c];
         }
 #pragma unroll
@@ -342,22 +364,27 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
         }
     }
     if (lane < 3) mine[4 * H + lane] = (lane == 0) ? dsum[0] : ((lane == 1) ? dsum[1] : dsum[2]);
+    if (lane < 3) mine[4 * H + 4 + lane] = (lane == 0) ? lsum[0] : ((lane == 1) ? lsum[1] : lsum[2]);
+    if (lane == 3) { mine[4 * H + 3] = 0.f; mine[4 * H + 7] = 0.f; }
     __syncthreads();
     float* out = scratch + (size_t)blockIdx.x * P;
-    for (int i = threadIdx.x; i < 4 * H + 3; i += 256) out[i] = ((s_acc[i] + s_acc[P + i]) + s_acc[2 * P + i]) + s_acc[3 * P + i];
+    for (int i = threadIdx.x; i < 4 * H + 7; i += 256) out[i] = ((s_acc[i] + s_acc[P + i]) + s_acc[2 * P + i]) + s_acc[3 * P + i];
 }
 
 // out[i] = sum_b scratch[b][i] in a fixed order: 16 outputs x 16 block-slices per workgroup, LDS tree at the end
+// rec = floats per block record (4H + 4, or 4H + 8 when the record carries the three loss sums at [4H+4 .. 4H+6]); loss (may be
+// NULL) then receives loss_samples = sum|pred_AB - labels| / Qb and loss_pred = (sum pred_AB / Qb + sum pred_BA / Qb) / 2.
 __global__ __launch_bounds__(256) void small_grads_reduce(const float* __restrict__ scratch, int nblk, int H,
                                                            float* __restrict__ db3, float* __restrict__ dW4,
-                                                           float* __restrict__ db4) {
+                                                           float* __restrict__ db4, int rec, float* __restrict__ loss, int Qb) {
     __shared__ float red[16][17];
+    __shared__ float s_loss[3];
     const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + li;
-    const int n = 4 * H + 3;
+    const int n = (rec > 4 * H + 4 && loss) ? 4 * H + 7 : 4 * H + 3;
     float s = 0.f;
     if (i < n)
-        for (int b = sl; b < nblk; b += 16) s += scratch[(size_t)b * (4 * H + 4) + i];
+        for (int b = sl; b < nblk; b += 16) s += scratch[(size_t)b * rec + i];
     red[sl][li] = s;
     __syncthreads();
     if (sl == 0 && i < n) {
@@ -366,7 +393,16 @@ __global__ __launch_bounds__(256) void small_grads_reduce(const float* __restric
         for (int k = 0; k < 16; ++k) t += red[k][li];
         if (i < H) { if (db3) db3[i] = t; }
         else if (i < 4 * H) { if (dW4) dW4[i - H] = t; }
-        else if (db4) db4[i - 4 * H] = t;
+        else if (i < 4 * H + 3) { if (db4) db4[i - 4 * H] = t; }
+        else if (i >= 4 * H + 4) s_loss[i - 4 * H - 4] = t;       // the three loss sums land in ONE workgroup (16 outputs each)
+    }
+    if (n > 4 * H + 3 && blockIdx.x == (4 * H + 4) / 16) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float inv = 1.0f / (float)Qb;
+            loss[0] = s_loss[0] * inv;
+            loss[1] = (s_loss[1] * inv + s_loss[2] * inv) / 2.0f;
+        }
     }
 }
 
@@ -622,7 +658,7 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
                                const dpd_planes* pl, void* stream) {
     using namespace dpd;
     pl = dpd::usable_planes(pl, dtype, Q, pl ? pl->Qb : 0, KP, H);
-    const bool skip1 = !X && !(pl && pl->X_rc);   // layer 1 already evaluated into h1 (dpd_layer1_fwd_unique)
+    if (!X && !(pl && pl->X_rc)) return DPD_E_NULL;
     if (!mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
     if (pl && (pl->Q != Q || pl->Qb > Q)) return DPD_E_DIM;
     if (int rc = dpd::check_planes(pl, dtype)) return rc;
@@ -635,7 +671,6 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     if (pl) {   // operands from / results to the persistent planes (no conversion passes)
         X3Out o1 = make_out(pl, pl->h1_rc, Q, pl->h1_r8, pl->Qb, H), o2 = make_out(pl, pl->h2_rc, Q, pl->h2_r8, pl->Qb, H);
         const bool w1 = o1.rc || o1.r8, w2 = o2.rc || o2.r8;
-        if (skip1) return DPD_E_UNSUPPORTED;   // the unique-row layer 1 exists for DPD_F32 only
         if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s, nullptr,
                              pl->X_rc, pl->W1_r8, w1 ? &o1 : nullptr)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s, nullptr,
@@ -644,8 +679,7 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
                              pl->h2_rc, pl->W3_r8, nullptr)) return rc;
     } else {
         if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
-        if (!skip1)
-            if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
+        if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
     }
@@ -709,11 +743,13 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
                                     const dpd_small_grads* sg, void* ws, size_t ws_bytes, const dpd_planes* pl, int phases,
                                     void* stream) {
     using namespace dpd;
-    if (!dpred || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
+    const bool l1 = sg && sg->l1_labels;        // fused training loss: dpred is derived inside the output-layer kernel
+    if ((!dpred && !l1) || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
+    if (l1 && (!sg->l1_pred || !sg->l1_loss)) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
     if ((H & 63) || (KP & 3) || dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
-    if (phases <= 0 || phases > 7) return DPD_E_DIM;
+    if (phases <= 0 || phases > 31) return DPD_E_DIM;
     hipStream_t s = (hipStream_t)stream;
     const Scratch scr = scratch_of(ws, ws_bytes, KP, H);
     pl = usable_planes(pl, dtype, pl ? pl->Q : 0, Qb, KP, H);
@@ -726,29 +762,40 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     float* dW4 = sg ? sg->dW4 : nullptr;
     float* db4 = sg ? sg->db4 : nullptr;
     const int nblk = (Qb + kOBRows - 1) / kOBRows;
-    const bool fused = (db3 || dW4 || db4) && H <= 64 * kOBMaxJ && (size_t)nblk * (4 * H + 4) <= (size_t)Qb * H;
+    const bool fused4 = H % 256 == 0 && H <= 1024;
+    const int rec = fused4 ? 4 * H + kOBRec : 4 * H + 4;          // floats per block record
+    const bool fused = (db3 || dW4 || db4 || l1) && H <= 64 * kOBMaxJ && (size_t)nblk * rec <= (size_t)Qb * H;
+    if (l1 && !(fused && fused4)) return DPD_E_UNSUPPORTED;       // the caller then uses dpd_l1_loss + dpred
+    const L1Fuse lf{l1 ? sg->l1_pred : nullptr, l1 ? sg->l1_labels : nullptr, l1 ? sg->l1_gscale : 1.0f};
+    float* lossp = l1 ? sg->l1_loss : nullptr;
+    const int nred = (4 * H + 7 + 15) / 16;
+    // block partials of db3 / dW4 / db4: by default in g2 (free until the first dH GEMM); a caller that defers their reduction
+    // (phases 16 / 8: it then runs beside the dH GEMMs on another stream) must provide sg->partials
+    float* part = (sg && sg->partials) ? sg->partials : g2;
+    if ((phases & 24) && !(sg && sg->partials)) return DPD_E_NULL;
+    if ((phases & 8) && fused) {   // deferred second stage of the small gradients (a side stream / graph branch runs it)
+        DPD_LAUNCH(small_grads_reduce, dim3(nred), dim3(256), 0, s, (const float*)part, nblk, H, db3, dW4, db4, rec, lossp, Qb);
+        DPD_CHECK_LAUNCH();
+    }
     if (!(phases & 1)) {
         // output layer already done by an earlier call
     } else if (fused) {
         // one pass over h3: dy, g3 and block partials of db3 / dW4 / db4 (g2 is free until the first dH GEMM: scratch)
         ZeroList zl{{db1, db2, nullptr, nullptr, nullptr}, {H, H, 0, 0, 0}};
-        if (H % 256 == 0 && H <= 1024) {
-            const size_t lds = (size_t)4 * (4 * H + 4) * sizeof(float);
-            if (lds > 64 * 1024) {
-                static bool done = false;
-                if (!done) {
-                    DPD_HIP(hipFuncSetAttribute((const void*)out_bwd_fused4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    done = true;
-                }
-            }
-            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, g2);
+        if (fused4) {
+            const size_t lds = (size_t)4 * rec * sizeof(float);
+            static LdsOptIn lds_opt;
+            if (int rc = ensure_dyn_lds(lds_opt, (const void*)out_bwd_fused4_kernel, lds)) return rc;
+            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf);
         } else {
             DPD_LAUNCH(out_bwd_fused_kernel, dim3(nblk), dim3(256), (size_t)(4 * H + 4) * sizeof(float), s, dpred, mask, y, h3,
-                       p->W4, dy, g3, Qb, H, zl, g2);
+                       p->W4, dy, g3, Qb, H, zl, part);
         }
         DPD_CHECK_LAUNCH();
-        DPD_LAUNCH(small_grads_reduce, dim3((4 * H + 3 + 15) / 16), dim3(256), 0, s, (const float*)g2, nblk, H, db3, dW4, db4);
-        DPD_CHECK_LAUNCH();
+        if (!(phases & 16)) {   // 16: the block partials stay in the scratch (= g2, which must not be overwritten before phase 8 ran)
+            DPD_LAUNCH(small_grads_reduce, dim3(nred), dim3(256), 0, s, (const float*)part, nblk, H, db3, dW4, db4, rec, lossp, Qb);
+            DPD_CHECK_LAUNCH();
+        }
     } else {
         ZeroList zl{{db1, db2, db3, dW4, db4}, {H, H, H, H * 3, 3}};
         DPD_LAUNCH(out_bwd_kernel, dim3((Qb + 3) / 4), dim3(256), 0, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl);
@@ -876,7 +923,7 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                        (hipStream_t)stream, nullptr, have ? pl->h2_r8 : nullptr, have ? pl->g3_r8 : nullptr, nullptr);
     }
     int tile = g_plan_tile[OP_BWD_DW23];
-    if (!((tile >= 4 && tile <= 20) || (tile >= 30 && tile <= 39))) tile = 8;
+    if (!((tile >= 4 && tile <= 14) || (tile >= 30 && tile <= 39))) tile = 8;
     return gemm_f32(1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, 1, tile, nullptr, 0,
                     (hipStream_t)stream, nullptr, actB, gB, dWB);
 }

@@ -15,6 +15,8 @@
 //   * optional split-K into fp32 slabs + a fused reduce/epilogue kernel (deterministic, no atomics).
 //
 // Roofline: MFMA-bound.  Algorithmic flops = 2*M*N*K; bytes/flop of a 128x128 tile = 1/32 -> 8 B/clk/CU from L2.
+#include <mutex>
+
 #include "gemm_shared.h"
 #include "gemm_rs.h"
 
@@ -28,18 +30,6 @@ struct TileStage {
     static constexpr int NV = (BMN * BK / 4) / 256;
     static constexpr int LD = KCONTIG ? BMN + 1 : BMN + 4;
     float4 r[NV];
-
-    // interior tiles: no bounds checks (wave-uniform decision made by the caller)
-    __device__ __forceinline__ void load_fast(const float* __restrict__ p, int ld, int mn0, int k0, int tid) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int idx = tid + v * 256;
-            const float* src;
-            if (KCONTIG) src = p + (size_t)(mn0 + idx / (BK / 4)) * ld + k0 + (idx % (BK / 4)) * 4;
-            else src = p + (size_t)(k0 + idx / (BMN / 4)) * ld + mn0 + (idx % (BMN / 4)) * 4;
-            r[v] = *reinterpret_cast<const float4*>(src);
-        }
-    }
 
     __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int mn0, int k0, int MN, int Kend,
                                          int tid) {
@@ -81,9 +71,7 @@ struct TileStage {
     }
 };
 
-// ABL: ablation switches for tools/gemm_bench.py (results are WRONG when != 0): bit0 = no global loads after the
-// first K-tile, bit1 = no LDS refill + no barrier in the loop.
-template <int BM, int BN, int BK, bool AK, bool BKC, int ABL = 0>
+template <int BM, int BN, int BK, bool AK, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;   // 2x2 wave grid
     constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
@@ -119,7 +107,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
     StA sa;
     StB sb;
     sa.load(g.A, g.lda, m0, kbeg, g.M, kend, tid);
@@ -130,15 +117,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     for (int it = 0; it < nt; ++it) {
         const int cur = it & 1;
-        if (it + 1 < nt && !(ABL & 1)) {  // prefetch the next K-tile into registers while this one is multiplied
+        if (it + 1 < nt) {  // prefetch the next K-tile into registers while this one is multiplied
             const int kn = kbeg + (it + 1) * BK;
-            if ((ABL & 8) && interior && kn + BK <= kend) {
-                sa.load_fast(g.A, g.lda, m0, kn, tid);
-                sb.load_fast(g.B, g.ldb, n0, kn, tid);
-            } else {
-                sa.load(g.A, g.lda, m0, kn, g.M, kend, tid);
-                sb.load(g.B, g.ldb, n0, kn, g.N, kend, tid);
-            }
+            sa.load(g.A, g.lda, m0, kn, g.M, kend, tid);
+            sb.load(g.B, g.ldb, n0, kn, g.N, kend, tid);
         }
         const float* as = As + cur * A_BUF + half * LDA + wm0 + l31;
         const float* bs = Bs + cur * B_BUF + half * LDB + wn0 + l31;
@@ -160,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[n][j] = bs[(kk + 2) * LDB + j * 32];
             }
-            if (kk == ((ABL & 4) ? BK - 4 : BK / 2) && it + 1 < nt && !(ABL & 2)) {
+            if (kk == BK / 2 && it + 1 < nt) {
                 sa.store(As + (cur ^ 1) * A_BUF, tid);
                 sb.store(Bs + (cur ^ 1) * B_BUF, tid);
             }
@@ -174,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(ABL & 2)) __syncthreads();
+        __syncthreads();
     }
 
 #pragma unroll
@@ -248,11 +230,9 @@ __device__ __forceinline__ void load_frag(const float* img, int mn0w, int l31, i
     }
 }
 
-// ABL (timing-only ablations, wrong results): bit0 no in-loop DMA, bit1 no mid-tile wait/barrier,
-// bit2 DMA replaced by plain global loads into registers (same L2 traffic, no LDS write)
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, int TM = 1, int TN = 1>
+template <int WR, int WC, int NS, bool AK, bool BKC, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
-    constexpr bool PRIO = (WR * WC >= 16) && !(ABL & 64);
+    constexpr bool PRIO = WR * WC >= 16;
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, BK = 32, NW = WR * WC;   // wave tile (32*TM) x (32*TN)
     static_assert(NS >= 3 && NS <= 5, "ring depth");
     constexpr int A_IMG = BM * BK, B_IMG = BN * BK, STAGE = A_IMG + B_IMG;   // floats
@@ -267,22 +247,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm0 = (wave / WC) * 32 * TM, wn0 = (wave % WC) * 32 * TN;
 
-    // data-dependent row count (row de-duplication): the grid is sized for g.M, the tile space -- and with it the XCD remap,
-    // so that the live tiles spread over all eight XCDs -- for the actual count; surplus workgroups exit
-    const int Mlim = g.M_dev ? min(g.M, *g.M_dev) : g.M;
-    const int tilesM = (Mlim + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int per_z = tilesM * tilesN;
     const int ngrp = g.A2 ? 2 : 1;
-    if ((int)blockIdx.x >= per_z * g.split_k * ngrp) return;   // whole workgroup: uniform, before any barrier
     const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
     const int grp = sid / (per_z * g.split_k);            // grouped launch: second problem of identical shape
     const int sid1 = sid % (per_z * g.split_k);
     const int z = sid1 / per_z, t = sid1 % per_z;
     const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
-    const int Klim = g.K_dev ? min(g.K, *g.K_dev) : g.K;  // data-dependent contraction length (multiple of 32)
-    const int kchunk = g.K_dev ? (((Klim + g.split_k - 1) / g.split_k + 31) / 32 * 32) : g.k_chunk;
-    const int kbeg = z * kchunk;
-    const int kend = min(Klim, kbeg + kchunk);
+    const int kbeg = z * g.k_chunk;
+    const int kend = min(g.K, kbeg + g.k_chunk);
     const int nt = max(0, (kend - kbeg) / BK);
     const float* gA = grp ? g.A2 : g.A;
     const float* gB = grp ? g.B2 : g.B;
@@ -301,7 +275,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         const float* base = isA ? gA : gB;
         const int ld = isA ? g.lda : g.ldb;
         const int mn0 = isA ? m0 : n0;
-        const int MN = isA ? Mlim : g.N;   // (M_dev is only accepted for row-major A, so Mlim == g.M in the TN form)
+        const int MN = isA ? g.M : g.N;
         const int BMN = isA ? BM : BN;
         dst[j] = lds_base + (unsigned)((isA ? 0 : A_IMG) + c * 256) * 4u;
         if (kc) {
@@ -314,16 +288,10 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
             step[j] = (size_t)32 * ld;
         }
     }
-    float4 sink = make_float4(0.f, 0.f, 0.f, 0.f);
     auto issue = [&](int stage) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            if (ABL & 4) {
-                const float4 v = *reinterpret_cast<const float4*>(src[j]);
-                sink.x += v.x; sink.y += v.y; sink.z += v.z; sink.w += v.w;
-            } else {
-                dma_piece(src[j], dst[j] + (unsigned)(stage * STAGE) * 4u);
-            }
+            dma_piece(src[j], dst[j] + (unsigned)(stage * STAGE) * 4u);
             src[j] += step[j];
         }
     };
@@ -335,8 +303,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    long long dbg_wait = 0, dbg_bar = 0;
-    const long long dbg_t0 = (ABL & 32) ? __builtin_readcyclecounter() : 0;
 
     // prologue: K-tiles 0 .. NS-2 in flight; wait for tile 0
 #pragma unroll
@@ -351,8 +317,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     }
     __builtin_amdgcn_s_barrier();
 
-    constexpr bool DEEP = (ABL & 512) == 0;   // 4-deep fragment ring, operands requested TWO k-blocks ahead (ABL 512: one ahead)
-    float fa[DEEP ? 4 : 2][TM][4], fb[DEEP ? 4 : 2][TN][4];
+    // 4-deep fragment ring: operands are requested TWO k-blocks ahead of their MFMAs
+    float fa[4][TM][4], fb[4][TN][4];
     auto frags = [&](const float* stA, int kb, int buf) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) load_frag<AK, BM>(stA, wm0 + 32 * i, l31, half, kb, fa[buf][i]);
@@ -360,54 +326,28 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) load_frag<BKC, BN>(stA + A_IMG, wn0 + 32 * j, l31, half, kb, fb[buf][j]);
     };
     frags(smem, 0, 0);
-    if (DEEP) frags(smem, 1, 1);
+    frags(smem, 1, 1);
 
     for (int it = 0; it < nt; ++it) {
         const float* sA = smem + (it % NS) * STAGE;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const int c = DEEP ? kb : (kb & 1), n = DEEP ? ((kb + 2) & 3) : (c ^ 1);
-            if (DEEP) {
-                // k-blocks 0,1 request k-blocks 2,3 of this tile; k-blocks 2,3 request 0,1 of the next tile (after
-                // this tile's barrier, which certifies that tile)
-                if (kb < 2) frags(sA, kb + 2, n);
-            } else if (ABL & 256) {           // timing-only ablation: no LDS fragment reads in the loop (stale operands)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[n][i][s2] = fa[c][i][s2];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[n][j][s2] = fb[c][j][s2];
-                }
-            } else if (kb < 3) {
-                frags(sA, kb + 1, n);
-            } else if (it + 1 < nt) {   // first fragments of the next K-tile (certified landed at this tile's barrier)
-                frags(smem + ((it + 1) % NS) * STAGE, 0, n);
-            }
+            const int c = kb, n = (kb + 2) & 3;
+            // k-blocks 0,1 request k-blocks 2,3 of this tile; k-blocks 2,3 request 0,1 of the next tile (after this tile's
+            // barrier, which certifies that tile)
+            if (kb < 2) frags(sA, kb + 2, n);
             if (kb == 2) {
-                // mid-tile sync: my pieces of K-tile it+1 have landed once only tile it+2's may be outstanding
-                if (!(ABL & 2)) {
-                    long long t0 = 0, t1 = 0, t2 = 0;
-                    if (ABL & 32) t0 = __builtin_readcyclecounter();
-                    if (!(ABL & 8)) {   // tiles it+2 .. it+NS-2 may stay in flight
-                        const int later = min(NS - 3, nt - 2 - it);
-                        if (later >= 2) wait_vmcnt<2 * PPW>();
-                        else if (later == 1) wait_vmcnt<PPW>();
-                        else wait_vmcnt<0>();
-                    }
-                    if (ABL & 32) t1 = __builtin_readcyclecounter();
-                    __builtin_amdgcn_s_barrier();
-                    if (ABL & 32) {
-                        t2 = __builtin_readcyclecounter();
-                        dbg_wait += t1 - t0;
-                        dbg_bar += t2 - t1;
-                    }
-                }
+                // mid-tile sync: my pieces of K-tile it+1 have landed once only tiles it+2 .. it+NS-2 may be outstanding
+                const int later = min(NS - 3, nt - 2 - it);
+                if (later >= 2) wait_vmcnt<2 * PPW>();
+                else if (later == 1) wait_vmcnt<PPW>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                // refill of the stage freed by that barrier with K-tile it+NS-1 (issuing it later / staggered over the
+                // following k-blocks was measured 7 % slower: the data then has less time to land)
+                if (it + NS - 1 < nt) issue((it + NS - 1) % NS);
             }
-            // refill of the stage freed by that barrier with K-tile it+NS-1 (issuing it later / staggered over the
-            // following k-blocks was measured 7 % slower: the data then has less time to land)
-            if (kb == 2 && !(ABL & 1) && it + NS - 1 < nt) issue((it + NS - 1) % NS);
-            if (DEEP && kb >= 2 && it + 1 < nt) frags(smem + ((it + 1) % NS) * STAGE, kb - 2, n);
+            if (kb >= 2 && it + 1 < nt) frags(smem + ((it + 1) % NS) * STAGE, kb - 2, n);
             // MFMA issue is arbitrated by priority, then age.  With equal priorities the oldest wave of a SIMD runs its
             // whole barrier interval first and the youngest runs last and ALONE, with nobody to cover its LDS/barrier
             // stalls.  Priority falls as a wave advances through the interval (k-blocks 2,3,0,1 -> 3,2,1,0), so laggards
@@ -420,52 +360,31 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
                 else __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (ABL & 16) {   // data-path-only ablation: consume the fragments with 4 VALU ops instead of 4 MFMAs
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc[0][0][s2] += fa[c][0][s2] * fb[c][0][s2];
-            } else {
+            for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][s2], fb[c][j][s2], acc[i][j], 0, 0, 0);
-            }
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][s2], fb[c][j][s2], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (ABL & 4) acc[0][0][0] += (sink.x + sink.y) + (sink.z + sink.w);
-    if ((ABL & 32) && lane == 0 && g.colsum) {   // debug: per-wave cycles [total, vmcnt wait, barrier wait]
-        float* d = g.colsum + ((size_t)blockIdx.x * NW + wave) * 4;
-        d[0] = (float)(__builtin_readcyclecounter() - dbg_t0);
-        d[1] = (float)dbg_wait;
-        d[2] = (float)dbg_bar;
-        d[3] = (float)nt;
-        return;
-    }
     GemmArgs gs = g;
     if (grp) gs.C = g.C2;
-    gs.M = Mlim;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) store_tile(gs, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
 }
 
-template <int WR, int WC, int NS, bool AK, bool BKC, int ABL = 0, int TM = 1, int TN = 1>
+template <int WR, int WC, int NS, bool AK, bool BKC, int TM = 1, int TN = 1>
 static int launch_dma(const GemmArgs& g, hipStream_t s) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
     constexpr size_t lds = NS * (size_t)(BM + BN) * 32 * sizeof(float);
-    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, ABL, TM, TN>;
-    if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            done = true;
-        }
-    }
+    auto kern = gemm_dma_kernel<WR, WC, NS, AK, BKC, TM, TN>;
+    static LdsOptIn lds_opt;   // one per template instantiation
+    if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
     const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.split_k * (g.A2 ? 2 : 1);
     DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
     return (int)hipGetLastError();
@@ -482,10 +401,13 @@ struct GemmProf {
     int created = 0;   // events [0, created) exist
 };
 static GemmProf g_prof;
+static std::mutex g_prof_mu;   // the profiler is process-wide (one GEMM stream at a time is the supported use); the lock keeps it memory-safe
 
 // Events are created on demand and destroyed by dpd_prof_enable(0): thousands of live timing events slow every
 // later kernel launch of the process down (host side; measured as sporadic 3x slower steps after a profiled pass).
 bool prof_begin(hipStream_t s) {
+    if (!g_prof.on) return false;                       // the common case takes no lock
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!(g_prof.on && g_prof.n < GemmProf::kMax)) return false;
     for (int i = 2 * g_prof.n; i < 2 * g_prof.n + 2; ++i)
         if (i >= g_prof.created) {
@@ -497,25 +419,21 @@ bool prof_begin(hipStream_t s) {
 }
 void prof_end(bool on, hipStream_t s, double flops) {
     if (!on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof.on) return;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
     g_prof.flops[g_prof.n] = flops;
     ++g_prof.n;
 }
 
-template <int BM, int BN, int BK, bool AK, bool BKC, int ABL = 0>
+template <int BM, int BN, int BK, bool AK, bool BKC>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     using StA = TileStage<BM, BK, AK>;
     using StB = TileStage<BN, BK, BKC>;
     constexpr size_t lds = (size_t)(2 * BK * StA::LD + 2 * BK * StB::LD) * sizeof(float);
-    auto kern = gemm_f32_kernel<BM, BN, BK, AK, BKC, ABL>;
-    if (lds > 64 * 1024) {
-        static bool done = false;  // benign race: idempotent attribute
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            done = true;
-        }
-    }
+    auto kern = gemm_f32_kernel<BM, BN, BK, AK, BKC>;
+    static LdsOptIn lds_opt;   // one per template instantiation
+    if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int nblk = tilesM * tilesN * g.split_k;
     DPD_LAUNCH(kern, dim3(nblk), dim3(256), lds, s, g);
@@ -533,44 +451,13 @@ static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
         case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
         case 10: return launch_dma<4, 4, 5, AK, BKC>(g, s);  // LDS-DMA ring, 128x128, 1024 thr, 160 KiB (all of a CU's LDS)
-        case 11: return launch_dma<2, 4, 3, AK, BKC, 0, 2, 1>(g, s);   // 128x128, 8 waves of 64x32 (2 accumulators), 96 KiB
-        case 12: return launch_dma<2, 2, 3, AK, BKC, 0, 2, 2>(g, s);   // 128x128, 4 waves of 64x64 (4 accumulators), 96 KiB
-        case 13: return launch_dma<2, 2, 3, AK, BKC, 0, 2, 1>(g, s);   // 128x64,  4 waves of 64x32, 72 KiB (2 blocks/CU)
-        case 14: return launch_dma<4, 2, 3, AK, BKC, 0, 1, 2>(g, s);   // 128x128, 8 waves of 32x64
-        case 19: return launch_dma<4, 4, 3, AK, BKC, 64>(g, s);    // 9 / 10 / 5 without the progress-based s_setprio
-        case 20: return launch_dma<4, 4, 5, AK, BKC, 64>(g, s);
-        case 15: return launch_dma<4, 4, 4, AK, BKC, 64>(g, s);
-#ifdef DPD_ABLATIONS   // timing-only / diagnostic variants for tools/gemm_bench.py and tools/gemm_dbg.py (python -m dpdist_amd.build --ablations)
-        case 5129: return launch_dma<4, 4, 3, AK, BKC, 512>(g, s);   // fragments only ONE k-block ahead (A/B reference)
-        case 5125: return launch_dma<4, 4, 4, AK, BKC, 512>(g, s);
-        case 5128: return launch_dma<2, 2, 3, AK, BKC, 512>(g, s);
-        case 2569: return launch_dma<4, 4, 3, AK, BKC, 256>(g, s);   // no LDS reads in the loop
-        case 2579: return launch_dma<4, 4, 3, AK, BKC, 257>(g, s);   // + no in-loop DMA
-        case 2589: return launch_dma<4, 4, 3, AK, BKC, 258>(g, s);   // no LDS reads, no barrier
-        case 325: return launch_dma<4, 4, 4, AK, BKC, 32>(g, s);   // s_memtime instrumentation (debug buffer in colsum)
-        case 165: return launch_dma<4, 4, 4, AK, BKC, 16>(g, s);   // data path only (no MFMA): L2 -> LDS -> VGPR rate
-        case 164: return launch_dma<2, 2, 4, AK, BKC, 16>(g, s);
-        case 115: return launch_dma<4, 4, 3, AK, BKC, 1>(g, s);   // timing-only ablations of the 128x128 kernel
-        case 25: return launch_dma<4, 4, 3, AK, BKC, 2>(g, s);
-        case 35: return launch_dma<4, 4, 3, AK, BKC, 3>(g, s);
-        case 45: return launch_dma<4, 4, 3, AK, BKC, 4>(g, s);
-        case 85: return launch_dma<4, 4, 3, AK, BKC, 8>(g, s);
-        case 95: return launch_dma<4, 4, 3, AK, BKC, 9>(g, s);
-#endif
+        case 11: return launch_dma<2, 4, 3, AK, BKC, 2, 1>(g, s);   // 128x128, 8 waves of 64x32 (2 accumulators), 96 KiB
+        case 12: return launch_dma<2, 2, 3, AK, BKC, 2, 2>(g, s);   // 128x128, 4 waves of 64x64 (4 accumulators), 96 KiB
+        case 13: return launch_dma<2, 2, 3, AK, BKC, 2, 1>(g, s);   // 128x64,  4 waves of 64x32, 72 KiB (2 blocks/CU)
+        case 14: return launch_dma<4, 2, 3, AK, BKC, 1, 2>(g, s);   // 128x128, 8 waves of 32x64
         case 1: return launch_cfg<128, 128, 32, AK, BKC>(g, s);
         case 2: return launch_cfg<128, 64, 32, AK, BKC>(g, s);
         case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);
-#ifdef DPD_ABLATIONS
-        case 43: return launch_cfg<64, 64, 32, AK, BKC, 4>(g, s);     // experiments (correct results)
-        case 83: return launch_cfg<64, 64, 32, AK, BKC, 8>(g, s);
-        case 123: return launch_cfg<64, 64, 32, AK, BKC, 12>(g, s);
-        case 111: return launch_cfg<128, 128, 32, AK, BKC, 1>(g, s);   // ablations (wrong results, timing only)
-        case 21: return launch_cfg<128, 128, 32, AK, BKC, 2>(g, s);
-        case 31: return launch_cfg<128, 128, 32, AK, BKC, 3>(g, s);
-        case 113: return launch_cfg<64, 64, 32, AK, BKC, 1>(g, s);
-        case 23: return launch_cfg<64, 64, 32, AK, BKC, 2>(g, s);
-        case 33: return launch_cfg<64, 64, 32, AK, BKC, 3>(g, s);
-#endif
         default: return DPD_E_UNSUPPORTED;
     }
 }
@@ -584,8 +471,7 @@ static double tile_eff(int M, int N, int BM, int BN, int split) {
 
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
-             size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2, const int* M_dev,
-             const int* K_dev) {
+             size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2) {
     if (!A || !B || !C) return DPD_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || split_k < 1) return DPD_E_DIM;
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3)) return DPD_E_UNSUPPORTED;
@@ -603,16 +489,13 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         (void)tile_eff;
         tile = 3;
     }
-    const bool whole_tiles = (tile >= 4 && tile <= 20) || (tile >= 30 && tile <= 39);   // kernels that need whole 32-deep K-tiles
-    if ((whole_tiles || tile > 2000) && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
-        tile = 3;   // DMA kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel   // LDS-DMA kernel: whole K-tiles only
+    const bool whole_tiles = (tile >= 4 && tile <= 14) || (tile >= 30 && tile <= 39);   // kernels that need whole 32-deep K-tiles
+    if (whole_tiles && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
+        tile = 3;   // these kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.colsum = (split_k > 1) ? nullptr : colsum;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
-    g.M_dev = M_dev; g.K_dev = K_dev;
-    if ((M_dev || K_dev) && !(tile >= 4 && tile <= 20)) return DPD_E_UNSUPPORTED;   // device-side extents: DMA kernels only
-    if (M_dev && transA) return DPD_E_UNSUPPORTED;
     if (A2 && (!B2 || !C2 || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
     if (A2 && !whole_tiles) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA / register-streamed kernels only
     if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
@@ -687,6 +570,7 @@ int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_byt
 // ---- profiler C ABI -------------------------------------------------------------------------------------
 extern "C" int dpd_prof_enable(int on) {
     using dpd::g_prof;
+    std::lock_guard<std::mutex> lk(dpd::g_prof_mu);
     g_prof.on = on != 0;
     if (on) {
         g_prof.n = 0;
@@ -702,6 +586,7 @@ extern "C" int dpd_prof_enable(int on) {
 // fills total milliseconds / total (padded-shape) flops 2*M*N*K of those launches.
 extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
     using dpd::g_prof;
+    std::lock_guard<std::mutex> lk(dpd::g_prof_mu);
     double ms = 0.0, fl = 0.0;
     for (int i = 0; i < g_prof.n; ++i) {
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return -1;
@@ -715,15 +600,9 @@ extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
     return g_prof.n;
 }
 
-extern "C" int dpd_gemm_f32_dbg(int M, int N, int K, const float* A, const float* B, float* Cout, float* dbg, int tile,
-                                void* stream) {
-    return dpd::gemm_f32(0, 0, M, N, K, A, K, B, N, Cout, N, nullptr, nullptr, 0, 1, tile, nullptr, 0, (hipStream_t)stream, dbg,
-                         nullptr, nullptr, nullptr, nullptr, nullptr);
-}
-
 extern "C" int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* Cout, int ldc, const float* bias, const float* gate, int epilogue,
                             int split_k, int tile, void* ws, size_t ws_bytes, void* stream) {
     return dpd::gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, Cout, ldc, bias, gate, epilogue, split_k, tile, ws,
-                         ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                         ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
 }

@@ -18,10 +18,6 @@ struct GemmArgs {
     const float* A2;  // optional second problem of identical shape (grouped launch): blocks [per_z, 2*per_z)
     const float* B2;
     float* C2;
-    // optional data-dependent extents read on the DEVICE (row de-duplication, decoder.hip): the grid is sized for M / K,
-    // tiles whose rows start at or beyond *M_dev exit, the contraction stops at *K_dev (a multiple of 32, <= K)
-    const int* M_dev;
-    const int* K_dev;
     // optional fused window gather (gemm_rs.h, ASRC != 0): the A operand is not read from memory at A/lda but gathered from
     // the Fisher vectors through the per-row / per-column tables of patch_rows.hip (A = fv base, ONE buffer with xyz behind it)
     const uint2* ktab;      // [K/4 or M/4] per float4 window column: {byte offset of the neighbour's channels, required-validity bits}

@@ -55,7 +55,7 @@ __device__ __forceinline__ int chunk_of(int o, int kg) {
     return KC ? o * CPR + (kg ^ ((o / (16 / CPR)) & (CPR - 1))) : kg * BO + o;
 }
 
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
     constexpr int CPR = BK / 8, KB = BK / 16;               // chunks per row, k16 steps per K-tile
@@ -93,7 +93,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     const uint16_t* src[PPW];
     long step[PPW];
     unsigned dst[PPW];
-    bool pieceA[PPW];
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem_x3;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
@@ -107,7 +106,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         const int o0 = isA ? m0 : n0;
         const int O = isA ? M : N;
         const int BO = isA ? BM : BN;
-        pieceA[j] = isA;
         dst[j] = lds_base + (unsigned)(plane * PL + (isA ? 0 : A_IMG) + c * 64) * 16u;
         if (kc) {
             const int row = c * (64 / CPR) + lane / CPR, slot = lane % CPR;
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     auto issue = [&](int stage) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            if (!((ABL & 32) && !pieceA[j]) && !((ABL & 64) && pieceA[j])) dma_piece(src[j], dst[j] + (unsigned)(stage * STAGE) * 16u);
+            dma_piece(src[j], dst[j] + (unsigned)(stage * STAGE) * 16u);
             src[j] += step[j];
         }
     };
@@ -176,21 +174,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         constexpr int cur = decltype(curc)::value;
         if (kb == KB - 1) {
             // my pieces of K-tile it+1 have landed once only tiles it+2 .. it+NS-2 may be outstanding
-            if (!(ABL & 2)) {
-                wait_later(min(NS - 3, nt - 2 - it));
-                __builtin_amdgcn_s_barrier();
-            }
+            wait_later(min(NS - 3, nt - 2 - it));
+            __builtin_amdgcn_s_barrier();
             // everybody is past K-tile it-1: refill its stage with K-tile it+NS-1
-            if (!(ABL & 1) && it + NS - 1 < nt) issue((it + NS - 1) % NS);
+            if (it + NS - 1 < nt) issue((it + NS - 1) % NS);
             if (it + 1 < nt) frags((it + 1) % NS, 0, cur ^ 1);
         } else {
             frags(it % NS, kb + 1, cur ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL & 16) {   // timing-only ablation: data path without the MFMA work
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][NP - 1][TM - 1], fb[cur][NP - 1][TN - 1], acc[0][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][0], fb[cur][0][0], acc[0][0], 0, 0, 0);
-        } else if (NP == 3) {
+        if (NP == 3) {
             constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int q = 0; q < NT; ++q)
@@ -291,21 +284,15 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     }
 }
 
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK>
 static int launch_x3(const X3Args& g, hipStream_t s) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
     constexpr size_t ring = (size_t)NS * NP * (BM + BN) * BK * 2, stage = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = ring > stage ? ring : stage;   // the plane epilogue stages the fp32 tile in the ring's LDS
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK, ABL>;
-    if (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            done = true;
-        }
-    }
+    auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK>;
+    static LdsOptIn lds_opt;   // one per template instantiation
+    if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
     const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * g.e.split_k * (g.A2 ? 2 : 1);
     DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
     return (int)hipGetLastError();
@@ -328,21 +315,6 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 10: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x128, 4 waves of 64x64
         case 11: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x256, 8 waves of 64x64
         case 12: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 1, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 64x128, 4 waves of 32x64
-#ifdef DPD_ABLATIONS   // timing-only ablations for tools/x3_bench.py (wrong results): python -m dpdist_amd.build --ablations
-        case 102: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 1>(g, s);    // ablations of tile 2
-        case 202: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 3>(g, s);
-        case 1602: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 16>(g, s);
-        case 3202: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 32>(g, s);   // A pieces only
-        case 6402: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 64>(g, s);   // B pieces only
-        case 3209: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 4, 16, 32>(g, s);
-        case 107: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16, 1>(g, s);
-        case 1607: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16, 16>(g, s);
-        case 8: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 5, 16>(g, s);
-        case 9: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 4, 16>(g, s);
-        case 101: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 1>(g, s);
-        case 201: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 3>(g, s);
-        case 1601: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 16>(g, s);
-#endif
         default: return DPD_E_UNSUPPORTED;
     }
 }

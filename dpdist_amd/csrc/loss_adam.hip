@@ -81,7 +81,82 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
     }
 }
 
+// Optimizer schedule on the device, so that a captured (hipGraph) training step needs no per-step host parameters.
+// state (8 floats, caller-owned, zero-filled = "before the first step" once state[1] = state[2] = 1):
+//   [0] global step (int32 bits)   [1] beta1_power   [2] beta2_power   [3] lr_t of the step being taken   [4] its learning rate
+// One thread: lr = max(base * rate^floor(step / decay_step), floor) on the step counter BEFORE the increment
+// (train_multi_gpu_pc_compare_dist.py:976-990, exponential_decay(staircase=True) + tf.maximum), the beta powers as the running
+// fp32 products TensorFlow keeps in its beta1_power / beta2_power variables, lr_t = lr sqrt(1 - b2^t) / (1 - b1^t).
+__global__ void adam_sched_kernel(float* __restrict__ st, float base_lr, int decay_step, float decay_rate, float floor_lr,
+                                  float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int step = __float_as_int(st[0]);
+    const int n = decay_step > 0 ? step / decay_step : 0;
+    float lr = base_lr;
+    for (int i = 0; i < n && lr > 0.f; ++i) lr *= decay_rate;
+    lr = fmaxf(lr, floor_lr);
+    const float b1p = st[1] * b1, b2p = st[2] * b2;
+    st[0] = __int_as_float(step + 1);
+    st[1] = b1p;
+    st[2] = b2p;
+    st[3] = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    st[4] = lr;
+}
+
+__global__ __launch_bounds__(256) void adam_tf_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, size_t n, const float* __restrict__ st, float b1,
+                                                           float b2, float eps, float gscale) {
+    const float lr_t = st[3];
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        const float4 Gr = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        float* pp = &P.x; const float* gg = &Gr.x; float* mm = &M.x; float* vv = &V.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = gg[j] * gscale;
+            mm[j] = b1 * mm[j] + (1.0f - b1) * gr;
+            vv[j] = b2 * vv[j] + (1.0f - b2) * gr * gr;
+            pp[j] = pp[j] - lr_t * mm[j] / (sqrtf(vv[j]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gr = g[i] * gscale;
+        m[i] = b1 * m[i] + (1.0f - b1) * gr;
+        v[i] = b2 * v[i] + (1.0f - b2) * gr * gr;
+        p[i] = p[i] - lr_t * m[i] / (sqrtf(v[i]) + eps);
+    }
+}
+
 }  // namespace dpd
+
+extern "C" int dpd_adam_sched(float* state, float base_lr, int decay_step, float decay_rate, float floor_lr, float b1, float b2,
+                              void* stream) {
+    if (!state) return DPD_E_NULL;
+    DPD_LAUNCH(dpd::adam_sched_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, base_lr, decay_step, decay_rate, floor_lr, b1, b2);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_adam_tf_dev(float* p, const float* g, float* m, float* v, size_t n, const float* state, float b1, float b2,
+                               float eps, float gscale, void* stream) {
+    if (!p || !g || !m || !v || !state) return DPD_E_NULL;
+    if (n == 0) return DPD_E_DIM;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DPD_E_UNSUPPORTED;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    DPD_LAUNCH(dpd::adam_tf_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, state, b1, b2, eps,
+               gscale);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" const char* dpd_version(void) { return "dpdist_hip 0.1 gfx950"; }
 

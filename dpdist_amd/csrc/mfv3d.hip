@@ -7,13 +7,11 @@
 // evaluations ~ 1.3 MFLOP per cloud), not a roofline kernel; it exists to keep the [B,N,G,3] TF tiles
 // (5 x 12.6 MB at B=32) out of HBM altogether.
 //
-// Mapping (wave64):
-//   pass 1  lane <-> point:    every thread owns (point n, quarter of the Gaussians) and sums p_ng -> denominators
-//   pass 2  lane <-> Gaussian: every thread owns a Gaussian and walks the N points (LDS broadcast reads),
-//                              keeping the 20 running statistics (sum/max/min) in registers -> no cross-lane
-//                              reductions at all for the per-Gaussian sums
-//   norm    power-1/2 per value, L2 over the Gaussian axis per channel (wave shuffle + LDS across 4 waves)
-//   store   staged through LDS ([G][21], conflict-free) and written with coalesced float4 stores
+// Mapping (wave64), forward (details at mfv3d_fwd_kernel): 4 workgroups of 1024 threads per cloud, each owning a slice of the
+//   Gaussians; tables zq[axis][point][cell] = {z, e/S} of the FACTORISED responsibilities in LDS; lane&7 <-> Gaussian,
+//   lane>>3 <-> one eighth of the points, 20 running statistics (sum/max/min) in registers, the eight point groups merged with
+//   three __shfl_xor; power-1/2 values staged through LDS and written with coalesced float4 stores; a second small kernel
+//   applies the per-channel L2 norm over the Gaussian axis.  Backward: sliced over the POINTS (two launches) or one launch.
 #include "common.h"
 
 namespace dpd {
@@ -730,12 +728,8 @@ static size_t bwd_lds_bytes(int N, int m) {
 
 template <typename K>
 static int set_lds(K kern, size_t lds) {
-    if (lds > 64 * 1024) {
-        if (lds > 160 * 1024) return DPD_E_UNSUPPORTED;
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
+    static LdsOptIn lds_opt;   // one per kernel (template on the kernel's type)
+    return ensure_dyn_lds(lds_opt, (const void*)kern, lds);
 }
 
 }  // namespace dpd

@@ -20,7 +20,8 @@ class DecoderParams(Structure):
 
 
 class SmallGrads(Structure):
-    _fields_ = [(n, c_void_p) for n in ("db1", "db2", "db3", "dW4", "db4")]
+    _fields_ = [(n, c_void_p) for n in ("db1", "db2", "db3", "dW4", "db4", "partials", "l1_pred", "l1_labels", "l1_loss")] + [
+        ("l1_gscale", c_float)]
 
 
 class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
@@ -57,11 +58,6 @@ SIGNATURES = {
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p]),
-    "dpd_dedupe_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
-    "dpd_patch_rows_fwd_unique": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 5),
-    "dpd_layer1_fwd_unique": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5),
-    "dpd_layer1_bwd_unique_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "dpd_layer1_bwd_weights_unique": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dpd_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "dpd_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
@@ -76,6 +72,8 @@ SIGNATURES = {
     "dpd_l1_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "dpd_adam_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                             c_float, c_void_p]),
+    "dpd_adam_sched": (c_int, [c_void_p, c_float, c_int, c_float, c_float, c_float, c_float, c_void_p]),
+    "dpd_adam_tf_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float, c_float, c_float, c_void_p]),
     "dpd_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                              c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dpd_set_gemm_plan": (c_int, [c_int, c_int, c_int]),
@@ -149,5 +147,6 @@ def make_params(W1p, b1, W2, b2, W3, b3, W4, b4, W2T=None, W3T=None, W1pT=None):
     return DecoderParams(*[None if t is None else t.data_ptr() for t in (W1p, b1, W2, b2, W3, b3, W4, b4, W2T, W3T, W1pT)])
 
 
-def make_small_grads(db1, db2, db3, dW4, db4):
-    return SmallGrads(*[None if t is None else t.data_ptr() for t in (db1, db2, db3, dW4, db4)])
+def make_small_grads(db1, db2, db3, dW4, db4, partials=None, l1_pred=None, l1_labels=None, l1_loss=None, l1_gscale=1.0):
+    return SmallGrads(*[None if t is None else t.data_ptr() for t in (db1, db2, db3, dW4, db4, partials, l1_pred, l1_labels, l1_loss)],
+                      float(l1_gscale))

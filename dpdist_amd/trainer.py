@@ -34,7 +34,7 @@ def learning_rate(step, base=1e-4, decay_step=300 * 512, decay_rate=0.5, floor=1
 class DPDistTrainer:
     def __init__(self, params: DPDistParams, batch_size, num_point=64, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4,
                  decay_step=300 * 512, decay_rate=0.5, beta1=0.9, beta2=0.999, eps=1e-8, group=None, distributed=None,
-                 compute_dtype=None, dedupe=None):
+                 compute_dtype=None):
         self.P = params
         self.dt = L.DTYPES[params.compute_dtype if compute_dtype is None else compute_dtype]
         dev = params.flat.device
@@ -53,8 +53,7 @@ class DPDistTrainer:
         # 91 us: the per-lane address arithmetic sits in the in-order issue stream of an MFMA-bound wave), so the default
         # keeps X.  fv and the q - centre columns share ONE allocation either way (one buffer descriptor).
         G = self.m ** 3
-        self.fused = (self.dt == 0 and KP % 32 == 0 and BN % 32 == 0 and not dedupe
-                      and os.environ.get("DPD_FUSED_GATHER", "0") == "1" and os.environ.get("DPD_DEDUPE", "0") != "1")
+        self.fused = self.dt == 0 and KP % 32 == 0 and BN % 32 == 0 and os.environ.get("DPD_FUSED_GATHER", "0") == "1"
         self._fvx = f(C * G * 20 + Q * 4)
         self.fv = self._fvx[:C * G * 20].view(C, G, 20)
         self.xyz = self._fvx[C * G * 20:].view(Q, 4)
@@ -77,17 +76,6 @@ class DPDistTrainer:
         self.m_state = torch.zeros_like(self.grad)
         self.v_state = torch.zeros_like(self.grad)
         self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H, self.dt) + 3) // 4, device=dev, dtype=torch.float32)
-        # Layer 1 on the UNIQUE (cloud, voxel) rows (csrc/dedupe.hip): exact-fp32 compute type only.  Experimental and off by
-        # default (slower at B = 32 until the layer-1 GEMM gets a stream-K decomposition, see the header of dedupe.hip)
-        if dedupe is None:
-            dedupe = os.environ.get("DPD_DEDUPE", "0") == "1"
-        self.dedupe = bool(dedupe) and self.dt == 0 and KP % 32 == 0 and Q * 3 * 4 <= 150 * 1024 and BN >= 32
-        if self.dedupe:
-            i32 = lambda n: torch.empty(n, device=dev, dtype=torch.int32)   # noqa: E731
-            self.u_of_q, self.rep_q, self.counts = i32(Q), i32(Q), torch.zeros(4, device=dev, dtype=torch.int32)
-            self.xyz, self.T = f(Q, 3), f(Q, H)
-            self.ws1 = torch.empty(L.load().dpd_layer1_bwd_unique_workspace_bytes(BN, KP, H) // 4 + 1, device=dev,
-                                   dtype=torch.float32)
         # bf16-matrix-core compute types: operand planes persist between the kernels (no conversion passes)
         self._planes = None
         if self.dt and Q % 8 == 0 and BN % 32 == 0 and KP % 32 == 0:
@@ -108,18 +96,30 @@ class DPDistTrainer:
         self._cparams = L.make_params(*params.views(), self.W2T, self.W3T, None)
         self._gviews = params.views(self.grad)
         gv = self._gviews
-        self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7])
+        self._partials = f(((BN + 7) // 8) * (4 * H + 8))      # block partials of db3 / dW4 / db4 (deferred reduction)
+        self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7], self._partials)
+        # training loss fused into the output-layer backward (no separate loss launch); labels pointer is filled in per step
+        self.fuse_loss = H % 256 == 0 and H <= 1024 and os.environ.get("DPD_FUSE_LOSS", "1") == "1"
+        # optimizer schedule on the device (include/dpdist_capi.h: dpd_adam_sched): [step, beta1_power, beta2_power, lr_t, lr]
+        self.opt_state = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.opt_state[1:3] = 1.0
+        # hipGraph mode (single GPU): the whole step is captured once per input-buffer set and replayed; weight-derived
+        # buffers and the small-gradient reduction run on parallel branches of the graph, off the critical path
+        self.use_graph = os.environ.get("DPD_GRAPH", "0") == "1"   # opt-in: measured 4 % SLOWER than eager launches on MI355X / ROCm 7
+        self._graphs, self._seen_keys, self._gstreams = {}, set(), None
+        self.graph_replays = 0
+        self._wdirty = True        # transposed copies / bf16 planes of the weights need a refresh before their next use
         self._after_dw1 = None
         self._side = None          # side stream of the prefetch pipeline (created on first use)
         self._pref_key = None      # identity of the batch whose front end is (being) computed on the side stream
         self._ev_front = self._ev_xfree = self._ev_fwd = None
         self.front_launches = 0    # front ends (stack + encoder + gather) enqueued so far, on either stream
         self.prefetch_hits = 0     # steps that found their front end already computed by the side stream
-        self.refresh_weight_planes()
 
     def refresh_weight_planes(self):
-        """Call after changing the weights from outside (load_tf_state_dict): re-derives the bf16 weight planes / the
-        transposed fp32 copies."""
+        """Re-derive what is computed FROM the weights (bf16 weight planes / transposed fp32 copies) on the current stream.
+        The trainer does this lazily before the first kernel that needs them (`_wdirty`); call it yourself only to force it."""
+        self._wdirty = False
         if self._planes is not None:
             L.check(L.load().dpd_weights_to_planes(self._cparams, self.P.KP, self.P.H, self._planes, L.cur_stream()),
                     "dpd_weights_to_planes")
@@ -163,12 +163,6 @@ class DPDistTrainer:
             return
         lib, s, P = L.load(), L.cur_stream(), self.P
         C, N = 2 * self.B, self.N
-        if self.dedupe:     # voxel lookup + unique-row numbering, then the window gather of the unique rows only
-            L.check(lib.dpd_dedupe_rows(L.ptr(self.q), C, N, self.m, self.B * N, L.ptr(self.u_of_q), L.ptr(self.rep_q),
-                                        L.ptr(self.counts), L.ptr(self.xyz), L.ptr(self.mask), L.ptr(self.vox), s), "dpd_dedupe_rows")
-            L.check(lib.dpd_patch_rows_fwd_unique(L.ptr(self.fv), C, N, self.m, self.k, P.KP, L.ptr(self.rep_q), L.ptr(self.vox),
-                                                  L.ptr(self.counts), L.ptr(self.X), s), "dpd_patch_rows_fwd_unique")
-            return
         L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP,
                                        None if self._planes is not None else L.ptr(self.X), L.ptr(self.mask), L.ptr(self.vox),
                                        self._planes, s), "dpd_patch_rows_fwd")
@@ -182,46 +176,43 @@ class DPDistTrainer:
     def _decode(self):
         lib, s, P = L.load(), L.cur_stream(), self.P
         Q = 2 * self.B * self.N
+        if self._wdirty:
+            self.refresh_weight_planes()
         if self.fused:
             L.check(lib.dpd_decoder_fwd_gather(self._gsrc, L.ptr(self.mask), Q, P.KP, P.H, self._cparams, L.ptr(self.h1),
                                                L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), s),
                     "dpd_decoder_fwd_gather")
             return
-        if self.dedupe:     # layer 1 on the unique rows, expanded to h1; the decoder entry point then starts at layer 2
-            v = P.views()
-            L.check(lib.dpd_layer1_fwd_unique(L.ptr(self.X), L.ptr(self.counts), L.ptr(self.u_of_q), L.ptr(self.xyz), Q, P.KP, P.H,
-                                              P.E, L.ptr(v[0]), L.ptr(v[1]), L.ptr(self.T), L.ptr(self.h1), s), "dpd_layer1_fwd_unique")
-            L.check(lib.dpd_decoder_fwd(None, L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
-                                        L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
-                                        self.ws.numel() * 4, None, s), "dpd_decoder_fwd")
-            return
         L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
                                     L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
                                     self.ws.numel() * 4, self._planes, s), "dpd_decoder_fwd")
 
-    def backward(self, labels):
+    def backward(self, labels, fork_small=None, join_weights=None):
+        """fork_small / join_weights (graph capture only): callables that move the small-gradient reduction to a parallel
+        branch right after the output layer, and join the branch that derives the transposed weights before the dH GEMMs."""
         lib, s, P = L.load(), L.cur_stream(), self.P
         BN = self.B * self.N
         L.req(labels, name="labels", numel=BN)
-        L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
+        if self._wdirty and join_weights is None:
+            self.refresh_weight_planes()
         d, wsb = self._gviews, self.ws.numel() * 4
+        if self.fuse_loss:      # d loss_samples / d pred and the two loss values come out of the output-layer backward
+            gv = self._gviews
+            small = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7], self._partials, self.pred, labels, self.loss, 1.0)
+        else:
+            L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
+            small = self._csmall
 
         def data(phases):   # db1..db3, dW4, db4 fall out of the data chain (fused epilogues / one small kernel)
             L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
                                              L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
-                                             L.ptr(self.g2), L.ptr(self.g1), None, self._csmall, L.ptr(self.ws), wsb, self._planes,
+                                             L.ptr(self.g2), L.ptr(self.g1), None, small, L.ptr(self.ws), wsb, self._planes,
                                              phases, s), "dpd_decoder_bwd_data")
 
         def dw(layer, act, g, dW):
             if layer == 1 and self.fused:
                 L.check(lib.dpd_decoder_bwd_weights_gather(self._gsrc, L.ptr(self.g1), BN, P.KP, P.H, L.ptr(dW), L.ptr(self.ws), wsb, L.cur_stream()),
                         "dpd_decoder_bwd_weights_gather")
-                return
-            if layer == 1 and self.dedupe:
-                L.check(lib.dpd_layer1_bwd_weights_unique(L.ptr(self.X), L.ptr(self.g1), L.ptr(self.u_of_q), L.ptr(self.rep_q),
-                                                          L.ptr(self.xyz), L.ptr(self.counts), self.N, BN, P.KP, P.H, P.E, L.ptr(dW),
-                                                          L.ptr(self.ws1), self.ws1.numel() * 4, L.cur_stream()),
-                        "dpd_layer1_bwd_weights_unique")
                 return
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
                                                 L.ptr(dW), None, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
@@ -243,7 +234,13 @@ class DPDistTrainer:
                 self._after_dw1()
             self.reducer.reduce_async(0)
             return
-        data(7)
+        if fork_small is not None:
+            data(1 | 16)
+            fork_small(lambda: data(8))
+            join_weights()
+            data(2 | 4)
+        else:
+            data(7)
         dw(1, self.X, self.g1, d[0])
         if self._after_dw1 is not None:
             self._after_dw1()             # X / mask are free from here on: the prefetch pipeline hooks in
@@ -260,18 +257,33 @@ class DPDistTrainer:
             self.reducer.reduce_async(1)
             self.reducer.reduce_async(2)
 
-    def apply_gradients(self):
+    def _sched(self):
+        """Advance the device-side optimizer schedule by one step (global step, beta powers, lr_t)."""
         base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
-        lr = learning_rate(self.t, base_lr, decay_step, decay_rate)     # global_step before the increment (TF semantics)
-        self.t += 1
-        lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        L.check(L.load().dpd_adam_sched(L.ptr(self.opt_state), base_lr, int(decay_step), decay_rate, 1e-7, b1, b2, L.cur_stream()),
+                "dpd_adam_sched")
+
+    def _adam(self):
+        base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
         gscale = 1.0
         if self.reducer:
             self.reducer.wait()
             gscale = self.reducer.grad_scale
-        L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
-                                     self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
-        self.refresh_weight_planes()
+        L.check(L.load().dpd_adam_tf_dev(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
+                                         self.P.numel, L.ptr(self.opt_state), b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf_dev")
+        self._wdirty = True
+
+    def apply_gradients(self):
+        """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990); the
+        schedule (global step, beta1_power, beta2_power, lr_t) lives on the device in `opt_state`."""
+        self._sched()
+        self.t += 1
+        self._adam()
+
+    @property
+    def lr(self):
+        """learning rate of the last step taken (device -> host sync)."""
+        return float(self.opt_state[4].item())
 
     def _take_front(self, pcA, pcB, noise):
         """Make the front-end buffers (pts, q, fv, X, mask, vox) hold this batch on the current stream."""
@@ -290,6 +302,10 @@ class DPDistTrainer:
         """One training step.  Returns the device tensor [loss_samples, loss_pred] of THIS rank's shard (no host sync).
         prefetch = (pcA', pcB', noise' or None): the NEXT step's inputs (already complete on the current stream); their
         front end runs on a side stream under this step's backward and optimizer."""
+        if self.use_graph and prefetch is None and self.reducer is None and self._pref_key is None:
+            out = self._graph_step(pcA, pcB, labels, noise)
+            if out is not None:
+                return out
         self._take_front(pcA, pcB, noise)
         self._decode()
         if prefetch is not None:
@@ -313,6 +329,63 @@ class DPDistTrainer:
             self._after_dw1 = None
         self.apply_gradients()
         return self.loss
+
+    # -- hipGraph mode --------------------------------------------------------------------------------------------
+    def _graph_step(self, pcA, pcB, labels, noise):
+        """Replay (or first capture) the whole step for this set of input buffers.  Returns None when the step should run
+        eagerly instead: the first time a buffer set is seen (that eager step also initialises every lazily-configured
+        kernel before a capture), or when too many different buffer sets have been captured."""
+        shp = (self.B, self.N, 3)
+        L.req(pcA, name="pcA", shape=shp), L.req(pcB, name="pcB", shape=shp), L.req(labels, name="labels", numel=self.B * self.N)
+        if noise is not None:
+            L.req(noise, name="add_noise", shape=shp)
+        key = (pcA.data_ptr(), pcB.data_ptr(), labels.data_ptr(), None if noise is None else noise.data_ptr())
+        g = self._graphs.get(key)
+        if g is None:
+            if key not in self._seen_keys or len(self._graphs) >= 8:
+                self._seen_keys.add(key)
+                return None
+            g = self._capture(pcA, pcB, labels, noise)
+            self._graphs[key] = g
+        g[0].replay()
+        self.t += 1
+        self.graph_replays += 1
+        self.front_launches += 1
+        self._wdirty = True            # the replay ends with Adam: derived buffers are one step behind the weights
+        return self.loss
+
+    def _capture(self, pcA, pcB, labels, noise):
+        dev = self.P.flat.device
+        if self._gstreams is None:
+            self._gstreams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        s1, s2 = self._gstreams
+        lab = labels.reshape(-1)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            main = torch.cuda.current_stream()
+            # branch 1: everything derived from the weights of the PREVIOUS step + the optimizer schedule of this one
+            s1.wait_stream(main)
+            with torch.cuda.stream(s1):
+                self.refresh_weight_planes()
+                self._sched()
+            need_w_fwd = self._planes is not None          # bf16 compute types read weight planes in the forward already
+            if need_w_fwd:
+                main.wait_stream(s1)
+            self.front_launches -= 1
+            self._front(pcA, pcB, noise)
+            self._decode()
+
+            def fork_small(fn):                            # branch 2: reduction of the db3 / dW4 / db4 block partials
+                s2.wait_stream(main)
+                with torch.cuda.stream(s2):
+                    fn()
+
+            self.backward(lab, fork_small=fork_small, join_weights=lambda: main.wait_stream(s1))
+            main.wait_stream(s2)
+            main.wait_stream(s1)
+            self._adam()
+        return (g, (pcA, pcB, labels, noise))               # keep the captured input tensors alive
 
     @torch.no_grad()
     def evaluate(self, pcA, pcB, labels, noise=None):

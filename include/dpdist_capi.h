@@ -9,7 +9,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous row-major float32 unless stated otherwise;
- *   - the caller owns every buffer (the library never allocates, frees or keeps global state);
+ *   - the caller owns every buffer: the library never allocates or frees device memory.  Process-wide state is limited to
+ *     (a) the GEMM tuning table of dpd_set_gemm_plan (defaults = measured best; not synchronised: set it before use),
+ *     (b) the opt-in profiler of dpd_prof_enable (off by default, mutex-protected, owns hipEvents while on) and
+ *     (c) a per-(kernel, device) "large LDS opted in" flag set on a kernel's first launch on that device;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and is asynchronous;
  *   - return value: 0 = ok, <0 = argument error (DPD_E_*), >0 = the hipError_t of the failing call;
  *   - thread-safe / re-entrant: safe from several host threads on distinct streams.
@@ -131,8 +134,6 @@ int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, con
                     int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
                     const dpd_planes* pl, void* stream);
 
-/* X may be NULL when layer 1 was already evaluated into h1 by dpd_layer1_fwd_unique (DPD_F32, no planes).          */
-
 /* dpd_decoder_fwd with layer 1 gathering its rows from `src` (DPD_F32; KP % 32 == 0), and the layer-1 weight gradient
  * dW1 [KP,H] = X^T g1 over the first Qb rows gathered the same way (Qb % 32 == 0).  Bitwise identical to running the
  * register-streamed kernels on a materialised X.                                                                  */
@@ -187,9 +188,17 @@ int dpd_weights_to_planes(const dpd_decoder_params* p, int KP, int H, const dpd_
  * dW4 [H,3] = h3^T dy, db4 [3].  Any member may be NULL.
  * `phases` selects the parts of the chain to run, so that a data-parallel caller can interleave the weight-gradient
  * GEMMs (and start their all-reduce) between them: 1 = output layer (dy, g3, db3, dW4, db4; clears db1/db2),
- * 2 = g2 (+db2), 4 = g1 (+db1) and dX; 7 = everything.  The same buffers must be passed to every call.     */
+ * 2 = g2 (+db2), 4 = g1 (+db1) and dX; 7 = everything.  The same buffers must be passed to every call.
+ * 16 (with 1): leave db3 / dW4 / db4 as per-block partial sums in sg->partials; 8: reduce those partials (a call with
+ * phases = 8 alone may run on another stream, beside the dH GEMMs, once the phase-1 call has been ordered before it).  */
 typedef struct dpd_small_grads {
     float* db1; float* db2; float* db3; float* dW4; float* db4;
+    float* partials;   /* optional scratch, ((Qb + 7) / 8) * (4 * H + 8) floats: required by phases 16 / 8 (see below) */
+    /* optional fused training loss (utils/dpdist_util.py:962-980 + its autodiff, the mode-1 call of dpd_l1_loss): with
+     * l1_labels [Qb] != NULL the output-layer backward derives d loss_samples / d pred_AB * l1_gscale from l1_pred [2*Qb,3]
+     * itself (`dpred` may be NULL) and l1_loss [2] = (loss_samples, loss_pred) comes out of the same reduction as db3/dW4/db4.
+     * Needs H % 256 == 0, H <= 1024 (else DPD_E_UNSUPPORTED: use dpd_l1_loss).                                              */
+    const float* l1_pred; const float* l1_labels; float* l1_loss; float l1_gscale;
 } dpd_small_grads;
 
 int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,
@@ -225,31 +234,6 @@ size_t dpd_workspace_bytes(int Q, int KP, int H, int dtype);
 int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float gscale, float* loss,
                 float* dpred, void* stream);
 
-/* ---------------------------------------------------------------------------------------------
- * Row de-duplication for layer 1 (DPD_F32) -- EXPERIMENTAL, not used by default (see csrc/dedupe.hip for the measured
- * status).  The 2500 window columns of a decoder input row depend only on (cloud,
- * voxel of the query) (get_emb_and_concat gathers the same embedding row, utils/dpdist_util.py:434-457; only the three
- * centre-relative coordinates differ, :455), and surface-shaped clouds put 64 queries into ~35-45 voxels, so layer 1
- * and its weight gradient can run on the UNIQUE rows.  Everything data dependent stays on the device:
- *   counts[0] = U (unique rows, numbered in query order), [1] = U_ab (those of the first Qb queries), [2],[3] = both
- *   rounded up to 32.
- * dpd_dedupe_rows        q [C,N,3] -> u_of_q [Q], rep_q [Q] (first query of each unique row), counts [4],
- *                        xyz [Q,3] (q - voxel centre), mask [Q], vox [Q]        (replaces that part of dpd_patch_rows_fwd)
- * dpd_patch_rows_fwd_unique   X_u [Q,KP]: rows [0,U) = window | 0 0 0 | 0-pad; rows [U, round32(U)) zeroed
- * dpd_layer1_fwd_unique  T [Q,H] (rows < U) = X_u W1p;  h1 [Q,H] = relu(T[u_of_q] + xyz W1p[E..E+2] + b1)
- * dpd_layer1_bwd_weights_unique   dW1 [KP,H] = X_u^T (segment sums of g1 over each unique row) ; rows E..E+2 = xyz^T g1
- * Same values as the row-by-row evaluation up to the association of the three xyz terms in the fp32 sum.          */
-int dpd_dedupe_rows(const float* q, int C, int N, int m, int Qb, int32_t* u_of_q, int32_t* rep_q, int32_t* counts,
-                    float* xyz, float* mask, int32_t* vox, void* stream);
-int dpd_patch_rows_fwd_unique(const float* fv, int C, int N, int m, int k, int KP, const int32_t* rep_q,
-                              const int32_t* vox, const int32_t* counts, float* X_u, void* stream);
-int dpd_layer1_fwd_unique(const float* X_u, const int32_t* counts, const int32_t* u_of_q, const float* xyz, int Q, int KP,
-                          int H, int E, const float* W1p, const float* b1, float* T, float* h1, void* stream);
-size_t dpd_layer1_bwd_unique_workspace_bytes(int Qb, int KP, int H);
-int dpd_layer1_bwd_weights_unique(const float* X_u, const float* g1, const int32_t* u_of_q, const int32_t* rep_q,
-                                  const float* xyz, const int32_t* counts, int N, int Qb, int KP, int H, int E, float* dW1,
-                                  void* ws, size_t ws_bytes, void* stream);
-
 /* Host utility: CRC32C (Castagnoli, reflected, init/xorout ~0) of n bytes continuing from `crc` (0 to start); used
  * by the TensorFlow-checkpoint interchange of dpdist_amd/tf_checkpoint.py.  No device work.                 */
 uint32_t dpd_crc32c(const void* data, size_t n, uint32_t crc);
@@ -272,6 +256,16 @@ int dpd_chamfer_bwd(const float* a, const float* b, int B, int N, int M, const i
 int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                 float eps, float gscale, void* stream);
 
+/* The same update with the schedule kept ON THE DEVICE, so that a captured (hipGraph) training step carries no per-step host
+ * parameters.  state: 8 floats, caller-owned: [0] global step (int32 bits), [1] beta1_power, [2] beta2_power (the running
+ * fp32 products TensorFlow keeps in the variables of those names), [3] lr_t, [4] learning rate of the step being taken.
+ * Initialise to {0, 1, 1, 0, ...}.  dpd_adam_sched advances it by one step: lr = max(base_lr * decay_rate^floor(step /
+ * decay_step), floor_lr) on the step counter before the increment (train_multi_gpu_pc_compare_dist.py:976-990), then
+ * lr_t = lr sqrt(1 - beta2_power) / (1 - beta1_power).  dpd_adam_tf_dev reads lr_t from state[3].              */
+int dpd_adam_sched(float* state, float base_lr, int decay_step, float decay_rate, float floor_lr, float b1, float b2, void* stream);
+int dpd_adam_tf_dev(float* p, const float* g, float* m, float* v, size_t n, const float* state, float b1, float b2, float eps,
+                    float gscale, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Building block, exported for tests and roofline measurement: C = epi(op(A) op(B)), fp32 MFMA.
  *   transA = 0: A is [M,K] (lda);  1: A is stored [K,M].   transB = 0: B is [K,N];  1: B is [N,K].
@@ -279,7 +273,9 @@ int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr
  *   K, N, lda, ldb, ldc multiples of 4; split_k >= 1 (slabs in ws, reduced by a second kernel,
  *   epilogue applied after the reduction); tile: 0 = auto; register-staged kernels 1 = 128x128, 2 = 128x64,
  *   3 = 64x64; LDS-DMA ring kernels (K % 32 == 0, else 3 is used) 4 = 64x64/4-stage, 5 = 128x128/4-stage,
- *   6 = 128x64, 7 = 64x128, 8 = 64x64/3-stage, 9 = 128x128/3-stage, 10 = 128x128/5-stage.                               */
+ *   6 = 128x64, 7 = 64x128, 8 = 64x64/3-stage, 9 = 128x128/3-stage, 10 = 128x128/5-stage, 11-14 multi-accumulator forms;
+ *   register-streamed kernels (no LDS, no barriers; K % 32 == 0; csrc/gemm_rs.h): workgroup of 4 waves, wave tile
+ *   30 = 64x64, 31 = 64x32, 32 = 32x64, 33 = 32x32, 34-36 = the same three with operands two K-tiles ahead, 37 = 8 waves. */
 int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* Cout, int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile,
                  void* ws, size_t ws_bytes, void* stream);
@@ -301,9 +297,11 @@ int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const voi
                     const void* B, int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate,
                     int epilogue, int tile, void* out_rc, void* out_r8, int r8_rows, void* stream);
 
-/* Tuning knob (the library's only process-wide state; never needed for correctness): GEMM tile / split-K per
- * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3.
- * tile as in dpd_gemm_f32 (0 = auto); split_k only applies to ops 4 and 5.  Defaults are the measured best.                                   */
+/* Tuning knob (process-wide, never needed for correctness): GEMM tile / split-K per
+ * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3, 6 / 7 bwd dH / dX with a
+ * transposed weight copy, 8 bwd dW1 with the fused gather; 16 + op: one-plane (bf16) tile of gemm_x3.hip for that call site
+ * (0 = automatic), 32: its grouped dW2/dW3 launch.  tile as in dpd_gemm_f32 (0 = auto); split_k only applies to ops 4, 5, 8.
+ * Defaults are the measured best.                                                                                        */
 int dpd_set_gemm_plan(int op, int tile, int split_k);
 
 /* Opt-in profiler for the roofline measurement (bench.py): when enabled, every GEMM kernel launch is bracketed

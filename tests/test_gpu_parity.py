@@ -884,56 +884,6 @@ def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
     assert (gB1 - gB2).abs().max().item() <= 1e-6 * max(1.0, gB2.abs().max().item())
 
 
-@pytest.mark.parametrize("case", ["s2", "s1", "degenerate"])
-def test_unique_row_layer1_matches_plain_path(dev, case):
-    """Layer 1 on the unique (cloud, voxel) rows == the row-by-row evaluation: same forward values (up to the association of
-    the three xyz terms), same weight gradients; the unique-row bookkeeping is exact integer work."""
-    from dpdist_amd.model import DPDistParams
-    from dpdist_amd.trainer import DPDistTrainer
-    B = 8
-    if case == "s2":
-        pcA, pcB, lab = synth.s2_modelnet_shaped(B, 64, 100)
-    elif case == "s1":
-        pcA, pcB = synth.s1_random_patches(B, 64, 3)          # includes boundary / outside-the-cube coordinates
-        lab = np.abs(pcB[..., 0]).astype(np.float32)
-    else:                                                      # every query of a cloud in ONE voxel; one cloud all outside
-        rng = np.random.default_rng(5)
-        pcA = (rng.uniform(0.01, 0.24, (B, 64, 3))).astype(np.float32)
-        pcB = (rng.uniform(0.26, 0.49, (B, 64, 3))).astype(np.float32)
-        pcB[3] = 1.5
-        lab = np.abs(pcB[..., 0]).astype(np.float32)
-    W0 = synth.make_weights("wide")
-    out = {}
-    for dd in (False, True):
-        P = DPDistParams(device=dev)
-        P.load_tf_state_dict(W0)
-        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False, dedupe=dd)
-        assert tr.dedupe == dd
-        tr._load_batch(_cu(pcA, dev), _cu(pcB, dev), None)
-        tr.forward()
-        tr.backward(_cu(lab, dev).reshape(-1))
-        torch.cuda.synchronize()
-        out[dd] = {k: getattr(tr, k).clone() for k in ("h1", "pred", "mask", "vox", "grad", "loss")}
-        if dd:
-            cnt = tr.counts.cpu().numpy()
-            u = tr.u_of_q.cpu().numpy()
-            vox = tr.vox.cpu().numpy()
-            key = (np.arange(2 * B * 64) // 64) * 1000 + vox
-            # exact bookkeeping: u is a dense numbering of the distinct (cloud, voxel) keys in first-occurrence order
-            _, first = np.unique(key, return_index=True)
-            order = np.sort(first)
-            want = np.searchsorted(order, np.array([order[order <= i][np.argmax(key[order[order <= i]] == key[i])] for i in range(len(key))]))
-            assert cnt[0] == len(order) and np.array_equal(u, want)
-            assert cnt[1] == (order < B * 64).sum() and cnt[2] == (cnt[1] + 31) // 32 * 32 and cnt[3] == (cnt[0] + 31) // 32 * 32
-            if case == "degenerate":
-                assert cnt[0] == 2 * B
-    a, b = out[False], out[True]
-    assert torch.equal(a["mask"], b["mask"]) and torch.equal(a["vox"], b["vox"])
-    assert (a["h1"] - b["h1"]).abs().max().item() <= 2e-6 * max(1.0, a["h1"].abs().max().item())
-    assert (a["pred"] - b["pred"]).abs().max().item() <= 1e-5
-    assert (a["loss"] - b["loss"]).abs().max().item() <= 1e-6
-    scale = a["grad"].abs().max().item()
-    assert (a["grad"] - b["grad"]).abs().max().item() <= 2e-5 * max(1.0, scale), ((a["grad"] - b["grad"]).abs().max().item(), scale)
 
 
 @pytest.mark.parametrize("N", [36, 100])
