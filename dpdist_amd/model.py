@@ -118,9 +118,20 @@ class DPDistParams(nn.Module):
         self.load_tf_state_dict(sd)
 
     @torch.no_grad()
-    def load_tf_state_dict(self, sd):
-        """sd: TF variable name -> array in the TF layout ([1,E+3,1,H], [1,1,H,H] x2, [1,1,H,3], biases)."""
+    def load_tf_state_dict(self, sd, flat=None, suffix=""):
+        """sd: TF variable name -> array in the TF layout ([1,E+3,1,H], [1,1,H,H] x2, [1,1,H,3], biases).
+        flat / suffix: fill another flat buffer of the same layout from the variables `<name><suffix>` instead (the Adam slots
+        of a TF checkpoint are `<variable>/Adam` and `<variable>/Adam_1`)."""
         dev = self.flat.device
+        if flat is not None or suffix:
+            sd = {n: sd[n + suffix] for n in (TF_NAME % (l, t) for l in (1, 2, 3, 4) for t in ("weights", "biases"))}
+            tgt = self.flat if flat is None else flat
+            keep = self.flat.data
+            try:                                    # reuse the layout code below on the other buffer
+                self.flat.data = tgt.data
+                return self.load_tf_state_dict(sd)
+            finally:
+                self.flat.data = keep
         get = lambda n: torch.as_tensor(np.asarray(sd[n]) if not torch.is_tensor(sd[n]) else sd[n], dtype=torch.float32)  # noqa: E731
         w1 = get(TF_NAME % (1, "weights")).reshape(self.E + 3, self.H)
         W1p = torch.zeros(self.KP, self.H)

@@ -201,10 +201,12 @@ def train(argv=None):
     test_ds = SyntheticDistanceDataset(F.test_shapes, 2 * N, F.batch_size, "test", F.seed)
     params = DPDistParams(k=K, mlp=(1024, 1024, 1024), device=dev)
     params.reset_parameters_tf(generator=torch.Generator().manual_seed(F.seed))               # replicated variables
-    if F.restore:                                                                            # saver.restore (:443-453)
-        params.load_tf_state_dict(dict(np.load(F.restore)) if F.restore.endswith(".npz") else read_checkpoint(F.restore))
     tr = DPDistTrainer(params, dev_bs, num_point=N, Embedding_Size=F.embedding_size, sigma3dmfv=sigma,
                        base_lr=F.learning_rate_dpdist, decay_step=F.decay_step, decay_rate=F.decay_rate)
+    if F.restore:                                                                            # saver.restore (:443-453)
+        # weights AND, when the checkpoint has them (ours do, like the reference's Saver()), global step + Adam state
+        got = tr.load_tf_global_variables(dict(np.load(F.restore)) if F.restore.endswith(".npz") else read_checkpoint(F.restore))
+        log_string("restored %s from %s (global step %d)" % (", ".join(got), F.restore, tr.t))
     lo, hi = shard_range(F.batch_size, rank, world)
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)       # noqa: E731
 
@@ -246,7 +248,7 @@ def train(argv=None):
             es, ep = run_epoch(test_ds, False)
             log_string("eval mean loss: %f" % es)
             if rank == 0:
-                sd = params.tf_state_dict()                                                    # TF variable names/layouts
+                sd = tr.tf_global_variables()       # what tf.train.Saver() saves: variables, `batch`, beta powers, Adam slots
                 np.savez(os.path.join(F.log_dir, "model.ckpt.npz"), **sd)
                 write_checkpoint(os.path.join(F.log_dir, "model.ckpt"), sd)                    # saver.save(...) (:354-357)
                 with open(os.path.join(F.log_dir, "metrics.jsonl"), "a") as f:

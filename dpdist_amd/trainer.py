@@ -19,6 +19,7 @@ all-reduce launched immediately), then dW2, dW3, dW4 (second bucket), then one f
 import math
 import os
 
+import numpy as np
 import torch
 
 from . import lib as L
@@ -329,6 +330,45 @@ class DPDistTrainer:
             self._after_dw1 = None
         self.apply_gradients()
         return self.loss
+
+    # -- optimizer state <-> TF global variables ------------------------------------------------------------------
+    def tf_global_variables(self):
+        """Everything the reference's `tf.train.Saver()` stores besides summaries (train_multi_gpu_pc_compare_dist.py:305,
+        354-357): the 8 decoder variables, the global step `batch` (float scalar, :205-207), AdamOptimizer's non-slot variables
+        `beta1_power` / `beta2_power` (TF keeps beta^(t+1) after t steps) and the slots `<variable>/Adam` (m), `<variable>/Adam_1`
+        (v), all in the TF layouts.  Host sync."""
+        _, _, _, b1, b2, _ = self.hp
+        sd = dict(self.P.tf_state_dict())
+        for suffix, flat in (("/Adam", self.m_state), ("/Adam_1", self.v_state)):
+            for n, a in self.P.tf_state_dict(flat).items():
+                sd[n + suffix] = a
+        st = self.opt_state.cpu().numpy()
+        sd["batch"] = np.float32(self.t)
+        sd["beta1_power"] = np.float32(st[1] * b1)
+        sd["beta2_power"] = np.float32(st[2] * b2)
+        return sd
+
+    @torch.no_grad()
+    def load_tf_global_variables(self, sd):
+        """Inverse of tf_global_variables; optimizer entries that are absent (a weights-only checkpoint) leave that part of the
+        state untouched.  Returns the list of state groups that were restored."""
+        _, _, _, b1, b2, _ = self.hp
+        got = ["weights"]
+        self.P.load_tf_state_dict(sd)
+        self._wdirty = True
+        if all((n + "/Adam") in sd and (n + "/Adam_1") in sd for n in self.P.tf_state_dict()):
+            self.P.load_tf_state_dict(sd, flat=self.m_state, suffix="/Adam")
+            self.P.load_tf_state_dict(sd, flat=self.v_state, suffix="/Adam_1")
+            got.append("adam_slots")
+        if "batch" in sd:
+            self.t = int(round(float(np.asarray(sd["batch"]))))
+            st = self.opt_state.cpu()
+            st[0] = torch.tensor(self.t, dtype=torch.int32).view(torch.float32)
+            st[1] = float(np.asarray(sd["beta1_power"])) / b1 if "beta1_power" in sd else b1 ** self.t
+            st[2] = float(np.asarray(sd["beta2_power"])) / b2 if "beta2_power" in sd else b2 ** self.t
+            self.opt_state.copy_(st)
+            got.append("schedule")
+        return got
 
     # -- hipGraph mode --------------------------------------------------------------------------------------------
     def _graph_step(self, pcA, pcB, labels, noise):

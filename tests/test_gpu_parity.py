@@ -1023,3 +1023,46 @@ def test_fused_trainer_matches_unfused(dev, monkeypatch):
     assert torch.equal(outs[0][0][0], outs[1][0][0])                       # first step: same bits
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-6
     assert (outs[0][1] - outs[1][1]).abs().mean().item() <= 1e-6         # later steps: db1/db2 atomics order only
+
+
+def test_checkpoint_resume_restores_optimizer_state(dev, tmp_path):
+    """What the reference's tf.train.Saver() stores (train_multi_gpu_pc_compare_dist.py:305,354-357) round-trips through the TF
+    V2 container: the 8 variables, `batch`, beta1_power / beta2_power and the `<variable>/Adam`, `/Adam_1` slots -- a resumed run
+    continues exactly where the uninterrupted one is (global step, staircase learning rate, Adam moments)."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.tf_checkpoint import list_variables, read_checkpoint, write_checkpoint
+    from dpdist_amd.trainer import DPDistTrainer
+    mlp = (64, 64, 64)
+    B = 4
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+
+    def fresh():
+        P = DPDistParams(mlp=mlp, device=dev)
+        P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
+        return P, DPDistTrainer(P, B, base_lr=1e-3, decay_step=2, decay_rate=0.5, distributed=False)
+
+    P0, t0 = fresh()
+    for _ in range(5):
+        t0.step(pcA, pcB, lab)
+    P1, t1 = fresh()
+    for _ in range(3):
+        t1.step(pcA, pcB, lab)
+    sd = t1.tf_global_variables()
+    names = sorted(sd)
+    base = sorted(P1.tf_state_dict())
+    assert names == sorted(base + [n + s for n in base for s in ("/Adam", "/Adam_1")] + ["batch", "beta1_power", "beta2_power"])
+    assert float(sd["batch"]) == 3.0 and abs(float(sd["beta1_power"]) - 0.9 ** 4) < 1e-6 and abs(float(sd["beta2_power"]) - 0.999 ** 4) < 1e-6
+    prefix = str(tmp_path / "model.ckpt")
+    write_checkpoint(prefix, sd)
+    assert sorted(list_variables(prefix)) == names
+    P2, t2 = fresh()
+    got = t2.load_tf_global_variables(read_checkpoint(prefix))
+    assert got == ["weights", "adam_slots", "schedule"] and t2.t == 3
+    assert torch.equal(t2.m_state, t1.m_state) and torch.equal(t2.v_state, t1.v_state) and torch.equal(P2.flat, P1.flat)
+    for _ in range(2):
+        t2.step(pcA, pcB, lab)
+    assert abs(t2.lr - t0.lr) == 0.0 and t2.t == t0.t == 5               # 1e-3 * 0.5^floor(4/2)
+    assert (P2.flat - P0.flat).abs().max().item() <= 1e-5                 # the 1024-wide layers' db atomics are absent at 64 wide
+    # a weights-only checkpoint leaves the optimizer state alone
+    P3, t3 = fresh()
+    assert t3.load_tf_global_variables(P1.tf_state_dict()) == ["weights"] and t3.t == 0

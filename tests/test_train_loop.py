@@ -106,5 +106,15 @@ def test_train_loop_converges_and_checkpoints(tmp_path):
     losses = [float(x.split("mean loss:")[1].split()[0]) for x in log.splitlines() if "---- epoch" in x]
     assert len(losses) == 6 and losses[-1] < losses[0] and np.isfinite(ls)
     ck = np.load(os.path.join(tmp_path, "model.ckpt.npz"))
-    assert sorted(ck.files) == sorted(synth.make_weights("xavier_tf"))
+    base = sorted(synth.make_weights("xavier_tf"))
+    # what tf.train.Saver() stores: the variables, the global step, the beta powers and the two Adam slots per variable
+    assert sorted(ck.files) == sorted(base + [n + s for n in base for s in ("/Adam", "/Adam_1")] + ["batch", "beta1_power", "beta2_power"])
     assert ck["pc_compare/dpdist_local/mapper_conv1/weights"].shape == (1, 2503, 1, 1024)
+    assert float(ck["batch"]) == 24.0
+    # resume from the TF container: global step and optimizer state come back
+    ls2 = train(["--log_dir", str(tmp_path / "resumed"), "--max_epoch", "1", "--batch_size", "32", "--train_shapes", "128",
+                 "--test_shapes", "32", "--eval_every", "5", "--learning_rate_dpdist", "0.0005",
+                 "--restore", os.path.join(tmp_path, "model.ckpt")])
+    log2 = open(os.path.join(tmp_path, "resumed", "log_trainours.txt")).read()
+    assert "restored weights, adam_slots, schedule" in log2 and "(global step 24)" in log2 and "step 28" in log2
+    assert np.isfinite(ls2) and ls2 < losses[0]
