@@ -179,3 +179,238 @@ void cpuref_forward(const float* pcA, const float* pcB, const float* noise, int 
         }
     free(pts); free(qs); free(fv); free(X); free(mask); free(h1); free(h2); free(y);
 }
+
+/* =====================================================================================================================
+ * Training step (forward + backward to the 8 decoder variables), the CPU baseline of bench.py.
+ *
+ * variant 0 "compact":  no [C, m^3, k^3*20] window tensor; every query row gathers its 5^3 window straight from fv.
+ * variant 1 "faithful": the dataflow of the TF graph -- local_z_3d materialises emb [C, m^3, k^3*20]
+ *                       (utils/dpdist_util.py:911-930, 164 MB per cloud set at B = 32), the cell lookup compares every query
+ *                       against all m^3 centres and takes the argmax (:459-492), rows are gathered from emb (:434-457).
+ * Both run the same dense layers: an OpenMP register-blocked SGEMM written here (no BLAS in the image).
+ * Backward = TF autodiff of loss_samples = mean |pred_AB[...,0] - labels| (utils/dpdist_util.py:967-974) w.r.t. the variables
+ * under 'pc_compare' (train_multi_gpu_pc_compare_dist.py:274-277): only the AB half of the rows carries gradient.
+ * ===================================================================================================================== */
+typedef float v8f __attribute__((vector_size(32)));   /* one AVX2 register */
+#define GEMM_FAST __attribute__((optimize("-ffp-contract=fast")))   /* FMA in the dense layers only (the encoder stays op by op) */
+
+/* micro-kernel: acc[6][2] += a[r][k] * b[k][0:16] over k; 12 accumulators + 2 operands + 1 broadcast = 15 of 16 ymm registers.
+ * a_rs / a_ks: row / k strides of A (NN: lda, 1;  TN with A stored [K,M]: 1, lda).  mr <= 6 live rows. */
+GEMM_FAST static inline void micro_6x16(int K, const float* a, long a_rs, long a_ks, const float* b, long ldb, float* c, long ldc, int mr) {
+    v8f acc[6][2];
+    for (int r = 0; r < 6; ++r) { acc[r][0] = (v8f){0}; acc[r][1] = (v8f){0}; }
+    const float* ar[6];
+    for (int r = 0; r < 6; ++r) ar[r] = a + (long)(r < mr ? r : 0) * a_rs;
+    for (int k = 0; k < K; ++k) {
+        v8f b0, b1;
+        memcpy(&b0, b + (long)k * ldb, 32);
+        memcpy(&b1, b + (long)k * ldb + 8, 32);
+#pragma GCC unroll 6
+        for (int r = 0; r < 6; ++r) {
+            const float av = ar[r][(long)k * a_ks];
+            const v8f avv = {av, av, av, av, av, av, av, av};
+            acc[r][0] += avv * b0;
+            acc[r][1] += avv * b1;
+        }
+    }
+    for (int r = 0; r < mr; ++r) {
+        memcpy(c + (long)r * ldc, &acc[r][0], 32);
+        memcpy(c + (long)r * ldc + 8, &acc[r][1], 32);
+    }
+}
+
+/* C [M,N] = A [M,K] * B [K,N] (row major, N % 16 == 0).  OpenMP over 6 x 16 output tiles, column tiles innermost so that the
+ * threads of a row band share the A rows. */
+static void sgemm_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc) {
+#pragma omp parallel for collapse(2) schedule(dynamic, 8)
+    for (int i0 = 0; i0 < M; i0 += 6)
+        for (int j0 = 0; j0 < N; j0 += 16)
+            micro_6x16(K, A + (size_t)i0 * lda, lda, 1, B + j0, ldb, C + (size_t)i0 * ldc + j0, ldc, (M - i0 < 6) ? M - i0 : 6);
+}
+
+/* C [M,N] = A^T B with A stored [K,M], B [K,N] (the weight gradients: act^T g).  N % 16 == 0. */
+static void sgemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc) {
+#pragma omp parallel for collapse(2) schedule(dynamic, 8)
+    for (int i0 = 0; i0 < M; i0 += 6)
+        for (int j0 = 0; j0 < N; j0 += 16)
+            micro_6x16(K, A + i0, 1, lda, B + j0, ldb, C + (size_t)i0 * ldc + j0, ldc, (M - i0 < 6) ? M - i0 : 6);
+}
+
+static void transpose(const float* A, int R, int Cc, float* AT) {
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < Cc; ++c)
+        for (int r = 0; r < R; ++r) AT[(size_t)c * R + r] = A[(size_t)r * Cc + c];
+}
+
+static void bias_relu(float* y, int R, int N, const float* b) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < R; ++r)
+        for (int n = 0; n < N; ++n) y[(size_t)r * N + n] = fmaxf(y[(size_t)r * N + n] + b[n], 0.f);
+}
+
+static void colsum(const float* g, int R, int N, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += g[(size_t)r * N + n];
+        out[n] = s;
+    }
+}
+
+/*
+ * One training step's forward + backward.  Weights as in cpuref_forward (TF layout, W1 rows 0-2 = local xyz); H % 16 == 0.
+ * Outputs: loss[2] = (loss_samples, loss_pred); gradients dW1 [D,H], db1 [H], dW2, db2, dW3, db3 [H,H],[H], dW4 [H,3], db4 [3]
+ * (any may be NULL -> that gradient is still computed but not returned); predAB/predBA [B,N,3] may be NULL.
+ * do_backward = 0: forward only.
+ */
+void cpuref_train_step(const float* pcA, const float* pcB, const float* noise, const float* labels, int B, int N, int m, int k,
+                       float sigma, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                       const float* b3, const float* W4, const float* b4, int H, int variant, int do_backward, float* loss,
+                       float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dW4, float* db4,
+                       float* predAB, float* predBA) {
+    const int G = m * m * m, E = k * k * k * F, D = E + 3, h = (k - 1) / 2, C = 2 * B, Q = C * N, Qb = B * N;
+    float ax[64];
+    grid_axis(m, ax);
+    const float half = fabsf(ax[0] - ax[1]) / 2.0f;
+    float* pts = (float*)malloc(sizeof(float) * (size_t)C * N * 3);
+    float* qs = (float*)malloc(sizeof(float) * (size_t)C * N * 3);
+    for (size_t i = 0; i < (size_t)B * N * 3; ++i) {
+        pts[i] = noise ? pcA[i] + noise[i] : pcA[i];
+        pts[(size_t)B * N * 3 + i] = pcB[i];
+        qs[i] = pcB[i];
+        qs[(size_t)B * N * 3 + i] = pcA[i];
+    }
+    float* fv = (float*)malloc(sizeof(float) * (size_t)C * G * F);
+    cpuref_mfv3d(pts, C, N, m, sigma, fv);
+    float* X = (float*)calloc((size_t)Q * D, sizeof(float));
+    float* mask = (float*)malloc(sizeof(float) * Q);
+    float* emb = NULL;
+    if (variant == 1) {   /* local_z_3d: the window of EVERY voxel of every cloud (:911-930) */
+        emb = (float*)calloc((size_t)C * G * E, sizeof(float));
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int c = 0; c < C; ++c)
+            for (int v = 0; v < G; ++v) {
+                const int iy = v / (m * m), ix = (v / m) % m, iz = v % m;
+                float* e = emb + ((size_t)c * G + v) * E;
+                for (int d0 = 0; d0 < k; ++d0)
+                    for (int d1 = 0; d1 < k; ++d1)
+                        for (int d2 = 0; d2 < k; ++d2) {
+                            const int g0 = iy + d0 - h, g1 = ix + d1 - h, g2 = iz + d2 - h;
+                            if (g0 >= 0 && g0 < m && g1 >= 0 && g1 < m && g2 >= 0 && g2 < m)
+                                memcpy(e + ((d0 * k + d1) * k + d2) * F, fv + ((size_t)c * G + (g0 * m + g1) * m + g2) * F, sizeof(float) * F);
+                        }
+            }
+    }
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < Q; ++r) {
+        const int c = r / N;
+        const float* q = qs + (size_t)r * 3;
+        int ix, iy, iz, valid;
+        if (variant == 1) {   /* mask against ALL centres + argmax (:470-490); centre v = (l[ix], l[iy], l[iz]), v = (iy*m+ix)*m+iz */
+            int best = 0, found = 0;
+            for (int v = 0; v < G && !found; ++v) {
+                const int vy = v / (m * m), vx = (v / m) % m, vz = v % m;
+                if (q[0] > ax[vx] - half && q[0] <= ax[vx] + half && q[1] > ax[vy] - half && q[1] <= ax[vy] + half &&
+                    q[2] > ax[vz] - half && q[2] <= ax[vz] + half) { best = v; found = 1; }
+            }
+            valid = found; iy = best / (m * m); ix = (best / m) % m; iz = best % m;
+        } else {
+            ix = cell_of(ax, m, half, q[0]); iy = cell_of(ax, m, half, q[1]); iz = cell_of(ax, m, half, q[2]);
+            valid = ix >= 0 && iy >= 0 && iz >= 0;
+            if (!valid) ix = iy = iz = 0;
+        }
+        mask[r] = valid ? 1.f : 0.f;
+        float* x = X + (size_t)r * D;
+        x[0] = q[0] - ax[ix]; x[1] = q[1] - ax[iy]; x[2] = q[2] - ax[iz];
+        if (variant == 1) {
+            memcpy(x + 3, emb + ((size_t)c * G + (iy * m + ix) * m + iz) * E, sizeof(float) * E);   /* gather_nd (:436-453) */
+        } else {
+            for (int d0 = 0; d0 < k; ++d0)
+                for (int d1 = 0; d1 < k; ++d1)
+                    for (int d2 = 0; d2 < k; ++d2) {
+                        const int g0 = iy + d0 - h, g1 = ix + d1 - h, g2 = iz + d2 - h;
+                        if (g0 >= 0 && g0 < m && g1 >= 0 && g1 < m && g2 >= 0 && g2 < m)
+                            memcpy(x + 3 + ((d0 * k + d1) * k + d2) * F, fv + ((size_t)c * G + (g0 * m + g1) * m + g2) * F, sizeof(float) * F);
+                    }
+        }
+    }
+    float* h1 = (float*)malloc(sizeof(float) * (size_t)Q * H);
+    float* h2 = (float*)malloc(sizeof(float) * (size_t)Q * H);
+    float* h3 = (float*)malloc(sizeof(float) * (size_t)Q * H);
+    float* y = (float*)malloc(sizeof(float) * (size_t)Q * 3);
+    sgemm_nn(Q, H, D, X, D, W1, H, h1, H); bias_relu(h1, Q, H, b1);      /* :516-544, tf_util.conv2d == dense */
+    sgemm_nn(Q, H, H, h1, H, W2, H, h2, H); bias_relu(h2, Q, H, b2);
+    sgemm_nn(Q, H, H, h2, H, W3, H, h3, H); bias_relu(h3, Q, H, b3);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < Q; ++r)
+        for (int ch = 0; ch < 3; ++ch) {
+            float s = 0.f;
+            for (int j = 0; j < H; ++j) s += h3[(size_t)r * H + j] * W4[(size_t)j * 3 + ch];
+            y[(size_t)r * 3 + ch] = s + b4[ch];
+        }
+    double sl = 0.0, sab = 0.0, sba = 0.0;
+    for (int r = 0; r < Q; ++r) {
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = fminf(fmaxf(y[(size_t)r * 3 + ch], 0.f), 6.f) / 3.0f * mask[r];
+            if (r < Qb) { if (predAB) predAB[(size_t)r * 3 + ch] = v; }
+            else if (predBA) predBA[(size_t)(r - Qb) * 3 + ch] = v;
+            if (ch == 0) {
+                if (r < Qb) { sl += fabsf(v - labels[r]); sab += v; } else sba += v;
+            }
+        }
+    }
+    if (loss) { loss[0] = (float)(sl / Qb); loss[1] = (float)((sab / Qb + sba / Qb) / 2.0); }
+    if (do_backward) {
+        float* dy = (float*)calloc((size_t)Qb * 3, sizeof(float));
+        float* g3 = (float*)malloc(sizeof(float) * (size_t)Qb * H);
+        float* g2 = (float*)malloc(sizeof(float) * (size_t)Qb * H);
+        float* g1 = (float*)malloc(sizeof(float) * (size_t)Qb * H);
+        float* WT = (float*)malloc(sizeof(float) * (size_t)H * H);
+        float* tmpW = (float*)malloc(sizeof(float) * (size_t)D * H);
+        float tb[3] = {0, 0, 0};
+        for (int r = 0; r < Qb; ++r) {   /* d mean|p - l| / d y: sign * 1/Qb * mask / 3 on (0, 6) (relu6 gradient) */
+            const float yv = y[(size_t)r * 3];
+            const float p = fminf(fmaxf(yv, 0.f), 6.f) / 3.0f * mask[r];
+            const float df = p - labels[r];
+            const float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+            dy[(size_t)r * 3] = (yv > 0.f && yv < 6.f) ? sg / (float)Qb * mask[r] / 3.0f : 0.f;
+            tb[0] += dy[(size_t)r * 3];
+        }
+        if (db4) { db4[0] = tb[0]; db4[1] = 0.f; db4[2] = 0.f; }
+        if (dW4) {
+#pragma omp parallel for schedule(static)
+            for (int j = 0; j < H; ++j) {
+                float s = 0.f;
+                for (int r = 0; r < Qb; ++r) s += h3[(size_t)r * H + j] * dy[(size_t)r * 3];
+                dW4[(size_t)j * 3] = s; dW4[(size_t)j * 3 + 1] = 0.f; dW4[(size_t)j * 3 + 2] = 0.f;
+            }
+        }
+#pragma omp parallel for schedule(static)
+        for (int r = 0; r < Qb; ++r)
+            for (int j = 0; j < H; ++j)
+                g3[(size_t)r * H + j] = (h3[(size_t)r * H + j] > 0.f) ? dy[(size_t)r * 3] * W4[(size_t)j * 3] : 0.f;
+        float* dWo[3] = {dW3, dW2, dW1};
+        float* dbo[3] = {db3, db2, db1};
+        const float* Wl[2] = {W3, W2};
+        float* gin[3] = {g3, g2, g1};
+        const float* act_in[3] = {h2, h1, X};
+        const float* act_gate[2] = {h2, h1};
+        for (int l = 0; l < 3; ++l) {
+            const int Kin = (l == 2) ? D : H;
+            if (dbo[l]) colsum(gin[l], Qb, H, dbo[l]);
+            float* dst = dWo[l] ? dWo[l] : tmpW;
+            sgemm_tn(Kin, H, Qb, act_in[l], Kin, gin[l], H, dst, H);        /* dW = act^T g */
+            if (l < 2) {                                                     /* g_prev = (g W^T) * [act > 0] */
+                transpose(Wl[l], H, H, WT);
+                sgemm_nn(Qb, H, H, gin[l], H, WT, H, gin[l + 1], H);
+                const float* gate = act_gate[l];
+                float* gp = gin[l + 1];
+#pragma omp parallel for schedule(static)
+                for (size_t i = 0; i < (size_t)Qb * H; ++i) gp[i] = (gate[i] > 0.f) ? gp[i] : 0.f;
+            }
+        }
+        free(dy); free(g3); free(g2); free(g1); free(WT); free(tmpW);
+    }
+    free(pts); free(qs); free(fv); free(X); free(mask); free(h1); free(h2); free(h3); free(y);
+    if (emb) free(emb);
+}

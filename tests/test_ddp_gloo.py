@@ -1,6 +1,7 @@
 """Data-parallel path on CPU: world_size 2 over gloo.  The bucketed all-reduce + 1/world scaling of ddp.py must
 reproduce the full-batch gradient (mean of equal shard means), the role of average_gradients in the reference
-(train_multi_gpu_pc_compare_dist.py:936-974)."""
+(train_multi_gpu_pc_compare_dist.py:936-974) -- for the fp32 and the bf16 wire, as one all-reduce per bucket and as
+reduce-scatter + all-gather."""
 import os
 import socket
 
@@ -44,16 +45,21 @@ def _worker(rank, world, port, out):
     pcA, pcB, lab = synth.s2_modelnet_shaped(GB, 64, 100)
     lo, hi = shard_range(GB, rank, world)
     P = DPDistParams(k=5, mlp=mlp, device="cpu", init=None)
-    flat = _flat_grad(P, pcA[lo:hi], pcB[lo:hi], lab[lo:hi], mlp).float()
-    red = BucketReducer(flat, P.bucket_bounds)
-    assert len(P.bucket_bounds) == 4
-    for b in (2, 1, 0):          # layers 3-4, layer 2, layer 1: the order trainer.backward produces them in
-        red.reduce_async(b)
-    red.wait()
-    flat *= red.grad_scale
+    shard = _flat_grad(P, pcA[lo:hi], pcB[lo:hi], lab[lo:hi], mlp).float()
+    full = _flat_grad(P, pcA, pcB, lab, mlp).float() if rank == 0 else None
+    res = {}
+    for wire, mode in (("f32", "allreduce"), ("f32", "rs_ag"), ("bf16", "allreduce"), ("bf16", "rs_ag")):
+        flat = shard.clone()
+        red = BucketReducer(flat, P.bucket_bounds, wire=wire, mode=mode)
+        assert len(P.bucket_bounds) == 4
+        for b in (2, 1, 0):          # layers 3-4, layer 2, layer 1: the order trainer.backward produces them in
+            red.reduce_async(b)
+        red.wait()
+        flat *= red.grad_scale
+        if rank == 0:
+            res[(wire, mode)] = (float((flat - full).abs().max()), float(full.abs().max()), red.world)
     if rank == 0:
-        full = _flat_grad(P, pcA, pcB, lab, mlp).float()
-        out.put((float((flat - full).abs().max()), float(full.abs().max()), red.world))
+        out.put(res)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,12 +71,15 @@ def test_bucketed_allreduce_equals_full_batch_gradient():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    err, scale, world = q.get(timeout=240)
+    res = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert world == 2
-    assert err <= 1e-6 * max(1.0, scale), (err, scale)
+    for (wire, mode), (err, scale, world) in res.items():
+        assert world == 2
+        # fp32 wire: summation order only; bf16 wire: every addend and the sum are rounded to 8 bits of mantissa
+        tol = 1e-6 * max(1.0, scale) if wire == "f32" else 2.0 ** -7 * scale
+        assert err <= tol, (wire, mode, err, scale)
 
 
 def test_shard_range():

@@ -46,3 +46,36 @@ def test_c_forward_golden(cref, golden_dir, case, wk):
     cref.cpuref_forward(_p(pcA), _p(pcB), None, 2, 64, 8, 5, 0.125, *[_p(w) for w in ws], 1024, _p(ab), _p(ba))
     assert np.abs(ab - d["pred_listAB_f64"][:, :, 0]).max() <= 5e-5
     assert np.abs(ba - d["pred_listBA_f64"][:, :, 0]).max() <= 5e-5
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_c_train_step_golden(cref, golden_dir, variant):
+    """cpuref_train_step (the CPU baseline of bench.py: forward + backward to the 8 variables; variant 0 'compact', 1 'faithful
+    dataflow' = materialised window tensor + all-centres mask/argmax) against the reference's losses and autodiff gradients
+    (tests/golden/path_bwd_s2_wide.npz)."""
+    fp = ctypes.POINTER(ctypes.c_float)
+    cref.cpuref_train_step.argtypes = [fp] * 4 + [ctypes.c_int] * 4 + [ctypes.c_float] + [fp] * 8 + [ctypes.c_int] * 3 + [fp] * 11
+    d = np.load(os.path.join(golden_dir, "path_bwd_s2_wide.npz"))
+    W = synth.make_weights("wide")
+    n = "pc_compare/dpdist_local/mapper_conv%d/%s"
+    ws = [np.ascontiguousarray(W[n % (l, t)].reshape(-1, W[n % (l, t)].shape[-1]) if t == "weights" else W[n % (l, t)], np.float32)
+          for l in (1, 2, 3, 4) for t in ("weights", "biases")]
+    pcA, pcB, lab, noise = (np.ascontiguousarray(d[k], np.float32) for k in ("pcA", "pcB", "labels", "noise"))
+    H, D = 1024, 2503
+    loss = np.zeros(2, np.float32)
+    g = {"1w": np.zeros((D, H), np.float32), "1b": np.zeros(H, np.float32), "2w": np.zeros((H, H), np.float32), "2b": np.zeros(H, np.float32),
+         "3w": np.zeros((H, H), np.float32), "3b": np.zeros(H, np.float32), "4w": np.zeros((H, 3), np.float32), "4b": np.zeros(3, np.float32)}
+    ab, ba = np.zeros((2, 64, 3), np.float32), np.zeros((2, 64, 3), np.float32)
+    cref.cpuref_train_step(_p(pcA), _p(pcB), _p(noise), _p(lab), 2, 64, 8, 5, 0.125, *[_p(w) for w in ws], H, variant, 1, _p(loss),
+                           _p(g["1w"]), _p(g["1b"]), _p(g["2w"]), _p(g["2b"]), _p(g["3w"]), _p(g["3b"]), _p(g["4w"]), _p(g["4b"]), _p(ab), _p(ba))
+    assert abs(loss[0] - float(d["loss_samples_f64"])) <= 2e-5 and abs(loss[1] - float(d["loss_pred_f64"])) <= 2e-5
+    assert np.abs(ab - d["pred_listAB_f64"][:, :, 0]).max() <= 5e-5
+    for key, arr in g.items():
+        ref_norm = float(d["g%s_norm_f64" % key])
+        got_norm = float(np.sqrt((arr.astype(np.float64) ** 2).sum()))
+        assert abs(got_norm - ref_norm) <= 1e-4 * max(ref_norm, 1e-6), (key, got_norm, ref_norm)
+        if key.endswith("w"):
+            assert np.abs(arr[:16, :16] - d["g%s_corner_f64" % key]).max() <= 2e-5 * max(1.0, np.abs(d["g%s_corner_f64" % key]).max())
+            assert np.abs(arr.sum(0) - d["g%s_colsum_f64" % key]).max() <= 1e-3 * max(1.0, np.abs(d["g%s_colsum_f64" % key]).max())
+        else:
+            assert np.abs(arr - d["g%s_f64" % key]).max() <= 2e-5 * max(1.0, np.abs(d["g%s_f64" % key]).max())
