@@ -14,7 +14,7 @@ namespace dpd {
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
              size_t ws_bytes, hipStream_t s, float* colsum = nullptr, const float* A2 = nullptr, const float* B2 = nullptr,
-             float* C2 = nullptr);
+             float* C2 = nullptr, const ColsumTwoStep* cs2 = nullptr);
 
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
@@ -62,7 +62,7 @@ static size_t plane_bytes(int dtype, int Q, int KP, int H) {
 static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                    int ldb, float* C, int ldc, const float* bias, const float* gate, int epilogue, void* ws, size_t ws_bytes,
                    Scratch scr, hipStream_t s, float* colsum = nullptr, const void* Apl = nullptr, const void* Bpl = nullptr,
-                   const X3Out* out = nullptr) {
+                   const X3Out* out = nullptr, const ColsumTwoStep* cs2 = nullptr) {
     const int ra = transA ? K : M, ca = transA ? M : K;   // stored shape of A, B
     const int rb = transB ? N : K, cb = transB ? K : N;
     const bool planes_ok = dtype != 0 && !(K % 32) && !(ra & 7) && !(ca & 7) && !(rb & 7) && !(cb & 7) && !(transA && transB);
@@ -75,8 +75,9 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
         const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         if ((tile == 9 || tile == 5 || tile == 10) && tiles128 < 200) tile = 8;
         return gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, gate, epilogue, colsum ? 1 : split, tile, ws, ws_bytes,
-                        s, colsum);
+                        s, colsum, nullptr, nullptr, nullptr, cs2);
     }
+    if (cs2) return DPD_E_UNSUPPORTED;
     const int np = dtype == 1 ? 3 : 1;
     const size_t ae = (size_t)M * K, be = (size_t)K * N;
     const size_t need = (size_t)np * 2 * ((Apl ? 0 : ae) + (Bpl ? 0 : be));
@@ -723,7 +724,7 @@ extern "C" int dpd_decoder_fwd_gather(const dpd_gather* src, const float* mask, 
 }
 
 extern "C" int dpd_decoder_bwd_weights_gather(const dpd_gather* src, const float* g1, int Qb, int KP, int H, float* dW1, void* ws,
-                                              size_t ws_bytes, void* stream) {
+                                              size_t ws_bytes, void* stream) {   // (db1: from dpd_decoder_bwd_data's sg->db1)
     using namespace dpd;
     if (!g1 || !dW1) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
@@ -833,12 +834,20 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     }
     // exact-fp32 path with transposed weight copies: the NT products become NN (weights read row-coalesced)
     const bool t3 = dtype == 0 && p->W3T, t2 = dtype == 0 && p->W2T, t1 = dtype == 0 && p->W1pT;
+    // deterministic db2 / db1: the dH GEMMs store 32-row partial column sums of g2 / g1 into sg->db_partials ([2][ceil(Qb/32)][H]);
+    // dpd_decoder_bwd_weights[_pair] called with the same pointer adds them up.  Needs the register-streamed kernels.
+    float* dbp = (sg && sg->db_partials && dtype == 0) ? sg->db_partials : nullptr;
+    const int nrb = (Qb + 31) / 32;
+    const int op3 = t3 ? OP_BWD_DH_T : OP_BWD_DH, op2 = t2 ? OP_BWD_DH_T : OP_BWD_DH;
+    if (dbp && !(g_plan_tile[op3] >= 30 && g_plan_tile[op2] >= 30)) return DPD_E_UNSUPPORTED;
+    ColsumTwoStep c2{}, c1{};
+    c2.part_out = dbp; c1.part_out = dbp ? dbp + (size_t)nrb * H : nullptr;
     if (phases & 2)
-        if (int rc = gemm_dt(dtype, t3 ? OP_BWD_DH_T : OP_BWD_DH, 0, t3 ? 0 : 1, Qb, H, H, g3, H, t3 ? p->W3T : p->W3, H, g2, H, nullptr, h2, 3,
-                             nullptr, 0, scr, s, db2)) return rc;
+        if (int rc = gemm_dt(dtype, op3, 0, t3 ? 0 : 1, Qb, H, H, g3, H, t3 ? p->W3T : p->W3, H, g2, H, nullptr, h2, 3,
+                             nullptr, 0, scr, s, dbp ? nullptr : db2, nullptr, nullptr, nullptr, dbp ? &c2 : nullptr)) return rc;
     if (phases & 4)
-        if (int rc = gemm_dt(dtype, t2 ? OP_BWD_DH_T : OP_BWD_DH, 0, t2 ? 0 : 1, Qb, H, H, g2, H, t2 ? p->W2T : p->W2, H, g1, H, nullptr, h1, 3,
-                             nullptr, 0, scr, s, db1)) return rc;
+        if (int rc = gemm_dt(dtype, op2, 0, t2 ? 0 : 1, Qb, H, H, g2, H, t2 ? p->W2T : p->W2, H, g1, H, nullptr, h1, 3,
+                             nullptr, 0, scr, s, dbp ? nullptr : db1, nullptr, nullptr, nullptr, dbp ? &c1 : nullptr)) return rc;
     if (dX && (phases & 4)) {   // as-loss mode: gradient w.r.t. the gathered rows, dX = g1 W1p^T  [Qb,KP]
         if (int rc = gemm_dt(dtype, t1 ? OP_BWD_DX_T : OP_BWD_DX, 0, t1 ? 0 : 1, Qb, KP, H, g1, H, t1 ? p->W1pT : p->W1p, t1 ? KP : H, dX, KP,
                              nullptr, nullptr, 0, nullptr, 0, scr, s)) return rc;
@@ -848,7 +857,7 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
 
 extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
                                        int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
-                                       void* stream) {
+                                       const float* db_partials, void* stream) {
     using namespace dpd;
     if (!act || !g || !dW) return DPD_E_NULL;
     if (layer == 4 && !db) return DPD_E_NULL;
@@ -880,11 +889,20 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     const void* apl = !pl ? nullptr : (layer == 1 ? pl->X_r8 : (layer == 2 ? pl->h1_r8 : pl->h2_r8));
     const void* gpl = !pl ? nullptr : (layer == 1 ? pl->g1_r8 : (layer == 2 ? pl->g2_r8 : pl->g3_r8));
     if (dtype != 0 && !(apl && gpl) && !scr.p) return DPD_E_WORKSPACE;
-    // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout]
+    // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout].  On the register-streamed fp32 kernels the bias gradient db = colsum(g) falls out
+    // of the B operand the GEMM streams anyway (deterministic, no atomics, no extra launch).
+    // With db_partials (the 32-row partial column sums dpd_decoder_bwd_data stored for this layer's g: layers 1 and 2) the bias
+    // gradient is finished by this GEMM's first-row-block waves: deterministic, no atomics, no extra launch.
+    const int tile_w = g_plan_tile[op];
+    const bool free_db = db && db_partials && (layer == 1 || layer == 2) && dtype == 0 && tile_w >= 30 && tile_w <= 39 && !(Qb % 32);
+    if (db && db_partials && !free_db) return DPD_E_UNSUPPORTED;
+    ColsumTwoStep cs{};
+    cs.part_in = db_partials ? db_partials + (layer == 1 ? (size_t)((Qb + 31) / 32) * Nout : 0) : nullptr;
+    cs.out = db; cs.nparts = (Qb + 31) / 32;
     if (int rc = gemm_dt(dtype, op, 1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, ws, slab_bytes, scr, s, nullptr,
-                         apl, gpl, nullptr))
+                         apl, gpl, nullptr, free_db ? &cs : nullptr))
         return rc;
-    if (!db) return 0;   // bias gradient already produced by dpd_decoder_bwd_data (fused)
+    if (!db || free_db) return 0;   // bias gradient not wanted / already produced
     float* part = (float*)((char*)ws + slab_bytes);
     DPD_LAUNCH(colsum_stage1<0>, dim3((Nout + 63) / 64, kColChunks), dim3(256), 0, s, g, Nout, (const float*)nullptr,
                        Qb, Nout, part);
@@ -898,11 +916,12 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
 // as well as two 256-tile launches and pay one prologue/epilogue instead of two.
 extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
                                             float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws,
-                                            size_t ws_bytes, const dpd_planes* pl, void* stream) {
+                                            size_t ws_bytes, const dpd_planes* pl, float* dbA, const float* db_partials, void* stream) {
     using namespace dpd;
     if (!actA || !gA || !dWA || !actB || !gB || !dWB) return DPD_E_NULL;
     if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
+    if (dtype != 0 && dbA) return DPD_E_UNSUPPORTED;
     if (dtype != 0) {   // plane path: two launches (the planes of one GEMM at a time live in the scratch)
         const Scratch scr = scratch_of(ws, ws_bytes, Kin > Nout ? Kin : Nout, Nout);
         pl = usable_planes(pl, dtype, pl ? pl->Q : 0, Qb, 32, Nout);
@@ -924,6 +943,9 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
     }
     int tile = g_plan_tile[OP_BWD_DW23];
     if (!((tile >= 4 && tile <= 14) || (tile >= 30 && tile <= 39))) tile = 8;
+    if (dbA && !(db_partials && tile >= 30 && tile <= 39)) return DPD_E_UNSUPPORTED;   // layer 2's bias gradient from the stored partials
+    ColsumTwoStep cs{};
+    cs.part_in = db_partials; cs.out = dbA; cs.nparts = (Qb + 31) / 32;     // (layer 2 = problem A: the first half of the scratch)
     return gemm_f32(1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, 1, tile, nullptr, 0,
-                    (hipStream_t)stream, nullptr, actB, gB, dWB);
+                    (hipStream_t)stream, nullptr, actB, gB, dWB, dbA ? &cs : nullptr);
 }

@@ -471,7 +471,7 @@ static double tile_eff(int M, int N, int BM, int BN, int split) {
 
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
-             size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2) {
+             size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2, const ColsumTwoStep* cs2) {
     if (!A || !B || !C) return DPD_E_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || split_k < 1) return DPD_E_DIM;
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3)) return DPD_E_UNSUPPORTED;
@@ -496,6 +496,12 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.colsum = (split_k > 1) ? nullptr : colsum;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
+    if (cs2) {   // deterministic bias gradients in two steps (register-streamed kernels only; rows of a partial block = 32)
+        if (!(tile >= 30 && tile <= 39) || (cs2->part_out && (split_k > 1 || colsum))) return DPD_E_UNSUPPORTED;
+        g.colsum_part = cs2->part_out;
+        g.colsum_part_in = cs2->part_in; g.colsum_part_in2 = cs2->part_in2;
+        g.colsum_b = cs2->out; g.colsum_b2 = cs2->out2; g.colsum_nparts = cs2->nparts;
+    }
     if (A2 && (!B2 || !C2 || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
     if (A2 && !whole_tiles) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA / register-streamed kernels only
     if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
@@ -604,5 +610,5 @@ extern "C" int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const f
                             int ldb, float* Cout, int ldc, const float* bias, const float* gate, int epilogue,
                             int split_k, int tile, void* ws, size_t ws_bytes, void* stream) {
     return dpd::gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, Cout, ldc, bias, gate, epilogue, split_k, tile, ws,
-                         ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
+                         ws_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, nullptr);
 }

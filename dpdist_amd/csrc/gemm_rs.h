@@ -121,6 +121,26 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- epilogue operands, requested before the main loop (they depend on nothing computed here): the bias value of this
+    // lane's column and, for the ReLU-gate epilogue of the backward data GEMMs, the 16 gate values per accumulator tile.  Held
+    // in registers when the wave tile is small enough (<= 2 accumulator tiles); otherwise fetched at the end like before.
+    constexpr bool PRE = TM * TN <= 2;
+    const int epi = g.epi;
+    float ebias[TN], egate[PRE ? TM : 1][PRE ? TN : 1][16];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        ebias[j] = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[min(n0 + 32 * j + l31, g.N - 1)] : 0.f;
+    if (PRE && epi == EPI_GATE && g.split_k == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
+                    egate[i][j][r] = g.gate[(size_t)row * g.ldc + min(n0 + 32 * j + l31, g.N - 1)];
+                }
+    }
     // ---- gather state (ASRC != 0) ----
     const uint2* __restrict__ ktab = g.ktab;
     unsigned gbase[TM], gmask[TM], gxyz[TM];      // ASRC 1: per row {fv byte offset, validity bits, xyz byte offset}
@@ -251,10 +271,46 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
 
     GemmArgs gs = g;
     if (grp) gs.C = g.C2;
+    // Bias gradient, second step (see GemmArgs::colsum_part): the first row block's waves add the 32-row partial column sums an
+    // EARLIER launch stored, in block order -> deterministic, no atomics, no extra launch.  (Adding them up inside the K loop of
+    // this kernel instead was measured 25 % slower on the dW GEMMs: VALU work between the dependent MFMAs of a single accumulator.)
+    float* csb_out = grp ? g.colsum_b2 : g.colsum_b;
+    const float* csb_in = grp ? g.colsum_part_in2 : g.colsum_part_in;
+    if (csb_out && csb_in && m0 == 0 && z == 0 && half == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + 32 * j + l31;
+            if (col < g.N) {
+                float t = 0.f;
+                for (int pb0 = 0; pb0 < g.colsum_nparts; pb0 += 16) {     // 16 loads in flight, added in block order
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = (pb0 + u < g.colsum_nparts) ? csb_in[(size_t)(pb0 + u) * g.N + col] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t += v[u];
+                }
+                csb_out[col] = t;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) store_tile(gs, acc[i][j], z, m0 + 32 * i, n0 + 32 * j + l31, half);
+        for (int j = 0; j < TN; ++j) {
+            if (PRE && g.split_k == 1 && epi != EPI_NONE) {     // epilogue on the preloaded operands (same arithmetic as tile_values)
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = acc[i][j][r] + ebias[j];
+                    if (epi == EPI_BIAS_RELU) x = fmaxf(x, 0.f);
+                    if (epi == EPI_GATE) x = (egate[i][j][r] > 0.f) ? x : 0.f;
+                    v[r] = x;
+                }
+                put_tile(gs, v, z, m0 + 32 * i, n0 + 32 * j + l31, half);
+            } else {
+                store_tile(gs, acc[i][j], z, m0 + 32 * i, n0 + 32 * j + l31, half);
+            }
+        }
 }
 
 template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D, int ASRC = 0>

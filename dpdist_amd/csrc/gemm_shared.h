@@ -15,6 +15,15 @@ struct GemmArgs {
     const float* bias;
     const float* gate;
     float* colsum;    // optional [N]: += column sums of the stored values (atomics; caller zeroes it)
+    // deterministic bias gradients without atomics or an extra launch: a GEMM whose rows are data rows stores, per 32-row block,
+    // the column sums of what it writes (colsum_part [ceil(M/32)][N]); a LATER GEMM's first-row-block waves add those partials
+    // in a fixed order into colsum_b [N] (reading colsum_part_in, nparts blocks; *_2: the grouped second problem)
+    float* colsum_part;
+    const float* colsum_part_in;
+    const float* colsum_part_in2;
+    float* colsum_b;
+    float* colsum_b2;
+    int colsum_nparts;
     const float* A2;  // optional second problem of identical shape (grouped launch): blocks [per_z, 2*per_z)
     const float* B2;
     float* C2;
@@ -30,6 +39,16 @@ struct GemmArgs {
     int split_k;      // >= 1
     int k_chunk;      // K range per split (multiple of BK)
     long slab_stride; // floats between split-K slabs (0 when split_k == 1)
+};
+
+// host-side bundle of the two-step bias-gradient pointers (see GemmArgs::colsum_part)
+struct ColsumTwoStep {
+    float* part_out = nullptr;         // step 1: [ceil(M/32)][N] partial column sums of the values this GEMM stores
+    const float* part_in = nullptr;    // step 2: partials of an earlier GEMM, `nparts` blocks of N floats ...
+    const float* part_in2 = nullptr;
+    float* out = nullptr;              // ... summed in block order into out [N] by this GEMM's first-row-block waves
+    float* out2 = nullptr;
+    int nparts = 0;
 };
 
 // Epilogue of one 32x32 MFMA tile: acc[r] is C[row0 + (r&3) + 8*(r>>2) + 4*half][col].  The gate / bias values are
@@ -69,9 +88,12 @@ __device__ __forceinline__ void put_tile(const GemmArgs& g, const float (&v)[16]
             cs += v[r];
         }
     }
-    if (g.colsum) {   // bias gradient fused into the dH GEMM: 32-row partial per wave, one atomic per column
+    if (g.colsum || g.colsum_part) {   // bias gradient fused into the dH GEMM: 32-row partial per wave
         cs += __shfl_xor(cs, 32, 64);
-        if (half == 0 && col_ok) atomicAdd(g.colsum + col, cs);
+        if (half == 0 && col_ok) {
+            if (g.colsum) atomicAdd(g.colsum + col, cs);                            // one atomic per column (order-dependent round-off)
+            else g.colsum_part[(size_t)(row0 >> 5) * g.N + col] = cs;              // or a plain store for the deterministic two-step form
+        }
     }
 }
 

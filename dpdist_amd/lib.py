@@ -21,7 +21,7 @@ class DecoderParams(Structure):
 
 class SmallGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("db1", "db2", "db3", "dW4", "db4", "partials", "l1_pred", "l1_labels", "l1_loss")] + [
-        ("l1_gscale", c_float)]
+        ("l1_gscale", c_float), ("db_partials", c_void_p)]
 
 
 class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
@@ -56,8 +56,8 @@ SIGNATURES = {
     "dpd_decoder_fwd_gather": (c_int, [POINTER(Gather), c_void_p, c_int, c_int, c_int, POINTER(DecoderParams)] + [c_void_p] * 6),
     "dpd_decoder_bwd_weights_gather": (c_int, [POINTER(Gather), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                        c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
-    "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p]),
+                                        c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p]),
+    "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p, c_void_p]),
     "dpd_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "dpd_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
@@ -147,6 +147,7 @@ def make_params(W1p, b1, W2, b2, W3, b3, W4, b4, W2T=None, W3T=None, W1pT=None):
     return DecoderParams(*[None if t is None else t.data_ptr() for t in (W1p, b1, W2, b2, W3, b3, W4, b4, W2T, W3T, W1pT)])
 
 
-def make_small_grads(db1, db2, db3, dW4, db4, partials=None, l1_pred=None, l1_labels=None, l1_loss=None, l1_gscale=1.0):
+def make_small_grads(db1, db2, db3, dW4, db4, partials=None, l1_pred=None, l1_labels=None, l1_loss=None, l1_gscale=1.0,
+                     db_partials=None):
     return SmallGrads(*[None if t is None else t.data_ptr() for t in (db1, db2, db3, dW4, db4, partials, l1_pred, l1_labels, l1_loss)],
-                      float(l1_gscale))
+                      float(l1_gscale), None if db_partials is None else db_partials.data_ptr())

@@ -131,7 +131,7 @@ def decoder_bwd_weights(layer, act, g, Qb, dW, db, ws, dtype=0):
     """dW/db of one layer from its input activation `act` [>=Qb, Kin] and output gradient `g` [Qb, Nout]."""
     Kin, Nout = dW.shape
     L.check(L.load().dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), Qb, Kin, Nout, L.DTYPES[dtype], L.ptr(dW),
-                                             L.ptr(db), L.ptr(ws), ws.numel() * 4, None, L.cur_stream()),
+                                             L.ptr(db), L.ptr(ws), ws.numel() * 4, None, None, L.cur_stream()),
             "dpd_decoder_bwd_weights(layer=%d)" % layer)
 
 

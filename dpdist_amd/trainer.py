@@ -101,6 +101,7 @@ class DPDistTrainer:
         self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7], self._partials)
         # training loss fused into the output-layer backward (no separate loss launch); labels pointer is filled in per step
         self.fuse_loss = H % 256 == 0 and H <= 1024 and os.environ.get("DPD_FUSE_LOSS", "1") == "1"
+        self._db_partials = f(2 * ((BN + 31) // 32) * H)       # 32-row partial column sums of g2 / g1 (deterministic db2 / db1)
         # optimizer schedule on the device (include/dpdist_capi.h: dpd_adam_sched): [step, beta1_power, beta2_power, lr_t, lr]
         self.opt_state = torch.zeros(8, device=dev, dtype=torch.float32)
         self.opt_state[1:3] = 1.0
@@ -197,12 +198,17 @@ class DPDistTrainer:
         if self._wdirty and join_weights is None:
             self.refresh_weight_planes()
         d, wsb = self._gviews, self.ws.numel() * 4
+        gv = self._gviews
+        # exact-fp32 compute type: db1 / db2 are by-products of the dW GEMMs (column sums of the operand they stream: deterministic),
+        # so the data chain's atomic column sums are switched off; the plane compute types keep the fused-epilogue form
+        det_db = self.dt == 0 and BN % 32 == 0 and not self.fused and os.environ.get("DPD_DET_DB", "1") == "1"
+        sdb1, sdb2 = (None, None) if det_db else (gv[1], gv[3])
+        dbp = self._db_partials if det_db else None
         if self.fuse_loss:      # d loss_samples / d pred and the two loss values come out of the output-layer backward
-            gv = self._gviews
-            small = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7], self._partials, self.pred, labels, self.loss, 1.0)
+            small = L.make_small_grads(sdb1, sdb2, gv[5], gv[6], gv[7], self._partials, self.pred, labels, self.loss, 1.0, dbp)
         else:
             L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
-            small = self._csmall
+            small = L.make_small_grads(sdb1, sdb2, gv[5], gv[6], gv[7], self._partials, db_partials=dbp)
 
         def data(phases):   # db1..db3, dW4, db4 fall out of the data chain (fused epilogues / one small kernel)
             L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
@@ -215,8 +221,10 @@ class DPDistTrainer:
                 L.check(lib.dpd_decoder_bwd_weights_gather(self._gsrc, L.ptr(self.g1), BN, P.KP, P.H, L.ptr(dW), L.ptr(self.ws), wsb, L.cur_stream()),
                         "dpd_decoder_bwd_weights_gather")
                 return
+            db = gv[2 * layer - 1] if (det_db and layer in (1, 2)) else None
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
-                                                L.ptr(dW), None, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
+                                                L.ptr(dW), L.ptr(db), L.ptr(self.ws), wsb, self._planes, L.ptr(dbp) if db is not None else None,
+                                                L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
         if self.reducer and os.environ.get("DPD_DP_SCHEDULE", "early") == "early":
@@ -249,7 +257,8 @@ class DPDistTrainer:
             self.reducer.reduce_async(0)
         if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
             L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
-                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes, L.cur_stream()),
+                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes,
+                                                     L.ptr(gv[3]) if det_db else None, L.ptr(dbp), L.cur_stream()),
                     "dpd_decoder_bwd_weights_pair")
         else:
             dw(2, self.h1, self.g2, d[2])

@@ -199,6 +199,11 @@ typedef struct dpd_small_grads {
      * itself (`dpred` may be NULL) and l1_loss [2] = (loss_samples, loss_pred) comes out of the same reduction as db3/dW4/db4.
      * Needs H % 256 == 0, H <= 1024 (else DPD_E_UNSUPPORTED: use dpd_l1_loss).                                              */
     const float* l1_pred; const float* l1_labels; float* l1_loss; float l1_gscale;
+    /* optional scratch, 2 * ((Qb + 31) / 32) * H floats (DPD_F32): instead of atomic column sums into db2 / db1 (order-dependent
+     * round-off), the dH GEMMs store 32-row partial sums of g2 / g1 here and dpd_decoder_bwd_weights(layer 2 / 1, db, ...,
+     * db_partials = this pointer) or dpd_decoder_bwd_weights_pair(..., dbA, db_partials) finishes them: bitwise reproducible.
+     * db1 / db2 above are then ignored.                                                                                       */
+    float* db_partials;
 } dpd_small_grads;
 
 int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,
@@ -213,13 +218,16 @@ int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, 
  * produced by dpd_decoder_bwd_data.  ws: dpd_workspace_bytes() bytes.                              */
 int dpd_decoder_bwd_weights(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout,
                             int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
-                            void* stream);
+                            const float* db_partials, void* stream);
 
 /* dW of two layers of identical shape (layers 2 and 3: dW = act^T g, [Kin,Nout]) in ONE grouped launch; no bias
- * gradients (they come from dpd_decoder_bwd_data).  Qb must be a multiple of 32.                          */
+ * gradients unless dbA / dbB are given (see below).  Qb must be a multiple of 32.                          */
 int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
                                  float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws, size_t ws_bytes,
-                                 const dpd_planes* pl, void* stream);
+                                 const dpd_planes* pl, float* dbA, const float* db_partials, void* stream);
+/* dbA + db_partials (may be NULL; DPD_F32 only): layer 2's bias gradient colsum(gA) [Nout], finished from the partial sums
+ * dpd_decoder_bwd_data stored in dpd_small_grads::db_partials (see there).  db_partials == NULL with db != NULL in
+ * dpd_decoder_bwd_weights keeps the older two-kernel column sum.                                                         */
 
 /* Scratch needed by the decoder entry points for the given sizes and compute type (split-K slabs, column-sum
  * partials and, for dtype != DPD_F32, the bf16 operand planes of one GEMM at a time).                   */
