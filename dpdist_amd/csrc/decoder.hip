@@ -38,7 +38,7 @@ enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 =
 // (run-to-run spread between boxes is ~10 %; the ranking inside one run is stable.  DMA kernels need K % 32 == 0;
 //  gemm_f32 falls back to the register-staged 64x64 kernel otherwise.)
 static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32, 30};
-static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 3};
+static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 3};   // (0 = tail split, gemm_rs.h: measured no gain on dW1, 0.525 vs 0.5215 ms of GEMM per step)
 static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
 static int g_x3_pair_tile = 0;
 
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeJobs J) {
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
     if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 12) { dpd::g_x3_tile[op - 16] = tile; return 0; }
     if (op == 32 && tile >= 0 && tile <= 12) { dpd::g_x3_pair_tile = tile; return 0; }
-    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 1 || split_k > 8) return DPD_E_DIM;
+    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;
     return 0;
@@ -878,8 +878,9 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     }
     if ((Nout & 3) || (Kin & 3) || (lda & 3)) return DPD_E_UNSUPPORTED;
     const int op = (layer == 1) ? OP_BWD_DW1 : OP_BWD_DW23;
-    const int split = dtype == 0 ? g_plan_split[op] : 1;
-    const size_t slab_bytes = (split > 1) ? (size_t)split * Kin * Nout * sizeof(float) : 0;
+    const int split = dtype == 0 ? g_plan_split[op] : 1;      // 0 = tail split: up to 3 slabs for the last round's K pieces
+    size_t slab_bytes = (split > 1) ? (size_t)split * Kin * Nout * sizeof(float) : 0;
+    if (split == 0) slab_bytes = (ws && ws_bytes >= (size_t)3 * Kin * Nout * sizeof(float)) ? (size_t)3 * Kin * Nout * sizeof(float) : 0;
     const size_t col_bytes = db ? colsum_ws_floats(Nout, 0) * sizeof(float) : 0;
     if ((slab_bytes + col_bytes) && (!ws || ws_bytes < slab_bytes + col_bytes)) return DPD_E_WORKSPACE;
     const Scratch scr = scratch_of(ws, ws_bytes, Kin > Nout ? Kin : Nout, Nout);

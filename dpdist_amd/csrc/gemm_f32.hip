@@ -473,6 +473,13 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
              size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2, const ColsumTwoStep* cs2) {
     if (!A || !B || !C) return DPD_E_NULL;
+    // split_k == 0: "tail split" (gemm_rs.h): whole-K tiles, only the partial last round of tiles is cut along K (needs ws for
+    // (pieces - 1) slabs of M*N floats; pieces <= 4).  Silently a plain launch when it does not apply.
+    bool tail_auto = false;
+    if (split_k == 0) {
+        split_k = 1;
+        tail_auto = tile >= 30 && tile <= 39 && ws && ws_bytes >= (size_t)3 * M * N * sizeof(float) && epilogue == EPI_NONE;
+    }
     if (M <= 0 || N <= 0 || K <= 0 || split_k < 1) return DPD_E_DIM;
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3)) return DPD_E_UNSUPPORTED;
     if (transA && (M & 3)) return DPD_E_UNSUPPORTED;
@@ -496,6 +503,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.colsum = (split_k > 1) ? nullptr : colsum;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
+    if (tail_auto && !colsum && !A2) { g.tail_split = -1; g.tail_slab = (float*)ws; }
     if (cs2) {   // deterministic bias gradients in two steps (register-streamed kernels only; rows of a partial block = 32)
         if (!(tile >= 30 && tile <= 39) || (cs2->part_out && (split_k > 1 || colsum))) return DPD_E_UNSUPPORTED;
         g.colsum_part = cs2->part_out;

@@ -85,14 +85,25 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
     const int per_z = tilesM * tilesN;
     const int ngrp = g.A2 ? 2 : 1;
-    const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
-    const int grp = sid / (per_z * g.split_k);
-    const int sid1 = sid % (per_z * g.split_k);
-    const int z = sid1 / per_z, t = sid1 % per_z;
+    int grp = 0, z, t;
+    unsigned kbeg, kend;
+    if (g.tail_split > 1) {     // whole-K tiles first, then the K pieces of the last round's tiles
+        const int sid = xcd_remap(blockIdx.x, g.tail_first + (per_z - g.tail_first) * g.tail_split);
+        if (sid < g.tail_first) { t = sid; z = 0; kbeg = 0; kend = g.K; }
+        else {
+            const int u = sid - g.tail_first;
+            t = g.tail_first + u / g.tail_split; z = u % g.tail_split;
+            kbeg = z * g.tail_chunk; kend = min(g.K, (int)kbeg + g.tail_chunk);
+        }
+    } else {
+        const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
+        grp = sid / (per_z * g.split_k);
+        const int sid1 = sid % (per_z * g.split_k);
+        z = sid1 / per_z; t = sid1 % per_z;
+        kbeg = z * g.k_chunk; kend = min(g.K, (int)kbeg + g.k_chunk);
+    }
     const int m0 = (t / tilesN) * BM + (wave / WC) * 32 * TM, n0 = (t % tilesN) * BN + (wave % WC) * 32 * TN;
     if (m0 >= g.M || n0 >= g.N) return;   // ragged edge: this wave has no output (no barriers anywhere, so it may leave)
-    const unsigned kbeg = z * g.k_chunk;
-    const unsigned kend = min(g.K, (int)kbeg + g.k_chunk);
     const int nt = (int)(kend - kbeg) / 32;
     const float* gA = grp ? g.A2 : g.A;
     const float* gB = grp ? g.B2 : g.B;
@@ -271,6 +282,11 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
 
     GemmArgs gs = g;
     if (grp) gs.C = g.C2;
+    if (g.tail_split > 1 && z > 0) {      // K piece of a tail tile: its own slab, dense [M, N]
+        gs.C = g.tail_slab + (size_t)(z - 1) * g.M * g.N;
+        gs.ldc = g.N;
+    }
+    const int zs = (g.tail_split > 1) ? 0 : z;     // slab index for put_tile (split-K slabs only)
     // Bias gradient, second step (see GemmArgs::colsum_part): the first row block's waves add the 32-row partial column sums an
     // EARLIER launch stored, in block order -> deterministic, no atomics, no extra launch.  (Adding them up inside the K loop of
     // this kernel instead was measured 25 % slower on the dW GEMMs: VALU work between the dependent MFMAs of a single accumulator.)
@@ -306,19 +322,64 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
                     if (epi == EPI_GATE) x = (egate[i][j][r] > 0.f) ? x : 0.f;
                     v[r] = x;
                 }
-                put_tile(gs, v, z, m0 + 32 * i, n0 + 32 * j + l31, half);
+                put_tile(gs, v, zs, m0 + 32 * i, n0 + 32 * j + l31, half);
             } else {
-                store_tile(gs, acc[i][j], z, m0 + 32 * i, n0 + 32 * j + l31, half);
+                store_tile(gs, acc[i][j], zs, m0 + 32 * i, n0 + 32 * j + l31, half);
             }
         }
 }
 
+// C[r][:] += sum_z slab_z[r][:] for the rows of the tail tiles (fixed order; float4, N % 4 == 0)
+__global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ C, int ldc, const float* __restrict__ slab, int nslab,
+                                                           long slab_stride, int row0, int M, int N) {
+    const long total4 = (long)(M - row0) * N / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const int row = row0 + (int)(e / N), col = (int)(e % N);
+        float4 a = *reinterpret_cast<const float4*>(C + (size_t)row * ldc + col);
+        for (int z = 0; z < nslab; ++z) {
+            const float4 x = *reinterpret_cast<const float4*>(slab + (size_t)z * slab_stride + (size_t)row * N + col);
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        }
+        *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = a;
+    }
+}
+
 template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D, int ASRC = 0>
-static int launch_rs(const GemmArgs& g, hipStream_t s) {
+static int launch_rs(const GemmArgs& g_in, hipStream_t s) {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
-    const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.split_k * (g.A2 ? 2 : 1);
+    GemmArgs g = g_in;
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN, T = tilesM * tilesN;
+    int nblk = T * g.split_k * (g.A2 ? 2 : 1);
+    int row0 = 0;
+    if (g.tail_split == -1) {
+        // Tail split requested (tail_slab given): T workgroup tiles on 256 CUs run in ceil(T / 256) rounds; when the last round
+        // is less than 3/4 full its tiles are cut into K pieces so that it takes 1/pieces of a round (dW1: 640 tiles = 2.5 rounds
+        // -> 512 whole tiles + 128 tiles x 2 halves: 3 rounds become 2.5).  Whole tile ROWS only, >= 8 K-tiles per piece.
+        g.tail_split = 0;
+        const int r = T % 256, nfull = T - r;
+        if (T > 256 && r > 0 && r < 192 && g.split_k == 1 && !g.A2 && g.epi == EPI_NONE && !g.colsum && !g.colsum_part && g.tail_slab) {
+            int pieces = (256 + r / 2) / r;
+            pieces = pieces > 4 ? 4 : pieces;
+            const int first = (nfull / tilesN) * tilesN;
+            const int chunk = ((g.K / 32 + pieces - 1) / pieces) * 32;
+            if (pieces >= 2 && first > 0 && chunk >= 256 && chunk * (pieces - 1) < g.K) {
+                g.tail_first = first; g.tail_split = pieces; g.tail_chunk = chunk;
+                nblk = first + (T - first) * pieces;
+                row0 = (first / tilesN) * BM;
+            }
+        }
+    }
     DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D, ASRC>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);
-    return (int)hipGetLastError();
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    if (g.tail_split > 1) {
+        const long total4 = (long)(g.M - row0) * g.N / 4;
+        const int blocks = (int)((total4 + 255) / 256 < 1024 ? (total4 + 255) / 256 : 1024);
+        DPD_LAUNCH(tail_reduce_kernel, dim3(blocks), dim3(256), 0, s, g.C, g.ldc, (const float*)g.tail_slab, g.tail_split - 1,
+                   (long)g.M * g.N, row0, g.M, g.N);
+        return (int)hipGetLastError();
+    }
+    return 0;
 }
 
 // fused-gather forms (g.ktab / g.rowinfo set): layer-1 forward (NN, A = gathered rows) and dW1 (TN, A = gathered columns)

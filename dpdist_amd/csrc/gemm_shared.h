@@ -37,6 +37,11 @@ struct GemmArgs {
     int lda, ldb, ldc;
     int epi;
     int split_k;      // >= 1
+    // "tail split" (register-streamed kernels, split_k == 1, no epilogue): output tiles [0, tail_first) run their whole K range; the
+    // tiles of the partial last round, [tail_first, tiles), are cut into tail_split K pieces of tail_chunk so that every CU ends
+    // at the same time; piece 0 stores to C, piece z > 0 to tail_slab + (z-1)*M*N, a small kernel adds the slabs (fixed order)
+    int tail_first, tail_split, tail_chunk;
+    float* tail_slab;
     int k_chunk;      // K range per split (multiple of BK)
     long slab_stride; // floats between split-K slabs (0 when split_k == 1)
 };

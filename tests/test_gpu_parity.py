@@ -1145,3 +1145,32 @@ def test_checkpoint_resume_restores_optimizer_state(dev, tmp_path):
     # a weights-only checkpoint leaves the optimizer state alone
     P3, t3 = fresh()
     assert t3.load_tf_global_variables(P1.tf_state_dict()) == ["weights"] and t3.t == 0
+
+
+@pytest.mark.parametrize("shape", [(2528, 1024, 2048, 33), (1184, 512, 1024, 33), (2528, 1024, 4096, 33), (2048, 1024, 1024, 32)])
+def test_gemm_tail_split(dev, shape):
+    """split_k = 0 ("tail split", csrc/gemm_rs.h): whole-K tiles, only the partial last round of workgroup tiles is cut along K and
+    re-added in a fixed order.  Against fp64; bitwise equal to the plain launch wherever a tile was not cut; shapes whose tile
+    count fills whole rounds run as a plain launch."""
+    from dpdist_amd import ops
+    M, N, K, tile = shape
+    g = torch.Generator().manual_seed(M + K)
+    At = torch.randn(K, M, generator=g).to(dev)          # TN: the weight-gradient form
+    Bm = torch.randn(K, N, generator=g).to(dev)
+    ref = At.double().t() @ Bm.double()
+    plain = ops.gemm_f32(At, Bm, transA=True, tile=tile, split_k=1)
+    ws_big = torch.empty(3 * M * N, device=dev)
+    C = torch.empty(M, N, device=dev)
+    from dpdist_amd import lib as L
+    L.check(L.load().dpd_gemm_f32(1, 0, M, N, K, L.ptr(At), M, L.ptr(Bm), N, L.ptr(C), N, None, None, 0, 0, tile, L.ptr(ws_big),
+                                  ws_big.numel() * 4, L.cur_stream()), "dpd_gemm_f32")
+    scale = float(ref.abs().max())
+    assert (C.double() - ref).abs().max().item() <= 2e-6 * scale * (K / 1024) ** 0.5 + 1e-4
+    same = (C == plain).all(dim=1)
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if tiles % 256 == 0 or tiles < 256 or tiles % 256 >= 192:
+        assert same.all()                                   # nothing to cut
+    else:
+        assert same.any() and not same.all()                # the whole-K rows are bitwise the plain result, the tail rows are re-associated
+        first_cut = int((~same).nonzero()[0])
+        assert same[:first_cut].all() and first_cut % 64 == 0
