@@ -134,11 +134,24 @@ __global__ __launch_bounds__(256) void out_fwd_kernel(const float* __restrict__ 
     if (row >= Q) return;
     const float* h = h3 + (size_t)row * H;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int k = lane; k < H; k += 64) {
-        const float x = h[k];
-        a0 += x * W4[k * 3 + 0];
-        a1 += x * W4[k * 3 + 1];
-        a2 += x * W4[k * 3 + 2];
+    if ((H & 255) == 0) {          // 16 bytes per lane per load: H / 256 loads in flight instead of H / 64 dependent-address ones
+        for (int k = 4 * lane; k < H; k += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(h + k);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0 += xs[e] * W4[(k + e) * 3 + 0];
+                a1 += xs[e] * W4[(k + e) * 3 + 1];
+                a2 += xs[e] * W4[(k + e) * 3 + 2];
+            }
+        }
+    } else {
+        for (int k = lane; k < H; k += 64) {
+            const float x = h[k];
+            a0 += x * W4[k * 3 + 0];
+            a1 += x * W4[k * 3 + 1];
+            a2 += x * W4[k * 3 + 2];
+        }
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
     if (lane < 3) {
@@ -536,17 +549,39 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeJobs J) {
     const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
     const float* __restrict__ in = J.in[j];
     float* __restrict__ out = J.out[j];
-    const int x = threadIdx.x & 63, y0 = threadIdx.x >> 6;
+    const int x4 = (threadIdx.x & 15) * 4, y0 = threadIdx.x >> 4;          // 16 float4 per 64-wide row, 16 rows per pass
+    const bool vec = !(C & 3) && !(R & 3);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int y = y0 + 4 * i;
-        t[y][x] = (r0 + y < R && c0 + x < C) ? in[(size_t)(r0 + y) * C + c0 + x] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + 16 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + y < R) {
+            const float* src = in + (size_t)(r0 + y) * C + c0 + x4;
+            if (vec && c0 + x4 + 3 < C) v = *reinterpret_cast<const float4*>(src);
+            else {
+                if (c0 + x4 < C) v.x = src[0];
+                if (c0 + x4 + 1 < C) v.y = src[1];
+                if (c0 + x4 + 2 < C) v.z = src[2];
+                if (c0 + x4 + 3 < C) v.w = src[3];
+            }
+        }
+        t[y][x4] = v.x; t[y][x4 + 1] = v.y; t[y][x4 + 2] = v.z; t[y][x4 + 3] = v.w;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int y = y0 + 4 * i;
-        if (c0 + y < C && r0 + x < R) out[(size_t)(c0 + y) * R + r0 + x] = t[x][y];
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + 16 * i;                                           // output row c0 + y, output columns r0 + x4 .. +3
+        if (c0 + y < C) {
+            const float4 v = make_float4(t[x4][y], t[x4 + 1][y], t[x4 + 2][y], t[x4 + 3][y]);
+            float* dst = out + (size_t)(c0 + y) * R + r0 + x4;
+            if (vec && r0 + x4 + 3 < R) *reinterpret_cast<float4*>(dst) = v;
+            else {
+                if (r0 + x4 < R) dst[0] = v.x;
+                if (r0 + x4 + 1 < R) dst[1] = v.y;
+                if (r0 + x4 + 2 < R) dst[2] = v.z;
+                if (r0 + x4 + 3 < R) dst[3] = v.w;
+            }
+        }
     }
 }
 

@@ -25,11 +25,12 @@ __device__ __forceinline__ int cell_of(const GridAxis& ax, int m, float q) {
     return r;
 }
 
-__global__ __launch_bounds__(128) void patch_rows_fwd_kernel(const float* __restrict__ q, const float* __restrict__ fv,
+__global__ __launch_bounds__(256) void patch_rows_fwd_kernel(const float* __restrict__ q, const float* __restrict__ fv,
                                                               float* __restrict__ X, float* __restrict__ mask,
                                                               int32_t* __restrict__ vox, int N, int m, int k, int KP,
-                                                              GridAxis ax) {
-    const int r = blockIdx.x, tid = threadIdx.x;
+                                                              GridAxis ax, int Q) {
+    const int r = blockIdx.x * 2 + (threadIdx.x >> 7), tid = threadIdx.x & 127;   // two rows per workgroup, 128 threads each
+    if (r >= Q) return;
     const int c = r / N;
     const int G = m * m * m, h = (k - 1) / 2;
     const float qx = q[(size_t)r * 3], qy = q[(size_t)r * 3 + 1], qz = q[(size_t)r * 3 + 2];
@@ -305,8 +306,8 @@ extern "C" int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N,
         DPD_CHECK_LAUNCH();
         return 0;
     }
-    DPD_LAUNCH(patch_rows_fwd_kernel, dim3(C * N), dim3(128), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
-                       KP, make_axis(m));
+    DPD_LAUNCH(patch_rows_fwd_kernel, dim3((C * N + 1) / 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
+                       KP, make_axis(m), C * N);
     DPD_CHECK_LAUNCH();
     return 0;
 }

@@ -105,6 +105,7 @@ class DPDistTrainer:
         # optimizer schedule on the device (include/dpdist_capi.h: dpd_adam_sched): [step, beta1_power, beta2_power, lr_t, lr]
         self.opt_state = torch.zeros(8, device=dev, dtype=torch.float32)
         self.opt_state[1:3] = 1.0
+        self._dev_t, self._last_lr = 0, base_lr
         # hipGraph mode (single GPU): the whole step is captured once per input-buffer set and replayed; weight-derived
         # buffers and the small-gradient reduction run on parallel branches of the graph, off the critical path
         self.use_graph = os.environ.get("DPD_GRAPH", "0") == "1"   # opt-in: measured 4 % SLOWER than eager launches on MI355X / ROCm 7
@@ -268,32 +269,49 @@ class DPDistTrainer:
             self.reducer.reduce_async(2)
 
     def _sched(self):
-        """Advance the device-side optimizer schedule by one step (global step, beta powers, lr_t)."""
+        """(graph mode) advance the device-side optimizer schedule by one step (global step, beta powers, lr_t)."""
         base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
         L.check(L.load().dpd_adam_sched(L.ptr(self.opt_state), base_lr, int(decay_step), decay_rate, 1e-7, b1, b2, L.cur_stream()),
                 "dpd_adam_sched")
 
     def _adam(self):
+        """(graph mode) Adam with lr_t read from the device-side schedule."""
         base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
+        L.check(L.load().dpd_adam_tf_dev(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
+                                         self.P.numel, L.ptr(self.opt_state), b1, b2, eps, 1.0, L.cur_stream()), "dpd_adam_tf_dev")
+        self._wdirty = True
+
+    def apply_gradients(self):
+        """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
+        steps compute lr_t on the host (a device-side schedule kernel of one thread costs 4.7 us per step on MI355X: launch
+        latency); only the captured hipGraph step keeps the schedule on the device."""
+        base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
+        lr = learning_rate(self.t, base_lr, decay_step, decay_rate)     # global_step before the increment (TF semantics)
+        self.t += 1
+        self._last_lr = lr
+        lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         gscale = 1.0
         if self.reducer:
             self.reducer.wait()
             gscale = self.reducer.grad_scale
-        L.check(L.load().dpd_adam_tf_dev(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
-                                         self.P.numel, L.ptr(self.opt_state), b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf_dev")
+        L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
+                                     self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
         self._wdirty = True
 
-    def apply_gradients(self):
-        """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990); the
-        schedule (global step, beta1_power, beta2_power, lr_t) lives on the device in `opt_state`."""
-        self._sched()
-        self.t += 1
-        self._adam()
+    def _sync_dev_schedule(self):
+        """Put the host's step count into the device-side schedule (before graph replays that follow eager steps / a restore)."""
+        if self._dev_t != self.t:
+            _, _, _, b1, b2, _ = self.hp
+            st = torch.zeros(8)
+            st[0] = torch.tensor(self.t, dtype=torch.int32).view(torch.float32)
+            st[1], st[2] = b1 ** self.t, b2 ** self.t
+            self.opt_state.copy_(st)
+            self._dev_t = self.t
 
     @property
     def lr(self):
-        """learning rate of the last step taken (device -> host sync)."""
-        return float(self.opt_state[4].item())
+        """learning rate of the last step taken."""
+        return self._last_lr
 
     def _take_front(self, pcA, pcB, noise):
         """Make the front-end buffers (pts, q, fv, X, mask, vox) hold this batch on the current stream."""
@@ -351,10 +369,9 @@ class DPDistTrainer:
         for suffix, flat in (("/Adam", self.m_state), ("/Adam_1", self.v_state)):
             for n, a in self.P.tf_state_dict(flat).items():
                 sd[n + suffix] = a
-        st = self.opt_state.cpu().numpy()
         sd["batch"] = np.float32(self.t)
-        sd["beta1_power"] = np.float32(st[1] * b1)
-        sd["beta2_power"] = np.float32(st[2] * b2)
+        sd["beta1_power"] = np.float32(b1 ** (self.t + 1))
+        sd["beta2_power"] = np.float32(b2 ** (self.t + 1))
         return sd
 
     @torch.no_grad()
@@ -369,13 +386,9 @@ class DPDistTrainer:
             self.P.load_tf_state_dict(sd, flat=self.m_state, suffix="/Adam")
             self.P.load_tf_state_dict(sd, flat=self.v_state, suffix="/Adam_1")
             got.append("adam_slots")
-        if "batch" in sd:
+        if "batch" in sd:      # beta1_power / beta2_power are functions of the step count (beta^(t+1)): nothing else to restore
             self.t = int(round(float(np.asarray(sd["batch"]))))
-            st = self.opt_state.cpu()
-            st[0] = torch.tensor(self.t, dtype=torch.int32).view(torch.float32)
-            st[1] = float(np.asarray(sd["beta1_power"])) / b1 if "beta1_power" in sd else b1 ** self.t
-            st[2] = float(np.asarray(sd["beta2_power"])) / b2 if "beta2_power" in sd else b2 ** self.t
-            self.opt_state.copy_(st)
+            self._dev_t = -1
             got.append("schedule")
         return got
 
@@ -396,8 +409,11 @@ class DPDistTrainer:
                 return None
             g = self._capture(pcA, pcB, labels, noise)
             self._graphs[key] = g
+        self._sync_dev_schedule()
         g[0].replay()
+        self._last_lr = learning_rate(self.t, *self.hp[:3])
         self.t += 1
+        self._dev_t = self.t
         self.graph_replays += 1
         self.front_launches += 1
         self._wdirty = True            # the replay ends with Adam: derived buffers are one step behind the weights
