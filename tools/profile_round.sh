@@ -3,34 +3,57 @@
 #   bench.json                     python bench.py                       (value, roofline, cpu_baseline)
 #   stats/*_kernel_stats.csv       rocprofv3 --kernel-trace --stats      (per-kernel average durations)
 #   pmc_FETCH_SIZE / pmc_WRITE_SIZE  separate --pmc passes               (HBM/fabric bytes per launch)
-# usage: tools/profile_round.sh r01
+#   pmc_MFMA                       MFMA-busy cycles per kernel           (own pass, --kernel-trace only)
+#   variants.txt                   the opt-in step variants, measured     (prefetch / fused gather / hipGraph / tail split ...)
+# usage: tools/profile_round.sh r02 [quick]
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+B="python $R/bench.py"
+NOCPU="--no-cpu-baseline"
+SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes > $OUT/bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+  timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- $B $SHORT > /dev/null 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_MFMA -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_MFMA -o p -- $B $SHORT > /dev/null 2>&1
+# the PMC summary must exist in profiles/ BEFORE the bench line is emitted (bench.py reads roofline.traffic from it)
+python $R/tools/summarize_profiles.py $TAG > /dev/null
+$B > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
+[ -n "$QUICK" ] && exit 0
 # compute types on the bf16 matrix cores (same step, --dtype) and the B=64 configuration of BASELINE configs 3-4
 for dt in f32x3 bf16; do
-  python $R/bench.py --dtype $dt --no-cpu-baseline > $OUT/bench_$dt.json 2>> $OUT/bench.err
+  $B --dtype $dt $NOCPU --no-other-dtypes > $OUT/bench_$dt.json 2>> $OUT/bench.err
 done
-python $R/bench.py --dtype bf16 --batch 64 --no-cpu-baseline > $OUT/bench_bf16_b64.json 2>> $OUT/bench.err
-python $R/bench.py --batch 64 --no-cpu-baseline > $OUT/bench_f32_b64.json 2>> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32x3 -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype f32x3 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16 -o $TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --dtype bf16 > /dev/null 2>&1
-python $R/tools/x3_bench.py 2 3 5 > $OUT/x3_bench.txt 2>&1
-# PMC passes for the plane compute types (same separate-pass rule)
+$B --dtype bf16 --batch 64 $NOCPU --no-other-dtypes > $OUT/bench_bf16_b64.json 2>> $OUT/bench.err
+$B --batch 64 $NOCPU --no-other-dtypes > $OUT/bench_f32_b64.json 2>> $OUT/bench.err
 for dt in f32x3 bf16; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$dt -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes --dtype $dt > /dev/null 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${dt}_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes --dtype $dt > /dev/null 2>&1
+    timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${dt}_$c -o p -- $B $SHORT --dtype $dt > /dev/null 2>&1
   done
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_${dt}_MFMA -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes --dtype $dt > /dev/null 2>&1
+  timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_${dt}_MFMA -o p -- $B $SHORT --dtype $dt > /dev/null 2>&1
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16_b64 -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes --dtype bf16 --batch 64 > /dev/null 2>&1
+# opt-in variants of the same step (each line: variant, ms/step, GEMM ms/step)
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s ms_per_step %.4f  gemm_ms_per_step %s  value %.0f' % ('$1', d['ms_per_step'], d['roofline'].get('gemm_ms_per_step'), d['value']))"; }
+{
+  $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line default
+  $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line default_again
+  $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes --prefetch 2>/dev/null | line prefetch
+  DPD_FUSED_GATHER=1 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line fused_gather
+  DPD_GRAPH=1 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line hipgraph
+  DPD_FUSE_LOSS=0 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line separate_l1_loss
+  DPD_DET_DB=0 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line atomic_bias_grads
+  $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes --plan 8:30:0 2>/dev/null | line dw1_tail_split
+} > $OUT/variants.txt 2>&1
+python $R/tools/gemm_bench.py --tiles 2,3,30,31,32,33 --splits 1,3 > $OUT/gemm_bench.txt 2>&1
+python $R/tools/x3_bench.py 2 3 5 > $OUT/x3_bench.txt 2>&1
+python $R/tools/determinism_check.py f32 > $OUT/determinism.txt 2>&1
+python $R/tools/summarize_profiles.py $TAG

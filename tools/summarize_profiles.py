@@ -25,11 +25,13 @@ def copy(a, b):
 
 for a, b in (("bench.json", "bench.json"), ("bench_f32x3.json", "bench_f32x3.json"), ("bench_bf16.json", "bench_bf16.json"),
              ("bench_bf16_b64.json", "bench_bf16_b64.json"), ("bench_f32_b64.json", "bench_f32_b64.json"),
-             ("x3_bench.txt", "x3_bench.txt"), ("gemm_bench.txt", "gemm_bench.txt")):
+             ("x3_bench.txt", "x3_bench.txt"), ("gemm_bench.txt", "gemm_bench.txt"), ("variants.txt", "variants.txt"),
+             ("determinism.txt", "determinism.txt")):
     copy(a, b)
 
 # per-kernel stats (our kernels only), one file per compute type
-for sub, out in (("stats", "kernel_stats.csv"), ("stats_f32x3", "kernel_stats_f32x3.csv"), ("stats_bf16", "kernel_stats_bf16.csv")):
+for sub, out in (("stats", "kernel_stats.csv"), ("stats_f32x3", "kernel_stats_f32x3.csv"), ("stats_bf16", "kernel_stats_bf16.csv"),
+                 ("stats_bf16_b64", "kernel_stats_bf16_b64.csv")):
     f = os.path.join(src, sub, "%s_kernel_stats.csv" % tag)
     if not os.path.exists(f):
         continue
