@@ -29,6 +29,8 @@
 
 namespace dpd {
 
+constexpr int kMfvSlices = DPD_MFV_SLICES;   // workgroups per cloud in the encoder forward = partial norms per cloud
+
 // Opt a kernel into more than 64 KiB of dynamic LDS, once per (kernel, device): `slot` is a per-call-site static array of
 // flags indexed by the CURRENT device, so a process that drives several GPUs configures each of them (the attribute is
 // per device), and concurrent first calls are a benign repeat of an idempotent setting.

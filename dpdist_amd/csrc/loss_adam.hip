@@ -81,6 +81,141 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
     }
 }
 
+// One-launch optimizer step: Adam + everything that is derived from the result or feeds its last few elements.
+//   role 1 (tile blocks): the matrices that have a transposed copy (W2, W3, optionally W1p) are updated in 64 x 64 tiles and
+//           the new values leave the block twice: in place and, through an LDS transpose, as rows of the copy -> the separate
+//           transpose launch (and its 2 x 8.4 MB round trip) disappears;
+//   role 2 (tail blocks): p[tail_off .. tail_off + 4H + 3) = [b3 | W4 | b4] take their gradient straight from the block partials
+//           of the output-layer backward (same fixed summation order as small_grads_reduce, which this replaces; the gradient is
+//           also stored, and the two loss values are finished here);
+//   role 3 (vector blocks): every other element, float4 grid-stride over up to four ranges.
+struct AdamFuse {
+    float* WT[3];
+    long w_off[3];
+    int w_rows[3], w_cols[3];
+    int tile_end[3];            // cumulative tile-block counts of the three matrices (0-size matrices repeat the previous value)
+    const float* partials;      // [nparts][rec] or NULL
+    int nparts, rec, H, Qb;
+    long tail_off;
+    float* loss;
+    int ntail;                  // tail blocks (16 outputs each)
+    long v_off[4], v_cnt[4];    // vector ranges
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
+    m = b1 * m + (1.0f - b1) * g;
+    v = b2 * v + (1.0f - b2) * g * g;
+    p = p - lr_t * m / (sqrtf(v) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, float lr_t, float b1, float b2, float eps,
+                                                          float gscale, AdamFuse f) {
+    __shared__ float tile[64][65];
+    int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (b < f.tile_end[2]) {
+        const int w = b < f.tile_end[0] ? 0 : (b < f.tile_end[1] ? 1 : 2);
+        const int t = b - (w ? f.tile_end[w - 1] : 0);
+        const int rows = f.w_rows[w], cols = f.w_cols[w], tc = cols / 64;
+        const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+        const size_t base = (size_t)f.w_off[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k, r = idx >> 4, c4 = (idx & 15) * 4;
+            if (r0 + r < rows) {
+                const size_t o = base + (size_t)(r0 + r) * cols + c0 + c4;
+                float4 P = *reinterpret_cast<float4*>(p + o);
+                const float4 G = *reinterpret_cast<const float4*>(g + o);
+                float4 M = *reinterpret_cast<float4*>(m + o);
+                float4 V = *reinterpret_cast<float4*>(v + o);
+                adam_one(P.x, G.x * gscale, M.x, V.x, lr_t, b1, b2, eps);
+                adam_one(P.y, G.y * gscale, M.y, V.y, lr_t, b1, b2, eps);
+                adam_one(P.z, G.z * gscale, M.z, V.z, lr_t, b1, b2, eps);
+                adam_one(P.w, G.w * gscale, M.w, V.w, lr_t, b1, b2, eps);
+                *reinterpret_cast<float4*>(p + o) = P;
+                *reinterpret_cast<float4*>(m + o) = M;
+                *reinterpret_cast<float4*>(v + o) = V;
+                tile[r][c4] = P.x; tile[r][c4 + 1] = P.y; tile[r][c4 + 2] = P.z; tile[r][c4 + 3] = P.w;
+            }
+        }
+        __syncthreads();
+        float* T = f.WT[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k, c = idx >> 4, r4 = (idx & 15) * 4;
+            if (r0 + r4 < rows)      // rows % 4 == 0: a float4 of rows is valid or absent as a whole
+                *reinterpret_cast<float4*>(T + (size_t)(c0 + c) * rows + r0 + r4) =
+                    make_float4(tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]);
+        }
+        return;
+    }
+    b -= f.tile_end[2];
+    if (b < f.ntail) {
+        // = small_grads_reduce (decoder.hip) followed by Adam on the 16 elements of this block
+        float (*red)[17] = reinterpret_cast<float (*)[17]>(&tile[0][0]);
+        float* s_loss = &tile[8][0];
+        const int li = tid & 15, sl = tid >> 4, H = f.H;
+        const int i = b * 16 + li;
+        const int n = (f.rec > 4 * H + 4 && f.loss) ? 4 * H + 7 : 4 * H + 3;
+        float s = 0.f;
+        if (i < n)
+            for (int k = sl; k < f.nparts; k += 16) s += f.partials[(size_t)k * f.rec + i];
+        red[sl][li] = s;
+        __syncthreads();
+        if (sl == 0 && i < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][li];
+            if (i < 4 * H + 3) {
+                const size_t o = (size_t)f.tail_off + i;
+                g[o] = t;
+                float P = p[o], M = m[o], V = v[o];
+                adam_one(P, t * gscale, M, V, lr_t, b1, b2, eps);
+                p[o] = P; m[o] = M; v[o] = V;
+            } else if (i >= 4 * H + 4) {
+                s_loss[i - 4 * H - 4] = t;
+            }
+        }
+        if (n > 4 * H + 3 && b == (4 * H + 4) / 16) {
+            __syncthreads();
+            if (tid == 0) {
+                const float inv = 1.0f / (float)f.Qb;
+                f.loss[0] = s_loss[0] * inv;
+                f.loss[1] = (s_loss[1] * inv + s_loss[2] * inv) / 2.0f;
+            }
+        }
+        return;
+    }
+    b -= f.ntail;
+    const int nvec = gridDim.x - f.tile_end[2] - f.ntail;
+    const size_t stride = (size_t)nvec * 256;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const size_t off = (size_t)f.v_off[r], cnt = (size_t)f.v_cnt[r], n4 = (off & 3) ? 0 : cnt / 4;
+        for (size_t i = (size_t)b * 256 + tid; i < n4; i += stride) {
+            const size_t o = off + 4 * i;
+            float4 P = *reinterpret_cast<float4*>(p + o);
+            const float4 G = *reinterpret_cast<const float4*>(g + o);
+            float4 M = *reinterpret_cast<float4*>(m + o);
+            float4 V = *reinterpret_cast<float4*>(v + o);
+            adam_one(P.x, G.x * gscale, M.x, V.x, lr_t, b1, b2, eps);
+            adam_one(P.y, G.y * gscale, M.y, V.y, lr_t, b1, b2, eps);
+            adam_one(P.z, G.z * gscale, M.z, V.z, lr_t, b1, b2, eps);
+            adam_one(P.w, G.w * gscale, M.w, V.w, lr_t, b1, b2, eps);
+            *reinterpret_cast<float4*>(p + o) = P;
+            *reinterpret_cast<float4*>(m + o) = M;
+            *reinterpret_cast<float4*>(v + o) = V;
+        }
+        for (size_t i = n4 * 4 + (size_t)b * 256 + tid; i < cnt; i += stride) {
+            const size_t o = off + i;
+            float P = p[o], M = m[o], V = v[o];
+            adam_one(P, g[o] * gscale, M, V, lr_t, b1, b2, eps);
+            p[o] = P; m[o] = M; v[o] = V;
+        }
+    }
+}
+
 // Optimizer schedule on the device, so that a captured (hipGraph) training step needs no per-step host parameters.
 // state (8 floats, caller-owned, zero-filled = "before the first step" once state[1] = state[2] = 1):
 //   [0] global step (int32 bits)   [1] beta1_power   [2] beta2_power   [3] lr_t of the step being taken   [4] its learning rate
@@ -181,6 +316,59 @@ extern "C" int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t 
     if (blocks == 0) blocks = 1;
     DPD_LAUNCH(dpd::adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t,
                        b1, b2, eps, gscale);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
+                                 float gscale, const dpd_adam_fuse* fu, void* stream) {
+    using namespace dpd;
+    if (!p || !g || !m || !v || !fu) return DPD_E_NULL;
+    if (n == 0) return DPD_E_DIM;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DPD_E_UNSUPPORTED;
+    AdamFuse f{};
+    // covered intervals, in ascending order of offset (the caller passes the matrices in flat order)
+    long lo[4], hi[4];
+    int nc = 0, tiles = 0;
+    for (int w = 0; w < 3; ++w) {
+        f.WT[w] = fu->WT[w]; f.w_off[w] = fu->w_off[w]; f.w_rows[w] = fu->w_rows[w]; f.w_cols[w] = fu->w_cols[w];
+        if (fu->WT[w]) {
+            const long cnt = (long)fu->w_rows[w] * fu->w_cols[w];
+            if (fu->w_rows[w] <= 0 || fu->w_cols[w] <= 0 || (fu->w_cols[w] & 63) || (fu->w_rows[w] & 3) || (fu->w_off[w] & 3) ||
+                fu->w_off[w] < 0 || (size_t)(fu->w_off[w] + cnt) > n || ((uintptr_t)fu->WT[w] & 15))
+                return DPD_E_UNSUPPORTED;
+            if (nc && fu->w_off[w] < hi[nc - 1]) return DPD_E_DIM;
+            lo[nc] = fu->w_off[w]; hi[nc] = fu->w_off[w] + cnt; ++nc;
+            tiles += ((fu->w_rows[w] + 63) / 64) * (fu->w_cols[w] / 64);
+        }
+        f.tile_end[w] = tiles;
+    }
+    if (fu->partials) {
+        const long tail = 4L * fu->H + 3;
+        if (fu->nparts <= 0 || fu->H <= 0 || fu->rec < 4 * fu->H + 4 || fu->tail_off < 0 || (size_t)(fu->tail_off + tail) != n)
+            return DPD_E_DIM;
+        if (nc && fu->tail_off < hi[nc - 1]) return DPD_E_DIM;
+        if (fu->loss && (fu->rec < 4 * fu->H + 8 || fu->Qb <= 0)) return DPD_E_DIM;
+        f.partials = fu->partials; f.nparts = fu->nparts; f.rec = fu->rec; f.H = fu->H; f.Qb = fu->Qb;
+        f.tail_off = fu->tail_off; f.loss = fu->loss;
+        f.ntail = (4 * fu->H + 7 + 15) / 16;
+        lo[nc] = fu->tail_off; hi[nc] = (long)n; ++nc;
+    }
+    // the vector ranges are the complement of the covered intervals in [0, n)
+    long at = 0;
+    int nv = 0;
+    size_t vec_elems = 0;
+    for (int i = 0; i <= nc; ++i) {
+        const long end = i < nc ? lo[i] : (long)n;
+        if (end > at) { f.v_off[nv] = at; f.v_cnt[nv] = end - at; vec_elems += (size_t)(end - at); ++nv; }
+        if (i < nc) at = hi[i];
+    }
+    size_t vblocks = (vec_elems / 4 + 255) / 256;
+    if (vblocks > 2048) vblocks = 2048;
+    if (vblocks == 0 && vec_elems) vblocks = 1;
+    const unsigned grid = (unsigned)(tiles + f.ntail + vblocks);
+    if (grid == 0) return DPD_E_DIM;
+    DPD_LAUNCH(adam_fused_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);
     DPD_CHECK_LAUNCH();
     return 0;
 }

@@ -71,10 +71,43 @@ __device__ __forceinline__ float pnorm(float x) {
 // dynamic LDS (floats): zq[3*N*m*2] | S[3*N] | minz2[3*N] | stage[slice*21] | flag
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kFwdThreads = 1024;
-constexpr int kSlices = 4;
+constexpr int kSlices = kMfvSlices;   // common.h (the window gather sums the per-slice norms)
+
+// Optional fusions of the training step's front end (all NULL = plain encoder over pts):
+//   pcA/pcB/noise: cloud c < B is pcA[c] + noise[c], cloud c >= B is pcB[c - B] (dpdist_and_aue.py:45,56-61); slice 0 of every
+//                  cloud also writes the stacked encoder input pts_out [2B,N,3] and the query clouds q_out = [pcB ; pcA] (:69),
+//                  so that dpd_stack_clouds is not launched;
+//   ssq:           [C][kSlices][20] receives this slice's per-channel sums of squares (slice_ssq order below); the caller then
+//                  skips mfv3d_norm_kernel and the window gather applies the L2 scale instead (patch_rows.hip).
+struct MfvFuse {
+    const float* pcA; const float* pcB; const float* noise;
+    float* pts_out; float* q_out;
+    float* ssq;
+    int B;
+};
+
+// Per-channel sum of squares of one slice of Gaussians, in THE summation order both consumers use (so that the separate norm
+// kernel and the fused form give the same bits): 8 parts of ceil(gcount / 8) consecutive Gaussians, summed sequentially,
+// then the 8 partials in order.  val(g, ch) reads the slice-local value.  Threads 0..159 take part; result valid for tid < 20.
+template <typename F>
+__device__ __forceinline__ float slice_ssq(int tid, int gcount, float* s_red /* [8][20] */, F val) {
+    const int per = (gcount + 7) / 8;
+    if (tid < 8 * kF) {
+        const int part = tid / kF, ch = tid % kF;
+        float ss = 0.f;
+        const int g1 = min(gcount, (part + 1) * per);
+        for (int g = part * per; g < g1; ++g) { const float x = val(g, ch); ss += x * x; }
+        s_red[part * kF + ch] = ss;
+    }
+    __syncthreads();
+    float t = 0.f;
+    if (tid < kF)
+        for (int part = 0; part < 8; ++part) t += s_red[part * kF + tid];
+    return t;
+}
 
 __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __restrict__ pts, float* __restrict__ fv,
-                                                                 MfvConst k, int gslice) {
+                                                                 MfvConst k, int gslice, MfvFuse fu) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = k.N, G = k.G, m = k.m;
     float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][N][m]
@@ -86,12 +119,22 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
     const int tid = threadIdx.x, c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
     const int g0 = sl * gslice, gcount = max(0, min(G, g0 + gslice) - g0);
     const int lane = tid & 63, wave = tid >> 6;
-    const float* p = pts + (size_t)c * N * 3;
+    const float* p = pts ? pts + (size_t)c * N * 3 : (c < fu.B ? fu.pcA + (size_t)c * N * 3 : fu.pcB + (size_t)(c - fu.B) * N * 3);
+    const float* nz = (!pts && fu.noise && c < fu.B) ? fu.noise + (size_t)c * N * 3 : nullptr;
     if (tid == 0) *s_bad = 0;
     for (int e = tid; e < 3 * N * m; e += kFwdThreads) {
         const int a = e / (N * m), n = (e / m) % N, i = e % m;
-        const float z = (p[n * 3 + a] - k.ax.c[i]) / k.sigma;    // (batch_points - batch_mu) / batch_sig  (:87)
+        const float x = nz ? p[n * 3 + a] + nz[n * 3 + a] : p[n * 3 + a];
+        const float z = (x - k.ax.c[i]) / k.sigma;               // (batch_points - batch_mu) / batch_sig  (:87)
         s_zq[e] = make_float2(z, expf(-0.5f * (z * z)));
+    }
+    if (!pts && sl == 0) {      // the stacked tensors the rest of the step reads
+        const int twin = c < fu.B ? c + fu.B : c - fu.B;          // q = [pcB ; pcA]: cloud c's raw points are the twin's queries
+        for (int e = tid; e < 3 * N; e += kFwdThreads) {
+            const float raw = p[e];
+            if (fu.pts_out) fu.pts_out[(size_t)c * N * 3 + e] = nz ? raw + nz[e] : raw;
+            if (fu.q_out) fu.q_out[(size_t)twin * N * 3 + e] = raw;
+        }
     }
     __syncthreads();
     for (int e = tid; e < 3 * N; e += kFwdThreads) {              // e = a*N + n
@@ -190,39 +233,46 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         if (bad) o = make_float4(qnan, qnan, qnan, qnan);   // 0/0 at :74 poisons every statistic of the cloud
         *reinterpret_cast<float4*>(out + e) = o;
     }
+    if (fu.ssq) {
+        float* s_red = reinterpret_cast<float*>(s_bad) + 4;  // [8][20] partials
+        __syncthreads();
+        const float t = slice_ssq(tid, gcount, s_red, [&](int g, int ch) { return s_stage[g * kFP + ch]; });
+        if (tid < kF) fu.ssq[((size_t)c * kSlices + sl) * kF + tid] = bad ? qnan : t;
+    }
 }
 
-// L2 normalisation over the Gaussian axis, per channel (:124-126), in place.  One 256-thread block per cloud; thread
-// t owns the float4 channel group t % 5 of the Gaussians t/5, t/5 + 51, ... -> 20 per-channel sums in a fixed order.
-__global__ __launch_bounds__(256) void mfv3d_norm_kernel(float* __restrict__ fv, int G) {
-    __shared__ float s_part[51][kF];
+// L2 normalisation over the Gaussian axis, per channel (:124-126), in place.  One 256-thread block per cloud.  The per-channel
+// sums are taken slice by slice in slice_ssq order and the slices added in order: the same bits as the fused form (ssq from the
+// forward kernel + scale applied by the window gather).
+__device__ __forceinline__ float l2_scale(float ss) { return 1.0f / sqrtf(fmaxf(ss, 1e-12f)); }   // x * rsqrt(max(sum x^2, eps))
+
+__global__ __launch_bounds__(256) void mfv3d_norm_kernel(float* __restrict__ fv, int G, int gslice) {
+    __shared__ float s_red[8 * kF];
     __shared__ float s_scale[kF];
+    __shared__ float s_stage[250 * kFP];       // one slice: m <= 10 -> gslice <= 250
     const int tid = threadIdx.x, c = blockIdx.x;
-    float4* base = reinterpret_cast<float4*>(fv + (size_t)c * G * kF);
-    const int part = tid % 5, row = tid / 5;    // 255 working threads = 51 rows x 5 channel groups
-    float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 255) {
-        for (int g = row; g < G; g += 51) {
-            const float4 v = base[g * 5 + part];
-            sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+    float* base = fv + (size_t)c * G * kF;
+    float total = 0.f;
+    for (int sl = 0; sl < kSlices; ++sl) {
+        const int g0 = sl * gslice, gcount = max(0, min(G, g0 + gslice) - g0);
+        for (int i = tid; i < gcount * 5; i += 256) {
+            const float4 x = reinterpret_cast<const float4*>(base + (size_t)g0 * kF)[i];
+            float* d = s_stage + (i / 5) * kFP + (i % 5) * 4;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
         }
-        s_part[row][part * 4 + 0] = sq.x; s_part[row][part * 4 + 1] = sq.y;
-        s_part[row][part * 4 + 2] = sq.z; s_part[row][part * 4 + 3] = sq.w;
+        __syncthreads();
+        const float t = slice_ssq(tid, gcount, s_red, [&](int g, int ch) { return s_stage[g * kFP + ch]; });
+        total += t;
+        __syncthreads();
     }
+    if (tid < kF) s_scale[tid] = l2_scale(total);
     __syncthreads();
-    if (tid < kF) {
-        float ss = 0.f;
-        for (int r = 0; r < 51; ++r) ss += s_part[r][tid];
-        s_scale[tid] = 1.0f / sqrtf(fmaxf(ss, 1e-12f));      // l2_normalize: x * rsqrt(max(sum x^2, eps))
-    }
-    __syncthreads();
-    if (tid < 255) {
-        const float4 sc = make_float4(s_scale[part * 4], s_scale[part * 4 + 1], s_scale[part * 4 + 2], s_scale[part * 4 + 3]);
-        for (int g = row; g < G; g += 51) {
-            float4 v = base[g * 5 + part];
-            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-            base[g * 5 + part] = v;
-        }
+    float4* b4 = reinterpret_cast<float4*>(base);
+    for (int i = tid; i < G * 5; i += 256) {
+        const int part = i % 5;
+        float4 v = b4[i];
+        v.x *= s_scale[part * 4]; v.y *= s_scale[part * 4 + 1]; v.z *= s_scale[part * 4 + 2]; v.w *= s_scale[part * 4 + 3];
+        b4[i] = v;
     }
 }
 
@@ -243,7 +293,7 @@ static int make_const(int N, int m, float sigma, MfvConst& k) {
 }
 
 static size_t fwd_lds_bytes(int N, int m, int gslice) {
-    return (size_t)(6 * N * m + 6 * N + gslice * kFP + 4) * sizeof(float);
+    return (size_t)(6 * N * m + 6 * N + gslice * kFP + 4 + 8 * kF) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -743,10 +793,30 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     const int gslice = (k.G + kSlices - 1) / kSlices;
     const size_t lds = fwd_lds_bytes(N, m, gslice);
     if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
-    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k, gslice);
+    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k, gslice, MfvFuse{});
     DPD_CHECK_LAUNCH();
-    DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, fv, k.G);
+    DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, fv, k.G, gslice);
     DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_mfv3d_fwd_stacked(const float* pcA, const float* pcB, const float* noise, int B, int N, int m, float sigma,
+                                     float* pts, float* q, float* fv, float* ssq, void* stream) {
+    using namespace dpd;
+    if (!pcA || !pcB || !fv) return DPD_E_NULL;
+    if (B <= 0) return DPD_E_DIM;
+    MfvConst k{};
+    if (int rc = make_const(N, m, sigma, k)) return rc;
+    const int C = 2 * B, gslice = (k.G + kSlices - 1) / kSlices;
+    const size_t lds = fwd_lds_bytes(N, m, gslice);
+    if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
+    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, (const float*)nullptr, fv, k, gslice,
+               MfvFuse{pcA, pcB, noise, pts, q, ssq, B});
+    DPD_CHECK_LAUNCH();
+    if (!ssq) {
+        DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, fv, k.G, gslice);
+        DPD_CHECK_LAUNCH();
+    }
     return 0;
 }
 

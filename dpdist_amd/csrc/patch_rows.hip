@@ -25,11 +25,25 @@ __device__ __forceinline__ int cell_of(const GridAxis& ax, int m, float q) {
     return r;
 }
 
+// L2 scale of a cloud's Fisher vectors from the per-slice sums of squares the encoder left (mfv3d.hip: MfvFuse::ssq): the
+// slices are added in order, then x * rsqrt(max(sum x^2, 1e-12)) (tf.nn.l2_normalize, dpdist_util.py:124-126).
+__device__ __forceinline__ float fv_scale(const float* __restrict__ ssq, int nsl, int c, int ch) {
+    float ss = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) ss += ssq[((size_t)c * nsl + sl) * kF + ch];
+    return 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+}
+
 __global__ __launch_bounds__(256) void patch_rows_fwd_kernel(const float* __restrict__ q, const float* __restrict__ fv,
                                                               float* __restrict__ X, float* __restrict__ mask,
                                                               int32_t* __restrict__ vox, int N, int m, int k, int KP,
-                                                              GridAxis ax, int Q) {
-    const int r = blockIdx.x * 2 + (threadIdx.x >> 7), tid = threadIdx.x & 127;   // two rows per workgroup, 128 threads each
+                                                              GridAxis ax, int Q, const float* __restrict__ ssq, int nsl) {
+    __shared__ __attribute__((aligned(16))) float s_sc[2][kF];
+    const int half = threadIdx.x >> 7;
+    const int r = blockIdx.x * 2 + half, tid = threadIdx.x & 127;   // two rows per workgroup, 128 threads each
+    if (ssq) {      // fv is only power-normalised: this kernel applies the per-channel L2 scale of the row's cloud
+        if (tid < kF && r < Q) s_sc[half][tid] = fv_scale(ssq, nsl, r / N, tid);
+        __syncthreads();
+    }
     if (r >= Q) return;
     const int c = r / N;
     const int G = m * m * m, h = (k - 1) / 2;
@@ -47,6 +61,10 @@ __global__ __launch_bounds__(256) void patch_rows_fwd_kernel(const float* __rest
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m)
             v = *reinterpret_cast<const float4*>(fvc + (size_t)((g0 * m + g1) * m + g2) * kF + part * 4);
+        if (ssq) {
+            const float4 sc = *reinterpret_cast<const float4*>(&s_sc[half][part * 4]);
+            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+        }
         *reinterpret_cast<float4*>(xr + j * 4) = v;
     }
     const int E = E4 * 4;
@@ -73,8 +91,14 @@ __global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __r
                                                                 float* __restrict__ X, float* __restrict__ mask,
                                                                 int32_t* __restrict__ vox, int Q, int N, int m, int k, int KP,
                                                                 GridAxis ax, int np, uint16_t* __restrict__ rc, long rc_plane,
-                                                                uint16_t* __restrict__ r8, long r8_plane, int r8_rows) {
+                                                                uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
+                                                                const float* __restrict__ ssq, int nsl) {
     __shared__ RowInfo s_row[8];
+    __shared__ __attribute__((aligned(16))) float s_sc[8][kF];
+    if (ssq && threadIdx.x < 8 * kF) {
+        const int rr = threadIdx.x / kF, ch = threadIdx.x % kF;
+        s_sc[rr][ch] = fv_scale(ssq, nsl, (8 * (int)(blockIdx.x >> 1) + rr) / N, ch);
+    }
     const int rg = blockIdx.x >> 1, part2 = blockIdx.x & 1, tid = threadIdx.x;
     const int G = m * m * m, h = (k - 1) / 2;
     if (tid < 8) {
@@ -105,6 +129,10 @@ __global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __r
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m)
                     x = *reinterpret_cast<const float4*>(fv + ((size_t)ri.cloud * G + (size_t)((g0 * m + g1) * m + g2)) * kF + part * 4);
+                if (ssq) {
+                    const float4 sc = *reinterpret_cast<const float4*>(&s_sc[rr][part * 4]);
+                    x.x *= sc.x; x.y *= sc.y; x.z *= sc.z; x.w *= sc.w;
+                }
                 v[rr] = x;
             }
         } else {
@@ -292,6 +320,11 @@ extern "C" int dpd_padded_width(int k) { return (k * k * k * DPD_FV_CHANNELS + 3
 
 extern "C" int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
                                   float* mask, int32_t* vox, const dpd_planes* pl, void* stream) {
+    return dpd_patch_rows_fwd_scaled(q, fv, nullptr, C, N, m, k, KP, X, mask, vox, pl, stream);
+}
+
+extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const float* ssq, int C, int N, int m, int k, int KP,
+                                         float* X, float* mask, int32_t* vox, const dpd_planes* pl, void* stream) {
     using namespace dpd;
     const int Q = C * N;
     const bool planes = pl && (pl->X_rc || pl->X_r8) && !(Q & 7) && !(pl->Qb & 31) && !(KP & 31);
@@ -302,12 +335,12 @@ extern "C" int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N,
     if (planes) {
         if ((pl->np != 1 && pl->np != 3) || pl->Q != Q || pl->Qb > Q || pl->Qb < 0) return DPD_E_DIM;
         DPD_LAUNCH(patch_rows_planes_kernel, dim3((Q / 8) * 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
-                   KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb);
+                   KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
         DPD_CHECK_LAUNCH();
         return 0;
     }
     DPD_LAUNCH(patch_rows_fwd_kernel, dim3((C * N + 1) / 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
-                       KP, make_axis(m), C * N);
+                       KP, make_axis(m), C * N, ssq, kMfvSlices);
     DPD_CHECK_LAUNCH();
     return 0;
 }

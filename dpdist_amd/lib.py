@@ -24,6 +24,11 @@ class SmallGrads(Structure):
         ("l1_gscale", c_float), ("db_partials", c_void_p)]
 
 
+class AdamFuse(Structure):   # include/dpdist_capi.h: dpd_adam_fuse
+    _fields_ = [("WT", c_void_p * 3), ("w_off", c_long * 3), ("w_rows", c_int * 3), ("w_cols", c_int * 3), ("partials", c_void_p),
+                ("nparts", c_int), ("rec", c_int), ("H", c_int), ("Qb", c_int), ("tail_off", c_long), ("loss", c_void_p)]
+
+
 class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
     _fields_ = [("fv", c_void_p), ("xyz", c_void_p), ("rowinfo", c_void_p), ("table", c_void_p), ("C", c_int), ("G", c_int)]
 
@@ -43,6 +48,10 @@ SIGNATURES = {
     "dpd_mfv3d_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dpd_patch_rows_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, POINTER(Planes), c_void_p]),
+    "dpd_mfv3d_fwd_stacked": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "dpd_patch_rows_fwd_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, POINTER(Planes), c_void_p]),
     "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p]),
     "dpd_decoder_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_int, c_void_p,
@@ -72,6 +81,8 @@ SIGNATURES = {
     "dpd_l1_loss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "dpd_adam_tf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                             c_float, c_void_p]),
+    "dpd_adam_tf_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float,
+                                  POINTER(AdamFuse), c_void_p]),
     "dpd_adam_sched": (c_int, [c_void_p, c_float, c_int, c_float, c_float, c_float, c_float, c_void_p]),
     "dpd_adam_tf_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float, c_float, c_float, c_void_p]),
     "dpd_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,

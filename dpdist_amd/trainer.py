@@ -106,6 +106,23 @@ class DPDistTrainer:
         self.opt_state = torch.zeros(8, device=dev, dtype=torch.float32)
         self.opt_state[1:3] = 1.0
         self._dev_t, self._last_lr = 0, base_lr
+        # one-launch optimizer (dpd_adam_tf_fused): Adam + the transposed copies + (single-GPU steps) the reduction of the
+        # output layer's block partials; DPD_FUSED_ADAM=0 keeps the three separate launches
+        self.fused_adam = os.environ.get("DPD_FUSED_ADAM", "1") == "1"
+        # front end in two launches (dpd_mfv3d_fwd_stacked + dpd_patch_rows_fwd_scaled) instead of four; DPD_FRONT2=0 = four
+        self.front2 = not self.fused and os.environ.get("DPD_FRONT2", "1") == "1"
+        self._ssq = f(C * 4 * 20)
+        self._fv_scaled = True
+        seg = params._segments
+        self._afuse = [L.AdamFuse(), L.AdamFuse()]           # [0]: gradients complete; [1]: tail from the block partials
+        for i, af in enumerate(self._afuse):
+            if self.W2T is not None:
+                for j, (n, T) in enumerate((("W2", self.W2T), ("W3", self.W3T))):
+                    af.WT[j], af.w_off[j], af.w_rows[j], af.w_cols[j] = T.data_ptr(), seg[n][0], H, H
+            if i == 1:
+                af.partials, af.nparts, af.rec, af.H, af.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
+                af.tail_off, af.loss = seg["b3"][0], self.loss.data_ptr()
+        self._tail_ok = seg["b3"][0] + 4 * H + 3 == params.numel and H % 256 == 0 and H <= 1024
         # hipGraph mode (single GPU): the whole step is captured once per input-buffer set and replayed; weight-derived
         # buffers and the small-gradient reduction run on parallel branches of the graph, off the critical path
         self.use_graph = os.environ.get("DPD_GRAPH", "0") == "1"   # opt-in: measured 4 % SLOWER than eager launches on MI355X / ROCm 7
@@ -139,8 +156,16 @@ class DPDistTrainer:
         """stacking + encoder + window gather of one batch on the CURRENT stream; `gate`: event to wait for before the
         gather overwrites X / mask / vox (their last reader of the previous step)."""
         self.front_launches += 1
-        self._load_batch(pcA, pcB, noise)
-        self._encode()
+        if self.front2:      # two launches: (stack + encoder), (norm + gather)
+            shp = (self.B, self.N, 3)
+            L.check(L.load().dpd_mfv3d_fwd_stacked(L.ptr(L.req(pcA, name="pcA", shape=shp)), L.ptr(L.req(pcB, name="pcB", shape=shp)),
+                                                   None if noise is None else L.ptr(L.req(noise, name="add_noise", shape=shp)),
+                                                   self.B, self.N, self.m, self.sigma, L.ptr(self.pts), L.ptr(self.q), L.ptr(self.fv),
+                                                   L.ptr(self._ssq), L.cur_stream()), "dpd_mfv3d_fwd_stacked")
+            self._fv_scaled = False
+        else:
+            self._load_batch(pcA, pcB, noise)
+            self._encode()
         if gate is not None:
             torch.cuda.current_stream().wait_event(gate)
         self._gather()
@@ -158,6 +183,7 @@ class DPDistTrainer:
                                           L.ptr(self.pts), L.ptr(self.q), L.cur_stream()), "dpd_stack_clouds")
 
     def _encode(self):
+        self._fv_scaled = True
         L.check(L.load().dpd_mfv3d_fwd(L.ptr(self.pts), 2 * self.B, self.N, self.m, self.sigma, L.ptr(self.fv), L.cur_stream()),
                 "dpd_mfv3d_fwd")
 
@@ -166,9 +192,10 @@ class DPDistTrainer:
             return
         lib, s, P = L.load(), L.cur_stream(), self.P
         C, N = 2 * self.B, self.N
-        L.check(lib.dpd_patch_rows_fwd(L.ptr(self.q), L.ptr(self.fv), C, N, self.m, self.k, P.KP,
-                                       None if self._planes is not None else L.ptr(self.X), L.ptr(self.mask), L.ptr(self.vox),
-                                       self._planes, s), "dpd_patch_rows_fwd")
+        # fv of the two-launch front end still lacks its L2 norm: the gather applies it from the per-slice sums of squares
+        L.check(lib.dpd_patch_rows_fwd_scaled(L.ptr(self.q), L.ptr(self.fv), None if self._fv_scaled else L.ptr(self._ssq), C, N,
+                                              self.m, self.k, P.KP, None if self._planes is not None else L.ptr(self.X),
+                                              L.ptr(self.mask), L.ptr(self.vox), self._planes, s), "dpd_patch_rows_fwd_scaled")
 
     def forward(self):
         """encoder + gather + decoder of the batch loaded by _load_batch (stream order)."""
@@ -190,7 +217,7 @@ class DPDistTrainer:
                                     L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
                                     self.ws.numel() * 4, self._planes, s), "dpd_decoder_fwd")
 
-    def backward(self, labels, fork_small=None, join_weights=None):
+    def backward(self, labels, fork_small=None, join_weights=None, defer_small=False):
         """fork_small / join_weights (graph capture only): callables that move the small-gradient reduction to a parallel
         branch right after the output layer, and join the branch that derives the transposed weights before the dH GEMMs."""
         lib, s, P = L.load(), L.cur_stream(), self.P
@@ -250,7 +277,7 @@ class DPDistTrainer:
             join_weights()
             data(2 | 4)
         else:
-            data(7)
+            data(7 | 16 if defer_small else 7)     # 16: db3 / dW4 / db4 and the loss stay block partials (the optimizer sums them)
         dw(1, self.X, self.g1, d[0])
         if self._after_dw1 is not None:
             self._after_dw1()             # X / mask are free from here on: the prefetch pipeline hooks in
@@ -281,7 +308,7 @@ class DPDistTrainer:
                                          self.P.numel, L.ptr(self.opt_state), b1, b2, eps, 1.0, L.cur_stream()), "dpd_adam_tf_dev")
         self._wdirty = True
 
-    def apply_gradients(self):
+    def apply_gradients(self, tail_from_partials=False):
         """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
         steps compute lr_t on the host (a device-side schedule kernel of one thread costs 4.7 us per step on MI355X: launch
         latency); only the captured hipGraph step keeps the schedule on the device."""
@@ -294,6 +321,12 @@ class DPDistTrainer:
         if self.reducer:
             self.reducer.wait()
             gscale = self.reducer.grad_scale
+        if self.fused_adam and (self.W2T is not None or tail_from_partials):
+            L.check(L.load().dpd_adam_tf_fused(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
+                                               self.P.numel, lr_t, b1, b2, eps, gscale, self._afuse[1 if tail_from_partials else 0],
+                                               L.cur_stream()), "dpd_adam_tf_fused")
+            self._wdirty = self._planes is not None      # the transposed copies are already those of the new weights
+            return
         L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                      self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
         self._wdirty = True
@@ -351,11 +384,12 @@ class DPDistTrainer:
                     self._ev_front.record(self._side)
                 self._pref_key = self._key(*prefetch)
             self._after_dw1 = launch_front
+        defer = self.fused_adam and self.fuse_loss and self._tail_ok and self.reducer is None
         try:
-            self.backward(labels.reshape(-1))
+            self.backward(labels.reshape(-1), defer_small=defer)
         finally:
             self._after_dw1 = None
-        self.apply_gradients()
+        self.apply_gradients(tail_from_partials=defer)
         return self.loss
 
     # -- optimizer state <-> TF global variables ------------------------------------------------------------------

@@ -83,6 +83,18 @@ struct dpd_planes;   /* bf16 operand planes that persist between entry points; d
 int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
                        float* mask, int32_t* vox, const struct dpd_planes* pl, void* stream);
 
+/* The front end of a training step in TWO launches instead of four (stack, encoder, norm, gather):
+ * dpd_mfv3d_fwd_stacked = dpd_stack_clouds + dpd_mfv3d_fwd in one kernel: it reads pcA (+noise) / pcB directly and also
+ *   writes pts [2B,N,3] and q [2B,N,3] (either may be NULL).  With ssq != NULL ([2B][DPD_MFV_SLICES][20] floats) fv is
+ *   left WITHOUT the final per-channel L2 normalisation (:124-126) and ssq receives the per-slice sums of squares;
+ * dpd_patch_rows_fwd_scaled = dpd_patch_rows_fwd that applies that normalisation while it gathers (ssq NULL = plain).
+ * Same bits as the four-launch form (both use one summation order for the norms).                                   */
+#define DPD_MFV_SLICES 4
+int dpd_mfv3d_fwd_stacked(const float* pcA, const float* pcB, const float* noise, int B, int N, int m, float sigma,
+                          float* pts, float* q, float* fv, float* ssq, void* stream);
+int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const float* ssq, int C, int N, int m, int k, int KP,
+                              float* X, float* mask, int32_t* vox, const struct dpd_planes* pl, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused-gather path (DPD_F32): the decoder input rows X [Q,KP] are never materialised -- layer 1 and its weight gradient read
  * them straight out of the Fisher vectors inside the GEMM (csrc/gemm_rs.h).
@@ -263,6 +275,27 @@ int dpd_chamfer_bwd(const float* a, const float* b, int B, int N, int M, const i
  * with lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller.  n elements (any n).              */
 int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2,
                 float eps, float gscale, void* stream);
+
+/* One-launch optimizer step (same arithmetic, element for element, as dpd_adam_tf):
+ *   WT[i] != NULL: the matrix p[w_off[i] ..] of shape [w_rows[i], w_cols[i]] (row-major; cols % 64 == 0, rows % 4 == 0, offsets
+ *     ascending) is updated tile-wise and its transposed copy WT[i] [w_cols[i], w_rows[i]] is rewritten in the same pass
+ *     (replaces dpd_weights_transpose after the step);
+ *   partials != NULL: the LAST 4H+3 elements p[tail_off .. n) = [b3 | W4 | b4] take their gradient from the block partials
+ *     that dpd_decoder_bwd_data(phases | 16) left in dpd_small_grads.partials (nparts = ceil(Qb / 8) records of `rec`
+ *     floats); the reduced gradient is stored to g, and when `loss` is given (rec >= 4H+8: fused L1 loss) loss[0..1] are
+ *     finished exactly as the deferred reduction would (single-GPU steps only: a data-parallel step needs the reduced
+ *     gradient before its all-reduce).                                                                                  */
+typedef struct dpd_adam_fuse {
+    float* WT[3];
+    long w_off[3];
+    int w_rows[3], w_cols[3];
+    const float* partials;
+    int nparts, rec, H, Qb;
+    long tail_off;
+    float* loss;
+} dpd_adam_fuse;
+int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, float gscale,
+                      const dpd_adam_fuse* fuse, void* stream);
 
 /* The same update with the schedule kept ON THE DEVICE, so that a captured (hipGraph) training step carries no per-step host
  * parameters.  state: 8 floats, caller-owned: [0] global step (int32 bits), [1] beta1_power, [2] beta2_power (the running

@@ -1104,6 +1104,100 @@ def test_fused_trainer_matches_unfused(dev, monkeypatch):
     assert (outs[0][1] - outs[1][1]).abs().mean().item() <= 1e-6         # later steps: db1/db2 atomics order only
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,m,k,noise", [(4, 64, 8, 5, True), (3, 50, 8, 5, False), (2, 64, 5, 3, True), (5, 33, 8, 5, True)])
+def test_two_launch_front_end_is_bitwise_the_four_launches(dev, B, N, m, k, noise):
+    """dpd_mfv3d_fwd_stacked (stacking + encoder, fv left without its L2 norm, per-slice sums of squares out) followed by
+    dpd_patch_rows_fwd_scaled (norm applied while gathering) == dpd_stack_clouds, dpd_mfv3d_fwd (+ norm kernel), dpd_patch_rows_fwd."""
+    from dpdist_amd import lib as L
+    lib = L.load()
+    s = L.cur_stream()
+    g = torch.Generator().manual_seed(B * 100 + N)
+    pcA = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev)
+    pcB = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev)
+    nz = (torch.randn(B, N, 3, generator=g) * 0.02).to(dev) if noise else None
+    pcA[0, 0] = 5.0                      # a query outside the cube (mask 0)
+    C, Q, G, KP = 2 * B, 2 * B * N, m ** 3, lib.dpd_padded_width(k)
+    f = lambda *sh: torch.full(sh, float("nan"), device=dev)   # noqa: E731
+    # four launches
+    pts, q, fv, X, mask = f(C, N, 3), f(C, N, 3), f(C, G, 20), f(Q, KP), f(Q)
+    vox = torch.zeros(Q, device=dev, dtype=torch.int32)
+    L.check(lib.dpd_stack_clouds(L.ptr(pcA), L.ptr(pcB), L.ptr(nz), B, N, L.ptr(pts), L.ptr(q), s), "stack")
+    L.check(lib.dpd_mfv3d_fwd(L.ptr(pts), C, N, m, 0.125, L.ptr(fv), s), "enc")
+    L.check(lib.dpd_patch_rows_fwd(L.ptr(q), L.ptr(fv), C, N, m, k, KP, L.ptr(X), L.ptr(mask), L.ptr(vox), None, s), "gather")
+    # two launches
+    pts2, q2, fv2, X2, mask2, ssq = f(C, N, 3), f(C, N, 3), f(C, G, 20), f(Q, KP), f(Q), f(C, 4, 20)
+    vox2 = torch.zeros(Q, device=dev, dtype=torch.int32)
+    L.check(lib.dpd_mfv3d_fwd_stacked(L.ptr(pcA), L.ptr(pcB), L.ptr(nz), B, N, m, 0.125, L.ptr(pts2), L.ptr(q2), L.ptr(fv2),
+                                      L.ptr(ssq), s), "enc2")
+    L.check(lib.dpd_patch_rows_fwd_scaled(L.ptr(q2), L.ptr(fv2), L.ptr(ssq), C, N, m, k, KP, L.ptr(X2), L.ptr(mask2), L.ptr(vox2),
+                                          None, s), "gather2")
+    # and the stacked encoder WITH its own norm (ssq = NULL) is the plain encoder
+    fv3 = f(C, G, 20)
+    L.check(lib.dpd_mfv3d_fwd_stacked(L.ptr(pcA), L.ptr(pcB), L.ptr(nz), B, N, m, 0.125, None, None, L.ptr(fv3), None, s), "enc3")
+    torch.cuda.synchronize()
+    assert torch.equal(pts, pts2) and torch.equal(q, q2)
+    assert torch.equal(mask, mask2) and torch.equal(vox, vox2)
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0))   # noqa: E731
+    assert eq(fv, fv3)                   # cloud 0 of the (5.0) case is NaN in both (every pdf underflows)
+    assert eq(X, X2)
+    scale = 1.0 / torch.sqrt(torch.clamp(ssq.sum(1), min=1e-12))
+    assert torch.allclose(torch.nan_to_num(fv2 * scale[:, None, :]), torch.nan_to_num(fv), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_two_launch_front_end_in_the_trainer(dev, monkeypatch, dt):
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 4
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DPD_FRONT2", flag)
+        P = DPDistParams(device=dev, compute_dtype=dt)
+        P.load_tf_state_dict(synth.make_weights("wide"))
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        assert tr.front2 == (flag == "1")
+        losses = [tr.step(pcA, pcB, lab).clone() for _ in range(3)]
+        ev = tr.evaluate(pcA, pcB, lab)[1].clone()
+        outs.append((torch.stack(losses), P.flat.detach().clone(), ev))
+    assert torch.equal(outs[0][0][0], outs[1][0][0])            # forward of the first step: same bits in every compute type
+    for a, b in zip(*outs):
+        if dt == "f32":
+            assert torch.equal(a, b)
+        else:       # the plane compute types take db1 / db2 with fp32 atomics: later steps agree to summation order only
+            assert (a - b).abs().max().item() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mlp", [(1024, 1024, 1024), (64, 64, 64), (256, 256, 256)])
+def test_one_launch_optimizer_is_bitwise_the_three_launches(dev, monkeypatch, mlp):
+    """dpd_adam_tf_fused (Adam + transposed weight copies + the reduction of the output layer's block partials in ONE launch)
+    against DPD_FUSED_ADAM=0 (dpd_adam_tf, dpd_weights_transpose, small_grads_reduce): same weights, moments, gradients,
+    transposed copies and losses, bit for bit, over four steps."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 4
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DPD_FUSED_ADAM", fused)
+        P = DPDistParams(mlp=mlp, device=dev)
+        P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        assert tr.fused_adam == (fused == "1")
+        losses = [tr.step(pcA, pcB, lab).clone() for _ in range(4)]
+        if tr._wdirty:
+            tr.refresh_weight_planes()
+        torch.cuda.synchronize()
+        outs.append((torch.stack(losses), P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), tr.grad.clone(),
+                     tr.W2T.clone(), tr.W3T.clone()))
+        assert torch.equal(tr.W2T, P.view("W2").t()) and torch.equal(tr.W3T, P.view("W3").t())
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_checkpoint_resume_restores_optimizer_state(dev, tmp_path):
     """What the reference's tf.train.Saver() stores (train_multi_gpu_pc_compare_dist.py:305,354-357) round-trips through the TF
     V2 container: the 8 variables, `batch`, beta1_power / beta2_power and the `<variable>/Adam`, `/Adam_1` slots -- a resumed run
