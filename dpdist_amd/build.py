@@ -28,12 +28,14 @@ def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # DPD_ABLATIONS=1: also compile the timing-only ablation variants of the plane GEMM (tools/x3_bench.py tile codes 100+)
+    flags = FLAGS + (["-DDPD_ABLATIONS"] if os.environ.get("DPD_ABLATIONS") == "1" else [])
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:

@@ -103,7 +103,7 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     // (measured, tools/x3_bench.py: 160 blocks of 128x128 beat 320 of 64x128 on the 2528x1024 dW1; 64x64 only when even
     //  64x128 leaves most CUs idle)
     int tile = blocks(128, 128) >= 150 ? 2 : (blocks(64, 128) >= 100 ? 3 : 5);
-    if (np == 1 && g_x3_tile[op] && !(K % 64)) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..23)
+    if (np == 1 && g_x3_tile[op] && !(K % 64)) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..24)
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
                    out);
 }

@@ -55,7 +55,9 @@ __device__ __forceinline__ int chunk_of(int o, int kg) {
     return KC ? o * CPR + (kg ^ ((o / (16 / CPR)) & (CPR - 1))) : kg * BO + o;
 }
 
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK>
+// ABL (timing-only ablations, instantiated only with -DDPD_ABLATIONS; results are wrong by construction):
+//   1 = no LDS-DMA refill in the K loop, 2 = no barrier, 4 = no fragment reads in the loop, 8 = one MFMA per step only.
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
     constexpr int CPR = BK / 8, KB = BK / 16;               // chunks per row, k16 steps per K-tile
@@ -127,6 +129,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         }
     };
 
+    static_assert((NS - 2) * PPW <= 63, "vmcnt range");
+    auto wait_later = [&](int later) {   // leave `later` whole K-tiles of this wave's pieces in flight
+        if (later >= 6) wait_vm<(NS >= 8 ? 6 : 0) * PPW>();
+        else if (later == 5) wait_vm<(NS >= 7 ? 5 : 0) * PPW>();
+        else if (later == 4) wait_vm<(NS >= 6 ? 4 : 0) * PPW>();
+        else if (later == 3) wait_vm<(NS >= 5 ? 3 : 0) * PPW>();
+        else if (later == 2) wait_vm<(NS >= 4 ? 2 : 0) * PPW>();
+        else if (later == 1) wait_vm<PPW>();
+        else wait_vm<0>();
+    };
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -139,16 +151,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
         if (p < nt) issue(p);
-    static_assert((NS - 2) * PPW <= 63, "vmcnt range");
-    auto wait_later = [&](int later) {   // leave `later` whole K-tiles of this wave's pieces in flight
-        if (later >= 6) wait_vm<(NS >= 8 ? 6 : 0) * PPW>();
-        else if (later == 5) wait_vm<(NS >= 7 ? 5 : 0) * PPW>();
-        else if (later == 4) wait_vm<(NS >= 6 ? 4 : 0) * PPW>();
-        else if (later == 3) wait_vm<(NS >= 5 ? 3 : 0) * PPW>();
-        else if (later == 2) wait_vm<(NS >= 4 ? 2 : 0) * PPW>();
-        else if (later == 1) wait_vm<PPW>();
-        else wait_vm<0>();
-    };
     wait_later(min(NS - 2, nt - 1));
     __builtin_amdgcn_s_barrier();
 
@@ -174,13 +176,15 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         constexpr int cur = decltype(curc)::value;
         if (kb == KB - 1) {
             // my pieces of K-tile it+1 have landed once only tiles it+2 .. it+NS-2 may be outstanding
-            wait_later(min(NS - 3, nt - 2 - it));
-            __builtin_amdgcn_s_barrier();
+            if (!(ABL & 1)) wait_later(min(NS - 3, nt - 2 - it));
+            if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
             // everybody is past K-tile it-1: refill its stage with K-tile it+NS-1
-            if (it + NS - 1 < nt) issue((it + NS - 1) % NS);
-            if (it + 1 < nt) frags((it + 1) % NS, 0, cur ^ 1);
+            if (!(ABL & 1) && it + NS - 1 < nt) issue((it + NS - 1) % NS);
+            // unconditional (the last iteration reads a stale stage and never uses it): behind a branch hipcc falls back to
+            // s_waitcnt lgkmcnt(0) before the MFMAs below, i.e. they would wait for the reads that were only just issued
+            if (!(ABL & 4)) frags((it + 1) % NS, 0, cur ^ 1);
         } else {
-            frags(it % NS, kb + 1, cur ^ 1);
+            if (!(ABL & 4)) frags(it % NS, kb + 1, cur ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (NP == 3) {
@@ -193,12 +197,14 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] =
                             __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][ta[q]][i], fb[cur][tb[q]][j], acc[i][j], 0, 0, 0);
+        } else if (ABL & 8) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][0], fb[cur][0][0], acc[0][0], 0, 0, 0);
         } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][0][i], fb[cur][0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(ABL & 4) ? 0 : cur][0][i], fb[(ABL & 4) ? 0 : cur][0][j], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -284,13 +290,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     }
 }
 
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK>
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
 static int launch_x3(const X3Args& g, hipStream_t s) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
     constexpr size_t ring = (size_t)NS * NP * (BM + BN) * BK * 2, stage = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = ring > stage ? ring : stage;   // the plane epilogue stages the fp32 tile in the ring's LDS
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK>;
+    auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK, ABL>;
     static LdsOptIn lds_opt;   // one per template instantiation
     if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
     const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * g.e.split_k * (g.A2 ? 2 : 1);
@@ -315,6 +321,11 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 10: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x128, 4 waves of 64x64
         case 11: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x256, 8 waves of 64x64
         case 12: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 1, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 64x128, 4 waves of 32x64
+#ifdef DPD_ABLATIONS
+#define DPD_X3_ABL(code) case 100 + code: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 1, 4, 32, code>(g, s); return DPD_E_UNSUPPORTED;
+        DPD_X3_ABL(1) DPD_X3_ABL(2) DPD_X3_ABL(3) DPD_X3_ABL(4) DPD_X3_ABL(5) DPD_X3_ABL(7) DPD_X3_ABL(8) DPD_X3_ABL(9) DPD_X3_ABL(12) DPD_X3_ABL(13) DPD_X3_ABL(15)
+#undef DPD_X3_ABL
+#endif
         default: return DPD_E_UNSUPPORTED;
     }
 }

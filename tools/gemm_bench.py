@@ -30,6 +30,7 @@ def main():
         ("fwd_L1  NN", (r(Q, KP), r(KP, H), False, False)),
         ("fwd_L23 NN", (r(Q, H), r(H, H), False, False)),
         ("bwd_dH  NT", (r(BN, H), r(H, H), False, True)),
+        ("bwd_dH  NN", (r(BN, H), r(H, H), False, False)),      # what the step runs: g x W^T as an NN product on the transposed copy
         ("bwd_dX  NT", (r(BN, H), r(KP, H), False, True)),
         ("bwd_dW1 TN", (r(BN, KP), r(BN, H), True, False)),
         ("bwd_dW23 TN", (r(BN, H), r(BN, H), True, False)),
