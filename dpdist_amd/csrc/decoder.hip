@@ -19,7 +19,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
             hipStream_t s, float* colsum, const X3Out* out = nullptr, const uint16_t* A2 = nullptr, const uint16_t* B2 = nullptr,
-            float* C2 = nullptr);
+            float* C2 = nullptr, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
 int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
                    const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
                    hipStream_t s, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
@@ -40,7 +40,7 @@ enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 =
 static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32, 30};
 static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 3};   // (0 = tail split, gemm_rs.h: measured no gain on dW1, 0.525 vs 0.5215 ms of GEMM per step)
 static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
-static int g_x3_pair_tile = 0;
+static int g_x3_pair_tile = 0, g_x3_pair_split = 1;   // plane dW2+dW3 pair: tile (0 = automatic), split-K
 
 // Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
 //   0  exact fp32 on the fp32 MFMA (gemm_f32.hip)
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeJobs J) {
 
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
     if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 12) { dpd::g_x3_tile[op - 16] = tile; return 0; }
-    if (op == 32 && tile >= 0 && tile <= 12) { dpd::g_x3_pair_tile = tile; return 0; }
+    if (op == 32 && tile >= 0 && tile <= 12 && split_k >= 1 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
     if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;
@@ -965,12 +965,19 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
         if (int rc = check_planes(pl, dtype)) return rc;
         const bool have = pl && pl->h1_r8 && pl->g2_r8 && pl->h2_r8 && pl->g3_r8;   // pair = (layer 2, layer 3)
         if (!have && !scr.p) return DPD_E_WORKSPACE;
-        if (have) {   // both GEMMs in ONE grouped launch of 64x128 tiles: 2 x 128 workgroups fill the chip in one round
+        if (have) {
+            // both GEMMs in ONE grouped launch of 64x128 tiles over the whole K (2 x 128 workgroups).  A split-K-2 form on 128x128
+            // tiles (2 x 64 x 2 workgroups, two fp32 slabs added in a fixed order) is available through dpd_set_gemm_plan(32,
+            // tile, 2) and tested, but measured slower in every compute type (bf16 B=64: 0.3903 vs 0.3861 ms per step; the slab
+            // traffic and the reduce launch cost more than the shorter K loop saves).
             const long pe = (long)Kin * Qb, ge = (long)Qb * Nout;
-            const int ptile = (pl->np == 1 && g_x3_pair_tile && !(Qb % 64)) ? g_x3_pair_tile : 3;
+            int split = g_x3_pair_split, ptile = g_x3_pair_tile;
+            if (split > 1 && (Qb % (128 * split) || !ws || (size_t)2 * split * Kin * Nout * sizeof(float) > ws_bytes)) split = 1;
+            if (!ptile) ptile = split > 1 ? 2 : 3;
+            if (ptile >= 8 && (pl->np != 1 || Qb % (64 * split))) ptile = split > 1 ? 2 : 3;
             return gemm_x3(pl->np, 1, 1, Kin, Nout, Qb, (const uint16_t*)pl->h1_r8, Kin, pe, (const uint16_t*)pl->g2_r8, Nout, ge, dWA, Nout,
                            nullptr, nullptr, 0, ptile, (hipStream_t)stream, nullptr, nullptr, (const uint16_t*)pl->h2_r8,
-                           (const uint16_t*)pl->g3_r8, dWB);
+                           (const uint16_t*)pl->g3_r8, dWB, split, ws, ws_bytes);
         }
         if (int rc = gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, nullptr, 0,
                              scr, (hipStream_t)stream, nullptr, have ? pl->h1_r8 : nullptr, have ? pl->g2_r8 : nullptr, nullptr)) return rc;

@@ -195,6 +195,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+int splitk_reduce(const float* slabs, int split_k, long slab_stride, int M, int N, float* C, int ldc, const float* bias,
+                  const float* gate, int epi, hipStream_t s) {
+    const long total4 = (long)M * N / 4;
+    const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    DPD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, split_k, slab_stride, M, N, C, ldc, bias, gate, epi);
+    return (int)hipGetLastError();
+}
+
 // =========================================================================================================
 // LDS-DMA kernel: (32*WR) x (32*WC) x 32 tiles, one 32x32 MFMA tile per wave, 4-stage LDS ring fed by
 // global_load_lds_dwordx4 (no VGPR staging, no ds_write).

@@ -176,6 +176,10 @@ __device__ __forceinline__ void split_chunk(const float (&v)[8], uint4 (&w)[3]) 
 
 // optional bf16-plane outputs of a gemm_x3 result (gemm_x3.hip): RC planes [np][M][ld_rc], R8 planes
 // [np][r8_rows/8][N][8] for the rows < r8_rows
+// out[m,n] = epi( sum_z slabs[z][m,n] ), fixed order (gemm_f32.hip); slabs are dense [M,N], N % 4 == 0
+int splitk_reduce(const float* slabs, int split_k, long slab_stride, int M, int N, float* C, int ldc, const float* bias,
+                  const float* gate, int epi, hipStream_t s);
+
 struct X3Out {
     uint16_t* rc = nullptr;
     uint16_t* r8 = nullptr;

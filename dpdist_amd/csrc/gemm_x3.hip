@@ -333,8 +333,19 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
 // C[M,N] (fp32) = epi( op(A) op(B) ) from bf16 planes.  a_fmt/b_fmt: 0 = RC (k contiguous), 1 = R8 (k = row index).
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
-            hipStream_t s, float* colsum, const X3Out* out, const uint16_t* A2, const uint16_t* B2, float* C2) {
+            hipStream_t s, float* colsum, const X3Out* out, const uint16_t* A2, const uint16_t* B2, float* C2, int split_k, void* ws,
+            size_t ws_bytes) {
     if (A2 && (!B2 || !C2 || out || colsum || epilogue != EPI_NONE)) return DPD_E_UNSUPPORTED;
+    // split-K (deterministic slabs in `ws` + the reduce kernel of gemm_f32.hip): plain products only (the dW shapes: K = query rows
+    // is long, M x N gives too few 128x128 tiles for 256 CUs)
+    int chunk = K;
+    if (split_k > 1) {
+        chunk = (((K + split_k - 1) / split_k) + 63) / 64 * 64;
+        if (out || colsum || epilogue != EPI_NONE || !C || chunk * (split_k - 1) >= K) return DPD_E_UNSUPPORTED;
+        if (!ws || (size_t)split_k * M * N * sizeof(float) * (A2 ? 2 : 1) > ws_bytes) return DPD_E_WORKSPACE;
+    } else {
+        split_k = 1;
+    }
     const bool planes_out = out && (out->rc || out->r8);
     if (!A || !B || (!C && !planes_out)) return DPD_E_NULL;
     if (planes_out && ((out->np != 1 && out->np != 3) || (M & 7) || (N & 7) || (out->r8_rows & 7) || (out->rc && (out->ld_rc & 7))))
@@ -353,6 +364,10 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     g.e.split_k = 1; g.e.k_chunk = K; g.e.slab_stride = 0;
     g.A = A; g.B = B; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
+    if (split_k > 1) {
+        g.e.split_k = split_k; g.e.k_chunk = chunk; g.e.slab_stride = (long)M * N; g.e.ldc = N;
+        g.e.C = (float*)ws; g.C2 = (float*)ws + (size_t)split_k * M * N;
+    }
     if (planes_out) {
         g.out_rc = out->rc; g.out_r8 = out->r8; g.rc_plane = out->rc_plane; g.r8_plane = out->r8_plane;
         g.ld_rc = out->ld_rc; g.r8_rows = out->r8_rows; g.np_out = out->np;
@@ -362,14 +377,20 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
         bool on; hipStream_t s; double fl;
         ~ProfScope() { prof_end(on, s, fl); }
     } prof_scope{prof_begin(s), s, 2.0 * M * N * K * (A2 ? 2 : 1)};
+    int rc;
     if (np == 3) {
-        if (!a_fmt && b_fmt) return launch_x3_tile<3, true, false>(tile, g, s);     // NN
-        if (!a_fmt && !b_fmt) return launch_x3_tile<3, true, true>(tile, g, s);     // NT
-        return launch_x3_tile<3, false, false>(tile, g, s);                          // TN
+        if (!a_fmt && b_fmt) rc = launch_x3_tile<3, true, false>(tile, g, s);       // NN
+        else if (!a_fmt && !b_fmt) rc = launch_x3_tile<3, true, true>(tile, g, s);  // NT
+        else rc = launch_x3_tile<3, false, false>(tile, g, s);                      // TN
+    } else {
+        if (!a_fmt && b_fmt) rc = launch_x3_tile<1, true, false>(tile, g, s);
+        else if (!a_fmt && !b_fmt) rc = launch_x3_tile<1, true, true>(tile, g, s);
+        else rc = launch_x3_tile<1, false, false>(tile, g, s);
     }
-    if (!a_fmt && b_fmt) return launch_x3_tile<1, true, false>(tile, g, s);
-    if (!a_fmt && !b_fmt) return launch_x3_tile<1, true, true>(tile, g, s);
-    return launch_x3_tile<1, false, false>(tile, g, s);
+    if (rc || split_k == 1) return rc;
+    if ((rc = splitk_reduce(g.e.C, split_k, (long)M * N, M, N, C, ldc, nullptr, nullptr, EPI_NONE, s))) return rc;
+    if (A2) rc = splitk_reduce(g.C2, split_k, (long)M * N, M, N, C2, ldc, nullptr, nullptr, EPI_NONE, s);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -455,5 +476,5 @@ extern "C" int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K
     o.rc = (uint16_t*)out_rc; o.r8 = (uint16_t*)out_r8; o.np = np; o.ld_rc = N; o.r8_rows = r8_rows;
     o.rc_plane = (long)M * N; o.r8_plane = (long)r8_rows * N;
     return dpd::gemm_x3(np, a_fmt, b_fmt, M, N, K, (const uint16_t*)A, lda, a_plane, (const uint16_t*)B, ldb, b_plane, C, ldc,
-                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr, nullptr, nullptr, nullptr);
+                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0);
 }

@@ -1105,6 +1105,45 @@ def test_fused_trainer_matches_unfused(dev, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32x3", "bf16"])
+def test_plane_weight_gradient_pair_split_k(dev, dt):
+    """dW2 + dW3 of the plane compute types at B = 32 (K = 2048 query rows): the opt-in grouped split-K-2 launch of 128x128 tiles
+    (two fp32 slabs added in a fixed order) against the default whole-K launch of 64x128 tiles -- same gradients up to fp32
+    summation order, and both against the fp32 trainer."""
+    from dpdist_amd import ops
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 32
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    grads = {}
+    try:
+        for name, (tile, split) in {"split2": (0, 2), "whole": (3, 1)}.items():
+            ops.set_gemm_plan(32, tile, split)
+            P = DPDistParams(device=dev, compute_dtype=dt)
+            P.load_tf_state_dict(synth.make_weights("wide"))
+            tr = DPDistTrainer(P, B, distributed=False)
+            tr._take_front(pcA, pcB, None)
+            tr._decode()
+            tr.backward(lab.reshape(-1))
+            torch.cuda.synchronize()
+            grads[name] = {n: P.view(n, tr.grad).clone() for n in ("W2", "W3")}
+    finally:
+        ops.set_gemm_plan(32, 0, 1)
+    P = DPDistParams(device=dev)
+    P.load_tf_state_dict(synth.make_weights("wide"))
+    tr = DPDistTrainer(P, B, distributed=False)
+    tr._take_front(pcA, pcB, None)
+    tr._decode()
+    tr.backward(lab.reshape(-1))
+    for n in ("W2", "W3"):
+        a, b, ref = grads["split2"][n], grads["whole"][n], P.view(n, tr.grad)
+        scale = ref.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-6 * scale + 1e-9, n          # same products, different fp32 summation order
+        tol = 2e-5 if dt == "f32x3" else 3e-2
+        assert (a - ref).abs().max().item() <= tol * scale, (n, (a - ref).abs().max().item(), scale)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,N,m,k,noise", [(4, 64, 8, 5, True), (3, 50, 8, 5, False), (2, 64, 5, 3, True), (5, 33, 8, 5, True)])
 def test_two_launch_front_end_is_bitwise_the_four_launches(dev, B, N, m, k, noise):
     """dpd_mfv3d_fwd_stacked (stacking + encoder, fv left without its L2 norm, per-slice sums of squares out) followed by
