@@ -3,7 +3,7 @@
 //   dpd_l1_loss  replaces utils/dpdist_util.py:962-980 (get_loss) and TF's autodiff of it
 //   dpd_adam_tf  replaces tf.train.AdamOptimizer (train_multi_gpu_pc_compare_dist.py:216,301): epsilon-hat form
 //                algorithmic HBM bytes per parameter: 16 read (p,g,m,v) + 12 written (p,m,v)
-#include "common.h"
+#include "gemm_shared.h"
 
 namespace dpd {
 
@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
 //   role 3 (vector blocks): every other element, float4 grid-stride over up to four ranges.
 struct AdamFuse {
     float* WT[3];
+    uint16_t* rc[3];            // bf16 operand planes of the updated matrix (gemm_x3.hip formats), np planes each, or NULL
+    uint16_t* r8[3];
+    int np;
     long w_off[3];
     int w_rows[3], w_cols[3];
     int tile_end[3];            // cumulative tile-block counts of the three matrices (0-size matrices repeat the previous value)
@@ -140,13 +143,48 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
             }
         }
         __syncthreads();
-        float* T = f.WT[w];
+        if (float* T = f.WT[w]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = tid + 256 * k, c = idx >> 4, r4 = (idx & 15) * 4;
-            if (r0 + r4 < rows)      // rows % 4 == 0: a float4 of rows is valid or absent as a whole
-                *reinterpret_cast<float4*>(T + (size_t)(c0 + c) * rows + r0 + r4) =
-                    make_float4(tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]);
+            for (int k = 0; k < 4; ++k) {
+                const int idx = tid + 256 * k, c = idx >> 4, r4 = (idx & 15) * 4;
+                if (r0 + r4 < rows)      // rows % 4 == 0: a float4 of rows is valid or absent as a whole
+                    *reinterpret_cast<float4*>(T + (size_t)(c0 + c) * rows + r0 + r4) =
+                        make_float4(tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]);
+            }
+        }
+        // bf16 operand planes of the new weights (what dpd_weights_to_planes would write: same split, same layouts)
+        const long plane = (long)rows * cols;
+        if (uint16_t* rc = f.rc[w]) {      // RC [np][rows][cols]: a chunk = 8 consecutive columns of one row
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + 256 * k, r = idx >> 3, cg = (idx & 7) * 8;
+                if (r0 + r < rows) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = tile[r][cg + j];
+                    uint4 wv[3];
+                    split_chunk(x, wv);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (q < f.np) *reinterpret_cast<uint4*>(rc + q * plane + (size_t)(r0 + r) * cols + c0 + cg) = wv[q];
+                }
+            }
+        }
+        if (uint16_t* r8 = f.r8[w]) {      // R8 [np][rows/8][cols][8]: a chunk = 8 consecutive rows of one column
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + 256 * k, rg = idx >> 6, c = idx & 63;
+                if (r0 + 8 * rg < rows) {  // rows % 8 == 0 when planes are requested
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = tile[8 * rg + j][c];
+                    uint4 wv[3];
+                    split_chunk(x, wv);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (q < f.np) *reinterpret_cast<uint4*>(r8 + q * plane + ((size_t)((r0 >> 3) + rg) * cols + c0 + c) * 8) = wv[q];
+                }
+            }
         }
         return;
     }
@@ -330,13 +368,19 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
     // covered intervals, in ascending order of offset (the caller passes the matrices in flat order)
     long lo[4], hi[4];
     int nc = 0, tiles = 0;
+    const bool planes = fu->np != 0;
+    if (planes && fu->np != 1 && fu->np != 3) return DPD_E_UNSUPPORTED;
+    f.np = fu->np;
     for (int w = 0; w < 3; ++w) {
         f.WT[w] = fu->WT[w]; f.w_off[w] = fu->w_off[w]; f.w_rows[w] = fu->w_rows[w]; f.w_cols[w] = fu->w_cols[w];
-        if (fu->WT[w]) {
+        f.rc[w] = planes ? (uint16_t*)fu->W_rc[w] : nullptr;
+        f.r8[w] = planes ? (uint16_t*)fu->W_r8[w] : nullptr;
+        if (fu->WT[w] || f.rc[w] || f.r8[w]) {
             const long cnt = (long)fu->w_rows[w] * fu->w_cols[w];
             if (fu->w_rows[w] <= 0 || fu->w_cols[w] <= 0 || (fu->w_cols[w] & 63) || (fu->w_rows[w] & 3) || (fu->w_off[w] & 3) ||
                 fu->w_off[w] < 0 || (size_t)(fu->w_off[w] + cnt) > n || ((uintptr_t)fu->WT[w] & 15))
                 return DPD_E_UNSUPPORTED;
+            if ((f.rc[w] || f.r8[w]) && ((fu->w_rows[w] & 7) || (((uintptr_t)f.rc[w] | (uintptr_t)f.r8[w]) & 15))) return DPD_E_UNSUPPORTED;
             if (nc && fu->w_off[w] < hi[nc - 1]) return DPD_E_DIM;
             lo[nc] = fu->w_off[w]; hi[nc] = fu->w_off[w] + cnt; ++nc;
             tiles += ((fu->w_rows[w] + 63) / 64) * (fu->w_cols[w] / 64);

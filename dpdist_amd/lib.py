@@ -25,7 +25,8 @@ class SmallGrads(Structure):
 
 
 class AdamFuse(Structure):   # include/dpdist_capi.h: dpd_adam_fuse
-    _fields_ = [("WT", c_void_p * 3), ("w_off", c_long * 3), ("w_rows", c_int * 3), ("w_cols", c_int * 3), ("partials", c_void_p),
+    _fields_ = [("WT", c_void_p * 3), ("w_off", c_long * 3), ("w_rows", c_int * 3), ("w_cols", c_int * 3),
+                ("W_rc", c_void_p * 3), ("W_r8", c_void_p * 3), ("np", c_int), ("partials", c_void_p),
                 ("nparts", c_int), ("rec", c_int), ("H", c_int), ("Qb", c_int), ("tail_off", c_long), ("loss", c_void_p)]
 
 

@@ -119,6 +119,12 @@ class DPDistTrainer:
             if self.W2T is not None:
                 for j, (n, T) in enumerate((("W2", self.W2T), ("W3", self.W3T))):
                     af.WT[j], af.w_off[j], af.w_rows[j], af.w_cols[j] = T.data_ptr(), seg[n][0], H, H
+            elif self._planes is not None and KP % 8 == 0 and H % 64 == 0:      # the weights' bf16 operand planes out of Adam
+                pl = self._planes
+                af.np = pl.np
+                for j, (n, rows) in enumerate((("W1p", KP), ("W2", H), ("W3", H))):
+                    af.w_off[j], af.w_rows[j], af.w_cols[j] = seg[n][0], rows, H
+                    af.W_rc[j], af.W_r8[j] = getattr(pl, "W%d_rc" % (j + 1)), getattr(pl, "W%d_r8" % (j + 1))
             if i == 1:
                 af.partials, af.nparts, af.rec, af.H, af.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
                 af.tail_off, af.loss = seg["b3"][0], self.loss.data_ptr()
@@ -321,11 +327,12 @@ class DPDistTrainer:
         if self.reducer:
             self.reducer.wait()
             gscale = self.reducer.grad_scale
-        if self.fused_adam and (self.W2T is not None or tail_from_partials):
+        if self.fused_adam and (self.W2T is not None or self._afuse[0].np or tail_from_partials):
             L.check(L.load().dpd_adam_tf_fused(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                                self.P.numel, lr_t, b1, b2, eps, gscale, self._afuse[1 if tail_from_partials else 0],
                                                L.cur_stream()), "dpd_adam_tf_fused")
-            self._wdirty = self._planes is not None      # the transposed copies are already those of the new weights
+            # the transposed copies / operand planes written in the same pass are already those of the new weights
+            self._wdirty = self._planes is not None and not self._afuse[0].np
             return
         L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                      self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")

@@ -277,7 +277,7 @@ int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr
                 float eps, float gscale, void* stream);
 
 /* One-launch optimizer step (same arithmetic, element for element, as dpd_adam_tf):
- *   WT[i] != NULL: the matrix p[w_off[i] ..] of shape [w_rows[i], w_cols[i]] (row-major; cols % 64 == 0, rows % 4 == 0, offsets
+ *   WT[i] != NULL (or planes, below): the matrix p[w_off[i] ..] of shape [w_rows[i], w_cols[i]] (row-major; cols % 64 == 0, rows % 4 == 0, offsets
  *     ascending) is updated tile-wise and its transposed copy WT[i] [w_cols[i], w_rows[i]] is rewritten in the same pass
  *     (replaces dpd_weights_transpose after the step);
  *   partials != NULL: the LAST 4H+3 elements p[tail_off .. n) = [b3 | W4 | b4] take their gradient from the block partials
@@ -289,6 +289,12 @@ typedef struct dpd_adam_fuse {
     float* WT[3];
     long w_off[3];
     int w_rows[3], w_cols[3];
+    /* bf16-matrix-core compute types: the operand planes of the updated matrices (dpd_planes.W*_rc / W*_r8; either may be NULL),
+     * np = 1 or 3 planes each, written in the same pass (replaces dpd_weights_to_planes after the step; rows % 8 == 0);
+     * np = 0: none */
+    void* W_rc[3];
+    void* W_r8[3];
+    int np;
     const float* partials;
     int nparts, rec, H, Qb;
     long tail_off;

@@ -1210,6 +1210,30 @@ def test_two_launch_front_end_in_the_trainer(dev, monkeypatch, dt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "f32x3"])
+@pytest.mark.parametrize("mlp", [(1024, 1024, 1024), (64, 64, 64)])
+def test_one_launch_optimizer_writes_the_weight_planes(dev, dt, mlp):
+    """Plane compute types: dpd_adam_tf_fused leaves the bf16 operand planes of W1/W2/W3 exactly as dpd_weights_to_planes
+    would write them from the updated weights (so the separate conversion launch is skipped)."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 4
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    P = DPDistParams(mlp=mlp, device=dev, compute_dtype=dt)
+    P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
+    tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+    assert tr._planes is not None and tr._afuse[0].np == (1 if dt == "bf16" else 3)
+    for _ in range(3):
+        tr.step(pcA, pcB, lab)
+    assert not tr._wdirty                                  # nothing left to re-derive after the optimizer
+    torch.cuda.synchronize()
+    got = tr._plane_mem.clone()
+    tr.refresh_weight_planes()                             # the separate conversion launch, from the same weights
+    torch.cuda.synchronize()
+    assert torch.equal(got, tr._plane_mem)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mlp", [(1024, 1024, 1024), (64, 64, 64), (256, 256, 256)])
 def test_one_launch_optimizer_is_bitwise_the_three_launches(dev, monkeypatch, mlp):
     """dpd_adam_tf_fused (Adam + transposed weight copies + the reduction of the output layer's block partials in ONE launch)
