@@ -308,6 +308,9 @@ def main():
         dist.barrier()
 
     keep = []
+    import gc
+    gc.collect()
+    gc.disable()          # like timeit: a generation-2 collection inside a 12-30 ms timed region shows up as a 20 ms host stall
 
     def bf16_b64(distributed, label):
         """BASELINE configs 3-4: the same training step in bf16 at 64 pairs per GPU, timed like the headline."""
@@ -385,14 +388,36 @@ def main():
     # with the LDS-ring GEMMs (144 of 160 KiB of LDS per CU) nothing overlapped (0.672 vs 0.674 ms); with the LDS-free
     # register-streamed GEMMs 0.598-0.605 vs 0.610-0.611 ms (1-2 %).  Off by default: it needs the next batch one step early.
     nxt = (pcA, pcB, None) if a.prefetch else None
+    # Device spin-up (NOT training steps, nothing of the model is touched): an MI355X that was idle -- or busy with a different
+    # kind of load -- needs ~25 ms of sustained fp32-MFMA work before its power management settles on the steady clock
+    # (tools/ramp_probe.py, DPD_BENCH_TRACE=1: 0.645 -> 0.58 ms per step over the first 40 steps, every time).  The driver's
+    # `--steps 20 --warmup 5` is a 15 ms measurement; without this it times the ramp, not the step.  Reported as `spinup_ms`.
+    spin_ms = float(os.environ.get("DPD_BENCH_SPINUP_MS", "40"))
+    if spin_ms > 0:
+        from dpdist_amd import ops
+        sa, sb = torch.randn(4096, 2528, device=dev), torch.randn(2528, 1024, device=dev)
+        torch.cuda.synchronize()
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
+            for _ in range(8):
+                ops.gemm_f32(sa, sb, tile=32)
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         tr.step(pcA, pcB, lab, prefetch=nxt)
     sync()
+    trace = os.environ.get("DPD_BENCH_TRACE") == "1"      # diagnostic: per-10-step times of the timed region (adds syncs)
+    marks = []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         tr.step(pcA, pcB, lab, prefetch=nxt)
+        if trace and i % 10 == 9:
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter())
     sync()
     el = time.perf_counter() - t0
+    gc.enable()
+    if trace and rank == 0:
+        print("trace ms/step per 10 steps:", " ".join("%.3f" % ((b - a_) / 10 * 1e3) for a_, b in zip([t0] + marks[:-1], marks)), file=sys.stderr)
     if use_dist:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -449,7 +474,7 @@ def main():
                                       "fwd both directions + bwd AB half + Adam), S2 ModelNet-shaped clouds",
                           "pairs_per_gpu": B, "global_batch": B * world, "num_point": N, "query_points_per_step": 2 * B * N * world,
                           "parallelism": "dp%d" % world, "loss_samples_last": round(float(loss[0]), 6)},
-               "roofline": roof}
+               "roofline": roof, "spinup_ms": spin_ms}
         if others is not None:
             out["other_compute_types"] = others
         if cfg34:
