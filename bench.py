@@ -484,9 +484,16 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(B, N)
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio (flushed at exit = after anything Python printed): flush it first so that
+        # the JSON line is the LAST line of stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
