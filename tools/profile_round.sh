@@ -16,16 +16,19 @@ B="python $R/bench.py"
 NOCPU="--no-cpu-baseline"
 SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes"
 export TMPDIR=/tmp
+# the profiler passes must see the training step only: no spin-up GEMMs (bench.py: spinup_ms) in the traces
+PROF="env DPD_BENCH_SPINUP_MS=0 rocprofv3"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes > $OUT/bench_under_rocprof.json 2>/dev/null
+$PROF --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes > $OUT/bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- $B $SHORT > /dev/null 2>&1
+  timeout 240 $PROF --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- $B $SHORT > /dev/null 2>&1
 done
-timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_MFMA -o p -- $B $SHORT > /dev/null 2>&1
+timeout 240 $PROF --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_MFMA -o p -- $B $SHORT > /dev/null 2>&1
 # the PMC summary must exist in profiles/ BEFORE the bench line is emitted (bench.py reads roofline.traffic from it)
 python $R/tools/summarize_profiles.py $TAG > /dev/null
 $B > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
+$B --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2>> $OUT/bench.err     # the command the driver runs
 [ -n "$QUICK" ] && exit 0
 # compute types on the bf16 matrix cores (same step, --dtype) and the B=64 configuration of BASELINE configs 3-4
 for dt in f32x3 bf16; do
@@ -34,15 +37,15 @@ done
 $B --dtype bf16 --batch 64 $NOCPU --no-other-dtypes > $OUT/bench_bf16_b64.json 2>> $OUT/bench.err
 $B --batch 64 $NOCPU --no-other-dtypes > $OUT/bench_f32_b64.json 2>> $OUT/bench.err
 for dt in f32x3 bf16; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$dt -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes --dtype $dt > /dev/null 2>&1
+  $PROF --kernel-trace --stats --output-format csv -d $OUT/stats_$dt -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes --dtype $dt > /dev/null 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${dt}_$c -o p -- $B $SHORT --dtype $dt > /dev/null 2>&1
+    timeout 240 $PROF --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${dt}_$c -o p -- $B $SHORT --dtype $dt > /dev/null 2>&1
   done
-  timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_${dt}_MFMA -o p -- $B $SHORT --dtype $dt > /dev/null 2>&1
+  timeout 240 $PROF --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_${dt}_MFMA -o p -- $B $SHORT --dtype $dt > /dev/null 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bf16_b64 -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes --dtype bf16 --batch 64 > /dev/null 2>&1
+$PROF --kernel-trace --stats --output-format csv -d $OUT/stats_bf16_b64 -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes --dtype bf16 --batch 64 > /dev/null 2>&1
 # opt-in variants of the same step (each line: variant, ms/step, GEMM ms/step)
-line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s ms_per_step %.4f  gemm_ms_per_step %s  value %.0f' % ('$1', d['ms_per_step'], d['roofline'].get('gemm_ms_per_step'), d['value']))"; }
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s ms_per_step %.4f  gemm_ms_per_step %s  value %.0f' % ('$1', d['ms_per_step'], (d.get('roofline') or {}).get('gemm_ms_per_step'), d['value']))"; }
 {
   $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line default
   $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line default_again
@@ -56,4 +59,10 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split
 python $R/tools/gemm_bench.py --tiles 2,3,30,31,32,33 --splits 1,3 > $OUT/gemm_bench.txt 2>&1
 python $R/tools/x3_bench.py 2 3 5 > $OUT/x3_bench.txt 2>&1
 python $R/tools/determinism_check.py f32 > $OUT/determinism.txt 2>&1
+{ python $R/tools/asloss_bench.py --batch 16; python $R/tools/asloss_bench.py --batch 32; } > $OUT/asloss_bench.txt 2>/dev/null
+python $R/tools/ramp_probe.py > $OUT/ramp_probe.txt 2>/dev/null
+{ python $R/tools/host_rate.py f32 32; python $R/tools/host_rate.py bf16 64; } > $OUT/host_rate.txt 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 $R/tools/ldsdma_bw.hip -o /tmp/ldsdma_bw 2>/dev/null && /tmp/ldsdma_bw > $OUT/ldsdma_bw.txt 2>&1
+{ for e in "DPD_FORCE_DIST=0" "DPD_FORCE_DIST=1" "DPD_FORCE_DIST=1 DPD_DP_SCHEDULE=late" "DPD_FORCE_DIST=1 DPD_DP_MODE=rs_ag" "DPD_FORCE_DIST=1 DPD_DP_WIRE=bf16"; do
+    env $e MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes --no-roofline 2>/dev/null | tail -1 | line "$e" ; done; } > $OUT/dp_single_rank.txt 2>&1
 python $R/tools/summarize_profiles.py $TAG

@@ -26,7 +26,9 @@ def copy(a, b):
 for a, b in (("bench.json", "bench.json"), ("bench_f32x3.json", "bench_f32x3.json"), ("bench_bf16.json", "bench_bf16.json"),
              ("bench_bf16_b64.json", "bench_bf16_b64.json"), ("bench_f32_b64.json", "bench_f32_b64.json"),
              ("x3_bench.txt", "x3_bench.txt"), ("gemm_bench.txt", "gemm_bench.txt"), ("variants.txt", "variants.txt"),
-             ("determinism.txt", "determinism.txt")):
+             ("determinism.txt", "determinism.txt"), ("bench_driver_flags.json", "bench_driver_flags.json"),
+             ("asloss_bench.txt", "asloss_bench.txt"), ("ramp_probe.txt", "ramp_probe.txt"), ("host_rate.txt", "host_rate.txt"),
+             ("ldsdma_bw.txt", "ldsdma_bw.txt"), ("dp_single_rank.txt", "dp_single_rank.txt")):
     copy(a, b)
 
 # per-kernel stats (our kernels only), one file per compute type
