@@ -246,29 +246,33 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
 // forward kernel + scale applied by the window gather).
 __device__ __forceinline__ float l2_scale(float ss) { return 1.0f / sqrtf(fmaxf(ss, 1e-12f)); }   // x * rsqrt(max(sum x^2, eps))
 
-__global__ __launch_bounds__(256) void mfv3d_norm_kernel(float* __restrict__ fv, int G, int gslice) {
-    __shared__ float s_red[8 * kF];
+__global__ __launch_bounds__(1024) void mfv3d_norm_kernel(float* __restrict__ fv, int G, int gslice) {
+    // thread (slice, part, ch): the same partial sums, in the same order, as slice_ssq computes inside the forward kernel
+    __shared__ float s_red[kSlices][8 * kF];
     __shared__ float s_scale[kF];
-    __shared__ float s_stage[250 * kFP];       // one slice: m <= 10 -> gslice <= 250
     const int tid = threadIdx.x, c = blockIdx.x;
     float* base = fv + (size_t)c * G * kF;
-    float total = 0.f;
-    for (int sl = 0; sl < kSlices; ++sl) {
+    if (tid < kSlices * 8 * kF) {
+        const int sl = tid / (8 * kF), part = (tid / kF) % 8, ch = tid % kF;
         const int g0 = sl * gslice, gcount = max(0, min(G, g0 + gslice) - g0);
-        for (int i = tid; i < gcount * 5; i += 256) {
-            const float4 x = reinterpret_cast<const float4*>(base + (size_t)g0 * kF)[i];
-            float* d = s_stage + (i / 5) * kFP + (i % 5) * 4;
-            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-        }
-        __syncthreads();
-        const float t = slice_ssq(tid, gcount, s_red, [&](int g, int ch) { return s_stage[g * kFP + ch]; });
-        total += t;
-        __syncthreads();
+        const int per = (gcount + 7) / 8, g1 = min(gcount, (part + 1) * per);
+        float ss = 0.f;
+        for (int g = part * per; g < g1; ++g) { const float x = base[(size_t)(g0 + g) * kF + ch]; ss += x * x; }
+        s_red[sl][part * kF + ch] = ss;
     }
-    if (tid < kF) s_scale[tid] = l2_scale(total);
+    __syncthreads();
+    if (tid < kF) {
+        float total = 0.f;
+        for (int sl = 0; sl < kSlices; ++sl) {
+            float t = 0.f;
+            for (int part = 0; part < 8; ++part) t += s_red[sl][part * kF + tid];
+            total += t;
+        }
+        s_scale[tid] = l2_scale(total);
+    }
     __syncthreads();
     float4* b4 = reinterpret_cast<float4*>(base);
-    for (int i = tid; i < G * 5; i += 256) {
+    for (int i = tid; i < G * 5; i += 1024) {
         const int part = i % 5;
         float4 v = b4[i];
         v.x *= s_scale[part * 4]; v.y *= s_scale[part * 4 + 1]; v.z *= s_scale[part * 4 + 2]; v.w *= s_scale[part * 4 + 3];
@@ -795,7 +799,7 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
     DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k, gslice, MfvFuse{});
     DPD_CHECK_LAUNCH();
-    DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, fv, k.G, gslice);
+    DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, fv, k.G, gslice);
     DPD_CHECK_LAUNCH();
     return 0;
 }
@@ -814,7 +818,7 @@ extern "C" int dpd_mfv3d_fwd_stacked(const float* pcA, const float* pcB, const f
                MfvFuse{pcA, pcB, noise, pts, q, ssq, B});
     DPD_CHECK_LAUNCH();
     if (!ssq) {
-        DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, fv, k.G, gslice);
+        DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, fv, k.G, gslice);
         DPD_CHECK_LAUNCH();
     }
     return 0;
