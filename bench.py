@@ -341,7 +341,8 @@ def main():
     cfg34 = None
     if not a.no_other_dtypes and a.dtype == "f32" and B == 32:
         try:
-            if world > 1:     # every rank takes part in both legs (the first has collectives)
+            if world > 1 or (use_dist and os.environ.get("DPD_BENCH_CFG4") == "1"):   # (the env: exercise this leg on one GPU)
+                # every rank takes part in both legs (the first has collectives)
                 c4 = bf16_b64(True, "BASELINE config 4: data-parallel bf16 step, 64 pairs per GPU, RCCL gradient all-reduce")
                 c4["n1_same_run"] = bf16_b64(False, "the same step on one rank without collectives (all ranks run it concurrently)")
                 c4["scaling"] = "weak"
