@@ -67,11 +67,13 @@ class BucketReducer:
             self._stage[bucket] = (full, shard)
         return self._stage[bucket]
 
-    def reduce_async(self, bucket):
-        """Call right after the kernels producing bucket `bucket` were enqueued on the current stream."""
+    def reduce_async(self, bucket, upto=None):
+        """Call right after the kernels producing bucket `bucket` (or the contiguous buckets bucket .. upto) were enqueued on
+        the current stream."""
         if not self.active:
             return
-        lo, hi = self.bounds[bucket], self.bounds[bucket + 1]
+        lo, hi = self.bounds[bucket], self.bounds[(bucket if upto is None else upto) + 1]
+        bucket = (bucket, upto)
         g = self.flat[lo:hi]
         if self.wire == "f32" and self.mode == "allreduce":
             self._pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))

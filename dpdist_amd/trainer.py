@@ -265,12 +265,17 @@ class DPDistTrainer:
             # Data-parallel schedule: every weight gradient is produced as early as its inputs exist, smallest bucket first,
             # so that the all-reduces (serial on the RCCL stream) start ~250 us before the backward ends instead of after dW1:
             #   output layer -> dW3 -> [bucket 2: W3,b3,W4,b4] -> g2 -> dW2 -> [bucket 1: W2,b2] -> g1 -> dW1 -> [bucket 0]
+            # DPD_DP_BUCKETS=2 (default): layers 2-4 travel as ONE collective after dW2 (8.4 MB, ~140 us of GEMMs still to come)
+            # -- every collective costs the compute stream a cross-stream event hop (~20 us on this runtime)
+            # and the exposed part is the layer-1 bucket either way; =3: one collective per bucket, the first after dW3.
+            three = os.environ.get("DPD_DP_BUCKETS", "2") == "3"
             data(1)
             dw(3, self.h2, self.g3, d[4])
-            self.reducer.reduce_async(2)
+            if three:
+                self.reducer.reduce_async(2)
             data(2)
             dw(2, self.h1, self.g2, d[2])
-            self.reducer.reduce_async(1)
+            self.reducer.reduce_async(1, upto=None if three else 2)
             data(4)
             dw(1, self.X, self.g1, d[0])
             if self._after_dw1 is not None:

@@ -857,10 +857,13 @@ def test_two_ranks_rccl_equals_full_batch(dev, dt, tmp_path):
     assert float(err) <= 2e-5 * max(1.0, float(scale)), (err, scale)
 
 
+@pytest.mark.parametrize("buckets", ["2", "3"])
 @pytest.mark.parametrize("dt", ["f32", "f32x3"])
-def test_data_parallel_schedule_matches_plain_backward(dev, dt):
-    """The interleaved data-parallel backward (phased data chain, dW3 -> dW2 -> dW1, three buckets all-reduced on the RCCL
-    stream; exercised here with a single-rank process group) produces the same gradients as the plain schedule."""
+def test_data_parallel_schedule_matches_plain_backward(dev, dt, buckets, monkeypatch):
+    """The interleaved data-parallel backward (phased data chain, dW3 -> dW2 -> dW1; layers 2-4 as one collective after dW2 or
+    one collective per bucket, all on the RCCL stream; exercised here with a single-rank process group) produces the same
+    gradients as the plain schedule."""
+    monkeypatch.setenv("DPD_DP_BUCKETS", buckets)
     import torch.distributed as dist
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer

@@ -1,5 +1,5 @@
 import time, torch, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dpdist_amd import synth
 from dpdist_amd.model import DPDistParams
 from dpdist_amd.trainer import DPDistTrainer
