@@ -1,4 +1,4 @@
-import time, torch, sys
+import os, time, torch, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dpdist_amd import synth
 from dpdist_amd.model import DPDistParams
