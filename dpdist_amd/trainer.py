@@ -261,6 +261,16 @@ class DPDistTrainer:
                                                 L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
+        def dw23():
+            if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
+                L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
+                                                         L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes,
+                                                         L.ptr(gv[3]) if det_db else None, L.ptr(dbp), L.cur_stream()),
+                        "dpd_decoder_bwd_weights_pair")
+            else:
+                dw(2, self.h1, self.g2, d[2])
+                dw(3, self.h2, self.g3, d[4])
+
         if self.reducer and os.environ.get("DPD_DP_SCHEDULE", "early") == "early":
             # Data-parallel schedule: every weight gradient is produced as early as its inputs exist, smallest bucket first,
             # so that the all-reduces (serial on the RCCL stream) start ~250 us before the backward ends instead of after dW1:
@@ -270,12 +280,16 @@ class DPDistTrainer:
             # and the exposed part is the layer-1 bucket either way; =3: one collective per bucket, the first after dW3.
             three = os.environ.get("DPD_DP_BUCKETS", "2") == "3"
             data(1)
-            dw(3, self.h2, self.g3, d[4])
             if three:
+                dw(3, self.h2, self.g3, d[4])
                 self.reducer.reduce_async(2)
-            data(2)
-            dw(2, self.h1, self.g2, d[2])
-            self.reducer.reduce_async(1, upto=None if three else 2)
+                data(2)
+                dw(2, self.h1, self.g2, d[2])
+                self.reducer.reduce_async(1)
+            else:
+                data(2)
+                dw23()                      # dW2 + dW3 as the grouped launch of the single-GPU order
+                self.reducer.reduce_async(1, upto=2)
             data(4)
             dw(1, self.X, self.g1, d[0])
             if self._after_dw1 is not None:
@@ -294,14 +308,7 @@ class DPDistTrainer:
             self._after_dw1()             # X / mask are free from here on: the prefetch pipeline hooks in
         if self.reducer:
             self.reducer.reduce_async(0)
-        if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
-            L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
-                                                     L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes,
-                                                     L.ptr(gv[3]) if det_db else None, L.ptr(dbp), L.cur_stream()),
-                    "dpd_decoder_bwd_weights_pair")
-        else:
-            dw(2, self.h1, self.g2, d[2])
-            dw(3, self.h2, self.g3, d[4])
+        dw23()
         if self.reducer:      # DPD_DP_SCHEDULE=late (A/B reference): plain order, all-reduces start after dW1
             self.reducer.reduce_async(1)
             self.reducer.reduce_async(2)

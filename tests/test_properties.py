@@ -37,7 +37,7 @@ def _scalar_rule(q, m=8):
     return (hit[0], 1.0) if hit else (0, 0.0)
 
 
-@settings(max_examples=40, deadline=None)
+@settings(max_examples=40, deadline=None, derandomize=True)
 @given(cloud)
 def test_oracle_voxel_rule_on_cell_boundaries(pts):
     v, mask, local = R.voxel_lookup(torch.tensor(pts[None]))
@@ -51,7 +51,7 @@ def test_oracle_voxel_rule_on_cell_boundaries(pts):
     assert np.array_equal(mask[0].numpy() > 0, inside)
 
 
-@settings(max_examples=15, deadline=None)
+@settings(max_examples=15, deadline=None, derandomize=True)
 @given(cloud, st.permutations(list(range(64))))
 def test_oracle_encoder_is_permutation_invariant(pts, perm):
     pts = np.clip(pts, -1.0, 1.0)
@@ -61,7 +61,7 @@ def test_oracle_encoder_is_permutation_invariant(pts, perm):
 
 
 # ------------------------------------------------------------------------------------------------------------ GPU
-gpu_settings = settings(max_examples=10, deadline=None, database=None, phases=[Phase.explicit, Phase.generate],
+gpu_settings = settings(max_examples=10, deadline=None, database=None, derandomize=True, phases=[Phase.explicit, Phase.generate],
                         suppress_health_check=[HealthCheck.function_scoped_fixture])    # no shrinking: GPU minutes are budgeted
 
 
@@ -98,5 +98,5 @@ def test_hip_encoder_permutation_and_duplicates(pts, perm, dup):
     ref32 = R.mfv3d(torch.tensor(both)).double()
     # sign(x) sqrt(max(|x|, 1e-12)) is ill-conditioned at x ~ 0 (a statistic that cancels to ~1e-9 moves by 1e-4 under ONE fp32
     # rounding): the bar is the fp64 oracle, widened by however far the reference's own fp32 evaluation strays from it
-    tol = max(5e-6, 4.0 * (ref32 - ref).abs().max().item())
+    tol = max(1e-5, 4.0 * (ref32 - ref).abs().max().item())
     assert (fv[[0, 2]].cpu().double() - ref).abs().max().item() <= tol
