@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--tiles", default="1,2,3")
     ap.add_argument("--warm", type=int, default=3)
     ap.add_argument("--splits", default="1,2,4", help="split-K factors tried on the TN (dW) shapes")
+    ap.add_argument("--split-all", action="store_true", help="try the split-K factors on every shape, not only TN")
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(",")]
     dev = torch.device("cuda:0")
@@ -44,7 +45,7 @@ def main():
         flops = 2.0 * M * N * K
         line = "%-12s M=%5d N=%5d K=%5d |" % (name, M, N, K)
         for tile in tiles:
-            for split in ((1,) if not tA else tuple(int(x) for x in a.splits.split(","))):
+            for split in ((1,) if not (tA or a.split_all) else tuple(int(x) for x in a.splits.split(","))):
                 out = torch.empty(M, N, device=dev)
                 for _ in range(a.warm):
                     ops.gemm_f32(A, B, transA=tA, transB=tB, tile=tile, split_k=split, out=out)
