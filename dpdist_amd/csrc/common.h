@@ -83,9 +83,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + loc;
 }
 
+// Cross-lane sums on the DPP path (VALU, ~10 cycles per step) instead of __shfl_xor (= ds_bpermute_b32 through the LDS crossbar,
+// > 100 cycles of latency per step, six dependent steps per sum).  Fixed reduction tree -> deterministic.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_move(float v) {      // lanes without a valid source (or outside ROW_MASK) read 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+// every lane of a 16-lane row gets the sum of its row
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    return v;
+}
+// sum over the 64 lanes, returned in every lane
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row_sum16(v);
+    v += dpp_move<0x142, 0xA>(v);    // row_bcast15 into rows 1 and 3: lanes 16-31 = rows 0+1, lanes 48-63 = rows 2+3
+    v += dpp_move<0x143, 0xC>(v);    // row_bcast31 into rows 2 and 3: lanes 48-63 = all four rows
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// sum over the 32 lanes of each half-wave; valid in lanes 16-31 (lower half) and 48-63 (upper half) -- read it at lane 31 / 63
+__device__ __forceinline__ float half_sum32_hi(float v) {
+    v = row_sum16(v);
+    v += dpp_move<0x142, 0xA>(v);
     return v;
 }
 

@@ -330,12 +330,6 @@ __device__ __forceinline__ PQ eval_pq(const float2 vx, const float2 vy, const fl
     return r;
 }
 
-__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of this half-wave
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ dfv,
                                                                  float* __restrict__ dpts, MfvConst k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -483,8 +477,8 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __r
             const float gb = dr[11 + d] + ((q.b[d] == raw[14 + d]) ? dr[14 + d] : 0.f) + ((q.b[d] == raw[17 + d]) ? dr[17 + d] : 0.f);
             dQ += ga * q.z[d] + gb * (q.z[d] * q.z[d] - 1.0f);
         }
-        const float t = half_sum32(live ? dQ * q.Q : 0.f);
-        if ((lane & 31) == 0) s_part[wave * N + n] = t;
+        const float t = half_sum32_hi(live ? dQ * q.Q : 0.f);
+        if ((lane & 31) == 31) s_part[wave * N + n] = t;
     }
     __syncthreads();
     for (int n = tid; n < N; n += kFwdThreads) {
@@ -509,8 +503,8 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __r
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float dz = live ? q.Q * (ga[d] + 2.0f * gb[d] * q.z[d]) - q.z[d] * q.Q * u : 0.f;
-            const float t = half_sum32(dz);
-            if ((lane & 31) == 0) s_part[(wave * N + n) * 3 + d] = t;
+            const float t = half_sum32_hi(dz);
+            if ((lane & 31) == 31) s_part[(wave * N + n) * 3 + d] = t;
         }
     }
     __syncthreads();
@@ -650,30 +644,29 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const floa
     const int hpts = (np_ + 1) / 2;
     const int nbeg = half * hpts, nend = min(np_, (half + 1) * hpts);
 
-    // ---- combine the slices' records (fixed order) ------------------------------------------------------------
+    // ---- combine the slices' records (fixed order), one statistic at a time: four loads live, not 4 x 33 --------------
     float raw[kF], cnt[13];
     {
-        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
-        float r[kSlices][kRec];
-#pragma unroll
-        for (int s2 = 0; s2 < kSlices; ++s2)
-#pragma unroll
-            for (int i = 0; i < kRec; ++i) r[s2][i] = part[((size_t)(c * kSlices + s2) * kRec + i) * G + gg];
+        const float* pc = part + (size_t)c * kSlices * kRec * G + gg;
+        auto rec = [&](int s2, int i) { return pc[((size_t)s2 * kRec + i) * G]; };
 #pragma unroll
         for (int f = 0; f < kF; ++f) {
             const bool is_sum = (f == 0) || (f >= 2 && f < 5) || (f >= 11 && f < 14);
             const bool is_max = (f == 1) || (f >= 5 && f < 8) || (f >= 14 && f < 17);
-            float v = r[0][f];
+            float x[kSlices];
 #pragma unroll
-            for (int s2 = 1; s2 < kSlices; ++s2) v = is_sum ? v + r[s2][f] : (is_max ? fmaxf(v, r[s2][f]) : fminf(v, r[s2][f]));
+            for (int s2 = 0; s2 < kSlices; ++s2) x[s2] = rec(s2, f);
+            float v = x[0];
+#pragma unroll
+            for (int s2 = 1; s2 < kSlices; ++s2) v = is_sum ? v + x[s2] : (is_max ? fmaxf(v, x[s2]) : fminf(v, x[s2]));
             raw[f] = is_sum ? v * invN : v;
-        }
+            if (!is_sum) {      // tie count of this extremum: the slices that attain it contribute theirs
+                const int ci = (f == 1) ? 0 : ((f < 11) ? f - 4 : f - 7);     // f = 1,5..10,14..19 -> 0,1..6,7..12
+                float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 13; ++i) {
-            float t = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < kSlices; ++s2) t += (r[s2][mm[i]] == raw[mm[i]]) ? r[s2][20 + i] : 0.f;
-            cnt[i] = t;
+                for (int s2 = 0; s2 < kSlices; ++s2) t += (x[s2] == v) ? rec(s2, 20 + ci) : 0.f;
+                cnt[ci] = t;
+            }
         }
     }
     // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv (every slice recomputes them: all G are in the block) ----
@@ -733,8 +726,8 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const floa
             const float gb = dr[11 + d] + ((q.b[d] == raw[14 + d]) ? dr[14 + d] : 0.f) + ((q.b[d] == raw[17 + d]) ? dr[17 + d] : 0.f);
             dQ += ga * q.z[d] + gb * (q.z[d] * q.z[d] - 1.0f);
         }
-        const float t = half_sum32(live ? dQ * q.Q : 0.f);
-        if ((lane & 31) == 0) s_part[wave * nslice + n] = t;
+        const float t = half_sum32_hi(live ? dQ * q.Q : 0.f);
+        if ((lane & 31) == 31) s_part[wave * nslice + n] = t;
     }
     __syncthreads();
     for (int n = tid; n < np_; n += kFwdThreads) {
@@ -758,8 +751,8 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const floa
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float dz = live ? q.Q * (ga[d] + 2.0f * gb[d] * q.z[d]) - q.z[d] * q.Q * u : 0.f;
-            const float t = half_sum32(dz);
-            if ((lane & 31) == 0) s_part[(wave * nslice + n) * 3 + d] = t;
+            const float t = half_sum32_hi(dz);
+            if ((lane & 31) == 31) s_part[(wave * nslice + n) * 3 + d] = t;
         }
     }
     __syncthreads();
