@@ -20,8 +20,8 @@ from dpdist_amd.model import DPDistLoss, DPDistModel  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)     # run_train_and_eval_PCRNet.bash:18,72
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=60)     # the chip needs ~25 ms under load to reach its steady clock (tools/ramp_probe.py)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
