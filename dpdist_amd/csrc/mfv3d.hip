@@ -523,7 +523,8 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __r
 // is local to the point's slice; the only cross-slice quantity is the per-Gaussian statistic record (7 sums, 7 maxima,
 // 6 minima over the points + how many points attain each extreme), exchanged through `part`:
 //   mfv3d_bwd_stats_kernel   slice -> part[c][s][33][G]    (sum / max / min over the slice's points, local tie counts)
-//   mfv3d_bwd_apply_kernel   combines the kSlices records (ties: counts of the slices whose extreme equals the global
+//   mfv3d_bwd_combine_kernel one workgroup per cloud: merges the records, channel sums, d raw statistics (in place over slice 0)
+//   mfv3d_bwd_apply_kernel   (was: every slice combined the kSlices records itself; ties: counts of the slices whose extreme equals the global
 //                            one), then runs P2-P4 of mfv3d_bwd_kernel for its own points and writes their dpts.
 // Same per-(point, Gaussian) expressions as the monolithic kernel -> identical tie tests; sums differ by association.
 // ------------------------------------------------------------------------------------------------------
@@ -618,68 +619,58 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const floa
     }
 }
 
-__global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const float* __restrict__ pts, const float* __restrict__ dfv,
-                                                                       const float* __restrict__ part, float* __restrict__ dpts,
-                                                                       MfvConst k, int nslice) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int N = k.N, G = k.G, m = k.m;
-    const int c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
-    const int n0 = min(N, sl * nslice), np_ = min(N, n0 + nslice) - n0;
-    float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][np_][m]
-    float* s_S = sm + 6 * nslice * m;               // [3][nslice]
-    float* s_chred = s_S + 3 * nslice;              // [16][40]
-    float* s_ch = s_chred + 16 * 2 * kF;            // [40]
-    float* s_T = s_ch + 2 * kF;                     // [nslice]
-    float* s_part = s_T + nslice;                   // [16][nslice][3]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    build_tables(pts + (size_t)c * N * 3, n0, np_, k, s_zq, s_S, tid);
-    const float2* zqx = s_zq;
-    const float2* zqy = s_zq + np_ * m;
-    const float2* zqz = s_zq + 2 * np_ * m;
-    const int g = wave * 32 + (lane & 31);
+// Per-cloud combine (ONE workgroup per cloud, thread = Gaussian): merges the kSlices statistic records, takes the channel sums over
+// ALL Gaussians, and turns dfv into the gradient w.r.t. the 20 raw statistics of every Gaussian.  This is the sqrt / divide heavy
+// part of the backward; it used to be repeated by both half-waves of every one of the kSlices apply workgroups (8x).  Output, in
+// place over slice 0's record of the cloud (every thread only touches its own column g): rows 0..19 = d raw statistic (tie
+// counts already divided in), rows 20..32 = the 13 global extrema the apply kernel needs for its tie tests.
+__global__ __launch_bounds__(512) void mfv3d_bwd_combine_kernel(const float* __restrict__ dfv, float* __restrict__ part, MfvConst k) {
+    __shared__ float s_chred[8 * 2 * kF];
+    __shared__ float s_ch[2 * kF];
+    const int N = k.N, G = k.G;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = tid;
     const bool live = g < G;
     const int gg = live ? g : 0;
-    const int gi = gg / (m * m), gj = (gg / m) % m, gt = gg % m;
-    const float invN = 1.0f / (float)N, inv_dpi = 1.0f / k.dpi_den;
-    const int hpts = (np_ + 1) / 2;
-    const int nbeg = half * hpts, nend = min(np_, (half + 1) * hpts);
-
-    // ---- combine the slices' records (fixed order), one statistic at a time: four loads live, not 4 x 33 --------------
+    const float invN = 1.0f / (float)N;
+    // ---- combine the slices' records (fixed order): all 4 x 33 values are requested at once (512 threads per workgroup leave
+    // 256 registers per lane; one statistic at a time would be 33 dependent L2 round trips on a 32-workgroup grid) ------------
     float raw[kF], cnt[13];
     {
+        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
         const float* pc = part + (size_t)c * kSlices * kRec * G + gg;
-        auto rec = [&](int s2, int i) { return pc[((size_t)s2 * kRec + i) * G]; };
+        float r[kSlices][kRec];
+#pragma unroll
+        for (int s2 = 0; s2 < kSlices; ++s2)
+#pragma unroll
+            for (int i = 0; i < kRec; ++i) r[s2][i] = pc[((size_t)s2 * kRec + i) * G];
 #pragma unroll
         for (int f = 0; f < kF; ++f) {
             const bool is_sum = (f == 0) || (f >= 2 && f < 5) || (f >= 11 && f < 14);
             const bool is_max = (f == 1) || (f >= 5 && f < 8) || (f >= 14 && f < 17);
-            float x[kSlices];
+            float v = r[0][f];
 #pragma unroll
-            for (int s2 = 0; s2 < kSlices; ++s2) x[s2] = rec(s2, f);
-            float v = x[0];
-#pragma unroll
-            for (int s2 = 1; s2 < kSlices; ++s2) v = is_sum ? v + x[s2] : (is_max ? fmaxf(v, x[s2]) : fminf(v, x[s2]));
+            for (int s2 = 1; s2 < kSlices; ++s2) v = is_sum ? v + r[s2][f] : (is_max ? fmaxf(v, r[s2][f]) : fminf(v, r[s2][f]));
             raw[f] = is_sum ? v * invN : v;
-            if (!is_sum) {      // tie count of this extremum: the slices that attain it contribute theirs
-                const int ci = (f == 1) ? 0 : ((f < 11) ? f - 4 : f - 7);     // f = 1,5..10,14..19 -> 0,1..6,7..12
-                float t = 0.f;
+        }
 #pragma unroll
-                for (int s2 = 0; s2 < kSlices; ++s2) t += (x[s2] == v) ? rec(s2, 20 + ci) : 0.f;
-                cnt[ci] = t;
-            }
+        for (int i = 0; i < 13; ++i) {      // tie count of an extremum: the slices that attain it contribute theirs
+            float t = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < kSlices; ++s2) t += (r[s2][mm[i]] == raw[mm[i]]) ? r[s2][20 + i] : 0.f;
+            cnt[i] = t;
         }
     }
-    // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv (every slice recomputes them: all G are in the block) ----
+    // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv -----------------------------------------------------------
     const float* df = dfv + ((size_t)c * G + gg) * kF;
     float dr[kF];
     {
-        const bool mine = live && half == 0;
 #pragma unroll
         for (int f = 0; f < kF; ++f) {
             const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
             const float sv = pnorm(raw[f] * cst);
-            const float dy = mine ? df[f] : 0.f;
-            const float a = wave_sum(mine ? sv * sv : 0.f), b = wave_sum(sv * dy);
+            const float dy = live ? df[f] : 0.f;
+            const float a = wave_sum(live ? sv * sv : 0.f), b = wave_sum(sv * dy);
             if (lane == 0) { s_chred[wave * 2 * kF + f] = a; s_chred[wave * 2 * kF + kF + f] = b; }
         }
     }
@@ -687,7 +678,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const floa
     if (tid < 2 * kF) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) t += s_chred[w * 2 * kF + tid];
+        for (int w = 0; w < 8; ++w) t += s_chred[w * 2 * kF + tid];
         s_ch[tid] = t;
     }
     __syncthreads();
@@ -715,6 +706,51 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const floa
         const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
 #pragma unroll
         for (int i = 0; i < 13; ++i) dr[mm[i]] = dr[mm[i]] / fmaxf(cnt[i], 1.f);
+    }
+    if (live) {
+        float* out = part + (size_t)c * kSlices * kRec * G + g;      // slice 0's record of this cloud
+        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
+        float ext[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) ext[i] = raw[mm[i]];
+#pragma unroll
+        for (int f = 0; f < kF; ++f) out[(size_t)f * G] = dr[f];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) out[(size_t)(20 + i) * G] = ext[i];
+    }
+}
+
+__global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const float* __restrict__ pts, const float* __restrict__ comb,
+                                                                       float* __restrict__ dpts, MfvConst k, int nslice) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = k.N, G = k.G, m = k.m;
+    const int c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
+    const int n0 = min(N, sl * nslice), np_ = min(N, n0 + nslice) - n0;
+    float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][np_][m]
+    float* s_S = sm + 6 * nslice * m;               // [3][nslice]
+    float* s_T = s_S + 3 * nslice;                  // [nslice]
+    float* s_part = s_T + nslice;                   // [16][nslice][3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    build_tables(pts + (size_t)c * N * 3, n0, np_, k, s_zq, s_S, tid);
+    const float2* zqx = s_zq;
+    const float2* zqy = s_zq + np_ * m;
+    const float2* zqz = s_zq + 2 * np_ * m;
+    const int g = wave * 32 + (lane & 31);
+    const bool live = g < G;
+    const int gg = live ? g : 0;
+    const int gi = gg / (m * m), gj = (gg / m) % m, gt = gg % m;
+    const float inv_dpi = 1.0f / k.dpi_den;
+    const int hpts = (np_ + 1) / 2;
+    const int nbeg = half * hpts, nend = min(np_, (half + 1) * hpts);
+    // d raw statistic and the global extrema of this lane's Gaussian, from mfv3d_bwd_combine_kernel
+    float dr[kF], raw[kF];
+    {
+        const float* pc = comb + (size_t)c * kSlices * kRec * G + gg;
+        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
+#pragma unroll
+        for (int f = 0; f < kF; ++f) { dr[f] = live ? pc[(size_t)f * G] : 0.f; raw[f] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) raw[mm[i]] = pc[(size_t)(20 + i) * G];
     }
     // ---- T_n and dz for the slice's own points (as P3 / P4 of mfv3d_bwd_kernel) ----------------------------------
     for (int n = nbeg; n < nend; ++n) {
@@ -766,9 +802,8 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const floa
 }
 
 static size_t bwd_sliced_lds_bytes(int nslice, int m) {
-    return (size_t)(6 * nslice * m + 3 * nslice + 16 * 2 * kF + 2 * kF + nslice + 16 * nslice * 3 + 4) * sizeof(float);
+    return (size_t)(6 * nslice * m + 3 * nslice + nslice + 16 * nslice * 3 + 4) * sizeof(float);
 }
-
 static size_t bwd_lds_bytes(int N, int m) {
     return (size_t)(6 * N * m + 3 * N + 16 * 2 * kF + 2 * kF + N + 16 * N * 3 + 4) * sizeof(float);
 }
@@ -837,8 +872,10 @@ extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, i
         if (int rc = set_lds(mfv3d_bwd_apply_kernel, l2)) return rc;
         DPD_LAUNCH(mfv3d_bwd_stats_kernel, dim3(C * kSlices), dim3(kFwdThreads), l1, (hipStream_t)stream, pts, (float*)ws, k, nslice);
         DPD_CHECK_LAUNCH();
-        DPD_LAUNCH(mfv3d_bwd_apply_kernel, dim3(C * kSlices), dim3(kFwdThreads), l2, (hipStream_t)stream, pts, dfv, (const float*)ws,
-                   dpts, k, nslice);
+        DPD_LAUNCH(mfv3d_bwd_combine_kernel, dim3(C), dim3(512), 0, (hipStream_t)stream, dfv, (float*)ws, k);
+        DPD_CHECK_LAUNCH();
+        DPD_LAUNCH(mfv3d_bwd_apply_kernel, dim3(C * kSlices), dim3(kFwdThreads), l2, (hipStream_t)stream, pts, (const float*)ws, dpts, k,
+                   nslice);
         DPD_CHECK_LAUNCH();
         return 0;
     }
