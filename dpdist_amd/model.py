@@ -224,9 +224,7 @@ class _AsLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pcA, pcB, flat, P, m, k, sigma):
         B, N, _ = pcA.shape
-        pts, q = ops.stack_clouds(pcA, pcB, None)
-        fv = ops.mfv3d_fwd(pts, m, sigma)
-        X, mask, vox = ops.patch_rows_fwd(q, fv, m, k, P.KP)
+        pts, X, mask, vox = ops.front_end(pcA, pcB, None, m, sigma, k, P.KP)     # two launches (stack+encoder, norm+gather)
         params = P.views(flat)
         h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype)
         loss, _ = ops.l1_loss(pred, mask[:B * N], mode=0)          # labels only enter loss_samples, which is not used here

@@ -35,6 +35,26 @@ def mfv3d_bwd(pts, dfv, m, sigma, sliced=True):
     return dpts
 
 
+def front_end(pcA, pcB, noise, m, sigma, k, KP=None):
+    """The front end in two launches (include/dpdist_capi.h: dpd_mfv3d_fwd_stacked + dpd_patch_rows_fwd_scaled):
+    -> pts [2B,N,3] (encoder input, kept for the backward), X [2BN,KP], mask, vox.  Same bits as stack_clouds + mfv3d_fwd +
+    patch_rows_fwd; the un-normalised Fisher vectors and the per-slice norms stay internal."""
+    L.req(pcA, name="pcA"), L.req(pcB, name="pcB")
+    if noise is not None:
+        L.req(noise, name="add_noise")
+    B, N, _ = pcA.shape
+    dev, lib, s = pcA.device, L.load(), L.cur_stream()
+    KP = KP or padded_width(k)
+    f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)   # noqa: E731
+    pts, q, fv, ssq = f(2 * B, N, 3), f(2 * B, N, 3), f(2 * B, m ** 3, F), f(2 * B, 4, F)
+    X, mask, vox = f(2 * B * N, KP), f(2 * B * N), torch.empty(2 * B * N, device=dev, dtype=torch.int32)
+    L.check(lib.dpd_mfv3d_fwd_stacked(L.ptr(pcA), L.ptr(pcB), L.ptr(noise), B, N, m, float(sigma), L.ptr(pts), L.ptr(q), L.ptr(fv),
+                                      L.ptr(ssq), s), "dpd_mfv3d_fwd_stacked")
+    L.check(lib.dpd_patch_rows_fwd_scaled(L.ptr(q), L.ptr(fv), L.ptr(ssq), 2 * B, N, m, k, KP, L.ptr(X), L.ptr(mask), L.ptr(vox),
+                                          None, s), "dpd_patch_rows_fwd_scaled")
+    return pts, X, mask, vox
+
+
 def patch_rows_fwd(q, fv, m, k, KP=None, out=None):
     """q [C,N,3], fv [C,m^3,20] -> X [C*N,KP], mask [C*N], vox [C*N] int32   (:911-930, :459-492, :434-457)"""
     L.req(q, name="q"), L.req(fv, name="fv")
