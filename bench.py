@@ -13,6 +13,11 @@ timed region.  value = 2*B*64 * N * K / max-over-ranks(time).  Weak scaling: per
 
 `python bench.py --gpus N` with no launcher starts its own N ranks (one process per GPU, RCCL).
 
+Order of one run: auxiliary legs (other compute types, config 3/4; their buffers stay allocated) -> device spin-up (`spinup_ms`
+of scratch fp32 GEMMs: an MI355X needs ~25 ms of sustained load to reach its steady clock, tools/ramp_probe.py) -> W untimed
+warm-up steps -> K timed steps between barrier + synchronize -> profiler pass (roofline) -> CPU baseline -> ONE JSON line (the
+last line of stdout).
+
 Extra objects on the JSON line:
   roofline     -- the fp32 MFMA GEMM kernel family (gemm_rs_kernel<...> + the LDS-ring fallback): algorithmic flops of the GEMM
                   launches of a step / their summed duration, measured with hipEvent pairs recorded in-stream around each
