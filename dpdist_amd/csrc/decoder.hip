@@ -289,12 +289,20 @@ struct L1Fuse {
     float gscale;
 };
 constexpr int kOBRec = 8;   // record = 4H + 8 floats: db3 [H] | dW4 [3H] | db4 [3] | pad | loss sums [3] | pad
+// Optional forward of the output layer inside the same pass (training step: no out_fwd launch, h3 rows of the AB half are read
+// once): with y != NULL the kernel computes y = h3 W4 + b4 and pred = relu6(y)/3 * mask for its AB rows AND their BA twins
+// (row + Qb), in out_fwd_kernel's summation order (bit-identical), writes both, and uses them instead of the y / l1.pred inputs.
+struct OutFwd {
+    const float* b4;
+    float* y;       // [2*Qb, 3]
+    float* pred;    // [2*Qb, 3]
+};
 
 __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __restrict__ dpred, const float* __restrict__ mask,
                                                               const float* __restrict__ y, const float* __restrict__ h3,
                                                               const float* __restrict__ W4, float* __restrict__ dy,
                                                               float* __restrict__ g3, int Qb, int H, ZeroList zl,
-                                                              float* __restrict__ scratch, L1Fuse l1) {
+                                                              float* __restrict__ scratch, L1Fuse l1, OutFwd of) {
     extern __shared__ float s_acc[];   // [4 waves][4H + 8]
     if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
         for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
@@ -324,9 +332,48 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
     for (int rr = 0; rr < RW; ++rr) {
         const int row = min(row0 + rr, Qb - 1);
         const bool live = row0 + rr < Qb;
+        float yab[3] = {0.f, 0.f, 0.f}, pab0 = 0.f, pba0 = 0.f;
+        if (of.y) {                // forward of the output layer for this AB row and its BA twin (out_fwd_kernel's order)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jj < ng) hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
+            float4 hb[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jj < ng) hb[jj] = *reinterpret_cast<const float4*>(h3 + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
+            float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj < ng) {
+                    const float xa[4] = {hv[rr][jj].x, hv[rr][jj].y, hv[rr][jj].z, hv[rr][jj].w};
+                    const float xb[4] = {hb[jj].x, hb[jj].y, hb[jj].z, hb[jj].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { a[c] += xa[e] * w4[jj][e][c]; b[c] += xb[e] * w4[jj][e][c]; }
+                }
+            }
+            float yba[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { yab[c] = wave_sum(a[c]) + of.b4[c]; yba[c] = wave_sum(b[c]) + of.b4[c]; }
+            const float ma = mask[row], mb = mask[Qb + row];
+            float pa[3], pb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pa[c] = fminf(fmaxf(yab[c], 0.f), 6.f) / 3.0f * ma;   // relu6(y)/3 (:691) * mask (:697)
+                pb[c] = fminf(fmaxf(yba[c], 0.f), 6.f) / 3.0f * mb;
+            }
+            pab0 = pa[0]; pba0 = pb[0];
+            if (live && lane < 3) {
+                const float ya = lane == 0 ? yab[0] : (lane == 1 ? yab[1] : yab[2]), yb = lane == 0 ? yba[0] : (lane == 1 ? yba[1] : yba[2]);
+                const float qa = lane == 0 ? pa[0] : (lane == 1 ? pa[1] : pa[2]), qb = lane == 0 ? pb[0] : (lane == 1 ? pb[1] : pb[2]);
+                of.y[(size_t)row * 3 + lane] = ya; of.y[((size_t)Qb + row) * 3 + lane] = yb;
+                of.pred[(size_t)row * 3 + lane] = qa; of.pred[((size_t)Qb + row) * 3 + lane] = qb;
+            }
+        }
         float dp[3];
         if (l1.labels) {           // d mean|pred_AB[:,0] - labels| / d pred_AB (tf.abs gradient = sign), channels 1, 2 get none
-            const float pab = l1.pred[(size_t)row * 3], pba = l1.pred[((size_t)Qb + row) * 3];
+            const float pab = of.y ? pab0 : l1.pred[(size_t)row * 3], pba = of.y ? pba0 : l1.pred[((size_t)Qb + row) * 3];
             const float df = pab - l1.labels[row];
             dp[0] = ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f)) * (1.0f / (float)Qb) * l1.gscale;
             dp[1] = 0.f; dp[2] = 0.f;
@@ -337,13 +384,15 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float yv = y[(size_t)row * 3 + c];
+            const float yv = of.y ? yab[c] : y[(size_t)row * 3 + c];
             d[rr][c] = (live && yv > 0.f && yv < 6.f) ? dp[c] * mask[row] / 3.0f : 0.f;   // relu6' = 1 on (0,6)
             dsum[c] += d[rr][c];
         }
+        if (!of.y) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-            if (jj < ng) hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
+            for (int jj = 0; jj < 4; ++jj)
+                if (jj < ng) hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
+        }
     }
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
@@ -698,7 +747,8 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     using namespace dpd;
     pl = dpd::usable_planes(pl, dtype, Q, pl ? pl->Qb : 0, KP, H);
     if (!X && !(pl && pl->X_rc)) return DPD_E_NULL;
-    if (!mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
+    if (!mask || !p || !h1 || !h2 || !h3 || (!y != !pred)) return DPD_E_NULL;   // y = pred = NULL: the output layer is left to
+                                                                                  // dpd_decoder_bwd_data (dpd_small_grads.fwd_y)
     if (pl && (pl->Q != Q || pl->Qb > Q)) return DPD_E_DIM;
     if (int rc = dpd::check_planes(pl, dtype)) return rc;
     if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
@@ -722,6 +772,7 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
     }
+    if (!y) return 0;
     DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
     DPD_CHECK_LAUNCH();
     return 0;
@@ -783,7 +834,7 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
                                     void* stream) {
     using namespace dpd;
     const bool l1 = sg && sg->l1_labels;        // fused training loss: dpred is derived inside the output-layer kernel
-    if ((!dpred && !l1) || !mask || !y || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
+    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
     if (l1 && (!sg->l1_pred || !sg->l1_loss)) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
@@ -806,6 +857,9 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     const bool fused = (db3 || dW4 || db4 || l1) && H <= 64 * kOBMaxJ && (size_t)nblk * rec <= (size_t)Qb * H;
     if (l1 && !(fused && fused4)) return DPD_E_UNSUPPORTED;       // the caller then uses dpd_l1_loss + dpred
     const L1Fuse lf{l1 ? sg->l1_pred : nullptr, l1 ? sg->l1_labels : nullptr, l1 ? sg->l1_gscale : 1.0f};
+    const bool ofwd = sg && (sg->fwd_y || sg->fwd_pred) && (phases & 1);   // output layer's forward inside the same pass (training step)
+    if (ofwd && !(l1 && fused4 && sg->fwd_y && sg->fwd_pred && p->b4)) return DPD_E_UNSUPPORTED;
+    const OutFwd ofw{ofwd ? p->b4 : nullptr, ofwd ? sg->fwd_y : nullptr, ofwd ? sg->fwd_pred : nullptr};
     float* lossp = l1 ? sg->l1_loss : nullptr;
     const int nred = (4 * H + 7 + 15) / 16;
     // block partials of db3 / dW4 / db4: by default in g2 (free until the first dH GEMM); a caller that defers their reduction
@@ -825,7 +879,7 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
             const size_t lds = (size_t)4 * rec * sizeof(float);
             static LdsOptIn lds_opt;
             if (int rc = ensure_dyn_lds(lds_opt, (const void*)out_bwd_fused4_kernel, lds)) return rc;
-            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf);
+            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf, ofw);
         } else {
             DPD_LAUNCH(out_bwd_fused_kernel, dim3(nblk), dim3(256), (size_t)(4 * H + 4) * sizeof(float), s, dpred, mask, y, h3,
                        p->W4, dy, g3, Qb, H, zl, part);

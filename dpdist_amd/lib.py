@@ -21,7 +21,7 @@ class DecoderParams(Structure):
 
 class SmallGrads(Structure):
     _fields_ = [(n, c_void_p) for n in ("db1", "db2", "db3", "dW4", "db4", "partials", "l1_pred", "l1_labels", "l1_loss")] + [
-        ("l1_gscale", c_float), ("db_partials", c_void_p)]
+        ("l1_gscale", c_float), ("db_partials", c_void_p), ("fwd_y", c_void_p), ("fwd_pred", c_void_p)]
 
 
 class AdamFuse(Structure):   # include/dpdist_capi.h: dpd_adam_fuse
@@ -160,6 +160,6 @@ def make_params(W1p, b1, W2, b2, W3, b3, W4, b4, W2T=None, W3T=None, W1pT=None):
 
 
 def make_small_grads(db1, db2, db3, dW4, db4, partials=None, l1_pred=None, l1_labels=None, l1_loss=None, l1_gscale=1.0,
-                     db_partials=None):
+                     db_partials=None, fwd_y=None, fwd_pred=None):
     return SmallGrads(*[None if t is None else t.data_ptr() for t in (db1, db2, db3, dW4, db4, partials, l1_pred, l1_labels, l1_loss)],
-                      float(l1_gscale), None if db_partials is None else db_partials.data_ptr())
+                      float(l1_gscale), *[None if t is None else t.data_ptr() for t in (db_partials, fwd_y, fwd_pred)])

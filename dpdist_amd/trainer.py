@@ -109,6 +109,9 @@ class DPDistTrainer:
         # one-launch optimizer (dpd_adam_tf_fused): Adam + the transposed copies + (single-GPU steps) the reduction of the
         # output layer's block partials; DPD_FUSED_ADAM=0 keeps the three separate launches
         self.fused_adam = os.environ.get("DPD_FUSED_ADAM", "1") == "1"
+        # training step: the output layer's forward runs inside its fused backward (no out_fwd launch); DPD_FUSE_OUT=0 = separate
+        self.fuse_out = self.fuse_loss and os.environ.get("DPD_FUSE_OUT", "1") == "1"
+        self._out_pending = False
         # front end in two launches (dpd_mfv3d_fwd_stacked + dpd_patch_rows_fwd_scaled) instead of four; DPD_FRONT2=0 = four
         self.front2 = not self.fused and os.environ.get("DPD_FRONT2", "1") == "1"
         self._ssq = f(C * 4 * 20)
@@ -209,9 +212,13 @@ class DPDistTrainer:
         self._gather()
         self._decode()
 
-    def _decode(self):
+    def _decode(self, skip_out=False):
+        """skip_out (training step): the output layer's forward is left to the fused output-layer backward, which reads the AB
+        half of h3 once for both directions of the layer (dpd_small_grads.fwd_y); `backward` must follow."""
         lib, s, P = L.load(), L.cur_stream(), self.P
         Q = 2 * self.B * self.N
+        skip_out = bool(skip_out and self.fuse_out and not self.fused)
+        self._out_pending = skip_out
         if self._wdirty:
             self.refresh_weight_planes()
         if self.fused:
@@ -220,8 +227,9 @@ class DPDistTrainer:
                     "dpd_decoder_fwd_gather")
             return
         L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
-                                    L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), L.ptr(self.ws),
-                                    self.ws.numel() * 4, self._planes, s), "dpd_decoder_fwd")
+                                    L.ptr(self.h2), L.ptr(self.h3), None if skip_out else L.ptr(self.y),
+                                    None if skip_out else L.ptr(self.pred), L.ptr(self.ws), self.ws.numel() * 4, self._planes, s),
+                "dpd_decoder_fwd")
 
     def backward(self, labels, fork_small=None, join_weights=None, defer_small=False):
         """fork_small / join_weights (graph capture only): callables that move the small-gradient reduction to a parallel
@@ -239,7 +247,9 @@ class DPDistTrainer:
         sdb1, sdb2 = (None, None) if det_db else (gv[1], gv[3])
         dbp = self._db_partials if det_db else None
         if self.fuse_loss:      # d loss_samples / d pred and the two loss values come out of the output-layer backward
-            small = L.make_small_grads(sdb1, sdb2, gv[5], gv[6], gv[7], self._partials, self.pred, labels, self.loss, 1.0, dbp)
+            fwd = (self.y, self.pred) if self._out_pending else (None, None)     # ... and, in a training step, y and pred too
+            self._out_pending = False
+            small = L.make_small_grads(sdb1, sdb2, gv[5], gv[6], gv[7], self._partials, self.pred, labels, self.loss, 1.0, dbp, *fwd)
         else:
             L.check(lib.dpd_l1_loss(L.ptr(self.pred), L.ptr(labels), BN, 1, 1.0, L.ptr(self.loss), L.ptr(self.dpred), s), "dpd_l1_loss")
             small = L.make_small_grads(sdb1, sdb2, gv[5], gv[6], gv[7], self._partials, db_partials=dbp)
@@ -387,7 +397,7 @@ class DPDistTrainer:
             if out is not None:
                 return out
         self._take_front(pcA, pcB, noise)
-        self._decode()
+        self._decode(skip_out=True)
         if prefetch is not None:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.P.flat.device)

@@ -216,6 +216,10 @@ typedef struct dpd_small_grads {
      * db_partials = this pointer) or dpd_decoder_bwd_weights_pair(..., dbA, db_partials) finishes them: bitwise reproducible.
      * db1 / db2 above are then ignored.                                                                                       */
     float* db_partials;
+    /* optional (both or neither; needs the fused loss above): the FORWARD of the output layer inside the same pass -- y and pred
+     * [2*Qb,3] of the AB rows and their BA twins are computed from h3 (bit-identical to dpd_decoder_fwd's), written here and
+     * used instead of the `y` / l1_pred inputs, which may then be NULL.  Call dpd_decoder_fwd with y = pred = NULL before.    */
+    float* fwd_y; float* fwd_pred;
 } dpd_small_grads;
 
 int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1, const float* h2,

@@ -1213,6 +1213,29 @@ def test_two_launch_front_end_in_the_trainer(dev, monkeypatch, dt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [4, 3])
+@pytest.mark.parametrize("mlp", [(1024, 1024, 1024), (256, 256, 256)])
+def test_output_layer_forward_inside_its_backward_is_bitwise(dev, monkeypatch, mlp, B):
+    """Training step: y / pred of BOTH directions computed inside out_bwd_fused4_kernel (dpd_small_grads.fwd_y, no out_fwd launch)
+    against the separate output-layer forward (DPD_FUSE_OUT=0): same y, pred, losses, gradients and weights, bit for bit."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DPD_FUSE_OUT", flag)
+        P = DPDistParams(mlp=mlp, device=dev)
+        P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        assert tr.fuse_out == (flag == "1")
+        losses = [tr.step(pcA, pcB, lab).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        outs.append((torch.stack(losses), tr.y.clone(), tr.pred.clone(), tr.grad.clone(), P.flat.detach().clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["bf16", "f32x3"])
 @pytest.mark.parametrize("mlp", [(1024, 1024, 1024), (64, 64, 64)])
 def test_one_launch_optimizer_writes_the_weight_planes(dev, dt, mlp):
