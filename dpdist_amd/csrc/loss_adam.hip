@@ -389,7 +389,9 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
     }
     if (fu->partials) {
         const long tail = 4L * fu->H + 3;
-        if (fu->nparts <= 0 || fu->H <= 0 || fu->rec < 4 * fu->H + 4 || fu->tail_off < 0 || (size_t)(fu->tail_off + tail) != n)
+        // the tail ends the buffer, up to 3 alignment-padding elements (zero parameters with zero gradients: Adam leaves them 0)
+        if (fu->nparts <= 0 || fu->H <= 0 || fu->rec < 4 * fu->H + 4 || fu->tail_off < 0 || (size_t)(fu->tail_off + tail) > n ||
+            n - (size_t)(fu->tail_off + tail) > 3)
             return DPD_E_DIM;
         if (nc && fu->tail_off < hi[nc - 1]) return DPD_E_DIM;
         if (fu->loss && (fu->rec < 4 * fu->H + 8 || fu->Qb <= 0)) return DPD_E_DIM;

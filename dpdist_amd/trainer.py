@@ -131,7 +131,8 @@ class DPDistTrainer:
             if i == 1:
                 af.partials, af.nparts, af.rec, af.H, af.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
                 af.tail_off, af.loss = seg["b3"][0], self.loss.data_ptr()
-        self._tail_ok = seg["b3"][0] + 4 * H + 3 == params.numel and H % 256 == 0 and H <= 1024
+        # [b3 | W4 | b4] end the flat buffer (up to 3 elements of alignment padding behind them)
+        self._tail_ok = 0 <= params.numel - (seg["b3"][0] + 4 * H + 3) <= 3 and H % 256 == 0 and H <= 1024
         # hipGraph mode (single GPU): the whole step is captured once per input-buffer set and replayed; weight-derived
         # buffers and the small-gradient reduction run on parallel branches of the graph, off the critical path
         self.use_graph = os.environ.get("DPD_GRAPH", "0") == "1"   # opt-in: measured 4 % SLOWER than eager launches on MI355X / ROCm 7

@@ -284,7 +284,8 @@ int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr
  *   WT[i] != NULL (or planes, below): the matrix p[w_off[i] ..] of shape [w_rows[i], w_cols[i]] (row-major; cols % 64 == 0, rows % 4 == 0, offsets
  *     ascending) is updated tile-wise and its transposed copy WT[i] [w_cols[i], w_rows[i]] is rewritten in the same pass
  *     (replaces dpd_weights_transpose after the step);
- *   partials != NULL: the LAST 4H+3 elements p[tail_off .. n) = [b3 | W4 | b4] take their gradient from the block partials
+ *   partials != NULL: the LAST 4H+3 elements p[tail_off .. tail_off+4H+3) = [b3 | W4 | b4] (followed by at most 3 zero padding
+ *     elements up to n) take their gradient from the block partials
  *     that dpd_decoder_bwd_data(phases | 16) left in dpd_small_grads.partials (nparts = ceil(Qb / 8) records of `rec`
  *     floats); the reduced gradient is stored to g, and when `loss` is given (rec >= 4H+8: fused L1 loss) loss[0..1] are
  *     finished exactly as the deferred reduction would (single-GPU steps only: a data-parallel step needs the reduced

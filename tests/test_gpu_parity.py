@@ -1276,6 +1276,7 @@ def test_one_launch_optimizer_is_bitwise_the_three_launches(dev, monkeypatch, ml
         P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
         tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
         assert tr.fused_adam == (fused == "1")
+        assert tr._tail_ok == (mlp[0] % 256 == 0)            # the block-partial tail really takes part at H = 1024 / 256
         losses = [tr.step(pcA, pcB, lab).clone() for _ in range(4)]
         if tr._wdirty:
             tr.refresh_weight_planes()
