@@ -326,16 +326,19 @@ def main():
         a2, b2, l2 = (torch.tensor(x, device=dev) for x in synth.s2_modelnet_shaped(B2, N, 100 + rank))
         for _ in range(a.warmup):
             tr2.step(a2, b2, l2)
-        (sync if distributed else torch.cuda.synchronize)()
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            tr2.step(a2, b2, l2)
-        (sync if distributed else torch.cuda.synchronize)()
-        e2 = time.perf_counter() - t1
-        if distributed:
-            tt = torch.tensor([e2], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            e2 = float(tt.item())
+        e2 = float("inf")
+        for _rep in range(2):          # auxiliary line: best of two loops (host stalls on a shared box; the headline is single-shot)
+            (sync if distributed else torch.cuda.synchronize)()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                tr2.step(a2, b2, l2)
+            (sync if distributed else torch.cuda.synchronize)()
+            e = time.perf_counter() - t1
+            if distributed:
+                tt = torch.tensor([e], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                e = float(tt.item())
+            e2 = min(e2, e)
         nr = world if distributed else 1
         out2 = {"what": label, "dtype": "bf16", "pairs_per_gpu": B2, "global_batch": B2 * nr, "n_gpus": nr,
                 "ms_per_step": round(e2 / a.steps * 1e3, 4), "value": round(2.0 * B2 * N * nr * a.steps / e2, 1),
@@ -421,7 +424,6 @@ def main():
             marks.append(time.perf_counter())
     sync()
     el = time.perf_counter() - t0
-    gc.enable()
     if trace and rank == 0:
         print("trace ms/step per 10 steps:", " ".join("%.3f" % ((b - a_) / 10 * 1e3) for a_, b in zip([t0] + marks[:-1], marks)), file=sys.stderr)
     if use_dist:
@@ -431,24 +433,35 @@ def main():
     loss = tr.loss.cpu().numpy()
 
     roof = None
-    if not a.no_roofline:
+    if a.no_roofline:
+        gc.enable()
+    else:
         # Separate pass of the same K steps (forward + backward, no Adam) with the library's in-stream profiler on.
         # EVERY rank runs it so that the gradient collectives stay matched; only rank 0 records and reports.
+        # Two passes, the one with the smaller GEMM time is reported: a host stall (shared box) idles the GPU, its clock drops
+        # and the kernels of the next ~25 ms run slower -- seen once as frac 0.765 next to an unaffected headline.
         tr._load_batch(pcA, pcB, None)
-        for it in range(a.warmup + a.steps):       # W unprofiled iterations (first launches load code objects, create events)
-            if it == a.warmup:
-                torch.cuda.synchronize()
-                if rank == 0:
-                    L.dpd_prof_enable(1)
-            tr.forward()
-            tr.backward(lab.reshape(-1))
-            if tr.reducer:
-                tr.reducer.wait()
-        torch.cuda.synchronize()
+        best = None
+        for _pass in range(2):
+            for it in range(a.warmup + a.steps):   # W unprofiled iterations (first launches load code objects, create events)
+                if it == a.warmup:
+                    torch.cuda.synchronize()
+                    if rank == 0:
+                        L.dpd_prof_enable(1)
+                tr.forward()
+                tr.backward(lab.reshape(-1))
+                if tr.reducer:
+                    tr.reducer.wait()
+            torch.cuda.synchronize()
+            if rank == 0:
+                ms_, fl_ = ctypes.c_double(0), ctypes.c_double(0)
+                n_ = L.dpd_prof_collect(ctypes.byref(ms_), ctypes.byref(fl_))
+                L.dpd_prof_enable(0)
+                if n_ > 0 and ms_.value > 0 and (best is None or ms_.value < best[1].value):
+                    best = (n_, ms_, fl_)
+        gc.enable()
         if rank == 0:
-            ms, fl = ctypes.c_double(0), ctypes.c_double(0)
-            n = L.dpd_prof_collect(ctypes.byref(ms), ctypes.byref(fl))
-            L.dpd_prof_enable(0)
+            n, ms, fl = best if best else (0, ctypes.c_double(0), ctypes.c_double(0))
             alg, per_step = gemm_flops_per_step(B, N, 2503, 1024)
             if n > 0 and ms.value > 0:
                 launches = n
