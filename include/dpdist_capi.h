@@ -77,7 +77,7 @@ size_t dpd_mfv3d_bwd_workspace_bytes(int C, int m);
  * get_pc_grid_binary_mask_from_centers (:459-492) and get_emb_and_concat (:434-457) WITHOUT
  * materialising the [C,m^3,k^3*20] window tensor.
  *   q [C,N,3], fv [C,m^3,20] -> X [Q,KP] rows, mask [Q] (1/0), vox [Q] (voxel id, 0 if outside). */
-struct dpd_planes;   /* bf16 operand planes that persist between entry points; defined with the decoder below */
+typedef struct dpd_planes dpd_planes;   /* bf16 operand planes that persist between entry points; defined with the decoder below */
 /* `pl` (may be NULL): also write X as operand planes pl->X_rc (all rows) and pl->X_r8 (rows < pl->Qb), so that
  * the decoder GEMMs of a bf16-matrix-core compute type need no separate conversion pass; X may then be NULL.  */
 int dpd_patch_rows_fwd(const float* q, const float* fv, int C, int N, int m, int k, int KP, float* X,
@@ -176,13 +176,13 @@ enum dpd_dtype { DPD_F32 = 0, DPD_F32_X3 = 1, DPD_BF16 = 2 };
  *   dpd_weights_to_planes            W1_r8, W2_r8, W3_r8 (forward), W1_rc, W2_rc, W3_rc (backward dH / dX)
  *   dpd_decoder_bwd_weights[_pair]   -                                                     consumes X_r8/h*_r8, g*_r8
  * Planes are only used when Q % 8 == 0, Qb % 32 == 0, KP % 32 == 0 (otherwise `pl` is ignored).              */
-typedef struct dpd_planes {
+struct dpd_planes {
     int np;       /* 3 for DPD_F32_X3, 1 for DPD_BF16 */
     int Q, Qb;    /* rows of X/h1/h2 planes; rows that carry gradient (R8 planes of X/h*, all g planes) */
     void *X_rc, *X_r8, *h1_rc, *h1_r8, *h2_rc, *h2_r8;
     void *g3_rc, *g3_r8, *g2_rc, *g2_r8, *g1_rc, *g1_r8;
     void *W1_r8, *W2_r8, *W3_r8, *W1_rc, *W2_rc, *W3_rc;
-} dpd_planes;
+};
 
 /* Bytes for ALL members (with_dx: also g1_rc and W1_rc, needed only when dX is requested), and the carve-up of one
  * caller buffer of that size into the members (host-side pointer arithmetic only).                          */
