@@ -116,7 +116,8 @@ class AUETask:
         if opt_type not in ("ours", "chamfer"):
             raise ValueError("opt_type must be 'ours' or 'chamfer'")
         self.ae, self.loss_p, self.opt_type = autoencoder, dpdist_loss, opt_type
-        self.opt = torch.optim.Adam(autoencoder.parameters(), lr=lr)
+        from .optim import TFAdam            # tf.train.AdamOptimizer (train_multi_gpu_pc_compare_dist.py:216,457-463)
+        self.opt = TFAdam(autoencoder.parameters(), lr=lr)
 
     def step(self, x1, x2):
         """x1: clouds fed to the autoencoder, x2: the second sampling of the same surfaces (input2 of DPDist)."""
@@ -124,7 +125,7 @@ class AUETask:
         out2 = self.ae(x1)
         loss_p = self.loss_p(out2, x2)               # input1 <- AE output, input2 <- x2, add_noise 0  (:417-424, :553)
         loss_c = chamfer_dist(x1, out2)              # :434
-        self.opt.zero_grad(set_to_none=True)
+        self.opt.zero_grad()
         (loss_p if self.opt_type == "ours" else loss_c).backward()
         self.opt.step()
         return loss_p.detach(), loss_c.detach()

@@ -102,7 +102,7 @@ struct AdamFuse {
     long tail_off;
     float* loss;
     int ntail;                  // tail blocks (16 outputs each)
-    long v_off[4], v_cnt[4];    // vector ranges
+    long v_off[5], v_cnt[5];    // vector ranges: the complement of up to four covered intervals (three matrices + the tail)
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
     const int nvec = gridDim.x - f.tile_end[2] - f.ntail;
     const size_t stride = (size_t)nvec * 256;
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 5; ++r) {
         const size_t off = (size_t)f.v_off[r], cnt = (size_t)f.v_cnt[r], n4 = (off & 3) ? 0 : cnt / 4;
         for (size_t i = (size_t)b * 256 + tid; i < n4; i += stride) {
             const size_t o = off + 4 * i;
@@ -395,6 +395,8 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
             return DPD_E_DIM;
         if (nc && fu->tail_off < hi[nc - 1]) return DPD_E_DIM;
         if (fu->loss && (fu->rec < 4 * fu->H + 8 || fu->Qb <= 0)) return DPD_E_DIM;
+        // the tail blocks own 16 parameters each; the three loss sums (elements 4H+4 .. 4H+6 of a record) must land in ONE block
+        if (fu->H % 4 || (4 * fu->H + 4) % 16 > 13) return DPD_E_UNSUPPORTED;
         f.partials = fu->partials; f.nparts = fu->nparts; f.rec = fu->rec; f.H = fu->H; f.Qb = fu->Qb;
         f.tail_off = fu->tail_off; f.loss = fu->loss;
         f.ntail = (4 * fu->H + 7 + 15) / 16;
@@ -406,7 +408,10 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
     size_t vec_elems = 0;
     for (int i = 0; i <= nc; ++i) {
         const long end = i < nc ? lo[i] : (long)n;
-        if (end > at) { f.v_off[nv] = at; f.v_cnt[nv] = end - at; vec_elems += (size_t)(end - at); ++nv; }
+        if (end > at) {
+            if (nv >= (int)(sizeof(f.v_off) / sizeof(f.v_off[0]))) return DPD_E_UNSUPPORTED;   // more gaps than the kernel's range table holds
+            f.v_off[nv] = at; f.v_cnt[nv] = end - at; vec_elems += (size_t)(end - at); ++nv;
+        }
         if (i < nc) at = hi[i];
     }
     size_t vblocks = (vec_elems / 4 + 255) / 256;

@@ -45,13 +45,23 @@ def quat_normalize(pred, rot_lim=45.0):
 class PoseNet(nn.Module):
     """models/ipcr_model.py:198-233 + :273-284 (1xW convs == per-point linear layers)."""
 
-    def __init__(self, out_features=1024, lim_rot=45.0):
+    def __init__(self, out_features=1024, lim_rot=45.0, keep_prob=0.7):
         super().__init__()
         dims = [3, 64, 64, 64, 128, out_features]
         self.point = nn.Sequential(*[m for i in range(5) for m in (nn.Linear(dims[i], dims[i + 1]), nn.ReLU())])
         self.head = nn.Sequential(nn.Linear(2 * out_features, 1024), nn.ReLU(), nn.Linear(1024, 512), nn.ReLU(),
-                                  nn.Linear(512, 256), nn.ReLU(), nn.Dropout(p=0.3), nn.Linear(256, 7))
+                                  nn.Linear(512, 256), nn.ReLU(), nn.Dropout(p=1.0 - keep_prob), nn.Linear(256, 7))
         self.lim_rot = lim_rot
+        self.reset_parameters_tf()
+
+    @torch.no_grad()
+    def reset_parameters_tf(self):
+        """The reference's initialisation (pcrnet-registration/utils/tf_util.py `_variable_with_weight_decay(use_xavier=True)`:
+        Xavier-uniform kernels, zero biases) instead of torch's kaiming-uniform(a=sqrt(5)) default with random biases."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
 
     @torch.no_grad()
     def load_tf_state_dict(self, sd):
@@ -137,6 +147,12 @@ def transformation_quat2mat(poses, TRANSFORMATIONS, templates_data):
     return TRANSFORMATIONS, templates_data
 
 
+def find_final_pose_inv(TRANSFORMATIONS):
+    """helper.py:347-361: the pose of the INVERSE transforms -- what results_itrPCRNet_no_stop.get_error (:465-474) compares
+    with the ground-truth pose that created the source from the template."""
+    return find_final_pose(np.linalg.inv(np.asarray(TRANSFORMATIONS, dtype=np.float64)))
+
+
 def find_final_pose(TRANSFORMATIONS):
     """helper.py:331-345: 4x4 transforms -> (x, y, z, rx, ry, rz)."""
     out = np.zeros((TRANSFORMATIONS.shape[0], 6))
@@ -157,34 +173,53 @@ def pose_errors(T_pred, R_gt, t_gt):
     return (T_pred[:, :3, 3] - t_id).norm(dim=-1), torch.rad2deg(torch.acos(cos))
 
 
+def predicted_pose_applied(source, pose):
+    """iterative_PCRNet_ours.py:211-224: split the 7-vector, re-normalise the quaternion (norm + 1e-7) and move the source."""
+    quat = pose[:, 3:7]
+    quat = quat / (quat.square().sum(1, keepdim=True).sqrt() + 1e-7)
+    return transformation_quat_tensor(source, quat, pose[:, :3])
+
+
 class IterativeRegistration:
     """One training step = iterative_PCRNet_ours.py:410-470: 7 forward-only refinements (no gradient), then one step
     in which the DPDist loss of (transformed source, template) is back-propagated THROUGH the frozen DPDist path into
-    the pose network."""
+    the pose network; the optimizer is `tf.train.AdamOptimizer(learning_rate, name='Adam2')` (:239) = `optim.TFAdam`.
+    `loss_fn(moved_source, template) -> scalar` is DPDistLoss (the reference's 'ours') or any other differentiable
+    cloud distance (the reference's Chamfer baseline, iterative_PCRNet.py)."""
 
-    def __init__(self, pose_net, dpdist_loss, lr=1e-3, max_loops=8):
+    def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None):
+        from .optim import TFAdam
         self.net, self.loss_fn, self.max_loops = pose_net, dpdist_loss, max_loops
-        self.opt = torch.optim.Adam(pose_net.parameters(), lr=lr)
+        self.opt = optimizer if optimizer is not None else TFAdam(pose_net.parameters(), lr=lr)
 
     def refine(self, source, template, loops):
         T = torch.eye(4, device=source.device).repeat(source.shape[0], 1, 1)
         with torch.no_grad():
             for _ in range(loops):
                 pose = self.net(source, template)
+                # helper.transformation_quat2mat (helper.py:309-329) normalises the quaternion (transforms3d.quat2mat)
+                pose = torch.cat([pose[:, :3], pose[:, 3:7] / pose[:, 3:7].norm(dim=1, keepdim=True).clamp_min(1e-12)], 1)
                 source = transformation_quat_tensor(source, pose[:, 3:7], pose[:, :3])
                 T = compose(T, pose)
         return source, T
 
+    def loss_and_gradients(self, refined_source, template):
+        """The training `sess.run` of :468 without the update: loss, predicted pose; gradients are left in the parameters'
+        `.grad` (d loss / d moved source comes from the HIP backward-to-input path when loss_fn is DPDistLoss)."""
+        pose = self.net(refined_source, template)
+        moved = predicted_pose_applied(refined_source, pose)
+        loss = self.loss_fn(moved, template)                 # (mean(AB[...,0]) + mean(BA[...,0])) / 2, :248-251
+        self.opt.zero_grad()
+        loss.backward()
+        return loss.detach(), pose.detach()
+
     def train_step(self, source, template):
         self.net.train()
         src, T = self.refine(source, template, self.max_loops - 1)
-        pose = self.net(src, template)
-        moved = transformation_quat_tensor(src, pose[:, 3:7], pose[:, :3])
-        loss = self.loss_fn(moved, template)                 # (mean(AB[...,0]) + mean(BA[...,0])) / 2, :248-251
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()                                      # d loss / d moved comes from the HIP backward-to-input path
+        loss, pose = self.loss_and_gradients(src, template)
         self.opt.step()
-        return loss.detach(), compose(T, pose.detach())
+        pose = torch.cat([pose[:, :3], pose[:, 3:7] / pose[:, 3:7].norm(dim=1, keepdim=True).clamp_min(1e-12)], 1)
+        return loss, compose(T, pose)
 
     @torch.no_grad()
     def evaluate(self, source, template):

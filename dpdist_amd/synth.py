@@ -115,13 +115,120 @@ def _dist_box(p, h):
     return np.abs(outside + inside)
 
 
-def s2_modelnet_shaped(B=64, N=64, seed=100):
+# ------------------------------------------------------------------------------------------
+# "chair-like" surfaces: unions of axis-aligned boxes (seat + back + four legs + optional arm rests).  ModelNet40 'chair'
+# (BASELINE config 5, pcrnet-registration/run_train_and_eval_PCRNet.bash:43) is not in the tree; spheres, ellipsoids and
+# single boxes have unobservable or ambiguous rotations, a chair does not (no symmetry except left/right mirroring, which
+# is not a rotation).  y is up, the back rest sits at -z.
+# ------------------------------------------------------------------------------------------
+class BoxUnion:
+    """Surface of a union of axis-aligned boxes: area-weighted surface samples (points buried inside another box are
+    rejected) and the exact distance to the surface for points outside every box."""
+
+    def __init__(self, centers, halves):
+        self.c = np.asarray(centers, np.float64)
+        self.h = np.asarray(halves, np.float64)
+
+    def sdf_each(self, p):
+        q = np.abs(p[:, None, :] - self.c[None]) - self.h[None]               # [n, K, 3]
+        return np.linalg.norm(np.maximum(q, 0.0), axis=2) + np.minimum(q.max(axis=2), 0.0)
+
+    def outside(self, p):
+        return (self.sdf_each(p) > 0).all(axis=1)
+
+    def dist(self, p):
+        """distance to the union's surface; exact where `outside(p)`"""
+        return np.abs(self.sdf_each(p)).min(axis=1)
+
+    def sample(self, rng, n):
+        hx, hy, hz = self.h[:, 0], self.h[:, 1], self.h[:, 2]
+        area = np.stack([hy * hz, hx * hz, hx * hy], 1)                        # face-pair areas per box (x4, irrelevant)
+        pr = (area / area.sum()).ravel()
+        out = np.zeros((0, 3))
+        while len(out) < n:
+            m = 2 * (n - len(out)) + 8
+            f = rng.choice(len(pr), m, p=pr)
+            bi, ax = f // 3, f % 3
+            p = rng.uniform(-1, 1, (m, 3)) * self.h[bi]
+            p[np.arange(m), ax] = rng.choice([-1.0, 1.0], m) * self.h[bi, ax]
+            p = p + self.c[bi]
+            sd = self.sdf_each(p)
+            sd[np.arange(m), bi] = 0.0
+            out = np.concatenate([out, p[(sd > -1e-9).all(axis=1)]])
+        return out[:n]
+
+    def scaled(self, shift, s):
+        return BoxUnion((self.c - shift) * s, self.h * s)
+
+
+def make_chair(rng):
+    """A random chair inside the ball of radius 0.8 (clouds are normalised to the unit sphere and scaled by 0.8,
+    dataset_sample_with_gt.py:82), centred on its bounding box."""
+    w, d = rng.uniform(0.40, 0.60), rng.uniform(0.40, 0.60)          # seat width (x) / depth (z)
+    ts, tb, tl = rng.uniform(0.04, 0.09), rng.uniform(0.04, 0.09), rng.uniform(0.04, 0.08)
+    hb, ll = rng.uniform(0.40, 0.75), rng.uniform(0.30, 0.55)        # back height above the seat, leg length
+    c = [[0.0, 0.0, 0.0]]
+    h = [[w / 2, ts / 2, d / 2]]
+    c.append([0.0, ts / 2 + hb / 2, -d / 2 + tb / 2])
+    h.append([w / 2, hb / 2, tb / 2])
+    for sx in (-1, 1):
+        for sz in (-1, 1):
+            c.append([sx * (w / 2 - tl / 2), -ts / 2 - ll / 2, sz * (d / 2 - tl / 2)])
+            h.append([tl / 2, ll / 2, tl / 2])
+    if rng.random() < 0.35:                                           # arm rests
+        ha, ta = rng.uniform(0.15, 0.25), rng.uniform(0.03, 0.06)
+        for sx in (-1, 1):
+            c.append([sx * (w / 2 - ta / 2), ts / 2 + ha, 0.05 * d])
+            h.append([ta / 2, ta / 2, 0.45 * d])
+            c.append([sx * (w / 2 - ta / 2), ts / 2 + ha / 2, 0.45 * d])
+            h.append([ta / 2, ha / 2, ta / 2])
+    u = BoxUnion(c, h)
+    lo, hi = (u.c - u.h).min(0), (u.c + u.h).max(0)
+    mid = (lo + hi) / 2
+    rad = np.linalg.norm(np.abs(u.c - mid) + u.h, axis=1).max()           # farthest box corner from the centre
+    return u.scaled(mid, 0.8 / rad)
+
+
+def euler_rotation(rx, ry, rz):
+    """R = Rx Ry Rz: what helper.apply_transformation (pcrnet-registration/helper.py:229-258) applies (z first, then y, x)."""
+    cx, sx, cy, sy, cz, sz = math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry), math.cos(rz), math.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def registration_pairs(B=16, N=64, seed=0, max_deg=45.0, t_clip=0.01, rng=None):
+    """(source, template, gt_pose) as the reference's registration trainer composes them with its shipped flags
+    (SPARSE_SAMPLING=1, s_random_points=1.0, centroid_sub=0, Noise=0: run_train_and_eval_PCRNet.bash:16-40):
+    helper.split_template_source (helper.py:925-961): template and source are DIFFERENT N-point samples of the same surface,
+    source = apply_transformation(source, pose); poses as utils/create_dataset/generate_poses_ours.py:4-18 draws them:
+    gt_pose [B,6] = (t ~ U(-t_clip, t_clip)^3, (rx, ry, rz) ~ U(-max_deg, max_deg)^3 in radians)."""
+    rng = np.random.default_rng(seed) if rng is None else rng
+    src = np.zeros((B, N, 3), np.float32)
+    tmpl = np.zeros((B, N, 3), np.float32)
+    t = rng.uniform(-t_clip, t_clip, (B, 3))
+    e = np.radians(rng.uniform(-max_deg, max_deg, (B, 3)))
+    for b in range(B):
+        ch = make_chair(rng)
+        pts = ch.sample(rng, 2 * N)
+        tmpl[b] = pts[:N]
+        src[b] = pts[N:] @ euler_rotation(*e[b]).T + t[b]
+    return src, tmpl, np.concatenate([t, e], 1)
+
+
+def s2_modelnet_shaped(B=64, N=64, seed=100, shapes="analytic", tilt_deg=0.0):
     """(pcA, pcB, labels_AB) following the trainer's recipe on spheres/boxes of extent <= 0.8.
 
     Per pair: a shape (sphere radius 0.3-0.7 or box half-extents 0.2-0.55), a random y-rotation
     and a shift U(-0.1,0.1)^3 (`modelnet_dataset.py:87,91`); pcA = N surface samples; pcB = N/2
     other surface samples + N/4 near-surface points (distance in (0.001, 0.1)) + N/4 points
     uniform in the unit ball with distance > 0.1; labels = exact distance to the surface.
+
+    shapes="chair": the same recipe on `make_chair` surfaces (what the config-5 / row-f2 demo trains DPDist on); tilt_deg > 0
+    adds a rotation by U(-tilt_deg, tilt_deg) about each of x and z before the y-rotation (NOT in the reference's augmentation:
+    its DPDist only sees upright chairs; the registration demo states which one it used).  The default "analytic" stream is
+    unchanged (benchmarks and fixtures depend on it bit for bit).
     """
     rng = np.random.default_rng(seed)
     H, Qn = N // 2, N // 4
@@ -129,6 +236,9 @@ def s2_modelnet_shaped(B=64, N=64, seed=100):
     pcB = np.zeros((B, N, 3), np.float32)
     lab = np.zeros((B, N), np.float32)
     for b in range(B):
+        if shapes == "chair":
+            _chair_pair(rng, N, pcA, pcB, lab, b, tilt_deg)
+            continue
         is_sphere = rng.random() < 0.5
         if is_sphere:
             r = rng.uniform(0.3, 0.7)
@@ -161,6 +271,34 @@ def s2_modelnet_shaped(B=64, N=64, seed=100):
         pcA[b] = (surfA @ R.T + shift).astype(np.float32)
         pcB[b] = (B_local @ R.T + shift).astype(np.float32)
     return pcA, pcB, lab
+
+
+def _chair_pair(rng, N, pcA, pcB, lab, b, tilt_deg):
+    H, Qn = N // 2, N // 4
+    ch = make_chair(rng)
+    R = _rot_y(rng.uniform(0, 2 * math.pi))
+    if tilt_deg > 0:
+        tx, tz = np.radians(rng.uniform(-tilt_deg, tilt_deg, 2))
+        R = R @ euler_rotation(tx, 0.0, tz)
+    shift = rng.uniform(-0.1, 0.1, 3)
+    surf = ch.sample(rng, N + H)
+    near = np.zeros((0, 3))
+    while len(near) < Qn:
+        c = ch.sample(rng, 4 * Qn) + rng.standard_normal((4 * Qn, 3)) * 0.04
+        d = ch.dist(c)
+        near = np.concatenate([near, c[(d > 0.001) & (d < 0.1) & ch.outside(c)]])
+    near = near[:Qn]
+    far = np.zeros((0, 3))
+    while len(far) < Qn:
+        c = rng.standard_normal((8 * Qn, 3))
+        c = c / np.linalg.norm(c, axis=1, keepdims=True) * rng.random((8 * Qn, 1)) ** (1 / 3) * 0.85
+        d = ch.dist(c)
+        far = np.concatenate([far, c[(d > 0.1) & ch.outside(c)]])
+    far = far[:Qn]
+    B_local = np.concatenate([surf[N:], near, far])
+    lab[b] = np.concatenate([np.zeros(H), ch.dist(near), ch.dist(far)]).astype(np.float32)
+    pcA[b] = (surf[:N] @ R.T + shift).astype(np.float32)
+    pcB[b] = (B_local @ R.T + shift).astype(np.float32)
 
 
 # ----------------------------------------------------------------------------------------------------------------

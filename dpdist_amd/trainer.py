@@ -174,6 +174,11 @@ class DPDistTrainer:
                                                    L.ptr(self._ssq), L.cur_stream()), "dpd_mfv3d_fwd_stacked")
             self._fv_scaled = False
         else:
+            if self.fused and gate is not None:
+                # fused-gather mode has no X: mask (output-layer backward) and fv / xyz / rowinfo (the gathering dW1 GEMM) are read
+                # by the CURRENT step's backward until dW1 is done -- the whole front end must wait, not only the gather
+                torch.cuda.current_stream().wait_event(gate)
+                gate = None
             self._load_batch(pcA, pcB, noise)
             self._encode()
         if gate is not None:
@@ -259,7 +264,7 @@ class DPDistTrainer:
             L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
                                              L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
                                              L.ptr(self.g2), L.ptr(self.g1), None, small, L.ptr(self.ws), wsb, self._planes,
-                                             phases, s), "dpd_decoder_bwd_data")
+                                             phases, L.cur_stream()), "dpd_decoder_bwd_data")   # stream at CALL time (graph branches)
 
         def dw(layer, act, g, dW):
             if layer == 1 and self.fused:
@@ -336,6 +341,7 @@ class DPDistTrainer:
         L.check(L.load().dpd_adam_tf_dev(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                          self.P.numel, L.ptr(self.opt_state), b1, b2, eps, 1.0, L.cur_stream()), "dpd_adam_tf_dev")
         self._wdirty = True
+        self.P._tr_key = None
 
     def apply_gradients(self, tail_from_partials=False):
         """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
@@ -356,19 +362,23 @@ class DPDistTrainer:
                                                L.cur_stream()), "dpd_adam_tf_fused")
             # the transposed copies / operand planes written in the same pass are already those of the new weights
             self._wdirty = self._planes is not None and not self._afuse[0].np
+            self.P._tr_key = None
             return
         L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                      self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
         self._wdirty = True
+        self.P._tr_key = None     # DPDistParams.transposed() keys its cache on flat._version, which a raw-pointer update never bumps
 
     def _sync_dev_schedule(self):
         """Put the host's step count into the device-side schedule (before graph replays that follow eager steps / a restore)."""
         if self._dev_t != self.t:
             _, _, _, b1, b2, _ = self.hp
             st = torch.zeros(8)
-            st[0] = torch.tensor(self.t, dtype=torch.int32).view(torch.float32)
             st[1], st[2] = b1 ** self.t, b2 ** self.t
             self.opt_state.copy_(st)
+            # slot 0 holds the int32 global step: written through an int32 view (a float32 round trip of a small integer's bit
+            # pattern is a denormal, which a flush-to-zero host silently turns into step 0)
+            self.opt_state.view(torch.int32)[0:1].copy_(torch.tensor([self.t], dtype=torch.int32))
             self._dev_t = self.t
 
     @property
@@ -469,6 +479,8 @@ class DPDistTrainer:
         g = self._graphs.get(key)
         if g is None:
             if key not in self._seen_keys or len(self._graphs) >= 8:
+                if len(self._seen_keys) >= 64:     # callers that pass fresh tensors every step: do not grow without bound
+                    self._seen_keys.clear()
                 self._seen_keys.add(key)
                 return None
             g = self._capture(pcA, pcB, labels, noise)
@@ -481,6 +493,7 @@ class DPDistTrainer:
         self.graph_replays += 1
         self.front_launches += 1
         self._wdirty = True            # the replay ends with Adam: derived buffers are one step behind the weights
+        self.P._tr_key = None
         return self.loss
 
     def _capture(self, pcA, pcB, labels, noise):

@@ -798,11 +798,15 @@ def test_patch_rows_planes_match_split(dev, np_):
     assert torch.equal(got_r8, want_r8)
 
 
-def test_prefetch_pipeline_is_bitwise_equivalent(dev):
+@pytest.mark.parametrize("fused_gather", [False, True])
+def test_prefetch_pipeline_is_bitwise_equivalent(dev, fused_gather, monkeypatch):
     """Running the next batch's encoder + gather on the side stream must not change a single bit of the weights
-    (except through the fp32 atomics of db1/db2, which are excluded by comparing the GEMM-produced tensors)."""
+    (except through the fp32 atomics of db1/db2, which are excluded by comparing the GEMM-produced tensors).
+    fused_gather (DPD_FUSED_GATHER=1): there the current step's backward reads mask / fv / xyz / rowinfo until dW1 is done, so
+    the WHOLE prefetched front end has to wait for it (round-2 advisor finding: only the gather waited)."""
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer
+    monkeypatch.setenv("DPD_FUSED_GATHER", "1" if fused_gather else "0")
     B = 8
     batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100 + i)) for i in range(4)]
     W0 = synth.make_weights("wide")
@@ -811,6 +815,7 @@ def test_prefetch_pipeline_is_bitwise_equivalent(dev):
         P = DPDistParams(device=dev)
         P.load_tf_state_dict(W0)
         tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        assert tr.fused == fused_gather
         losses = []
         for i, (a, b, l) in enumerate(batches):
             nxt = batches[i + 1][:2] + (None,) if (use_prefetch and i + 1 < len(batches)) else None

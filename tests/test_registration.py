@@ -118,22 +118,104 @@ def test_pose_errors_on_matrices():
     assert abs(re.item() - 30.0) < 1e-6
 
 
-@pytest.mark.gpu
-def test_dpdist_loss_trains_the_pose_network():
-    """Gradients flow source -> transformed source -> (HIP) DPDist backward-to-input -> pose network."""
-    from dpdist_amd import synth
+def _gpu_harness(dev, max_loops=8, keep_prob=0.7, weights="wide"):
     from dpdist_amd.model import DPDistLoss, DPDistModel
     from dpdist_amd.registration import IterativeRegistration
+    model = DPDistModel(device=dev)
+    model.load_tf_state_dict(synth.make_weights(weights))
+    return model, IterativeRegistration(PoseNet(keep_prob=keep_prob).to(dev), DPDistLoss(model), lr=1e-4, max_loops=max_loops)
+
+
+@pytest.mark.gpu
+def test_dpdist_loss_trains_the_pose_network():
+    """Gradients flow source -> transformed source -> (HIP) DPDist backward-to-input -> pose network; the update is the
+    library's TF-form Adam (one flat buffer), DPDist stays frozen."""
+    from dpdist_amd.optim import TFAdam
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = DPDistModel(device=dev)
-    model.load_tf_state_dict(synth.make_weights("wide"))
-    reg = IterativeRegistration(PoseNet().to(dev), DPDistLoss(model), lr=1e-4, max_loops=3)
-    pcA, pcB, _ = synth.s2_modelnet_shaped(8, 64, 100)
-    src, tmpl = torch.tensor(pcA, device=dev), torch.tensor(pcB, device=dev)
+    model, reg = _gpu_harness(dev, max_loops=3)
+    assert isinstance(reg.opt, TFAdam)
+    src, tmpl, _ = synth.registration_pairs(8, 64, seed=100)
+    src, tmpl = torch.tensor(src, device=dev), torch.tensor(tmpl, device=dev)
     before = [p.detach().clone() for p in reg.net.parameters()]
     loss, T = reg.train_step(src, tmpl)
     assert torch.isfinite(loss) and T.shape == (8, 4, 4)
     changed = sum(float((p.detach() - b).abs().max()) > 0 for p, b in zip(reg.net.parameters(), before))
     assert changed >= len(before) - 1          # every layer received a gradient
     assert all(not p.requires_grad for p in model.parameters())      # DPDist stays frozen
+    # all parameters still live in the optimizer's flat buffer
+    lo, hi = reg.opt.flat.data_ptr(), reg.opt.flat.data_ptr() + reg.opt.flat.numel() * 4
+    assert all(lo <= p.data_ptr() < hi for p in reg.net.parameters())
+
+
+@pytest.mark.gpu
+def test_registration_step_gradients_vs_oracle():
+    """ONE training step of config 5's workload (B=16, 64 points, 8 loops: run_train_and_eval_PCRNet.bash:17-32,
+    iterative_PCRNet_ours.py:410-470) -- the pose-network gradients that come back through the HIP as-loss path
+    (d loss_pred / d input1) against the oracle: float64 autograd through the pose network -> quaternion normalisation
+    (:213-221) -> transformation_quat_tensor -> oracle get_model -> loss_pred (:248-251).  Dropout is switched off so that
+    both sides see the same network; the seven no-gradient refinements run on the GPU and their result feeds both."""
+    from oracle import restate as R
+    from dpdist_amd.registration import predicted_pose_applied
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model, reg = _gpu_harness(dev, max_loops=8, keep_prob=1.0)
+    with torch.no_grad():                      # a pose head that actually moves the cloud (Xavier init predicts ~identity)
+        reg.net.head[-1].bias.copy_(torch.tensor([0.3, -0.2, 0.1, 0.25, 0.4, -0.3, 0.8], device=dev))
+    src, tmpl, _ = synth.registration_pairs(16, 64, seed=5)
+    src, tmpl = torch.tensor(src, device=dev), torch.tensor(tmpl, device=dev)
+    reg.net.train()
+    refined, T = reg.refine(src, tmpl, reg.max_loops - 1)
+    assert (refined - src).abs().max() > 1e-2                         # the refinements did move the source
+    loss, pose = reg.loss_and_gradients(refined, tmpl)
+    got = {n: p.grad.detach().double().cpu() for n, p in reg.net.named_parameters()}
+
+    def oracle(dtype):
+        net = PoseNet(keep_prob=1.0).to(dtype)
+        net.load_state_dict({k: v.detach().cpu().to(dtype) for k, v in reg.net.state_dict().items()})
+        net.train()
+        W = R.as_torch_weights(synth.make_weights("wide"), dtype)
+        s, t = refined.detach().cpu().to(dtype), tmpl.cpu().to(dtype)
+        moved = predicted_pose_applied(s, net(s, t))
+        ps, _ = R.get_model(moved, t, W)
+        _, lp = R.get_loss(ps, torch.ones(16, 64, dtype=dtype))      # labels12 is fed with ones and unused (:422)
+        lp.backward()
+        return lp.item(), {n: p.grad.double() for n, p in net.named_parameters()}
+
+    l64, ref = oracle(torch.float64)
+    l32, ref32 = oracle(torch.float32)
+    assert abs(loss.item() - l64) <= 2e-5
+    gmax = max(float(g.abs().max()) for g in ref.values())
+    assert gmax > 1e-4                                                # a real gradient, not a saturated zero
+    for n, g in ref.items():
+        # the float32 evaluation of the oracle itself sits this far from float64; allow 4x that, or 1e-3 of the layer's scale
+        bar = max(4.0 * float((ref32[n] - g).abs().max()), 1e-3 * float(g.abs().max()), 1e-7)
+        err = float((got[n] - g).abs().max())
+        assert err <= bar, (n, err, bar, float(g.abs().max()))
+
+
+@pytest.mark.gpu
+def test_tf_adam_optimizer_matches_the_oracle_update():
+    """optim.TFAdam (what the f2 / f4 consumers now use instead of torch.optim.Adam) == tf.train.AdamOptimizer's update as the
+    oracle restates it (epsilon OUTSIDE the bias correction), over several steps and parameters of ragged sizes."""
+    from oracle import restate as R
+    from dpdist_amd.optim import TFAdam
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    shapes = [(7, 5), (5,), (3, 11), (1,)]
+    ps = [torch.nn.Parameter(torch.tensor(rng.standard_normal(s).astype(np.float32), device=dev)) for s in shapes]
+    ref = [p.detach().cpu().numpy().astype(np.float64) for p in ps]
+    ms, vs = [np.zeros_like(r) for r in ref], [np.zeros_like(r) for r in ref]
+    opt = TFAdam(ps, lr=1e-2)
+    for t in range(1, 6):
+        opt.zero_grad()
+        gs = [rng.standard_normal(s).astype(np.float32) * (1e-4 if t == 3 else 1.0) for s in shapes]   # tiny |g|: epsilon matters
+        loss = sum((p * torch.tensor(g, device=dev)).sum() for p, g in zip(ps, gs))
+        loss.backward()
+        opt.step()
+        for i, g in enumerate(gs):
+            R.adam_tf_step(ref[i], g.astype(np.float64), ms[i], vs[i], t, 1e-2)        # in place
+        for p, r in zip(ps, ref):
+            assert np.abs(p.detach().cpu().numpy() - r).max() <= 2e-6
+    with pytest.raises(RuntimeError):
+        TFAdam([torch.nn.Parameter(torch.zeros(3))])                 # CPU parameters: no fallback
