@@ -55,6 +55,74 @@ __device__ __forceinline__ int chunk_of(int o, int kg) {
     return KC ? o * CPR + (kg ^ ((o / (16 / CPR)) & (CPR - 1))) : kg * BO + o;
 }
 
+// Epilogue shared by the plane GEMM kernels: fp32 store with bias / ReLU / gate / column sums, and -- when plane outputs are
+// requested -- the finished tile staged through the (idle) LDS ring so that the next GEMMs find their operands as bf16 planes.
+template <int BM, int BN, int NW, int TM, int TN>
+__device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][TN], char* smem_x3, int grp, int z, int m0, int n0,
+                                            int wm0, int wn0, int tid, int l31, int half) {
+    const int M = g.e.M, N = g.e.N;
+    if (!g.out_rc && !g.out_r8) {
+        GemmArgs ge = g.e;
+        if (grp) ge.C = g.C2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) store_tile(ge, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
+        return;
+    }
+    // Plane outputs: the finished tile is staged through the (now idle) LDS ring as fp32 [BM][BN+4] and re-read in
+    // the two chunk orientations, so that the next GEMMs find their operands as bf16 planes (no separate split pass).
+    constexpr int LDW = BN + 4;
+    float* st = reinterpret_cast<float*>(smem_x3);
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the ring (all DMA pieces were waited for above)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float v[16];
+            const int row0 = wm0 + 32 * i, col = wn0 + 32 * j + l31;
+            tile_values(g.e, acc[i][j], m0 + row0, n0 + col, half, v);
+            put_tile(g.e, v, z, m0 + row0, n0 + col, half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[(row0 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDW + col] = v[r];
+        }
+    __syncthreads();
+    constexpr int NTHR = 64 * NW;
+    const int npo = g.np_out;
+    if (g.out_rc) {
+        for (int t2 = tid; t2 < BM * (BN / 8); t2 += NTHR) {
+            const int row = t2 / (BN / 8), cg = t2 % (BN / 8);
+            const int grow = m0 + row, gcol = n0 + 8 * cg;
+            if (grow < M && gcol < N) {
+                const float4 x0 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg);
+                const float4 x1 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg + 4);
+                const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                uint4 w[3];
+                split_chunk(v, w);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)   // compile-time plane index: w[] stays in registers
+                    if (q < npo) *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
+            }
+        }
+    }
+    if (g.out_r8 && m0 < g.r8_rows) {
+        for (int t2 = tid; t2 < (BM / 8) * BN; t2 += NTHR) {
+            const int rg = t2 / BN, col = t2 % BN;
+            const int grow = m0 + 8 * rg, gcol = n0 + col;
+            if (grow < g.r8_rows && gcol < N) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = st[(8 * rg + j) * LDW + col];
+                uint4 w[3];
+                split_chunk(v, w);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < npo) *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
+            }
+        }
+    }
+}
+
 // ABL (timing-only ablations, instantiated only with -DDPD_ABLATIONS; results are wrong by construction):
 //   1 = no LDS-DMA refill in the K loop, 2 = no barrier, 4 = no fragment reads in the loop, 8 = one MFMA per step only.
 template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
@@ -228,66 +296,221 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
             if (it + 1 < nt) do_step(it + 1, 0, C1{});
         }
     }
-    if (!g.out_rc && !g.out_r8) {
-        GemmArgs ge = g.e;
-        if (grp) ge.C = g.C2;
+    x3_epilogue<BM, BN, NW, TM, TN>(g, acc, smem_x3, grp, z, m0, n0, wm0, wn0, tid, l31, half);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gemm_p8_kernel: one bf16 plane, BK = 64, phase-staggered schedule (the "8-phase" structure of the CDNA4 guide, section 5,
+// re-derived for this library's chunked plane layouts and 32x32x16 MFMAs).
+//
+// The lock-step ring kernel above is additive: every wave issues its LDS-DMA pieces, then its fragment reads, then its MFMAs,
+// and all eight waves do each of these at the same time (MFMA 25 us + DMA issue 16 us + fragment reads 7 us on
+// the layer-1 shape).  Here the workgroup is two GROUPS of NW/2 waves (waves w and w + NW/2 share a SIMD) that run the same
+// program ONE BARRIER APART, so that on every SIMD one wave is inside its MFMA cluster (at raised priority) while the other
+// issues ds_reads and DMA pieces:
+//
+//     K-tile t = phases 2t (k16 steps 0,1) and 2t+1 (steps 2,3); stage = t % 3 (three whole K-tiles of LDS).
+//     phase p of a wave:   LOAD(p): fragment reads of phase p; DMA pieces: p = 2t   -> second half of this wave's pieces of K-tile t+1
+//                                                                          p = 2t+1 -> first half of K-tile t+2;
+//                                   odd p: s_waitcnt vmcnt(first half of t+2 stays in flight)  => my pieces of K-tile t+1 landed
+//                          s_barrier (B1)    MFMA(p): TM*TN*2 MFMAs, s_setprio 1    s_barrier (B2)
+//     group 1 executes one extra barrier before phase 0 and group 0 one after the last phase: between two consecutive
+//     workgroup barriers one group is in LOAD, the other in MFMA.
+//
+// Hazards (global barrier index: group 0 passes 2p / 2p+1 around MFMA(p), group 1 passes 2p+1 / 2p+2):
+//   RAW  K-tile t+1 is read from LOAD(2t+2) on.  Every wave waits for its own pieces of t+1 before ITS B1(2t+1) (index 4t+2 for
+//        group 0, 4t+3 for group 1); group 0's LOAD(2t+2) starts after index 4t+3, group 1's after 4t+4: behind both.
+//   WAR  K-tile t+2 goes to stage (t+2)%3 = (t-1)%3, last read in LOAD(2t-1), whose reads have returned before that wave's
+//        MFMA(2t-1) ends (the MFMAs consume them), i.e. before index 4t-1 (group 0) / 4t (group 1).  The first pieces of t+2 are
+//        issued in LOAD(2t+1): after index 4t+1 (group 0) / 4t+2 (group 1): behind both.
+// K % 64 == 32 (the decoder's 2528): the lanes whose chunk lies beyond K in the last K-tile fetch a zero chunk instead.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const unsigned g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
+    constexpr int BK = 64, NS = 3, CPR = 8;
+    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
+    constexpr int A_IMG = BM * CPR, B_IMG = BN * CPR, STAGE = A_IMG + B_IMG;   // chunks of 16 B
+    constexpr int PA = A_IMG / 64, PB = B_IMG / 64;                            // 1-KiB pieces per image
+    constexpr int PPW = (PA + PB) / NW, HP = PPW / 2;                          // pieces per wave per K-tile / per phase
+    static_assert((PA + PB) % NW == 0 && PPW % 2 == 0, "piece split");
+    static_assert(NW % 2 == 0, "two wave groups");
+    static_assert(AK || BM % 64 == 0, "R8 images need 64-row pieces");
+    static_assert(BKC || BN % 64 == 0, "R8 images need 64-row pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wgrp = __builtin_amdgcn_readfirstlane(wave / (NW / 2));          // 0: waves 0..NW/2-1, 1: the rest
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm0 = (wave / WC) * 32 * TM, wn0 = (wave % WC) * 32 * TN;
+
+    const int M = g.e.M, N = g.e.N;
+    const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
+    const int per_z = tilesM * tilesN;
+    const int sid0 = xcd_remap(blockIdx.x, per_z * (g.A2 ? 2 : 1));
+    const int grp = sid0 / per_z;
+    const int t0 = sid0 % per_z;
+    const uint16_t* gA = grp ? g.A2 : g.A;
+    const uint16_t* gB = grp ? g.B2 : g.B;
+    const int m0 = (t0 / tilesN) * BM, n0 = (t0 % tilesN) * BN;
+    const int K = g.e.K;
+    const int nt = (K + BK - 1) / BK;
+    const bool ktail = (K % BK) != 0;          // == 32: the last K-tile has 4 valid k-groups out of 8
+
+    const uint16_t* src[PPW];
+    long step[PPW];
+    unsigned dst[PPW];
+    unsigned tail_ok = 0;                      // bit j: this lane's chunk of piece j is inside K in the tail K-tile
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem_x3;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) store_tile(ge, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
-        return;
+    for (int j = 0; j < PPW; ++j) {
+        const int p = wave + j * NW;
+        const bool isA = p < PA;
+        const int c = isA ? p : p - PA;
+        const bool kc = isA ? AK : BKC;
+        const uint16_t* base = isA ? gA : gB;
+        const int ld = isA ? g.lda : g.ldb;
+        const int o0 = isA ? m0 : n0;
+        const int O = isA ? M : N;
+        const int BO = isA ? BM : BN;
+        dst[j] = lds_base + (unsigned)((isA ? 0 : A_IMG) + c * 64) * 16u;
+        int kg;
+        if (kc) {
+            const int row = c * (64 / CPR) + lane / CPR, slot = lane % CPR;
+            kg = slot ^ ((row / (16 / CPR)) & (CPR - 1));
+            src[j] = base + (size_t)min(o0 + row, O - 1) * ld + 8 * kg;
+            step[j] = BK;
+        } else {
+            const int lin = c * 64 + lane;
+            kg = lin / BO;
+            const int o = lin % BO;
+            src[j] = base + ((size_t)kg * ld + min(o0 + o, O - 1)) * 8;
+            step[j] = (long)CPR * ld * 8;
+        }
+        tail_ok |= (kg < 4 ? 1u : 0u) << j;
     }
-    // Plane outputs: the finished tile is staged through the (now idle) LDS ring as fp32 [BM][BN+4] and re-read in
-    // the two chunk orientations, so that the next GEMMs find their operands as bf16 planes (no separate split pass).
-    constexpr int LDW = BN + 4;
-    float* st = reinterpret_cast<float*>(smem_x3);
-    __builtin_amdgcn_s_barrier();   // every wave is done reading the ring (all DMA pieces were waited for above)
+    // pieces [j0, j0 + cnt) of K-tile `tile` into stage `stage`; every piece is issued exactly once per K-tile, in K-tile order
+    auto issue = [&](int tile, int stage, auto j0c, auto cntc) {
+        constexpr int j0 = decltype(j0c)::value, cnt = decltype(cntc)::value;
+        const bool tail = ktail && tile == nt - 1;
+#pragma unroll
+        for (int j = j0; j < j0 + cnt; ++j) {
+            const void* sp = src[j];
+            if (tail && !((tail_ok >> j) & 1u)) sp = g_zero_chunk;
+            dma_piece(sp, dst[j] + (unsigned)(stage * STAGE) * 16u);
+            src[j] += step[j];
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IH = std::integral_constant<int, HP>;
+    using IP = std::integral_constant<int, PPW>;
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float v[16];
-            const int row0 = wm0 + 32 * i, col = wn0 + 32 * j + l31;
-            tile_values(g.e, acc[i][j], m0 + row0, n0 + col, half, v);
-            put_tile(g.e, v, z, m0 + row0, n0 + col, half);
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[(row0 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDW + col] = v[r];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: K-tiles 0 and 1 whole; K-tile 0 landed and visible before anybody's LOAD(0)
+    issue(0, 0, I0{}, IP{});
+    if (nt > 1) {
+        issue(1, 1, I0{}, IP{});
+        wait_vm<PPW>();
+    } else {
+        wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wgrp == 1) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
+
+    bf16x8 fa[2][TM], fb[2][TN];
+    auto phase = [&](int t, auto stc, auto hc) {
+        constexpr int st = decltype(stc)::value, h = decltype(hc)::value;
+        const char* sbase = smem_x3 + (size_t)st * STAGE * 16;
+        // ---- LOAD(p) ----
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kg = 2 * (2 * h + s2) + half;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[s2][i] = *reinterpret_cast<const bf16x8*>(sbase + chunk_of<AK, BM, CPR>(wm0 + 32 * i + l31, kg) * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[s2][j] = *reinterpret_cast<const bf16x8*>(sbase + (A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
         }
-    __syncthreads();
-    constexpr int NTHR = 64 * NW;
-    const int npo = g.np_out;
-    if (g.out_rc) {
-        for (int t2 = tid; t2 < BM * (BN / 8); t2 += NTHR) {
-            const int row = t2 / (BN / 8), cg = t2 % (BN / 8);
-            const int grow = m0 + row, gcol = n0 + 8 * cg;
-            if (grow < M && gcol < N) {
-                const float4 x0 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg);
-                const float4 x1 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg + 4);
-                const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                uint4 w[3];
-                split_chunk(v, w);
-#pragma unroll
-                for (int q = 0; q < 3; ++q)   // compile-time plane index: w[] stays in registers
-                    if (q < npo) *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
+        __builtin_amdgcn_sched_barrier(0);
+        if (h == 0) {
+            if (t >= 1 && t + 1 < nt) issue(t + 1, (st + 1) % NS, IH{}, IH{});
+        } else {
+            if (t + 2 < nt) issue(t + 2, (st + 2) % NS, I0{}, IH{});
+            if (!LATE_WAIT || wgrp == 1) {
+                if (t + 1 < nt) {
+                    if (t + 2 < nt) wait_vm<HP>();
+                    else wait_vm<0>();
+                }
             }
         }
-    }
-    if (g.out_r8 && m0 < g.r8_rows) {
-        for (int t2 = tid; t2 < (BM / 8) * BN; t2 += NTHR) {
-            const int rg = t2 / BN, col = t2 % BN;
-            const int grow = m0 + 8 * rg, gcol = n0 + col;
-            if (grow < g.r8_rows && gcol < N) {
-                float v[8];
+        __builtin_amdgcn_s_barrier();                  // B1
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA(p) ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = st[(8 * rg + j) * LDW + col];
-                uint4 w[3];
-                split_chunk(v, w);
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if (q < npo) *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][i], fb[s2][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LATE_WAIT && h == 1 && wgrp == 0) {        // group 0's B2 is the barrier group 1 waits before: one MFMA cluster more to land
+            if (t + 1 < nt) {
+                if (t + 2 < nt) wait_vm<HP>();
+                else wait_vm<0>();
             }
         }
+        __builtin_amdgcn_s_barrier();                  // B2
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    int t = 0;
+    for (; t + 3 <= nt; t += 3) {
+        phase(t, C0{}, C0{});
+        phase(t, C0{}, C1{});
+        phase(t + 1, C1{}, C0{});
+        phase(t + 1, C1{}, C1{});
+        phase(t + 2, C2{}, C0{});
+        phase(t + 2, C2{}, C1{});
     }
+    if (t < nt) {
+        phase(t, C0{}, C0{});
+        phase(t, C0{}, C1{});
+        if (t + 1 < nt) {
+            phase(t + 1, C1{}, C0{});
+            phase(t + 1, C1{}, C1{});
+        }
+    }
+    if (wgrp == 0) __builtin_amdgcn_s_barrier();      // group 0 catches up: every wave has passed the same number of barriers
+    x3_epilogue<BM, BN, NW, TM, TN>(g, acc, smem_x3, grp, 0, m0, n0, wm0, wn0, tid, l31, half);
+}
+
+template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT>
+static int launch_p8(const X3Args& g, hipStream_t s) {
+    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
+    constexpr size_t ring = (size_t)3 * (BM + BN) * 64 * 2, stage = (size_t)BM * (BN + 4) * 4;
+    constexpr size_t lds = ring > stage ? ring : stage;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = gemm_p8_kernel<AK, BKC, WR, WC, TM, TN, LATE_WAIT>;
+    static LdsOptIn lds_opt;
+    if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
+    const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * (g.A2 ? 2 : 1);
+    DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
+    return (int)hipGetLastError();
 }
 
 template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
@@ -321,6 +544,11 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 10: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x128, 4 waves of 64x64
         case 11: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x256, 8 waves of 64x64
         case 12: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 1, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 64x128, 4 waves of 32x64
+        // phase-staggered kernels (gemm_p8_kernel; one plane, BK = 64, K % 32 == 0, no split-K)
+        case 20: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 4, 2, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64
+        case 21: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // ... group 0 waits after its MFMAs
+        case 22: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 2, 4, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x256, 8 waves of 64x64
+        case 23: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 32x64
 #ifdef DPD_ABLATIONS
 #define DPD_X3_ABL(code) case 100 + code: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 1, 4, 32, code>(g, s); return DPD_E_UNSUPPORTED;
         DPD_X3_ABL(1) DPD_X3_ABL(2) DPD_X3_ABL(3) DPD_X3_ABL(4) DPD_X3_ABL(5) DPD_X3_ABL(7) DPD_X3_ABL(8) DPD_X3_ABL(9) DPD_X3_ABL(12) DPD_X3_ABL(13) DPD_X3_ABL(15)
