@@ -106,7 +106,11 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     // (measured, tools/x3_bench.py: 160 blocks of 128x128 beat 320 of 64x128 on the 2528x1024 dW1; 64x64 only when even
     //  64x128 leaves most CUs idle)
     int tile = blocks(128, 128) >= 150 ? 2 : (blocks(64, 128) >= 100 ? 3 : 5);
-    if (np == 1 && g_x3_tile[op] && !(K % 64)) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..24)
+    // one plane (bf16) and enough rows for one 256x128 workgroup per CU (B = 64: 8192 x 1024 -> 256 tiles): the phase-staggered
+    // BK = 64 kernel (gemm_p8_kernel, tile 21).  Measured on the forward shapes, profiles/r03_x3_bench_p8.txt: layer 1 53.2 -> 48.8 us,
+    // layers 2/3 28.1 -> 27.0 us; the backward shapes (M = 4096: 128 such tiles) stay on the 128x128 ring kernel
+    if (np == 1 && !transA && blocks(256, 128) >= 224) tile = 21;
+    if (np == 1 && g_x3_tile[op] && (g_x3_tile[op] >= 20 || !(K % 64))) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..24)
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
                    out);
 }

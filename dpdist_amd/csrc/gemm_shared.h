@@ -80,6 +80,35 @@ __device__ __forceinline__ void tile_values(const GemmArgs& g, const f32x16& acc
     }
 }
 
+// 4x4 transpose inside every quad of lanes (two DPP butterfly stages): in: a[i] on lane j = E[i][j]; out: a[c] on lane j = E[j][c].
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    // stage 1: register bit 0 <-> lane bit 0 (partner = lane ^ 1, quad_perm [1,0,3,2])
+    {
+        const float x0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[0]), 0xB1, 0xf, 0xf, true));
+        const float x1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[1]), 0xB1, 0xf, 0xf, true));
+        const float x2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[2]), 0xB1, 0xf, 0xf, true));
+        const float x3 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[3]), 0xB1, 0xf, 0xf, true));
+        const float n0 = b0 ? x1 : a[0], n1 = b0 ? a[1] : x0, n2 = b0 ? x3 : a[2], n3 = b0 ? a[3] : x2;
+        a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3;
+    }
+    // stage 2: register bit 1 <-> lane bit 1 (partner = lane ^ 2, quad_perm [2,3,0,1])
+    {
+        const float x0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[0]), 0x4E, 0xf, 0xf, true));
+        const float x1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[1]), 0x4E, 0xf, 0xf, true));
+        const float x2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[2]), 0x4E, 0xf, 0xf, true));
+        const float x3 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(a[3]), 0x4E, 0xf, 0xf, true));
+        const float n0 = b1 ? x2 : a[0], n1 = b1 ? x3 : a[1], n2 = b1 ? a[2] : x0, n3 = b1 ? a[3] : x1;
+        a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3;
+    }
+}
+
+// Store of one 32x32 MFMA tile.  A row-per-instruction dword store (32 lanes x 4 B of one row, 16 instructions per tile) is
+// store-ISSUE bound on gfx950: ~25 cycles per wave-instruction per CU whatever its width, i.e. ~10 B/clk/CU -- measured with
+// s_memtime stamps (tools/p8_stamps.py) at 12.6k cycles for a 256x128 fp32 tile, 5.5 us of a 12.8 us launch.  So the tile is
+// transposed inside each quad of lanes (lane 4q+j then holds the four consecutive columns 4q..4q+3 of row 8g + 4 half + j) and
+// leaves as four 16-byte stores per lane: the same 128-byte row segments, a quarter of the instructions.  Needs a 16-byte
+// aligned C, ldc % 4 == 0, N % 4 == 0 and a tile that starts on a multiple of four columns; anything else keeps the dword form.
 __device__ __forceinline__ void put_tile(const GemmArgs& g, const float (&v)[16], int z, int row0, int col_in, int half) {
     const bool col_ok = col_in < g.N;
     const int col = col_ok ? col_in : g.N - 1;
@@ -88,9 +117,27 @@ __device__ __forceinline__ void put_tile(const GemmArgs& g, const float (&v)[16]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M && col_ok) {
-            if (Cz) Cz[(size_t)row * g.ldc + col] = v[r];
-            cs += v[r];
+        if (row < g.M && col_ok) cs += v[r];
+    }
+    if (Cz) {
+        const int l31 = threadIdx.x & 31;
+        const int col0 = __builtin_amdgcn_readfirstlane(col_in - l31);   // first column of the tile (wave-uniform)
+        const bool wide = !((g.ldc | g.N | col0) & 3) && !(((uintptr_t)Cz) & 15);
+        if (wide) {
+            const int cq = col0 + (l31 & ~3), j = l31 & 3;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                float a[4] = {v[4 * gi], v[4 * gi + 1], v[4 * gi + 2], v[4 * gi + 3]};
+                quad_transpose4(a, l31);
+                const int row = row0 + 8 * gi + 4 * half + j;
+                if (row < g.M && cq < g.N) *reinterpret_cast<float4*>(Cz + (size_t)row * g.ldc + cq) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < g.M && col_ok) Cz[(size_t)row * g.ldc + col] = v[r];
+            }
         }
     }
     if (g.colsum || g.colsum_part) {   // bias gradient fused into the dH GEMM: 32-row partial per wave

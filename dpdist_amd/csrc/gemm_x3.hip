@@ -326,8 +326,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
 // K % 64 == 32 (the decoder's 2528): the lanes whose chunk lies beyond K in the last K-tile fetch a zero chunk instead.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) const unsigned g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+#ifdef DPD_ABLATIONS
+// ABL & 32: wave 0 of every workgroup leaves s_memtime stamps at the kernel's milestones (tools/p8_stamps.py)
+__device__ unsigned long long g_p8_stamps[1024 * 8];
+#define P8_STAMP(i) do { if ((ABL & 32) && tid == 0) g_p8_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#endif
 
-template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT>
+// ABL (timing-only, -DDPD_ABLATIONS): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no stagger, 16 = no setprio
+template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
     constexpr int BK = 64, NS = 3, CPR = 8;
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem_x3[];
 
     const int tid = threadIdx.x;
+    P8_STAMP(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wgrp = __builtin_amdgcn_readfirstlane(wave / (NW / 2));          // 0: waves 0..NW/2-1, 1: the rest
@@ -417,6 +426,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // prologue: K-tiles 0 and 1 whole; K-tile 0 landed and visible before anybody's LOAD(0)
+    P8_STAMP(1);
     issue(0, 0, I0{}, IP{});
     if (nt > 1) {
         issue(1, 1, I0{}, IP{});
@@ -425,7 +435,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
         wait_vm<0>();
     }
     __builtin_amdgcn_s_barrier();
-    if (wgrp == 1) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
+    P8_STAMP(2);
+    if (wgrp == 1 && !(ABL & 8)) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
 
     bf16x8 fa[2][TM], fb[2][TN];
     auto phase = [&](int t, auto stc, auto hc) {
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
         const char* sbase = smem_x3 + (size_t)st * STAGE * 16;
         // ---- LOAD(p) ----
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
+        for (int s2 = 0; s2 < ((ABL & 4) ? (t == 0 && h == 0 ? 2 : 0) : 2); ++s2) {
             const int kg = 2 * (2 * h + s2) + half;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -443,7 +454,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
                 fb[s2][j] = *reinterpret_cast<const bf16x8*>(sbase + (A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (h == 0) {
+        if (ABL & 1) {
+        } else if (h == 0) {
             if (t >= 1 && t + 1 < nt) issue(t + 1, (st + 1) % NS, IH{}, IH{});
         } else {
             if (t + 2 < nt) issue(t + 2, (st + 2) % NS, I0{}, IH{});
@@ -454,10 +466,10 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
                 }
             }
         }
-        __builtin_amdgcn_s_barrier();                  // B1
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                  // B1
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA(p) ----
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 16)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -465,15 +477,15 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][i], fb[s2][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 16)) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (LATE_WAIT && h == 1 && wgrp == 0) {        // group 0's B2 is the barrier group 1 waits before: one MFMA cluster more to land
+        if (LATE_WAIT && h == 1 && wgrp == 0 && !(ABL & 1)) {        // group 0's B2 is the barrier group 1 waits before: one MFMA cluster more to land
             if (t + 1 < nt) {
                 if (t + 2 < nt) wait_vm<HP>();
                 else wait_vm<0>();
             }
         }
-        __builtin_amdgcn_s_barrier();                  // B2
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                  // B2
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
@@ -495,17 +507,19 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
             phase(t + 1, C1{}, C1{});
         }
     }
-    if (wgrp == 0) __builtin_amdgcn_s_barrier();      // group 0 catches up: every wave has passed the same number of barriers
+    if (wgrp == 0 && !(ABL & 8)) __builtin_amdgcn_s_barrier();      // group 0 catches up: every wave has passed the same number of barriers
+    P8_STAMP(3);
     x3_epilogue<BM, BN, NW, TM, TN>(g, acc, smem_x3, grp, 0, m0, n0, wm0, wn0, tid, l31, half);
+    P8_STAMP(4);
 }
 
-template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT>
+template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
 static int launch_p8(const X3Args& g, hipStream_t s) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
     constexpr size_t ring = (size_t)3 * (BM + BN) * 64 * 2, stage = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = ring > stage ? ring : stage;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = gemm_p8_kernel<AK, BKC, WR, WC, TM, TN, LATE_WAIT>;
+    auto kern = gemm_p8_kernel<AK, BKC, WR, WC, TM, TN, LATE_WAIT, ABL>;
     static LdsOptIn lds_opt;
     if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
     const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * (g.A2 ? 2 : 1);
@@ -550,6 +564,9 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 22: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 2, 4, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x256, 8 waves of 64x64
         case 23: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 32x64
 #ifdef DPD_ABLATIONS
+#define DPD_P8_ABL(code) case 200 + code: if (NP == 1) return launch_p8<AK, BKC, 4, 2, 2, 2, true, code>(g, s); return DPD_E_UNSUPPORTED;
+        DPD_P8_ABL(32) DPD_P8_ABL(1) DPD_P8_ABL(2) DPD_P8_ABL(3) DPD_P8_ABL(4) DPD_P8_ABL(5) DPD_P8_ABL(7) DPD_P8_ABL(8) DPD_P8_ABL(16) DPD_P8_ABL(24)
+#undef DPD_P8_ABL
 #define DPD_X3_ABL(code) case 100 + code: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 1, 4, 32, code>(g, s); return DPD_E_UNSUPPORTED;
         DPD_X3_ABL(1) DPD_X3_ABL(2) DPD_X3_ABL(3) DPD_X3_ABL(4) DPD_X3_ABL(5) DPD_X3_ABL(7) DPD_X3_ABL(8) DPD_X3_ABL(9) DPD_X3_ABL(12) DPD_X3_ABL(13) DPD_X3_ABL(15)
 #undef DPD_X3_ABL
@@ -690,6 +707,12 @@ int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, i
 }
 
 }  // namespace dpd
+
+#ifdef DPD_ABLATIONS
+extern "C" int dpd_debug_p8_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dpd::g_p8_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // ---- C ABI (building blocks; the decoder entry points use them when dtype != 0) -----------------------------
 extern "C" int dpd_split_planes(const float* src, int R, int C, int ld, int np, void* rc, int ld_rc, long rc_plane, void* r8,

@@ -9,6 +9,8 @@
 // (d_axis0, d_axis1, d_axis2) like extract_volume_patches) | q - centre (3) | zero pad ].  Everything is float4
 // aligned (20 channels = 5 float4; KP*4 bytes is a multiple of 16).  HBM-bound: algorithmic bytes per query row
 // = KP*4 written (+ 12 read; fv[c] = 40 KB per cloud is L2 resident and shared by the cloud's 64 rows).
+#include <cstdlib>
+
 #include "gemm_shared.h"
 
 namespace dpd {
@@ -166,6 +168,129 @@ __global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __r
                     *reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + 4 * j + t) * 8) =
                         make_uint4(pl[0][t][p] | (pl[1][t][p] << 16), pl[2][t][p] | (pl[3][t][p] << 16),
                                    pl[4][t][p] | (pl[5][t][p] << 16), pl[6][t][p] | (pl[7][t][p] << 16));
+            }
+        }
+    }
+}
+
+// Round 3: the same outputs.  Measured on the kernel above (tools/gather_bench.py, B = 64: 31 us for 62 MB, no faster with one plane
+// than with three): five divisions by the RUN-TIME window side per gathered float4 (no integer divider on gfx950: ~35 VALU
+// instructions each), and R8 planes written as 16-byte pieces 64 bytes apart.  Here a workgroup owns the 8 rows of one row group:
+//   * the window geometry of a float4 unit (offset from the row's own voxel, the three neighbour displacements) is an LDS table
+//     built once per workgroup instead of once per gather;
+//   * pass A: wave w owns row w, its lanes walk the row's 8-column groups (no index division): two float4 gathers, convert, one
+//     uint4 per plane to the RC plane (lanes contiguous: 1 KiB per wave-instruction) and into an LDS image [plane][8 rows][KP];
+//   * pass B (rows that carry gradient): work item = one column: its 8 rows from the LDS image, one uint4 per plane to the R8 plane
+//     (lanes contiguous).
+// 31.2 -> 24 us (one plane, B = 64), 30.8 -> 24.5 us (three planes, B = 32).  What is left is the L2: the 64 rows of a cloud re-read its
+// 40 KB of Fisher vectors as 83 MB of scattered 16-byte gathers per launch.  Measured and dropped: the cloud's Fisher vectors staged
+// in LDS with several row groups per workgroup (30.8 us: one 8-wave workgroup per CU cannot hide its own barriers), five work items
+// per lane with all gathers in flight before the first store (26.6 us), unit pairs of 8 rows per thread (39 us at 180 VGPRs).
+template <int NP>
+__global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __restrict__ q, const float* __restrict__ fv,
+                                                                 float* __restrict__ X, float* __restrict__ mask,
+                                                                 int32_t* __restrict__ vox, int Q, int N, int m, int k, int KP,
+                                                                 GridAxis ax, uint16_t* __restrict__ rc, long rc_plane,
+                                                                 uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
+                                                                 const float* __restrict__ ssq, int nsl) {
+    extern __shared__ __attribute__((aligned(16))) int2 s_tab[];               // [KP/4] per float4 unit: {offset in floats from the row's voxel, d0 | d1<<8 | d2<<16 | kind<<24}
+    uint16_t* s_img = reinterpret_cast<uint16_t*>(s_tab + KP / 4);             // [NP][8][KP] (only when R8 planes are written)
+    __shared__ RowInfo s_row[8];
+    __shared__ __attribute__((aligned(16))) float s_sc[8][kF];
+    const int tid = threadIdx.x;
+    const int G = m * m * m, h = (k - 1) / 2;
+    const int E4 = k * k * k * (kF / 4), U = KP / 4, U2 = KP / 8;            // window units; units / 8-column groups per row
+    for (int j = tid; j < U; j += 512) {
+        int2 e = make_int2(0, (j == E4 ? 1 : 2) << 24);               // y >> 24: 0 = window unit, 1 = the q - centre unit, 2 = zero padding
+        if (j < E4) {
+            const int nb = j / 5, part = j % 5;
+            const int d0 = nb / (k * k), d1 = (nb / k) % k, d2 = nb % k;       // 0 .. k-1 (displacement + h), grid axes (y, x, z)
+            e = make_int2((((d0 - h) * m + (d1 - h)) * m + (d2 - h)) * kF + part * 4, d0 | (d1 << 8) | (d2 << 16));
+        }
+        s_tab[j] = e;
+    }
+    {
+        const int rg = blockIdx.x;
+        if (ssq && tid < 8 * kF) {
+            const int rr = tid / kF, ch = tid % kF;
+            s_sc[rr][ch] = fv_scale(ssq, nsl, (8 * rg + rr) / N, ch);
+        }
+        if (tid < 8) {
+            const int r = 8 * rg + tid;
+            const float qx = q[(size_t)r * 3], qy = q[(size_t)r * 3 + 1], qz = q[(size_t)r * 3 + 2];
+            int ix = cell_of(ax, m, qx), iy = cell_of(ax, m, qy), iz = cell_of(ax, m, qz);
+            const bool valid = (ix >= 0) && (iy >= 0) && (iz >= 0);
+            if (!valid) { ix = 0; iy = 0; iz = 0; }
+            s_row[tid] = RowInfo{ix, iy, iz, r / N, qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz]};
+            mask[r] = valid ? 1.f : 0.f;
+            vox[r] = (iy * m + ix) * m + iz;
+        }
+        __syncthreads();
+        const bool want_r8 = r8 && (8 * rg < r8_rows);
+        // ---- pass A: wave = row ----
+        {
+            const int rr = tid >> 6, lane = tid & 63;
+            const RowInfo ri = s_row[rr];
+            const size_t row = (size_t)(8 * rg + rr);
+            const int own = ((ri.iy * m + ri.ix) * m + ri.iz) * kF;                               // this row's own voxel
+            const float* fvr = fv + (size_t)ri.cloud * G * kF + own;
+            const int by = ri.iy - h, bx = ri.ix - h, bz = ri.iz - h;
+            for (int t = lane; t < U2; t += 64) {
+                float4 v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int2 e = s_tab[2 * t + u];
+                    const int kind = e.y >> 24;
+                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kind == 0) {
+                        const int g0 = by + (e.y & 0xff), g1 = bx + ((e.y >> 8) & 0xff), g2 = bz + ((e.y >> 16) & 0xff);
+                        if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m) {
+                            x = *reinterpret_cast<const float4*>(fvr + e.x);
+                            if (ssq) {
+                                const float4 sc = *reinterpret_cast<const float4*>(&s_sc[rr][((2 * t + u) % 5) * 4]);
+                                x.x *= sc.x; x.y *= sc.y; x.z *= sc.z; x.w *= sc.w;
+                            }
+                        }
+                    } else if (kind == 1) {
+                        x = make_float4(ri.dx, ri.dy, ri.dz, 0.f);
+                    }
+                    v[u] = x;
+                }
+                if (X) {
+                    *reinterpret_cast<float4*>(X + row * KP + 8 * t) = v[0];
+                    *reinterpret_cast<float4*>(X + row * KP + 8 * t + 4) = v[1];
+                }
+                const float e8[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+                uint4 wv[NP];
+                if (NP == 1) {
+                    unsigned b[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) b[c] = bf16_bits(e8[c]);
+                    wv[0] = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+                } else {
+                    uint4 w3[3];
+                    split_chunk(e8, w3);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) wv[p] = w3[p];
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if (rc) *reinterpret_cast<uint4*>(rc + p * rc_plane + row * KP + 8 * t) = wv[p];
+                    if (want_r8) *reinterpret_cast<uint4*>(s_img + ((size_t)(p * 8 + rr) * KP + 8 * t)) = wv[p];
+                }
+            }
+        }
+        if (!want_r8) return;                                         // uniform per workgroup
+        __syncthreads();
+        // ---- pass B ----
+        for (int c = tid; c < KP; c += 512) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                unsigned b[8];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) b[rr] = s_img[(size_t)(p * 8 + rr) * KP + c];
+                *reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + c) * 8) =
+                    make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
             }
         }
     }
@@ -347,8 +472,25 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
     if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
     if (planes) {
         if ((pl->np != 1 && pl->np != 3) || pl->Q != Q || pl->Qb > Q || pl->Qb < 0) return DPD_E_DIM;
-        DPD_LAUNCH(patch_rows_planes_kernel, dim3((Q / 8) * 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
-                   KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+        static const bool old_form = getenv("DPD_GATHER_PLANES_V1") != nullptr;      // A/B reference: the round-1 kernel
+        if (old_form) {
+            DPD_LAUNCH(patch_rows_planes_kernel, dim3((Q / 8) * 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
+                       KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+        } else {
+            const size_t lds = (pl->X_r8 ? (size_t)pl->np * 8 * KP * sizeof(uint16_t) : 0) + (size_t)(KP / 4) * sizeof(int2);
+            if (lds > 150 * 1024) return DPD_E_UNSUPPORTED;
+            if (pl->np == 1) {
+                static LdsOptIn lo1;
+                if (int rc2 = ensure_dyn_lds(lo1, (const void*)patch_rows_planes3_kernel<1>, lds)) return rc2;
+                DPD_LAUNCH(patch_rows_planes3_kernel<1>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
+                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+            } else {
+                static LdsOptIn lo3;
+                if (int rc2 = ensure_dyn_lds(lo3, (const void*)patch_rows_planes3_kernel<3>, lds)) return rc2;
+                DPD_LAUNCH(patch_rows_planes3_kernel<3>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
+                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+            }
+        }
         DPD_CHECK_LAUNCH();
         return 0;
     }

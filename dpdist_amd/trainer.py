@@ -177,12 +177,12 @@ class DPDistTrainer:
             if self.fused and gate is not None:
                 # fused-gather mode has no X: mask (output-layer backward) and fv / xyz / rowinfo (the gathering dW1 GEMM) are read
                 # by the CURRENT step's backward until dW1 is done -- the whole front end must wait, not only the gather
-                torch.cuda.current_stream().wait_event(gate)
+                gate.wait()
                 gate = None
             self._load_batch(pcA, pcB, noise)
             self._encode()
         if gate is not None:
-            torch.cuda.current_stream().wait_event(gate)
+            gate.wait()
         self._gather()
 
     def _load_batch(self, pcA, pcB, noise):
@@ -390,7 +390,7 @@ class DPDistTrainer:
         """Make the front-end buffers (pts, q, fv, X, mask, vox) hold this batch on the current stream."""
         main = torch.cuda.current_stream()
         if self._pref_key is not None:
-            main.wait_event(self._ev_front)            # whatever the side stream was doing with the buffers is ordered first
+            self._ev_front.wait(main)                  # whatever the side stream was doing with the buffers is ordered first
             hit = self._pref_key == self._key(pcA, pcB, noise)
             self._pref_key = None
             if hit:
@@ -411,15 +411,19 @@ class DPDistTrainer:
         self._decode(skip_out=True)
         if prefetch is not None:
             if self._side is None:
+                from .hipevents import LightEvent
                 self._side = torch.cuda.Stream(device=self.P.flat.device)
-                self._ev_front, self._ev_xfree, self._ev_fwd = (torch.cuda.Event() for _ in range(3))
+                # device-local ordering only: events without the system-scope fence (a torch.cuda.Event record in mid-stream costs
+                # the compute stream ~6 us, these 0.3 us: tools/event_cost.py)
+                light = os.environ.get("DPD_LIGHT_EVENTS", "1") == "1"
+                self._ev_front, self._ev_xfree, self._ev_fwd = (LightEvent(system_fence=not light) for _ in range(3))
             main = torch.cuda.current_stream()
             self._ev_fwd.record(main)                  # inputs complete + this step's gather/decoder ordered before the side work
 
             def launch_front():
                 self._ev_xfree.record(main)            # recorded right after dW1, the last reader of X / mask
                 with torch.cuda.stream(self._side):
-                    self._side.wait_event(self._ev_fwd)
+                    self._ev_fwd.wait(self._side)
                     self._front(*prefetch, gate=self._ev_xfree)
                     self._ev_front.record(self._side)
                 self._pref_key = self._key(*prefetch)

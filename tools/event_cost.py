@@ -12,22 +12,26 @@ class FakeReducer:
     def __init__(self, mode):
         self.mode, self.grad_scale = mode, 1.0
         self.side = torch.cuda.Stream()
-        self.evs = [torch.cuda.Event() for _ in range(8)]
+        from dpdist_amd.hipevents import LightEvent
+        light = mode.startswith('light')
+        self.mode = mode = mode.replace('light-', '')
+        self.evs = [LightEvent() if light else torch.cuda.Event() for _ in range(8)]
+        self.light = light
         self.i = 0
-    def reduce_async(self, bucket):
+    def reduce_async(self, bucket, upto=None):
         if self.mode == 'nothing':
             return
         ev = self.evs[self.i % 8]; self.i += 1
         ev.record()                                   # event on the compute stream
         if self.mode == 'record+sidewait':
-            self.side.wait_event(ev)
+            ev.wait(self.side) if self.light else self.side.wait_event(ev)
     def wait(self):
         if self.mode == 'record+sidewait':
             ev = self.evs[self.i % 8]; self.i += 1
             ev.record(self.side)
-            torch.cuda.current_stream().wait_event(ev)
+            ev.wait() if self.light else torch.cuda.current_stream().wait_event(ev)
 
-for mode in ['nothing', 'record', 'record+sidewait']:
+for mode in ['nothing', 'record', 'record+sidewait', 'light-record', 'light-record+sidewait', 'nothing']:
     P = DPDistParams(device=dev); P.reset_parameters_tf(generator=torch.Generator().manual_seed(1))
     tr = DPDistTrainer(P, B, distributed=False)
     tr.reducer = FakeReducer(mode)
@@ -35,4 +39,4 @@ for mode in ['nothing', 'record', 'record+sidewait']:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(200): tr.step(a, b, l)
     torch.cuda.synchronize()
-    print(mode, '%.4f ms/step' % ((time.perf_counter() - t0) / 200 * 1e3))
+    print(tr.reducer.mode, 'light' if getattr(tr.reducer, 'light', False) else '', '%.4f ms/step' % ((time.perf_counter() - t0) / 200 * 1e3))
