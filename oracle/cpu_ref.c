@@ -187,53 +187,102 @@ void cpuref_forward(const float* pcA, const float* pcB, const float* noise, int 
  * variant 1 "faithful": the dataflow of the TF graph -- local_z_3d materialises emb [C, m^3, k^3*20]
  *                       (utils/dpdist_util.py:911-930, 164 MB per cloud set at B = 32), the cell lookup compares every query
  *                       against all m^3 centres and takes the argmax (:459-492), rows are gathered from emb (:434-457).
- * Both run the same dense layers: an OpenMP register-blocked SGEMM written here (no BLAS in the image).
+ * Both run the same dense layers: an OpenMP cache-blocked, packed SGEMM written here (no BLAS in the image).
  * Backward = TF autodiff of loss_samples = mean |pred_AB[...,0] - labels| (utils/dpdist_util.py:967-974) w.r.t. the variables
  * under 'pc_compare' (train_multi_gpu_pc_compare_dist.py:274-277): only the AB half of the rows carries gradient.
  * ===================================================================================================================== */
-typedef float v8f __attribute__((vector_size(32)));   /* one AVX2 register */
+/* Dense layers: a cache-blocked, packed SGEMM in the BLIS loop order (no BLAS in the image).  The widest vector the build
+ * target has: AVX-512 (16 floats, 12 x 32 register tile: 24 accumulators + 2 operands + 1 broadcast of 32 zmm) or AVX2 (8 floats,
+ * 6 x 16 tile: 15 of 16 ymm).  K is cut into KC-deep slices; a slice of B is packed once into NR-wide panels (shared, L2/L3), every
+ * task packs its MC x KC block of A into MR-tall panels (private, L2) and walks the register tiles with both operands streaming
+ * from contiguous memory.  Round 2's kernel streamed the full K per register tile from the unpacked operands (0.5 TFLOP/s on a
+ * 128-core host, under 2 % of its fp32 peak).  Tasks = (row block, column block) pairs, OpenMP dynamic. */
+#ifdef __AVX512F__
+#define VL 16
+#define MR 12
+#else
+#define VL 8
+#define MR 6
+#endif
+typedef float vNf __attribute__((vector_size(4 * VL)));
+#define NR (2 * VL)
+#define KC 256
+#define MC (MR * 8)
+#define NC 256
 #define GEMM_FAST __attribute__((optimize("-ffp-contract=fast")))   /* FMA in the dense layers only (the encoder stays op by op) */
 
-/* micro-kernel: acc[6][2] += a[r][k] * b[k][0:16] over k; 12 accumulators + 2 operands + 1 broadcast = 15 of 16 ymm registers.
- * a_rs / a_ks: row / k strides of A (NN: lda, 1;  TN with A stored [K,M]: 1, lda).  mr <= 6 live rows. */
-GEMM_FAST static inline void micro_6x16(int K, const float* a, long a_rs, long a_ks, const float* b, long ldb, float* c, long ldc, int mr) {
-    v8f acc[6][2];
-    for (int r = 0; r < 6; ++r) { acc[r][0] = (v8f){0}; acc[r][1] = (v8f){0}; }
-    const float* ar[6];
-    for (int r = 0; r < 6; ++r) ar[r] = a + (long)(r < mr ? r : 0) * a_rs;
-    for (int k = 0; k < K; ++k) {
-        v8f b0, b1;
-        memcpy(&b0, b + (long)k * ldb, 32);
-        memcpy(&b1, b + (long)k * ldb + 8, 32);
-#pragma GCC unroll 6
-        for (int r = 0; r < 6; ++r) {
-            const float av = ar[r][(long)k * a_ks];
-            const v8f avv = {av, av, av, av, av, av, av, av};
-            acc[r][0] += avv * b0;
-            acc[r][1] += avv * b1;
+/* acc[MR][2] (+)= Ap[k][0:MR] (x) Bp[k][0:NR] over k < kc; stores the first mr rows */
+GEMM_FAST static inline void micro_tile(int kc, const float* ap, const float* bp, float* c, long ldc, int mr, int accumulate) {
+    vNf acc[MR][2];
+    for (int r = 0; r < MR; ++r) { acc[r][0] = (vNf){0}; acc[r][1] = (vNf){0}; }
+    for (int k = 0; k < kc; ++k) {
+        vNf b0, b1;
+        memcpy(&b0, bp + (long)k * NR, sizeof(vNf));
+        memcpy(&b1, bp + (long)k * NR + VL, sizeof(vNf));
+#pragma GCC unroll 12
+        for (int r = 0; r < MR; ++r) {
+            const float av = ap[(long)k * MR + r];     /* scalar * vector: GCC splats the scalar (one vbroadcastss) */
+            acc[r][0] += av * b0;
+            acc[r][1] += av * b1;
         }
     }
     for (int r = 0; r < mr; ++r) {
-        memcpy(c + (long)r * ldc, &acc[r][0], 32);
-        memcpy(c + (long)r * ldc + 8, &acc[r][1], 32);
+        float* cr = c + (long)r * ldc;
+        if (accumulate) {
+            vNf c0, c1;
+            memcpy(&c0, cr, sizeof(vNf)); memcpy(&c1, cr + VL, sizeof(vNf));
+            acc[r][0] += c0; acc[r][1] += c1;
+        }
+        memcpy(cr, &acc[r][0], sizeof(vNf));
+        memcpy(cr + VL, &acc[r][1], sizeof(vNf));
     }
 }
 
-/* C [M,N] = A [M,K] * B [K,N] (row major, N % 16 == 0).  OpenMP over 6 x 16 output tiles, column tiles innermost so that the
- * threads of a row band share the A rows. */
-static void sgemm_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc) {
-#pragma omp parallel for collapse(2) schedule(dynamic, 8)
-    for (int i0 = 0; i0 < M; i0 += 6)
-        for (int j0 = 0; j0 < N; j0 += 16)
-            micro_6x16(K, A + (size_t)i0 * lda, lda, 1, B + j0, ldb, C + (size_t)i0 * ldc + j0, ldc, (M - i0 < 6) ? M - i0 : 6);
+/* C [M,N] = op(A) B, B [K,N] row major, N % NR == 0.  a_rs / a_ks: row / k strides of A (NN: lda, 1;  TN with A stored [K,M]: 1, lda). */
+static void sgemm_blocked(int M, int N, int K, const float* A, long a_rs, long a_ks, const float* B, int ldb, float* C, int ldc) {
+    const int nblk_m = (M + MC - 1) / MC, nblk_n = (N + NC - 1) / NC;
+    float* Bp = (float*)aligned_alloc(64, sizeof(float) * (size_t)KC * (size_t)((N + NR - 1) / NR * NR));
+    for (int pc = 0; pc < K; pc += KC) {
+        const int kc = (K - pc < KC) ? K - pc : KC;
+#pragma omp parallel
+        {
+#pragma omp for schedule(static)
+            for (int jr = 0; jr < N; jr += NR) {          /* pack B[pc:pc+kc, jr:jr+NR] -> panel [kc][NR] */
+                float* dst = Bp + (size_t)(jr / NR) * KC * NR;
+                for (int k = 0; k < kc; ++k) memcpy(dst + (size_t)k * NR, B + (size_t)(pc + k) * ldb + jr, sizeof(float) * NR);
+            }
+            float* Ap = (float*)aligned_alloc(64, sizeof(float) * (size_t)MC * KC);
+#pragma omp for collapse(2) schedule(dynamic, 1)
+            for (int ib = 0; ib < nblk_m; ++ib)
+                for (int jb = 0; jb < nblk_n; ++jb) {
+                    const int ic = ib * MC, mc = (M - ic < MC) ? M - ic : MC;
+                    const int jc = jb * NC, nc = (N - jc < NC) ? N - jc : NC;
+                    for (int ir = 0; ir < mc; ir += MR) {  /* pack A[ic+ir : +MR, pc : pc+kc] -> panel [kc][MR], zero rows beyond M */
+                        float* dst = Ap + (size_t)(ir / MR) * KC * MR;
+                        const int mr = (mc - ir < MR) ? mc - ir : MR;
+                        for (int k = 0; k < kc; ++k) {
+                            const float* src = A + (long)(ic + ir) * a_rs + (long)(pc + k) * a_ks;
+                            for (int r = 0; r < MR; ++r) dst[(size_t)k * MR + r] = (r < mr) ? src[(long)r * a_rs] : 0.f;
+                        }
+                    }
+                    for (int jr = 0; jr < nc; jr += NR)
+                        for (int ir = 0; ir < mc; ir += MR)
+                            micro_tile(kc, Ap + (size_t)(ir / MR) * KC * MR, Bp + (size_t)((jc + jr) / NR) * KC * NR,
+                                       C + (size_t)(ic + ir) * ldc + jc + jr, ldc, (mc - ir < MR) ? mc - ir : MR, pc > 0);
+                }
+            free(Ap);
+        }
+    }
+    free(Bp);
 }
 
-/* C [M,N] = A^T B with A stored [K,M], B [K,N] (the weight gradients: act^T g).  N % 16 == 0. */
+static void sgemm_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc) {
+    sgemm_blocked(M, N, K, A, lda, 1, B, ldb, C, ldc);
+}
+
+/* C [M,N] = A^T B with A stored [K,M], B [K,N] (the weight gradients: act^T g). */
 static void sgemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc) {
-#pragma omp parallel for collapse(2) schedule(dynamic, 8)
-    for (int i0 = 0; i0 < M; i0 += 6)
-        for (int j0 = 0; j0 < N; j0 += 16)
-            micro_6x16(K, A + i0, 1, lda, B + j0, ldb, C + (size_t)i0 * ldc + j0, ldc, (M - i0 < 6) ? M - i0 : 6);
+    sgemm_blocked(M, N, K, A, 1, lda, B, ldb, C, ldc);
 }
 
 static void transpose(const float* A, int R, int Cc, float* AT) {
