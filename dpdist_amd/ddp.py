@@ -107,3 +107,175 @@ class BucketReducer:
     @property
     def grad_scale(self):
         return 1.0 / self.world
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RCCL driven directly (ctypes on the librccl torch already loaded): the collectives run on streams WE choose.
+# ----------------------------------------------------------------------------------------------------------------------
+class _Rccl:
+    """Minimal binding: ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes
+            import os
+            cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so", "librccl.so.1"]
+            err = None
+            for c in cand:
+                try:
+                    cls._lib = ctypes.CDLL(c)
+                    break
+                except OSError as e:
+                    err = e
+            if cls._lib is None:
+                raise RuntimeError("librccl.so not found: %r" % (err,))
+
+            class UniqueId(ctypes.Structure):
+                _fields_ = [("internal", ctypes.c_char * 128)]
+            cls.UniqueId = UniqueId
+            L = cls._lib
+            L.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+            L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+            L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_void_p]
+            L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            L.ncclGetErrorString.restype = ctypes.c_char_p
+            L.ncclGetErrorString.argtypes = [ctypes.c_int]
+        return cls._lib
+
+    @classmethod
+    def check(cls, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, cls.lib().ncclGetErrorString(rc).decode()))
+
+    @classmethod
+    def new_comm(cls, group, device):
+        """One communicator over the ranks of `group`; the unique id travels through the existing process group."""
+        import ctypes
+        L = cls.lib()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = cls.UniqueId()
+        if rank == 0:
+            cls.check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        comm = ctypes.c_void_p()
+        cls.check(L.ncclCommInitRank(ctypes.byref(comm), world, uid, rank), "ncclCommInitRank")
+        return comm
+
+
+class DirectRcclReducer:
+    """BucketReducer's contract (reduce_async / wait / grad_scale) with RCCL called directly.
+
+    `torch.distributed` puts every collective on ProcessGroupNCCL's own stream and orders it with events recorded in the middle
+    of the compute stream -- on this runtime a barrier packet with a system-scope release, ~20 us of idle compute stream each, and
+    a cross-queue hop (~14 us) each way for the LAST bucket, which nothing hides (+52..57 us per step before a
+    single byte moves).  Here:
+      * the early buckets (everything but the last call of a step) run on a side stream behind a `hipEventDisableSystemFence` event:
+        recording it costs the compute stream ~0.3 us, the hop is paid by the side stream;
+      * the LAST bucket's all-reduce is enqueued on the COMPUTE stream itself (its own communicator): no event, no hop -- it starts
+        the moment dW1 ends and Adam follows it in stream order;
+      * `wait()` joins the side stream with one more light event (its collective finished long before: dW1 ran meanwhile).
+    wire = "f32" | "bf16" as in BucketReducer (staging copies on the stream of the collective).  One rank (force) works: RCCL's
+    single-rank all-reduce is a copy."""
+
+    def __init__(self, flat_grad, bounds, group=None, wire=None):
+        import os
+        from .hipevents import LightEvent
+        if not (dist.is_initialized() and flat_grad.is_cuda):
+            raise RuntimeError("DirectRcclReducer needs an initialised process group and a GPU gradient buffer")
+        self.flat, self.bounds, self.group = flat_grad, list(bounds), group
+        self.world = dist.get_world_size(group)
+        self.active = True
+        self.wire = wire or os.environ.get("DPD_DP_WIRE", "f32")
+        if self.wire not in ("f32", "bf16"):
+            raise ValueError("wire must be f32|bf16")
+        self.mode = "allreduce"
+        dev = flat_grad.device
+        self._side = torch.cuda.Stream(device=dev)
+        self._comm_side = _Rccl.new_comm(group, dev)
+        self._comm_main = _Rccl.new_comm(group, dev)
+        self._ev_fork = [LightEvent() for _ in range(4)]
+        self._ev_join = LightEvent()
+        self._nfork = 0
+        self._covered = 0           # elements reduced so far in this step
+        self._side_used = False
+        self._stage = {}
+        self._copyback = []         # bf16 wire: (stream is_main, g, full) pending conversions back to fp32
+
+    def _allreduce(self, t, comm, stream):
+        dt = 9 if t.dtype == torch.bfloat16 else 7          # ncclBfloat16 / ncclFloat
+        _Rccl.check(_Rccl.lib().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, 0, comm, stream.cuda_stream), "ncclAllReduce")
+
+    def _staging(self, key, n):
+        if key not in self._stage:
+            self._stage[key] = torch.zeros(n, device=self.flat.device, dtype=torch.bfloat16)
+        return self._stage[key]
+
+    def reduce_async(self, bucket, upto=None):
+        lo, hi = self.bounds[bucket], self.bounds[(bucket if upto is None else upto) + 1]
+        g = self.flat[lo:hi]
+        self._covered += hi - lo
+        last = self._covered >= self.bounds[-1] - self.bounds[0]
+        main = torch.cuda.current_stream()
+        if last:
+            if self.wire == "bf16":
+                full = self._staging((lo, hi), hi - lo)
+                full.copy_(g)
+                self._allreduce(full, self._comm_main, main)
+                g.copy_(full)
+            else:
+                self._allreduce(g, self._comm_main, main)
+            return
+        ev = self._ev_fork[self._nfork % len(self._ev_fork)]
+        self._nfork += 1
+        ev.record(main)
+        ev.wait(self._side)
+        self._side_used = True
+        if self.wire == "bf16":
+            full = self._staging((lo, hi), hi - lo)
+            with torch.cuda.stream(self._side):
+                full.copy_(g)
+                self._allreduce(full, self._comm_side, self._side)
+                g.copy_(full)
+        else:
+            self._allreduce(g, self._comm_side, self._side)
+
+    def wait(self):
+        if self._side_used:
+            self._ev_join.record(self._side)
+            self._ev_join.wait(torch.cuda.current_stream())
+        self._side_used = False
+        self._covered = 0
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def close(self):
+        for c in ("_comm_side", "_comm_main"):
+            comm = getattr(self, c, None)
+            if comm:
+                torch.cuda.synchronize()
+                _Rccl.lib().ncclCommDestroy(comm)
+                setattr(self, c, None)
+
+
+def make_reducer(flat_grad, bounds, group=None, force=False):
+    """The gradient reducer of a data-parallel trainer: RCCL driven directly on GPU buffers under an NCCL/RCCL process group
+    (DPD_DP_BACKEND=torch, a DPD_DP_MODE other than allreduce, or a failure to bind librccl keep `BucketReducer`), torch.distributed
+    otherwise (gloo / CPU tensors: the tests)."""
+    import os
+    import sys
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    want = os.environ.get("DPD_DP_BACKEND", "rccl")
+    if (dist.is_initialized() and (world > 1 or force) and flat_grad.is_cuda and want == "rccl" and dist.get_backend(group) == "nccl"
+            and os.environ.get("DPD_DP_MODE", "allreduce") == "allreduce"):
+        try:
+            return DirectRcclReducer(flat_grad, bounds, group)
+        except Exception as e:      # plumbing only: the torch.distributed path computes the same sums
+            sys.stderr.write("dpdist_amd.ddp: direct RCCL unavailable (%r), using torch.distributed collectives\n" % (e,))
+    return BucketReducer(flat_grad, bounds, group, force=force)

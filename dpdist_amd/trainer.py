@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .ddp import BucketReducer
+from .ddp import make_reducer
 from .model import DPDistParams
 
 
@@ -87,8 +87,8 @@ class DPDistTrainer:
             L.check(lib.dpd_planes_carve(L.ptr(self._plane_mem), nbytes, Q, BN, KP, H, self.dt, 0, self._planes), "dpd_planes_carve")
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
-        self.reducer = BucketReducer(self.grad, params.bucket_bounds, group,
-                                     force=os.environ.get("DPD_FORCE_DIST") == "1") if use_dist else None
+        self.reducer = make_reducer(self.grad, params.bucket_bounds, group,
+                                    force=os.environ.get("DPD_FORCE_DIST") == "1") if use_dist else None
         # exact-fp32 compute type: transposed copies of W2 / W3 so that the backward data GEMMs (g W^T) read the weights
         # row-coalesced (register-streamed kernel, csrc/gemm_rs.h); refreshed after every optimizer step
         self.W2T = self.W3T = None

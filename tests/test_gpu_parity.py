@@ -934,13 +934,16 @@ def test_two_ranks_rccl_equals_full_batch(dev, dt, tmp_path):
     assert float(err) <= 2e-5 * max(1.0, float(scale)), (err, scale)
 
 
+@pytest.mark.parametrize("backend", ["rccl", "torch"])
 @pytest.mark.parametrize("buckets", ["2", "3"])
 @pytest.mark.parametrize("dt", ["f32", "f32x3"])
-def test_data_parallel_schedule_matches_plain_backward(dev, dt, buckets, monkeypatch):
+def test_data_parallel_schedule_matches_plain_backward(dev, dt, buckets, backend, monkeypatch):
     """The interleaved data-parallel backward (phased data chain, dW3 -> dW2 -> dW1; layers 2-4 as one collective after dW2 or
-    one collective per bucket, all on the RCCL stream; exercised here with a single-rank process group) produces the same
-    gradients as the plain schedule."""
+    one collective per bucket; exercised here with a single-rank process group) produces the same gradients as the plain
+    schedule.  backend "rccl": ddp.DirectRcclReducer (librccl through ctypes: early buckets on a side stream behind events without
+    the system fence, the last bucket on the compute stream itself); "torch": ddp.BucketReducer over torch.distributed."""
     monkeypatch.setenv("DPD_DP_BUCKETS", buckets)
+    monkeypatch.setenv("DPD_DP_BACKEND", backend)
     import torch.distributed as dist
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer
@@ -960,7 +963,10 @@ def test_data_parallel_schedule_matches_plain_backward(dev, dt, buckets, monkeyp
             P.load_tf_state_dict(W0)
             tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=(mode == "dp"))
             assert (tr.reducer is not None and tr.reducer.active) == (mode == "dp")
+            if mode == "dp":
+                assert type(tr.reducer).__name__ == ("DirectRcclReducer" if backend == "rccl" else "BucketReducer")
             tr.step(pcA, pcB, lab)
+            tr.step(pcA, pcB, lab)                   # a second step: the per-step state of the reducer resets in wait()
             torch.cuda.synchronize()
             grads[mode] = (tr.grad.clone(), tr.loss.clone())
     finally:
@@ -1041,6 +1047,12 @@ def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
     assert abs(loss1.item() - lp.item()) <= 1e-7
     assert (gA1 - gA2).abs().max().item() <= 1e-6 * max(1.0, gA2.abs().max().item())
     assert (gB1 - gB2).abs().max().item() <= 1e-6 * max(1.0, gB2.abs().max().item())
+    # ... and the fused node against the golden float64 gradients of the reference graph (same bar as
+    # test_losses_and_input_gradients_golden; the factor 2 above scales the loss)
+    for g, n in ((gA1, "d_pcA"), (gB1, "d_pcB")):
+        ref = 2.0 * d[n + "_f64"]
+        bar = max(4.0 * np.abs(2.0 * d[n + "_f32"] - ref).max(), 2e-4 * max(1.0, np.abs(ref).max()))
+        assert np.abs(g.cpu().numpy() - ref).max() <= bar, (n, np.abs(g.cpu().numpy() - ref).max(), bar)
 
 
 
