@@ -115,3 +115,53 @@ def test_native_crc_matches_pure_python():
         b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         assert T.crc32c(b) == T.crc32c(b, pure_python=True)
         assert T.crc32c(b[100:], T.crc32c(b[:100])) == T.crc32c(b, pure_python=True)
+
+
+def test_hand_assembled_sharded_bundle(tmp_path):
+    """A bundle as tensor_bundle.proto / tensor_bundle.cc describe it when `tf.train.Saver(sharded=True)` (or a merge of per-device
+    bundles) wrote it, assembled here field by field -- NOT by write_checkpoint, which only ever emits one shard:
+      * key "" first: BundleHeaderProto {num_shards = 2, endianness = LITTLE (0), version {producer = 1}};
+      * the remaining keys in BYTEWISE order ("A/..." < "a/..." < "a/b" < "a0": uppercase and '/' sort before digits and lowercase),
+        each a BundleEntryProto {dtype, shape, shard_id, offset, size, crc32c (masked, fixed32)}; shard_id 0 and offset 0 are
+        omitted on the wire (proto3 defaults);
+      * tensor bytes in <prefix>.data-0000S-of-00002, S = shard_id, at `offset`.
+    Still not a TensorFlow-written file (row f3 stays "parity unpinned"); it pins the reader's handling of the fields the
+    one-shard writer never produces."""
+    import struct
+    prefix = str(tmp_path / "model.ckpt")
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    b = np.array([7, 8, 9], dtype=np.int32)
+    c = np.array(153600, dtype=np.int64)
+    shard0 = a.tobytes()                                   # "a/b" at offset 0 of shard 0
+    shard1 = b"\xAA" * 8 + b.tobytes() + c.tobytes()       # 8 bytes of something else first: offsets 8 and 20 in shard 1
+    open(T._data_path(prefix, 0, 2), "wb").write(shard0)
+    open(T._data_path(prefix, 1, 2), "wb").write(shard1)
+
+    def entry(dtype, shape, shard, offset, raw):
+        dims = b"".join(T._pb(2, 2, T._put_varint(len(d)) + d) for d in (T._pb(1, 0, T._put_varint(x)) for x in shape))
+        out = T._pb(1, 0, T._put_varint(dtype)) + T._pb(2, 2, T._put_varint(len(dims)) + dims)
+        if shard:
+            out += T._pb(3, 0, T._put_varint(shard))
+        if offset:
+            out += T._pb(4, 0, T._put_varint(offset))
+        return out + T._pb(5, 0, T._put_varint(len(raw))) + T._pb(6, 5, struct.pack("<I", T.mask_crc(T.crc32c(raw))))
+
+    version = T._pb(1, 0, T._put_varint(1))
+    header = T._pb(1, 0, T._put_varint(2)) + T._pb(3, 2, T._put_varint(len(version)) + version)     # endianness 0 omitted
+    items = [(b"", header),
+             (b"A/global_step", entry(9, (), 1, 20, c.tobytes())),        # DT_INT64 = 9, scalar
+             (b"a/b", entry(1, (2, 3), 0, 0, a.tobytes())),               # DT_FLOAT = 1
+             (b"a0", entry(3, (3,), 1, 8, b.tobytes()))]                  # DT_INT32 = 3
+    assert [k for k, _ in items] == sorted(k for k, _ in items)          # the table requires (and TF writes) bytewise key order
+    T.write_table(prefix + ".index", items)
+    lv = T.list_variables(prefix)
+    assert lv == {"A/global_step": (np.int64, ()), "a/b": (np.float32, (2, 3)), "a0": (np.int32, (3,))}
+    got = T.read_checkpoint(prefix, verify_data=True)
+    assert np.array_equal(got["a/b"], a) and np.array_equal(got["a0"], b) and int(got["A/global_step"]) == 153600
+    # a big-endian header is refused, a slice-spec entry (partitioned variable) is refused
+    T.write_table(prefix + ".index", [(b"", header + T._pb(2, 0, T._put_varint(1)))] + items[1:])
+    with pytest.raises(ValueError, match="big-endian"):
+        T.read_checkpoint(prefix)
+    T.write_table(prefix + ".index", [items[0], (b"a/b", items[2][1] + T._pb(7, 2, T._put_varint(0)))])
+    with pytest.raises(NotImplementedError):
+        T.read_checkpoint(prefix)
