@@ -110,7 +110,11 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     // BK = 64 kernel (gemm_p8_kernel, tile 21).  Measured on the forward shapes, profiles/r03_x3_bench_p8.txt: layer 1 53.2 -> 48.8 us,
     // layers 2/3 28.1 -> 27.0 us; the backward shapes (M = 4096: 128 such tiles) stay on the 128x128 ring kernel
     if (np == 1 && !transA && blocks(256, 128) >= 224) tile = 21;
+    // three planes: the same schedule at BK = 32 on 128x128 tiles (tile 24) wherever the ring kernel ran 128x128 tiles: layer 1 at
+    // B = 32 132 -> 118 us, layers 2/3 52.6 -> 50.0 us, dW1 88 -> 79 us (tools/p8_probe.py, NP=3)
+    if (np == 3 && tile == 2) tile = 24;
     if (np == 1 && g_x3_tile[op] && (g_x3_tile[op] >= 20 || !(K % 64))) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..24)
+    if (np == 3 && g_x3_tile[op] >= 24 && g_x3_tile[op] <= 26) tile = g_x3_tile[op];
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
                    out);
 }

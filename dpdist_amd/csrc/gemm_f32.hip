@@ -452,17 +452,24 @@ template <bool AK, bool BKC>
 static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
     if (tile >= 30 && tile <= 39) return launch_rs_tile<AK, BKC>(tile, g, s);   // register-streamed kernels (gemm_rs.h)
     switch (tile) {
+        // LDS-DMA ring kernels (round 1).  Product call sites: tile 8 (the NT forms g W^T when the caller passes no transposed weight
+        // copies) and tile 9 (128x128 reference of tools/x3_bench.py); the other ring configurations are A/B references of the tuning
+        // tools and of tests/test_gpu_parity.py::test_gemm_f32 and are compiled only with -DDPD_ABLATIONS (DPD_ABLATIONS=1 build).
+        case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
+        case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
         case 4: return launch_dma<2, 2, 4, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 64 KiB  (2 blocks/CU)
+#ifdef DPD_ABLATIONS
         case 5: return launch_dma<4, 4, 4, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 128 KiB (1 block/CU)
         case 6: return launch_dma<4, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x64,  512 thr, 72 KiB  (2 blocks/CU)
         case 7: return launch_dma<2, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x128, 512 thr, 72 KiB  (2 blocks/CU)
-        case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
-        case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
         case 10: return launch_dma<4, 4, 5, AK, BKC>(g, s);  // LDS-DMA ring, 128x128, 1024 thr, 160 KiB (all of a CU's LDS)
         case 11: return launch_dma<2, 4, 3, AK, BKC, 2, 1>(g, s);   // 128x128, 8 waves of 64x32 (2 accumulators), 96 KiB
         case 12: return launch_dma<2, 2, 3, AK, BKC, 2, 2>(g, s);   // 128x128, 4 waves of 64x64 (4 accumulators), 96 KiB
         case 13: return launch_dma<2, 2, 3, AK, BKC, 2, 1>(g, s);   // 128x64,  4 waves of 64x32, 72 KiB (2 blocks/CU)
         case 14: return launch_dma<4, 2, 3, AK, BKC, 1, 2>(g, s);   // 128x128, 8 waves of 32x64
+#else
+        case 5: case 6: case 7: case 10: case 11: case 12: case 13: case 14: return DPD_E_UNSUPPORTED;
+#endif
         case 1: return launch_cfg<128, 128, 32, AK, BKC>(g, s);
         case 2: return launch_cfg<128, 64, 32, AK, BKC>(g, s);
         case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);

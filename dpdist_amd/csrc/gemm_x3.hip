@@ -335,17 +335,20 @@ __device__ unsigned long long g_p8_stamps[1024 * 8];
 #endif
 
 // ABL (timing-only, -DDPD_ABLATIONS): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no stagger, 16 = no setprio
-template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
+// NP planes (1: BK = 64, two k16 steps per phase; 3: BK = 32, one k16 step = six MFMA terms per phase): a K-tile is 48 KiB of LDS for
+// a 256x128 (NP = 1) or 128x128 (NP = 3) tile either way.
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
-    constexpr int BK = 64, NS = 3, CPR = 8;
+    constexpr int BK = NP == 1 ? 64 : 32, NS = 3, CPR = BK / 8, KS = BK / 32;   // KS = k16 steps per phase (half a K-tile)
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
-    constexpr int A_IMG = BM * CPR, B_IMG = BN * CPR, STAGE = A_IMG + B_IMG;   // chunks of 16 B
-    constexpr int PA = A_IMG / 64, PB = B_IMG / 64;                            // 1-KiB pieces per image
-    constexpr int PPW = (PA + PB) / NW, HP = PPW / 2;                          // pieces per wave per K-tile / per phase
-    static_assert((PA + PB) % NW == 0 && PPW % 2 == 0, "piece split");
+    constexpr int A_IMG = BM * CPR, B_IMG = BN * CPR, PL = A_IMG + B_IMG, STAGE = NP * PL;   // chunks of 16 B
+    constexpr int PA = A_IMG / 64, PB = B_IMG / 64;                            // 1-KiB pieces per plane image
+    constexpr int PPW = NP * (PA + PB) / NW, HP = PPW / 2;                     // pieces per wave per K-tile / per phase
+    static_assert((NP * (PA + PB)) % NW == 0 && PPW % 2 == 0, "piece split");
     static_assert(NW % 2 == 0, "two wave groups");
     static_assert(AK || BM % 64 == 0, "R8 images need 64-row pieces");
     static_assert(BKC || BN % 64 == 0, "R8 images need 64-row pieces");
+    static_assert(NS * STAGE * 16 <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) char smem_x3[];
 
     const int tid = threadIdx.x;
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
     const int m0 = (t0 / tilesN) * BM, n0 = (t0 % tilesN) * BN;
     const int K = g.e.K;
     const int nt = (K + BK - 1) / BK;
-    const bool ktail = (K % BK) != 0;          // == 32: the last K-tile has 4 valid k-groups out of 8
+    const int tail_groups = (K % BK) / 8;      // != 0: the last K-tile has this many valid k-groups (K % 8 == 0)
+    const bool ktail = tail_groups != 0;
 
     const uint16_t* src[PPW];
     long step[PPW];
@@ -377,15 +381,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int p = wave + j * NW;
-        const bool isA = p < PA;
-        const int c = isA ? p : p - PA;
+        const int plane = p / (PA + PB), w = p % (PA + PB);
+        const bool isA = w < PA;
+        const int c = isA ? w : w - PA;
         const bool kc = isA ? AK : BKC;
-        const uint16_t* base = isA ? gA : gB;
+        const uint16_t* base = isA ? gA + plane * g.a_plane : gB + plane * g.b_plane;
         const int ld = isA ? g.lda : g.ldb;
         const int o0 = isA ? m0 : n0;
         const int O = isA ? M : N;
         const int BO = isA ? BM : BN;
-        dst[j] = lds_base + (unsigned)((isA ? 0 : A_IMG) + c * 64) * 16u;
+        dst[j] = lds_base + (unsigned)(plane * PL + (isA ? 0 : A_IMG) + c * 64) * 16u;
         int kg;
         if (kc) {
             const int row = c * (64 / CPR) + lane / CPR, slot = lane % CPR;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
             src[j] = base + ((size_t)kg * ld + min(o0 + o, O - 1)) * 8;
             step[j] = (long)CPR * ld * 8;
         }
-        tail_ok |= (kg < 4 ? 1u : 0u) << j;
+        tail_ok |= (kg < tail_groups ? 1u : 0u) << j;
     }
     // pieces [j0, j0 + cnt) of K-tile `tile` into stage `stage`; every piece is issued exactly once per K-tile, in K-tile order
     auto issue = [&](int tile, int stage, auto j0c, auto cntc) {
@@ -438,20 +443,24 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
     P8_STAMP(2);
     if (wgrp == 1 && !(ABL & 8)) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
 
-    bf16x8 fa[2][TM], fb[2][TN];
+    bf16x8 fa[KS][NP][TM], fb[KS][NP][TN];
     auto phase = [&](int t, auto stc, auto hc) {
         constexpr int st = decltype(stc)::value, h = decltype(hc)::value;
         const char* sbase = smem_x3 + (size_t)st * STAGE * 16;
         // ---- LOAD(p) ----
 #pragma unroll
-        for (int s2 = 0; s2 < ((ABL & 4) ? (t == 0 && h == 0 ? 2 : 0) : 2); ++s2) {
-            const int kg = 2 * (2 * h + s2) + half;
+        for (int s2 = 0; s2 < ((ABL & 4) ? (t == 0 && h == 0 ? KS : 0) : KS); ++s2) {
+            const int kg = 2 * (KS * h + s2) + half;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[s2][i] = *reinterpret_cast<const bf16x8*>(sbase + chunk_of<AK, BM, CPR>(wm0 + 32 * i + l31, kg) * 16);
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[s2][j] = *reinterpret_cast<const bf16x8*>(sbase + (A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
+                for (int i = 0; i < TM; ++i)
+                    fa[s2][p][i] = *reinterpret_cast<const bf16x8*>(sbase + (p * PL + chunk_of<AK, BM, CPR>(wm0 + 32 * i + l31, kg)) * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[s2][p][j] =
+                        *reinterpret_cast<const bf16x8*>(sbase + (p * PL + A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ABL & 1) {
@@ -470,13 +479,27 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA(p) ----
         if (!(ABL & 16)) __builtin_amdgcn_s_setprio(1);
+        if (NP == 3) {      // lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi, small terms first (same order as gemm_x3_kernel)
+            constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < KS; ++s2)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][i], fb[s2][j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][ta[q] < NP ? ta[q] : 0][i], fb[s2][tb[q] < NP ? tb[q] : 0][j],
+                                                                                acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0][i], fb[s2][0][j], acc[i][j], 0, 0, 0);
+        }
         if (!(ABL & 16)) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (LATE_WAIT && h == 1 && wgrp == 0 && !(ABL & 1)) {        // group 0's B2 is the barrier group 1 waits before: one MFMA cluster more to land
@@ -513,13 +536,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
     P8_STAMP(4);
 }
 
-template <bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
 static int launch_p8(const X3Args& g, hipStream_t s) {
-    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
-    constexpr size_t ring = (size_t)3 * (BM + BN) * 64 * 2, stage = (size_t)BM * (BN + 4) * 4;
+    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, BK = NP == 1 ? 64 : 32;
+    constexpr size_t ring = (size_t)3 * NP * (BM + BN) * BK * 2, stage = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = ring > stage ? ring : stage;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = gemm_p8_kernel<AK, BKC, WR, WC, TM, TN, LATE_WAIT, ABL>;
+    auto kern = gemm_p8_kernel<NP, AK, BKC, WR, WC, TM, TN, LATE_WAIT, ABL>;
     static LdsOptIn lds_opt;
     if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
     const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * (g.A2 ? 2 : 1);
@@ -558,13 +581,16 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 10: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x128, 4 waves of 64x64
         case 11: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x256, 8 waves of 64x64
         case 12: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 1, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 64x128, 4 waves of 32x64
-        // phase-staggered kernels (gemm_p8_kernel; one plane, BK = 64, K % 32 == 0, no split-K)
-        case 20: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 4, 2, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64
-        case 21: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // ... group 0 waits after its MFMAs
-        case 22: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 2, 4, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x256, 8 waves of 64x64
-        case 23: if (NP == 1 && g.e.split_k == 1) return launch_p8<AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 32x64
+        // phase-staggered kernels (gemm_p8_kernel; K % 32 == 0, no split-K): one plane at BK = 64, three planes at BK = 32
+        case 20: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64
+        case 21: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // ... group 0 waits after its MFMAs
+        case 22: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 2, 4, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x256, 8 waves of 64x64
+        case 23: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 32x64
+        case 24: if (NP == 3 && g.e.split_k == 1) return launch_p8<3, AK, BKC, 4, 2, 1, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // 128x128, 8 waves of 32x64, 3 planes
+        case 25: if (NP == 3 && g.e.split_k == 1) return launch_p8<3, AK, BKC, 2, 4, 2, 1, true>(g, s); return DPD_E_UNSUPPORTED;    // 128x128, 8 waves of 64x32, 3 planes
+        case 26: if (NP == 3 && g.e.split_k == 1) return launch_p8<3, AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 24 with both groups waiting before B1
 #ifdef DPD_ABLATIONS
-#define DPD_P8_ABL(code) case 200 + code: if (NP == 1) return launch_p8<AK, BKC, 4, 2, 2, 2, true, code>(g, s); return DPD_E_UNSUPPORTED;
+#define DPD_P8_ABL(code) case 200 + code: if (NP == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true, code>(g, s); return DPD_E_UNSUPPORTED;
         DPD_P8_ABL(32) DPD_P8_ABL(1) DPD_P8_ABL(2) DPD_P8_ABL(3) DPD_P8_ABL(4) DPD_P8_ABL(5) DPD_P8_ABL(7) DPD_P8_ABL(8) DPD_P8_ABL(16) DPD_P8_ABL(24)
 #undef DPD_P8_ABL
 #define DPD_X3_ABL(code) case 100 + code: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 1, 4, 32, code>(g, s); return DPD_E_UNSUPPORTED;

@@ -163,7 +163,13 @@ def test_patch_rows_backward_is_transpose(dev):
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 34, 35, 36, 37])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
 def test_gemm_f32(dev, tile, mode):
-    from dpdist_amd import ops
+    from dpdist_amd import lib as L, ops
+    if tile in (5, 6, 7, 10, 11, 12, 13, 14):
+        # ring configurations that no plan uses: compiled only into a DPD_ABLATIONS=1 build (A/B references of the tuning tools)
+        x = torch.zeros(64, 64, device=dev)
+        if L.load().dpd_gemm_f32(0, 0, 64, 64, 64, L.ptr(x), 64, L.ptr(x), 64, L.ptr(x), 64, None, None, 0, 1, tile, None, 0,
+                                 L.cur_stream()) == -3:
+            pytest.skip("tile %d is an ablation-build configuration" % tile)
     rng = np.random.default_rng(10)
     M, N, K = 328, 196, 224            # ragged in M and N against every tile size; asymmetric operands catch transposes
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -583,54 +589,64 @@ def _bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float64)
 
 
-@pytest.mark.parametrize("tile", [20, 21, 22, 23])
+@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
-@pytest.mark.parametrize("K", [64, 96, 128, 160, 544, 576, 2528])
+@pytest.mark.parametrize("K", [32, 64, 96, 128, 160, 544, 576, 2528])
 def test_gemm_planes_phase_staggered(dev, mode, tile, K):
-    """gemm_p8_kernel (one bf16 plane, BK = 64, two wave groups one barrier apart, three whole K-tiles of LDS, zero chunks beyond
-    a K that ends in half a K-tile) against the EXACT product of the bf16-rounded operands in float64: a chunk that is read
-    before its LDS-DMA landed, a stale stage or a missing zero fill is an O(1) error, fp32 accumulation is ~1e-6 relative.
-    K covers 1, 1.5, 2, 2.5 K-tiles (prologue / drain corner cases), the unrolled-by-three steady state with and without a
+    """gemm_p8_kernel (two wave groups one barrier apart, three whole K-tiles of LDS, zero chunks beyond a K that ends inside a
+    K-tile; tiles 20-23: one bf16 plane at BK = 64, tiles 24-26: three planes at BK = 32) against float64: for one plane the EXACT
+    product of the bf16-rounded operands (fp32 accumulation is ~1e-6 relative: a chunk read before its LDS-DMA landed, a stale
+    stage or a missing zero fill is an O(1) error), for three planes the fp32-equivalence bar of test_gemm_planes.
+    K covers 1 .. 5 half/whole K-tiles (prologue / drain corner cases), the unrolled-by-three steady state with and without a
     remainder, and the decoder's 2528; M, N ragged (clamped rows / columns), several output tiles."""
-    from dpdist_amd import lib as L
+    from dpdist_amd import lib as L, ops
+    np_ = 3 if tile >= 24 else 1
     M, N = 600, 328
     g = torch.Generator().manual_seed(tile * 100 + K)
     A = torch.randn(M, K, generator=g).to(dev)
     B = torch.randn(K, N, generator=g).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
-    ref = torch.relu(_bf16_round(A) @ _bf16_round(B) + bias.double())
+    if np_ == 1:
+        ref = torch.relu(_bf16_round(A) @ _bf16_round(B) + bias.double())
+    else:
+        ref = torch.relu(A.double() @ B.double() + bias.double())
     lib = L.load()
     if mode == "NN":
-        a, _ = _planes(A, 1, True, False); _, b = _planes(B, 1, False, True)
-        args = (1, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N)
+        a, _ = _planes(A, np_, True, False); _, b = _planes(B, np_, False, True)
+        args = (np_, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N)
     elif mode == "NT":
-        a, _ = _planes(A, 1, True, False); b, _ = _planes(B.t().contiguous(), 1, True, False)
-        args = (1, 0, 0, M, N, K, L.ptr(a), K, M * K, L.ptr(b), K, N * K)
+        a, _ = _planes(A, np_, True, False); b, _ = _planes(B.t().contiguous(), np_, True, False)
+        args = (np_, 0, 0, M, N, K, L.ptr(a), K, M * K, L.ptr(b), K, N * K)
     else:
-        _, a = _planes(A.t().contiguous(), 1, False, True); _, b = _planes(B, 1, False, True)
-        args = (1, 1, 1, M, N, K, L.ptr(a), M, K * M, L.ptr(b), N, K * N)
+        _, a = _planes(A.t().contiguous(), np_, False, True); _, b = _planes(B, np_, False, True)
+        args = (np_, 1, 1, M, N, K, L.ptr(a), M, K * M, L.ptr(b), N, K * N)
     outs = []
     for _ in range(3):                      # same launch three times: a race shows up as run-to-run differences as well
         C = torch.full((M, N), float("nan"), device=dev)
         L.check(lib.dpd_gemm_planes(*args, L.ptr(C), N, L.ptr(bias), None, 2, tile, None, None, 0, L.cur_stream()), "dpd_gemm_planes")
         outs.append(C)
     err = (outs[0].double() - ref).abs().max().item()
-    assert err <= 2e-5 * max(1.0, ref.abs().max().item()) * max(1.0, K / 256), (err, ref.abs().max().item())
+    if np_ == 1:
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()) * max(1.0, K / 256), (err, ref.abs().max().item())
+    else:
+        err32 = (ops.gemm_f32(A, B, bias=bias, epilogue=2, tile=8).double() - ref).abs().max().item()
+        assert err <= max(1.5 * err32, 2e-5), (err, err32)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("tile", [20, 21])
+@pytest.mark.parametrize("tile", [20, 21, 24])
 def test_gemm_planes_phase_staggered_full_size_is_stable(dev, tile):
-    """The layer-1 shape of BASELINE config 3 (8192 x 1024 x 2528, one workgroup per CU, 40 K-tiles) ten times under a
-    memory-hungry side stream: identical bits every time and the exact bf16 product."""
+    """The layer-1 shape of BASELINE config 3 (8192 x 1024 x 2528; tile 24: the B = 32 shape 4096 x 1024 x 2528 in three planes; one
+    workgroup per CU) ten times under a memory-hungry side stream: identical bits every time and the right product."""
     from dpdist_amd import lib as L
-    M, N, K = 8192, 1024, 2528
+    np_ = 3 if tile >= 24 else 1
+    M, N, K = (8192 if np_ == 1 else 4096), 1024, 2528
     g = torch.Generator().manual_seed(7)
     A = torch.randn(M, K, generator=g).to(dev)
     B = torch.randn(K, N, generator=g).to(dev)
-    ref = _bf16_round(A[:512]) @ _bf16_round(B)
-    a, _ = _planes(A, 1, True, False)
-    _, b = _planes(B, 1, False, True)
+    ref = (_bf16_round(A[:512]) @ _bf16_round(B)) if np_ == 1 else (A[:512].double() @ B.double())
+    a, _ = _planes(A, np_, True, False)
+    _, b = _planes(B, np_, False, True)
     lib = L.load()
     side = torch.cuda.Stream()
     junk = torch.empty(64 << 20, device=dev)
@@ -639,7 +655,7 @@ def test_gemm_planes_phase_staggered_full_size_is_stable(dev, tile):
         with torch.cuda.stream(side):
             junk.add_(1.0)                  # 512 MB of read-modify-write next to the GEMM
         C = torch.full((M, N), float("nan"), device=dev)
-        L.check(lib.dpd_gemm_planes(1, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N, L.ptr(C), N, None, None, 0, tile,
+        L.check(lib.dpd_gemm_planes(np_, 0, 1, M, N, K, L.ptr(a), K, M * K, L.ptr(b), N, K * N, L.ptr(C), N, None, None, 0, tile,
                                     None, None, 0, L.cur_stream()), "dpd_gemm_planes")
         if first is None:
             first = C
@@ -811,13 +827,13 @@ def test_bf16_step_vs_oracle_b64(dev):
         assert abs(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30) - 1.0) <= 0.02, n
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 5, 20, 22])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 20, 22, 24])
 @pytest.mark.parametrize("np_", [3, 1])
 def test_gemm_planes_fused_outputs(dev, np_, tile):
     """The LDS-staged epilogue writes the result as operand planes: bit-identical to splitting the fp32 result."""
     from dpdist_amd import lib as L
-    if tile >= 20 and np_ == 3:
-        pytest.skip("the phase-staggered kernel exists for one plane only")
+    if tile >= 20 and (np_ == 3) != (tile >= 24):
+        pytest.skip("phase-staggered tiles 20-23 take one plane, 24-26 three")
     M, N, K, R8 = 320, 264, 96, 192
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).to(dev)
