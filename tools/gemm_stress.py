@@ -38,7 +38,7 @@ def main():
         tol = 5e-6 * K ** 0.5 * 16
         At, Bt = A.t().contiguous(), B.t().contiguous()
         cases = []
-        for tile in (8, 9, 5, 6, 7, 10):
+        for tile in (8, 9, 4):      # (5, 6, 7, 10-14 exist in a DPD_ABLATIONS=1 build only)
             if mode == "NN":
                 cases.append(("f32 tile %d" % tile, lambda t=tile: ops.gemm_f32(A, B, tile=t)))
             elif mode == "NT":

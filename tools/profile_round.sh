@@ -5,9 +5,9 @@
 #   pmc_FETCH_SIZE / pmc_WRITE_SIZE  separate --pmc passes               (HBM/fabric bytes per launch)
 #   pmc_MFMA                       MFMA-busy cycles per kernel           (own pass, --kernel-trace only)
 #   variants.txt                   the opt-in step variants, measured     (prefetch / fused gather / hipGraph / tail split ...)
-# usage: tools/profile_round.sh r02 [quick]
+# usage: tools/profile_round.sh r03 [quick]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -44,6 +44,12 @@ for dt in f32x3 bf16; do
   timeout 240 $PROF --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_${dt}_MFMA -o p -- $B $SHORT --dtype $dt > /dev/null 2>&1
 done
 $PROF --kernel-trace --stats --output-format csv -d $OUT/stats_bf16_b64 -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes --dtype bf16 --batch 64 > /dev/null 2>&1
+# BASELINE config 3 (bf16, 64 pairs): MFMA-busy and fabric bytes of its own launches, and the per-launch timeline of the three steps
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 240 $PROF --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_bf16_b64_$c -o p -- $B $SHORT --dtype bf16 --batch 64 > /dev/null 2>&1
+done
+timeout 240 $PROF --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_bf16_b64_MFMA -o p -- $B $SHORT --dtype bf16 --batch 64 > /dev/null 2>&1
+{ for t in "stats f32_B32" "stats_f32x3 f32x3_B32" "stats_bf16_b64 bf16_B64"; do set -- $t; echo "== $2"; python $R/tools/step_timeline.py $OUT/$1/${TAG}_kernel_trace.csv; done; } > $OUT/step_timeline.txt 2>&1
 # opt-in variants of the same step (each line: variant, ms/step, GEMM ms/step)
 line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-28s ms_per_step %.4f  gemm_ms_per_step %s  value %.0f' % ('$1', d['ms_per_step'], (d.get('roofline') or {}).get('gemm_ms_per_step'), d['value']))"; }
 {
@@ -56,13 +62,17 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split
   DPD_DET_DB=0 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes 2>/dev/null | line atomic_bias_grads
   $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes --plan 8:30:0 2>/dev/null | line dw1_tail_split
 } > $OUT/variants.txt 2>&1
-python $R/tools/gemm_bench.py --tiles 2,3,30,31,32,33 --splits 1,3 > $OUT/gemm_bench.txt 2>&1
+python $R/tools/gemm_bench.py --tiles 8,9,30,31,32,33 --splits 1,3 > $OUT/gemm_bench.txt 2>&1
 python $R/tools/x3_bench.py 2 3 5 > $OUT/x3_bench.txt 2>&1
+{ B64=1 python $R/tools/x3_bench.py 2 9 20 21 23; NP=3 python $R/tools/p8_probe.py 2 3 24 25; } 2>&1 | grep -v 'rc=-3' > $OUT/x3_bench_p8.txt
+{ python $R/tools/gather_bench.py 64; python $R/tools/gather_bench.py 32; DPD_GATHER_PLANES_V1=1 python $R/tools/gather_bench.py 64; } > $OUT/gather_bench.txt 2>&1
+python $R/tools/event_cost.py > $OUT/event_cost.txt 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 $R/tools/launch_floor.hip -o /tmp/launch_floor 2>/dev/null && /tmp/launch_floor > $OUT/launch_floor.txt 2>&1
 python $R/tools/determinism_check.py f32 > $OUT/determinism.txt 2>&1
 { python $R/tools/asloss_bench.py --batch 16; python $R/tools/asloss_bench.py --batch 32; } > $OUT/asloss_bench.txt 2>/dev/null
 python $R/tools/ramp_probe.py > $OUT/ramp_probe.txt 2>/dev/null
 { python $R/tools/host_rate.py f32 32; python $R/tools/host_rate.py bf16 64; } > $OUT/host_rate.txt 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 $R/tools/ldsdma_bw.hip -o /tmp/ldsdma_bw 2>/dev/null && /tmp/ldsdma_bw > $OUT/ldsdma_bw.txt 2>&1
-{ for e in "DPD_FORCE_DIST=0" "DPD_FORCE_DIST=1" "DPD_FORCE_DIST=1 DPD_DP_BUCKETS=3" "DPD_FORCE_DIST=1 DPD_DP_SCHEDULE=late" "DPD_FORCE_DIST=1 DPD_DP_MODE=rs_ag" "DPD_FORCE_DIST=1 DPD_DP_WIRE=bf16"; do
+{ for e in "DPD_FORCE_DIST=0" "DPD_FORCE_DIST=1" "DPD_FORCE_DIST=1 DPD_DP_BACKEND=torch" "DPD_FORCE_DIST=1 DPD_DP_BUCKETS=3" "DPD_FORCE_DIST=1 DPD_DP_SCHEDULE=late" "DPD_FORCE_DIST=1 DPD_DP_MODE=rs_ag" "DPD_FORCE_DIST=1 DPD_DP_WIRE=bf16"; do
     env $e MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes --no-roofline 2>/dev/null | tail -1 | line "$e" ; done; } > $OUT/dp_single_rank.txt 2>&1
 python $R/tools/summarize_profiles.py $TAG

@@ -28,7 +28,9 @@ for a, b in (("bench.json", "bench.json"), ("bench_f32x3.json", "bench_f32x3.jso
              ("x3_bench.txt", "x3_bench.txt"), ("gemm_bench.txt", "gemm_bench.txt"), ("variants.txt", "variants.txt"),
              ("determinism.txt", "determinism.txt"), ("bench_driver_flags.json", "bench_driver_flags.json"),
              ("asloss_bench.txt", "asloss_bench.txt"), ("ramp_probe.txt", "ramp_probe.txt"), ("host_rate.txt", "host_rate.txt"),
-             ("ldsdma_bw.txt", "ldsdma_bw.txt"), ("dp_single_rank.txt", "dp_single_rank.txt")):
+             ("ldsdma_bw.txt", "ldsdma_bw.txt"), ("dp_single_rank.txt", "dp_single_rank.txt"), ("step_timeline.txt", "step_timeline.txt"),
+             ("x3_bench_p8.txt", "x3_bench_p8.txt"), ("gather_bench.txt", "gather_bench.txt"), ("event_cost.txt", "event_cost.txt"),
+             ("launch_floor.txt", "launch_floor.txt")):
     copy(a, b)
 
 # per-kernel stats (our kernels only), one file per compute type
@@ -80,4 +82,5 @@ def pmc_summary(prefix, stats_sub, out_name):
 pmc_summary("pmc_", "stats", "pmc_summary.csv")
 pmc_summary("pmc_f32x3_", "stats_f32x3", "pmc_summary_f32x3.csv")
 pmc_summary("pmc_bf16_", "stats_bf16", "pmc_summary_bf16.csv")
+pmc_summary("pmc_bf16_b64_", "stats_bf16_b64", "pmc_summary_bf16_b64.csv")
 print("wrote", sorted(x for x in os.listdir(dst) if x.startswith(tag)))
