@@ -347,6 +347,22 @@ __global__ __launch_bounds__(256) void patch_rows_dq_kernel(const float* __restr
     if (i < Q * 3) dq[i] = dX[(size_t)(i / 3) * KP + E + i % 3];
 }
 
+// End of the as-loss backward (pcrnet-registration/iterative_PCRNet_ours.py:255-257: gradients to input1 / input2 only) in ONE launch:
+//   d loss / d pcA = upstream * (encoder route dpts[0:B] + query route of the BA half, dX[(B+b)*N+n, E:E+3])
+//   d loss / d pcB = upstream * (encoder route dpts[B:2B] + query route of the AB half, dX[b*N+n, E:E+3])
+// (was: a dq extraction launch plus three elementwise torch launches).  `scale` = the upstream gradient, a device scalar (may be NULL).
+__global__ __launch_bounds__(256) void asloss_combine_kernel(const float* __restrict__ dpts, const float* __restrict__ dX,
+                                                              const float* __restrict__ scale, int BN, int KP, int E,
+                                                              float* __restrict__ gA, float* __restrict__ gB) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // over [2, B*N, 3]
+    if (i >= 2 * BN * 3) return;
+    const float sc = scale ? *scale : 1.0f;
+    const int which = i / (BN * 3), r = (i % (BN * 3)) / 3, c = i % 3;
+    const int qrow = which ? r : BN + r;               // pcB is queried by the AB half (rows < BN), pcA by the BA half
+    const float v = (dpts[i] + dX[(size_t)qrow * KP + E + c]) * sc;
+    (which ? gB : gA)[(size_t)r * 3 + c] = v;
+}
+
 // pts = [pcA + noise ; pcB] (encoder input), q = [pcB ; pcA] (query clouds): models/dpdist_and_aue.py:45,56-61,69
 __global__ __launch_bounds__(256) void stack_clouds_kernel(const float* __restrict__ pcA, const float* __restrict__ pcB,
                                                             const float* __restrict__ noise, int n, float* __restrict__ pts,
@@ -496,6 +512,19 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
     }
     DPD_LAUNCH(patch_rows_fwd_kernel, dim3((C * N + 1) / 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
                        KP, make_axis(m), C * N, ssq, kMfvSlices);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_asloss_combine(const float* dpts, const float* dX, const float* scale, int B, int N, int k, int KP, float* gA,
+                                  float* gB, void* stream) {
+    using namespace dpd;
+    if (!dpts || !dX || !gA || !gB) return DPD_E_NULL;
+    if (B <= 0 || N <= 0) return DPD_E_DIM;
+    if (k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
+    if (KP < k * k * k * kF + 3) return DPD_E_DIM;
+    const int n = 2 * B * N * 3;
+    DPD_LAUNCH(asloss_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpts, dX, scale, B * N, KP, k * k * k * kF, gA, gB);
     DPD_CHECK_LAUNCH();
     return 0;
 }

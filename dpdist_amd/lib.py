@@ -53,6 +53,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p]),
     "dpd_patch_rows_fwd_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                           c_void_p, POINTER(Planes), c_void_p]),
+    "dpd_asloss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p]),
     "dpd_decoder_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_int, c_void_p,

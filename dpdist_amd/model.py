@@ -227,27 +227,27 @@ class _AsLossFn(torch.autograd.Function):
         pts, X, mask, vox = ops.front_end(pcA, pcB, None, m, sigma, k, P.KP)     # two launches (stack+encoder, norm+gather)
         params = P.views(flat)
         h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype)
-        loss, _ = ops.l1_loss(pred, mask[:B * N], mode=0)          # labels only enter loss_samples, which is not used here
+        # loss_pred AND d loss_pred / d pred [Q,3] from one launch (labels only enter loss_samples, which is not used here); the
+        # upstream gradient is applied once, at the very end of the backward (everything in between is linear in dpred)
+        need_grad = pcA.requires_grad or pcB.requires_grad
+        loss, dpred = ops.l1_loss(pred, mask[:B * N], mode=2 if need_grad else 0)
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
-        ctx.save_for_backward(pts, flat, mask, vox, h1, h2, h3, y, pred)
+        ctx.save_for_backward(pts, flat, mask, vox, h1, h2, h3, y, dpred if need_grad else pred)
         return loss[1]
 
     @staticmethod
     def backward(ctx, g):
         P = ctx.P
         B, N, m, k, sigma = ctx.cfg
-        pts, flat, mask, vox, h1, h2, h3, y, pred = ctx.saved_tensors
+        pts, flat, mask, vox, h1, h2, h3, y, dpred = ctx.saved_tensors
         Q = 2 * B * N
-        _, dpred = ops.l1_loss(pred, mask[:B * N], mode=2)          # d loss_pred / d pred, [Q,3]
-        dpred.mul_(g)                                               # upstream gradient (device scalar, no host sync)
         dt = P.compute_dtype
         ws = ops.workspace(Q, P.KP, P.H, flat.device, dt) if dt else None
         wT = P.transposed(flat) if dt in ("f32", 0) else None
         _, _, _, _, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, P.views(flat), P.KP, True, dtype=dt, ws=ws, transposed=wT)
-        dq, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k)
+        _, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k, want_dq=False)
         dpts = ops.mfv3d_bwd(pts, dfv, m, sigma)
-        gA = dpts[:B] + dq[B:]      # encoder route + query route (BA half queries pcA)
-        gB = dpts[B:] + dq[:B]
+        gA, gB = ops.asloss_combine(dpts, dX, g, B, N, k)           # upstream * (encoder route + query route), one launch
         return gA, gB, None, None, None, None, None
 
 

@@ -81,6 +81,19 @@ def patch_rows_bwd(dX, vox, C, N, m, k, want_dq=True, want_dfv=True):
     return dq, dfv
 
 
+def asloss_combine(dpts, dX, scale, B, N, k):
+    """dpts [2B,N,3], dX [2BN,KP], scale = 0-dim device tensor (upstream gradient) -> (d loss / d pcA, d loss / d pcB) [B,N,3]"""
+    L.req(dpts, name="dpts"), L.req(dX, name="dX")
+    gA = torch.empty(B, N, 3, device=dpts.device, dtype=torch.float32)
+    gB = torch.empty_like(gA)
+    sc = None
+    if scale is not None:
+        sc = scale.reshape(1).to(torch.float32).contiguous()
+    L.check(L.load().dpd_asloss_combine(L.ptr(dpts), L.ptr(dX), L.ptr(sc), B, N, k, dX.shape[1], L.ptr(gA), L.ptr(gB), L.cur_stream()),
+            "dpd_asloss_combine")
+    return gA, gB
+
+
 def _ws_args(ws):
     return (L.ptr(ws), ws.numel() * ws.element_size()) if ws is not None else (None, 0)
 

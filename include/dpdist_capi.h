@@ -121,6 +121,14 @@ typedef struct dpd_gather {
 int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, int N, int m, int k, int KP, float* dq,
                        float* dfv, void* stream);
 
+/* Tail of the as-loss backward (pcrnet-registration/iterative_PCRNet_ours.py:255-257, train_multi_gpu_pc_compare_dist.py:457-463:
+ * gradients w.r.t. input1 / input2 only) in one launch: dpts [2B,N,3] from dpd_mfv3d_bwd (encoder route), dX [2BN,KP] from
+ * dpd_decoder_bwd_data (its q - centre columns are the query route), `scale` = the upstream gradient as a DEVICE scalar (NULL = 1):
+ *   gA [B,N,3] = scale * (dpts[0:B]  + dq[B:2B])      (pcA is the query cloud of the BA half)
+ *   gB [B,N,3] = scale * (dpts[B:2B] + dq[0:B])                                                                         */
+int dpd_asloss_combine(const float* dpts, const float* dX, const float* scale, int B, int N, int k, int KP, float* gA, float* gB,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Implicit decoder (shared MLP).  Replaces tf_util.conv2d x4 (utils/dpdist_util.py:513-544,
  * utils/tf_util.py:161-228), relu6/3 (:691) and the mask multiply (:695-698).
