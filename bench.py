@@ -75,6 +75,21 @@ def _cpu_model():
     return "unknown"
 
 
+def _cpu_quota():
+    """CPUs this container may use: the cgroup v2 quota (cpu.max = "<quota> <period>") when there is one, else the affinity mask.
+    The GPU boxes report 256 hardware threads but run the container under a 16-CPU quota: more OpenMP threads than that only thrash."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def _c_port():
     """oracle/cpu_ref.c (the plain-C restatement, pinned against the reference's goldens in tests/test_oracle_c.py) compiled
     for THIS host (-march=native) into a temp dir; falls back to the portable AVX2 build that travelled with the repo."""
@@ -104,6 +119,7 @@ def cpu_baseline(B, N, budget_s=26.0):
     from dpdist_amd import synth
     from oracle import restate as R
     ncpu = os.cpu_count() or 1
+    quota = min(ncpu, _cpu_quota())
     t_all = time.perf_counter()
     variants = {}
     pcA, pcB, lab = synth.s2_modelnet_shaped(B, N, 100)
@@ -137,7 +153,7 @@ def cpu_baseline(B, N, budget_s=26.0):
         # does not); then the faithful dataflow at the compact port's best count; one-thread numbers on a 4-pair sample
         best = None
         sweep = {}
-        for nt in sorted({min(ncpu, c) for c in (16, 32, 64, 128, ncpu // 2, ncpu)}):
+        for nt in sorted({min(ncpu, c) for c in (max(2, quota // 2), quota, 2 * quota, 4 * quota)}):
             if nt < 2 or time.perf_counter() - t_all > budget_s * 0.45:
                 continue
             omp.omp_set_num_threads(nt)
@@ -171,7 +187,7 @@ def cpu_baseline(B, N, budget_s=26.0):
         torch.autograd.grad(ls, list(W.values()))
 
     best = None
-    for nt in [1] + sorted({min(ncpu, c) for c in (16, 32, 64, 128, ncpu)}):
+    for nt in [1] + sorted({min(ncpu, c) for c in (max(2, quota // 2), quota, 2 * quota)}):
         if time.perf_counter() - t_all > budget_s and best is not None:
             break
         torch.set_num_threads(nt)
@@ -192,9 +208,9 @@ def cpu_baseline(B, N, budget_s=26.0):
     top = max((v for v in variants.values() if isinstance(v, dict)), key=lambda v: v["value"])
     which = [k for k, v in variants.items() if v is top][0]
     return {"value": top["value"], "unit": "query-points/sec", "cores": top["threads"], "kind": "port",
-            "sample": "fwd+bwd of the same S2 workload, best of the ports below: %s (%s); host: %s, %d hardware threads; total %.0f s of CPU "
-                      "timing" % (which, top["sample"], _cpu_model(), ncpu, time.perf_counter() - t_all),
-            "cpu_model": _cpu_model(), "nproc": ncpu, "variants": variants}
+            "sample": "fwd+bwd of the same S2 workload, best of the ports below: %s (%s); host: %s, %d hardware threads, cgroup quota %d CPUs; "
+                      "total %.0f s of CPU timing" % (which, top["sample"], _cpu_model(), ncpu, quota, time.perf_counter() - t_all),
+            "cpu_model": _cpu_model(), "nproc": ncpu, "cpu_quota": quota, "variants": variants}
 
 
 def pmc_traffic(kernel_substr):
