@@ -587,6 +587,11 @@ def main():
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
     if use_dist:
+        torch.cuda.synchronize()
+        for t_ in [tr] + [k[0] for k in keep]:      # communicators of the direct RCCL reducers go before the process group does
+            red = getattr(t_, "reducer", None)
+            if red is not None and hasattr(red, "close"):
+                red.close()
         dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio (flushed at exit = after anything Python printed): flush it first so that

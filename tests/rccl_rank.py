@@ -55,6 +55,8 @@ def main(out_path, dtype):
         same = all(bool(torch.equal(ws[0], x)) for x in ws[1:])
         open(out_path, "w").write("%d %.6e %.6e %d" % (world, err, scale, int(same)))
     dist.barrier()
+    if hasattr(tr.reducer, "close"):
+        tr.reducer.close()
     dist.destroy_process_group()
 
 
