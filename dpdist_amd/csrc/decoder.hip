@@ -19,7 +19,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
             hipStream_t s, float* colsum, const X3Out* out = nullptr, const uint16_t* A2 = nullptr, const uint16_t* B2 = nullptr,
-            float* C2 = nullptr, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
+            float* C2 = nullptr, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0, const uint16_t* gate16 = nullptr);
 int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
                    const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
                    hipStream_t s, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
@@ -62,12 +62,12 @@ static size_t plane_bytes(int dtype, int Q, int KP, int H) {
 static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                    int ldb, float* C, int ldc, const float* bias, const float* gate, int epilogue, void* ws, size_t ws_bytes,
                    Scratch scr, hipStream_t s, float* colsum = nullptr, const void* Apl = nullptr, const void* Bpl = nullptr,
-                   const X3Out* out = nullptr, const ColsumTwoStep* cs2 = nullptr) {
+                   const X3Out* out = nullptr, const ColsumTwoStep* cs2 = nullptr, const void* gate16 = nullptr) {
     const int ra = transA ? K : M, ca = transA ? M : K;   // stored shape of A, B
     const int rb = transB ? N : K, cb = transB ? K : N;
     const bool planes_ok = dtype != 0 && !(K % 32) && !(ra & 7) && !(ca & 7) && !(rb & 7) && !(cb & 7) && !(transA && transB);
     if (!planes_ok) {   // exact fp32 (also for shapes the plane kernels do not take)
-        if (Apl || Bpl || out) return DPD_E_UNSUPPORTED;   // callers only pass planes for shapes planes_shape_ok() accepts
+        if (Apl || Bpl || out || (gate16 && !gate)) return DPD_E_UNSUPPORTED;   // callers only pass planes for shapes planes_shape_ok() accepts
         const int split = (dtype == 0) ? g_plan_split[op] : 1;
         int tile = g_plan_tile[op];
         // the 128x128 one-workgroup-per-CU kernels need >= ~200 tiles to fill the chip (B = 32 forward); smaller batches
@@ -116,7 +116,7 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     if (np == 1 && g_x3_tile[op] && (g_x3_tile[op] >= 20 || !(K % 64))) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..24)
     if (np == 3 && g_x3_tile[op] >= 24 && g_x3_tile[op] <= 26) tile = g_x3_tile[op];
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
-                   out);
+                   out, nullptr, nullptr, nullptr, 1, nullptr, 0, (const uint16_t*)gate16);
 }
 
 // `pl` is honoured only for these shapes (everything the fused producers and the plane GEMMs assume)
@@ -755,8 +755,11 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     using namespace dpd;
     pl = dpd::usable_planes(pl, dtype, Q, pl ? pl->Qb : 0, KP, H);
     if (!X && !(pl && pl->X_rc)) return DPD_E_NULL;
-    if (!mask || !p || !h1 || !h2 || !h3 || (!y != !pred)) return DPD_E_NULL;   // y = pred = NULL: the output layer is left to
-                                                                                  // dpd_decoder_bwd_data (dpd_small_grads.fwd_y)
+    // y = pred = NULL: the output layer is left to dpd_decoder_bwd_data (dpd_small_grads.fwd_y).  h1 / h2 = NULL: plane compute
+    // types whose planes keep h1_rc / h2_rc need no fp32 copy (the next layer, the weight gradients and the ReLU gate of the backward
+    // all read the planes): 2 x Q x H x 4 bytes less to write per forward
+    if (!mask || !p || !h3 || (!y != !pred)) return DPD_E_NULL;
+    if ((!h1 && !(pl && pl->h1_rc)) || (!h2 && !(pl && pl->h2_rc))) return DPD_E_NULL;
     if (pl && (pl->Q != Q || pl->Qb > Q)) return DPD_E_DIM;
     if (int rc = dpd::check_planes(pl, dtype)) return rc;
     if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
@@ -842,7 +845,8 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
                                     void* stream) {
     using namespace dpd;
     const bool l1 = sg && sg->l1_labels;        // fused training loss: dpred is derived inside the output-layer kernel
-    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h1 || !h2 || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
+    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
+    if ((!h1 && !(pl && pl->h1_rc)) || (!h2 && !(pl && pl->h2_rc))) return DPD_E_NULL;   // gate from the fp32 activation or its bf16 plane
     if (l1 && (!sg->l1_pred || !sg->l1_loss)) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
@@ -922,10 +926,10 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         const bool w2 = o2.rc || o2.r8, w1 = o1.rc || o1.r8;
         if (phases & 2)
             if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2, pl->g3_rc,
-                                 pl->W3_rc, w2 ? &o2 : nullptr)) return rc;
+                                 pl->W3_rc, w2 ? &o2 : nullptr, nullptr, h2 ? nullptr : pl->h2_rc)) return rc;
         if (phases & 4)
             if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1, pl->g2_rc,
-                                 pl->W2_rc, w1 ? &o1 : nullptr)) return rc;
+                                 pl->W2_rc, w1 ? &o1 : nullptr, nullptr, h1 ? nullptr : pl->h1_rc)) return rc;
         if (dX && (phases & 4)) {
             if (int rc = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s, nullptr,
                                  pl->g1_rc, pl->W1_rc, nullptr)) return rc;
@@ -959,8 +963,8 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
                                        int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
                                        const float* db_partials, void* stream) {
     using namespace dpd;
-    if (!act || !g || !dW) return DPD_E_NULL;
-    if (layer == 4 && !db) return DPD_E_NULL;
+    if (!g || !dW || (!act && !(pl && dtype != 0))) return DPD_E_NULL;     // (act may be NULL when its R8 plane exists: checked below)
+    if (layer == 4 && (!db || !act)) return DPD_E_NULL;
     if (layer < 1 || layer > 4 || Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -990,6 +994,7 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     const void* apl = !pl ? nullptr : (layer == 1 ? pl->X_r8 : (layer == 2 ? pl->h1_r8 : pl->h2_r8));
     const void* gpl = !pl ? nullptr : (layer == 1 ? pl->g1_r8 : (layer == 2 ? pl->g2_r8 : pl->g3_r8));
     if (dtype != 0 && !(apl && gpl) && !scr.p) return DPD_E_WORKSPACE;
+    if (!act && !apl) return DPD_E_NULL;
     // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout].  On the register-streamed fp32 kernels the bias gradient db = colsum(g) falls out
     // of the B operand the GEMM streams anyway (deterministic, no atomics, no extra launch).
     // With db_partials (the 32-row partial column sums dpd_decoder_bwd_data stored for this layer's g: layers 1 and 2) the bias
@@ -1019,7 +1024,8 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                                             float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws,
                                             size_t ws_bytes, const dpd_planes* pl, float* dbA, const float* db_partials, void* stream) {
     using namespace dpd;
-    if (!actA || !gA || !dWA || !actB || !gB || !dWB) return DPD_E_NULL;
+    if (!gA || !dWA || !gB || !dWB) return DPD_E_NULL;
+    if ((!actA || !actB) && !(dtype != 0 && pl && pl->h1_r8 && pl->h2_r8 && pl->g2_r8 && pl->g3_r8)) return DPD_E_NULL;
     if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
     if (dtype != 0 && dbA) return DPD_E_UNSUPPORTED;

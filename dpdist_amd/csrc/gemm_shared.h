@@ -14,6 +14,7 @@ struct GemmArgs {
     float* C;
     const float* bias;
     const float* gate;
+    const uint16_t* gate16;   // alternative to `gate` (plane GEMMs): the gating activation as a bf16 RC plane [M][ldc]; > 0 <=> non-zero, sign clear
     float* colsum;    // optional [N]: += column sums of the stored values (atomics; caller zeroes it)
     // deterministic bias gradients without atomics or an extra launch: a GEMM whose rows are data rows stores, per 32-row block,
     // the column sums of what it writes (colsum_part [ceil(M/32)][N]); a LATER GEMM's first-row-block waves add those partials
@@ -65,10 +66,19 @@ __device__ __forceinline__ void tile_values(const GemmArgs& g, const f32x16& acc
     const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
     float gv[16];
     if (epi == EPI_GATE) {
+        if (g.gate16) {      // bf16 rounding keeps the sign and never turns a positive fp32 into zero (same exponent range)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
-            gv[r] = g.gate[(size_t)row * g.ldc + col];
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
+                const unsigned b = g.gate16[(size_t)row * g.ldc + col];
+                gv[r] = ((b & 0x7fffu) && !(b >> 15)) ? 1.f : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
+                gv[r] = g.gate[(size_t)row * g.ldc + col];
+            }
         }
     }
 #pragma unroll

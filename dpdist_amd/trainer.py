@@ -68,7 +68,7 @@ class DPDistTrainer:
             self._gsrc = L.Gather(self.fv.data_ptr(), self.xyz.data_ptr(), self.rowinfo.data_ptr(), self.ktab.data_ptr(), C, G)
         else:
             self.X = f(Q, KP)
-        self.h1, self.h2, self.h3 = f(Q, H), f(Q, H), f(Q, H)
+        self.h1, self.h2, self.h3 = None, None, f(Q, H)      # h1 / h2: allocated below unless the planes stand in for them
         self.y, self.pred = f(Q, 3), f(Q, 3)
         self.dpred, self.dy = f(BN, 3), f(BN, 3)
         self.g1, self.g2, self.g3 = f(BN, H), f(BN, H), f(BN, H)
@@ -85,6 +85,10 @@ class DPDistTrainer:
             self._plane_mem = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             self._planes = L.Planes()
             L.check(lib.dpd_planes_carve(L.ptr(self._plane_mem), nbytes, Q, BN, KP, H, self.dt, 0, self._planes), "dpd_planes_carve")
+        # Plane compute types: layer 2/3, the weight gradients and the ReLU gate of the backward all read h1 / h2 from their bf16
+        # planes, so the fp32 copies are not written at all (2 x 33.5 MB per forward at B = 64); DPD_KEEP_F32_H=1 keeps them
+        if self._planes is None or os.environ.get("DPD_KEEP_F32_H", "0") == "1":
+            self.h1, self.h2 = f(Q, H), f(Q, H)
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
         self.reducer = make_reducer(self.grad, params.bucket_bounds, group,
@@ -272,7 +276,7 @@ class DPDistTrainer:
                         "dpd_decoder_bwd_weights_gather")
                 return
             db = gv[2 * layer - 1] if (det_db and layer in (1, 2)) else None
-            L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
+            L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0) if act is not None else dW.shape[0], L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
                                                 L.ptr(dW), L.ptr(db), L.ptr(self.ws), wsb, self._planes, L.ptr(dbp) if db is not None else None,
                                                 L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)

@@ -150,6 +150,8 @@ typedef struct dpd_decoder_params {
  * loading weights and after every optimizer step (training), once for frozen weights (as-loss mode).  DPD_F32 only.  */
 int dpd_weights_transpose(const dpd_decoder_params* p, int KP, int H, float* W2T, float* W3T, float* W1pT, void* stream);
 
+/* With planes that keep h1_rc / h2_rc (plane compute types), h1 / h2 may be NULL: the fp32 copies are then not written; pass
+ * NULL for them to dpd_decoder_bwd_data / dpd_decoder_bwd_weights[_pair] as well (the ReLU gate is read from the bf16 plane).      */
 int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
                     int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
                     const dpd_planes* pl, void* stream);
