@@ -845,8 +845,13 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
                                     void* stream) {
     using namespace dpd;
     const bool l1 = sg && sg->l1_labels;        // fused training loss: dpred is derived inside the output-layer kernel
-    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !p || !dy || !g3 || !g2 || !g1) return DPD_E_NULL;
+    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !p || !dy || !g3) return DPD_E_NULL;
     if ((!h1 && !(pl && pl->h1_rc)) || (!h2 && !(pl && pl->h2_rc))) return DPD_E_NULL;   // gate from the fp32 activation or its bf16 plane
+    // g2 / g1 = NULL: plane compute types whose planes keep g2_rc + g2_r8 (g1_r8, and g1_rc when dX is wanted) need no fp32 copy of
+    // the pre-activation gradients either (the next dH GEMM and the weight gradients read the planes; db2 / db1 come out of the
+    // epilogue); the block partials then need their own scratch (sg->partials)
+    if (!g2 && !(pl && pl->g2_rc && pl->g2_r8 && sg && sg->partials)) return DPD_E_NULL;
+    if (!g1 && !(pl && pl->g1_r8 && (!dX || pl->g1_rc))) return DPD_E_NULL;
     if (l1 && (!sg->l1_pred || !sg->l1_loss)) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
@@ -963,8 +968,8 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
                                        int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
                                        const float* db_partials, void* stream) {
     using namespace dpd;
-    if (!g || !dW || (!act && !(pl && dtype != 0))) return DPD_E_NULL;     // (act may be NULL when its R8 plane exists: checked below)
-    if (layer == 4 && (!db || !act)) return DPD_E_NULL;
+    if (!dW || ((!act || !g) && !(pl && dtype != 0))) return DPD_E_NULL;   // (act / g may be NULL when their R8 planes exist: checked below)
+    if (layer == 4 && (!db || !act || !g)) return DPD_E_NULL;
     if (layer < 1 || layer > 4 || Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -994,7 +999,7 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     const void* apl = !pl ? nullptr : (layer == 1 ? pl->X_r8 : (layer == 2 ? pl->h1_r8 : pl->h2_r8));
     const void* gpl = !pl ? nullptr : (layer == 1 ? pl->g1_r8 : (layer == 2 ? pl->g2_r8 : pl->g3_r8));
     if (dtype != 0 && !(apl && gpl) && !scr.p) return DPD_E_WORKSPACE;
-    if (!act && !apl) return DPD_E_NULL;
+    if ((!act && !apl) || (!g && !gpl) || (!g && db)) return DPD_E_NULL;
     // dW [Kin,Nout] = act^T [Kin,Qb] * g [Qb,Nout].  On the register-streamed fp32 kernels the bias gradient db = colsum(g) falls out
     // of the B operand the GEMM streams anyway (deterministic, no atomics, no extra launch).
     // With db_partials (the 32-row partial column sums dpd_decoder_bwd_data stored for this layer's g: layers 1 and 2) the bias
@@ -1024,8 +1029,8 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                                             float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws,
                                             size_t ws_bytes, const dpd_planes* pl, float* dbA, const float* db_partials, void* stream) {
     using namespace dpd;
-    if (!gA || !dWA || !gB || !dWB) return DPD_E_NULL;
-    if ((!actA || !actB) && !(dtype != 0 && pl && pl->h1_r8 && pl->h2_r8 && pl->g2_r8 && pl->g3_r8)) return DPD_E_NULL;
+    if (!dWA || !dWB) return DPD_E_NULL;
+    if ((!actA || !actB || !gA || !gB) && !(dtype != 0 && pl && pl->h1_r8 && pl->h2_r8 && pl->g2_r8 && pl->g3_r8)) return DPD_E_NULL;
     if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
     if (dtype != 0 && dbA) return DPD_E_UNSUPPORTED;

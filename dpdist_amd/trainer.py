@@ -71,7 +71,7 @@ class DPDistTrainer:
         self.h1, self.h2, self.h3 = None, None, f(Q, H)      # h1 / h2: allocated below unless the planes stand in for them
         self.y, self.pred = f(Q, 3), f(Q, 3)
         self.dpred, self.dy = f(BN, 3), f(BN, 3)
-        self.g1, self.g2, self.g3 = f(BN, H), f(BN, H), f(BN, H)
+        self.g1, self.g2, self.g3 = None, None, f(BN, H)      # g1 / g2: allocated below unless the planes stand in for them
         self.loss = f(2)
         self.grad = torch.zeros(params.numel, device=dev, dtype=torch.float32)
         self.m_state = torch.zeros_like(self.grad)
@@ -89,6 +89,7 @@ class DPDistTrainer:
         # planes, so the fp32 copies are not written at all (2 x 33.5 MB per forward at B = 64); DPD_KEEP_F32_H=1 keeps them
         if self._planes is None or os.environ.get("DPD_KEEP_F32_H", "0") == "1":
             self.h1, self.h2 = f(Q, H), f(Q, H)
+            self.g1, self.g2 = f(BN, H), f(BN, H)
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
         self.reducer = make_reducer(self.grad, params.bucket_bounds, group,

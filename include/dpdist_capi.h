@@ -151,7 +151,8 @@ typedef struct dpd_decoder_params {
 int dpd_weights_transpose(const dpd_decoder_params* p, int KP, int H, float* W2T, float* W3T, float* W1pT, void* stream);
 
 /* With planes that keep h1_rc / h2_rc (plane compute types), h1 / h2 may be NULL: the fp32 copies are then not written; pass
- * NULL for them to dpd_decoder_bwd_data / dpd_decoder_bwd_weights[_pair] as well (the ReLU gate is read from the bf16 plane).      */
+ * NULL for them to dpd_decoder_bwd_data / dpd_decoder_bwd_weights[_pair] as well (the ReLU gate is read from the bf16 plane).  In the same
+ * way g2 / g1 of dpd_decoder_bwd_data may be NULL when the planes keep g2_rc + g2_r8 / g1_r8 (and sg->partials is given).          */
 int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
                     int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
                     const dpd_planes* pl, void* stream);
