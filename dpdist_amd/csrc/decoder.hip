@@ -297,6 +297,14 @@ struct L1Fuse {
     float gscale;
 };
 constexpr int kOBRec = 8;   // record = 4H + 8 floats: db3 [H] | dW4 [3H] | db4 [3] | pad | loss sums [3] | pad
+// Optional bf16 operand planes of g3 written by the same pass (plane compute types: no fp32 g3, no conversion launch): RC
+// [np][Qb][H] straight from the registers, R8 [np][Qb/8][H][8] through an LDS image of the block's 8 rows (behind the four slabs).
+struct G3Planes {
+    uint16_t* rc;
+    uint16_t* r8;
+    long plane;     // elements per plane (Qb * H)
+    int np;
+};
 // Optional forward of the output layer inside the same pass (training step: no out_fwd launch, h3 rows of the AB half are read
 // once): with y != NULL the kernel computes y = h3 W4 + b4 and pred = relu6(y)/3 * mask for its AB rows AND their BA twins
 // (row + Qb), in out_fwd_kernel's summation order (bit-identical), writes both, and uses them instead of the y / l1.pred inputs.
@@ -310,8 +318,8 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
                                                               const float* __restrict__ y, const float* __restrict__ h3,
                                                               const float* __restrict__ W4, float* __restrict__ dy,
                                                               float* __restrict__ g3, int Qb, int H, ZeroList zl,
-                                                              float* __restrict__ scratch, L1Fuse l1, OutFwd of) {
-    extern __shared__ float s_acc[];   // [4 waves][4H + 8]
+                                                              float* __restrict__ scratch, L1Fuse l1, OutFwd of, G3Planes gp) {
+    extern __shared__ float s_acc[];   // [4 waves][4H + 8]; reused at the end (gp.r8) as uint16 [np][8][H]
     if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
         for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
     }
@@ -402,6 +410,7 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
                 if (jj < ng) hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
         }
     }
+    uint2 wpk[RW][4][3] = {};
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
         const int row = row0 + rr;
@@ -420,7 +429,19 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
 #pragma unroll
                     for (int c = 0; c < 3; ++c) a4[jj][e][c] += hh[e] * d[rr][c];
                 }
-                *reinterpret_cast<float4*>(g3 + (size_t)row * H + 256 * jj + 4 * lane) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+                if (g3) *reinterpret_cast<float4*>(g3 + (size_t)row * H + 256 * jj + 4 * lane) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+                if (gp.rc || gp.r8) {
+                    unsigned pl4[4][3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split3(gg[e], pl4[e]);
+                    const int col = 256 * jj + 4 * lane;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const uint2 w = make_uint2(pl4[0][q] | (pl4[1][q] << 16), pl4[2][q] | (pl4[3][q] << 16));
+                        wpk[rr][jj][q] = w;      // kept in registers: the LDS image for the R8 chunks reuses the slabs once they are summed
+                        if (gp.rc && q < gp.np) *reinterpret_cast<uint2*>(gp.rc + q * gp.plane + (size_t)row * H + col) = w;
+                    }
+                }
             }
         }
     }
@@ -443,6 +464,26 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
     __syncthreads();
     float* out = scratch + (size_t)blockIdx.x * P;
     for (int i = threadIdx.x; i < 4 * H + 7; i += 256) out[i] = ((s_acc[i] + s_acc[P + i]) + s_acc[2 * P + i]) + s_acc[3 * P + i];
+    if (gp.r8) {      // the block's 8 rows = one row group: column c's chunk = its 8 rows (Qb % 8 == 0 when planes are in use)
+        uint16_t* s_g = reinterpret_cast<uint16_t*>(s_acc);      // [np][8][H] <= 48 KiB: inside the four slabs, which are summed by now
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jj < ng)
+                    for (int q = 0; q < gp.np; ++q)
+                        *reinterpret_cast<uint2*>(s_g + ((size_t)(q * kOBRows + wave * RW + rr) * H + 256 * jj + 4 * lane)) = wpk[rr][jj][q < 3 ? q : 0];
+        __syncthreads();
+        for (int c = threadIdx.x; c < H; c += 256)
+            for (int q = 0; q < gp.np; ++q) {
+                unsigned b[8];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) b[rr] = s_g[(size_t)(q * kOBRows + rr) * H + c];
+                *reinterpret_cast<uint4*>(gp.r8 + q * gp.plane + ((size_t)blockIdx.x * H + c) * 8) =
+                    make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+            }
+    }
 }
 
 // out[i] = sum_b scratch[b][i] in a fixed order: 16 outputs x 16 block-slices per workgroup, LDS tree at the end
@@ -845,7 +886,7 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
                                     void* stream) {
     using namespace dpd;
     const bool l1 = sg && sg->l1_labels;        // fused training loss: dpred is derived inside the output-layer kernel
-    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !p || !dy || !g3) return DPD_E_NULL;
+    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !p || !dy) return DPD_E_NULL;
     if ((!h1 && !(pl && pl->h1_rc)) || (!h2 && !(pl && pl->h2_rc))) return DPD_E_NULL;   // gate from the fp32 activation or its bf16 plane
     // g2 / g1 = NULL: plane compute types whose planes keep g2_rc + g2_r8 (g1_r8, and g1_rc when dX is wanted) need no fp32 copy of
     // the pre-activation gradients either (the next dH GEMM and the weight gradients read the planes; db2 / db1 come out of the
@@ -883,6 +924,9 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     // (phases 16 / 8: it then runs beside the dH GEMMs on another stream) must provide sg->partials
     float* part = (sg && sg->partials) ? sg->partials : g2;
     if ((phases & 24) && !(sg && sg->partials)) return DPD_E_NULL;
+    // g3 = NULL: only when the fused output-layer kernel writes g3 as operand planes itself (plane compute types, below)
+    bool g3_planes_done = false;
+    if (!g3 && !(pl && pl->g3_rc && pl->g3_r8 && fused && fused4 && !(Qb % kOBRows))) return DPD_E_NULL;
     if ((phases & 8) && fused) {   // deferred second stage of the small gradients (a side stream / graph branch runs it)
         DPD_LAUNCH(small_grads_reduce, dim3(nred), dim3(256), 0, s, (const float*)part, nblk, H, db3, dW4, db4, rec, lossp, Qb);
         DPD_CHECK_LAUNCH();
@@ -893,10 +937,14 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         // one pass over h3: dy, g3 and block partials of db3 / dW4 / db4 (g2 is free until the first dH GEMM: scratch)
         ZeroList zl{{db1, db2, nullptr, nullptr, nullptr}, {H, H, 0, 0, 0}};
         if (fused4) {
-            const size_t lds = (size_t)4 * rec * sizeof(float);
+            // plane compute types: g3 leaves this kernel as the operand planes of the first dH GEMM (RC) and of dW3 (R8)
+            G3Planes gpl{nullptr, nullptr, (long)Qb * H, pl ? pl->np : 0};
+            if (pl && !(Qb % kOBRows)) { gpl.rc = (uint16_t*)pl->g3_rc; gpl.r8 = (uint16_t*)pl->g3_r8; }
+            g3_planes_done = gpl.rc || gpl.r8;
+            const size_t lds = (size_t)4 * rec * sizeof(float);      // (the R8 image of g3, np * 8 * H * 2 bytes, reuses the slabs)
             static LdsOptIn lds_opt;
             if (int rc = ensure_dyn_lds(lds_opt, (const void*)out_bwd_fused4_kernel, lds)) return rc;
-            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf, ofw);
+            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf, ofw, gpl);
         } else {
             DPD_LAUNCH(out_bwd_fused_kernel, dim3(nblk), dim3(256), (size_t)(4 * H + 4) * sizeof(float), s, dpred, mask, y, h3,
                        p->W4, dy, g3, Qb, H, zl, part);
@@ -923,7 +971,8 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     }
     // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0];  db2 / db1 = column sums, fused into the epilogue
     if (pl) {
-        if ((phases & 1) && (pl->g3_rc || pl->g3_r8)) {   // g3 comes from the small fused kernel above: one conversion launch for both layouts
+        if ((phases & 1) && (pl->g3_rc || pl->g3_r8) && !g3_planes_done) {   // g3 from a kernel that wrote no planes: one conversion launch for both layouts
+            if (!g3) return DPD_E_NULL;
             if (int rc = split_planes(g3, Qb, H, H, pl->np, (uint16_t*)pl->g3_rc, H, (long)Qb * H, (uint16_t*)pl->g3_r8, (long)Qb * H, s))
                 return rc;
         }

@@ -71,7 +71,7 @@ class DPDistTrainer:
         self.h1, self.h2, self.h3 = None, None, f(Q, H)      # h1 / h2: allocated below unless the planes stand in for them
         self.y, self.pred = f(Q, 3), f(Q, 3)
         self.dpred, self.dy = f(BN, 3), f(BN, 3)
-        self.g1, self.g2, self.g3 = None, None, f(BN, H)      # g1 / g2: allocated below unless the planes stand in for them
+        self.g1 = self.g2 = self.g3 = None                   # allocated below unless the planes stand in for them
         self.loss = f(2)
         self.grad = torch.zeros(params.numel, device=dev, dtype=torch.float32)
         self.m_state = torch.zeros_like(self.grad)
@@ -90,6 +90,9 @@ class DPDistTrainer:
         if self._planes is None or os.environ.get("DPD_KEEP_F32_H", "0") == "1":
             self.h1, self.h2 = f(Q, H), f(Q, H)
             self.g1, self.g2 = f(BN, H), f(BN, H)
+        # g3: the fused output-layer backward writes it as planes when it can (H % 256 == 0, H <= 1024, block partials fit)
+        if self.g3 is None and (self.g1 is not None or not (H % 256 == 0 and H <= 1024 and (BN // 8) * (4 * H + 8) <= BN * H)):
+            self.g3 = f(BN, H)
         import torch.distributed as dist
         use_dist = dist.is_initialized() if distributed is None else distributed
         self.reducer = make_reducer(self.grad, params.bucket_bounds, group,
