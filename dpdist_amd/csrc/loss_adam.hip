@@ -111,6 +111,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - lr_t * m / (sqrtf(v) + eps);
 }
 
+// NP = number of bf16 planes written next to the update (0: none / transposed fp32 copies only): compile time, so that the one-plane
+// type converts once per value instead of running the three-plane split and discarding two thirds of it
+template <int NP>
 __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                           float* __restrict__ v, float lr_t, float b1, float b2, float eps,
                                                           float gscale, AdamFuse f) {
@@ -163,10 +166,16 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] = tile[r][cg + j];
                     uint4 wv[3];
-                    split_chunk(x, wv);
+                    if (NP == 1) {
+                        unsigned b[8];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        if (q < f.np) *reinterpret_cast<uint4*>(rc + q * plane + (size_t)(r0 + r) * cols + c0 + cg) = wv[q];
+                        for (int j = 0; j < 8; ++j) b[j] = bf16_bits(x[j]);
+                        wv[0] = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+                    } else {
+                        split_chunk(x, wv);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint4*>(rc + q * plane + (size_t)(r0 + r) * cols + c0 + cg) = wv[q];
                 }
             }
         }
@@ -179,10 +188,16 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] = tile[8 * rg + j][c];
                     uint4 wv[3];
-                    split_chunk(x, wv);
+                    if (NP == 1) {
+                        unsigned b[8];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        if (q < f.np) *reinterpret_cast<uint4*>(r8 + q * plane + ((size_t)((r0 >> 3) + rg) * cols + c0 + c) * 8) = wv[q];
+                        for (int j = 0; j < 8; ++j) b[j] = bf16_bits(x[j]);
+                        wv[0] = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+                    } else {
+                        split_chunk(x, wv);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint4*>(r8 + q * plane + ((size_t)((r0 >> 3) + rg) * cols + c0 + c) * 8) = wv[q];
                 }
             }
         }
@@ -419,7 +434,9 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
     if (vblocks == 0 && vec_elems) vblocks = 1;
     const unsigned grid = (unsigned)(tiles + f.ntail + vblocks);
     if (grid == 0) return DPD_E_DIM;
-    DPD_LAUNCH(adam_fused_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);
+    if (f.np == 1) DPD_LAUNCH(adam_fused_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);
+    else if (f.np == 3) DPD_LAUNCH(adam_fused_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);
+    else DPD_LAUNCH(adam_fused_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);
     DPD_CHECK_LAUNCH();
     return 0;
 }
