@@ -112,3 +112,12 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert bench.spawn_ranks(2, [sys.executable, "-c", _RANK_SCRIPT, str(out), "-1"]) == 0
     assert out.read_text() == "2 3.0"
     assert bench.spawn_ranks(2, [sys.executable, "-c", _RANK_SCRIPT, str(out), "1"]) == 7
+
+
+def test_make_reducer_keeps_torch_distributed_off_the_gpu():
+    """ddp.make_reducer: the direct librccl reducer needs an RCCL process group and a GPU buffer; anything else (gloo, CPU tensors,
+    no process group) gets the torch.distributed BucketReducer."""
+    import torch
+    from dpdist_amd.ddp import BucketReducer, make_reducer
+    r = make_reducer(torch.zeros(16), [0, 4, 8, 16])
+    assert isinstance(r, BucketReducer) and not r.active

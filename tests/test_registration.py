@@ -232,3 +232,71 @@ def test_tf_adam_optimizer_matches_the_oracle_update():
             assert np.abs(p.detach().cpu().numpy() - r).max() <= 2e-6
     with pytest.raises(RuntimeError):
         TFAdam([torch.nn.Parameter(torch.zeros(3))])                 # CPU parameters: no fallback
+
+
+# ---------------------------------------------------------------------------------------------------------------- synthetic chairs
+def test_chair_surface_samples_and_exact_distance():
+    """synth.make_chair / BoxUnion (the rotation-observable stand-in for ModelNet40 'chair'): inside the radius-0.8 ball
+    (dataset_sample_with_gt.py:82), samples lie ON the union's surface and outside every other box, and dist() is the exact
+    point-to-surface distance for outside points (against 60 k brute-force surface samples)."""
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        ch = synth.make_chair(rng)
+        assert len(ch.c) in (6, 10)                                    # seat + back + 4 legs (+ 2 x 2 arm-rest boxes)
+        S = ch.sample(rng, 60000)
+        assert np.linalg.norm(S, axis=1).max() <= 0.8 + 1e-9
+        sd = ch.sdf_each(S)
+        assert np.abs(sd).min(axis=1).max() <= 1e-9                    # on the surface of (at least) one box
+        assert (sd > -1e-9).all()                                      # and not buried in another one
+        q = rng.uniform(-0.85, 0.85, (300, 3))
+        q = q[ch.outside(q)]
+        brute = np.sqrt(((q[:, None] - S[None]) ** 2).sum(-1)).min(1)
+        assert np.abs(ch.dist(q) - brute).max() <= 1.2e-2             # sampling density of the brute force (dist <= brute always)
+        assert (ch.dist(q) <= brute + 1e-9).all()
+
+
+def test_chair_batches_follow_the_trainers_recipe():
+    """s2_modelnet_shaped(shapes='chair') = the recipe of train_multi_gpu_pc_compare_dist.py:747-766 on chairs: 32 surface labels of 0,
+    16 near (0.001 .. 0.1) and 16 far (> 0.1) exact distances; the default analytic stream is untouched by the new option."""
+    pcA, pcB, lab = synth.s2_modelnet_shaped(6, 64, 7, shapes="chair")
+    assert pcA.shape == (6, 64, 3) and pcB.shape == (6, 64, 3) and lab.shape == (6, 64)
+    assert (lab[:, :32] == 0).all() and (lab[:, 32:48] > 0.001).all() and (lab[:, 32:48] < 0.1).all() and (lab[:, 48:] > 0.1).all()
+    assert np.abs(pcA).max() <= 0.8 + 0.1 + 1e-6                      # radius 0.8 + the +-0.1 shift
+    a = synth.s2_modelnet_shaped(3, 64, 100)
+    b = synth.s2_modelnet_shaped(3, 64, 100, shapes="analytic")
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    t = synth.s2_modelnet_shaped(2, 64, 7, shapes="chair", tilt_deg=20.0)
+    assert np.isfinite(t[0]).all() and not np.array_equal(t[0], synth.s2_modelnet_shaped(2, 64, 7, shapes="chair")[0])
+
+
+def test_registration_pairs_follow_the_reference_recipe():
+    """helper.split_template_source + generate_poses_ours.py: different samples of one surface, source = R_x R_y R_z p + t with
+    Euler angles in +-45 deg and |t| <= 0.01; the metric of results_itrPCRNet_no_stop.py reads 0 for the true transform and the
+    rotation angle of the pose for the identity."""
+    from dpdist_amd.registration import find_final_pose_inv
+    src, tmpl, gt = synth.registration_pairs(8, 64, seed=3)
+    assert src.shape == tmpl.shape == (8, 64, 3) and gt.shape == (8, 6)
+    assert np.abs(gt[:, :3]).max() <= 0.01 and np.abs(gt[:, 3:]).max() <= np.pi / 4 + 1e-12
+    assert not np.allclose(src, tmpl)
+    for b in range(8):
+        R = synth.euler_rotation(*gt[b, 3:])
+        back = (src[b].astype(np.float64) - gt[b, :3]) @ R                    # R^T (s - t): the source's samples in the template frame
+        assert np.abs(np.linalg.norm(back, axis=1)).max() <= 0.8 + 1e-5       # a rotation about the origin: still inside the ball
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R.T, -R.T @ gt[b, :3]                            # the transform a perfect registration would compose
+        te, re = find_errors(gt[b], find_final_pose_inv(T[None])[0])
+        assert te <= 1e-12 and re <= 1e-5
+        te0, re0 = find_errors(gt[b], np.zeros(6))
+        ang = np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1)))
+        assert abs(re0 - ang) <= 1e-6
+
+
+def test_gpu_only_helpers_refuse_the_cpu():
+    """optim.TFAdam / hipevents are bindings to the GPU library and the HIP runtime: no CPU form, loud failure."""
+    from dpdist_amd.optim import TFAdam
+    with pytest.raises(RuntimeError):
+        TFAdam([torch.nn.Parameter(torch.zeros(3))])
+    if not torch.cuda.is_available():
+        from dpdist_amd import hipevents
+        with pytest.raises(RuntimeError):
+            hipevents.LightEvent()

@@ -23,7 +23,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=60)     # the chip needs ~25 ms under load to reach its steady clock (tools/ramp_probe.py)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"])
+    ap.add_argument("--plan", default="", help="GEMM plan overrides, e.g. '7:30' = op:tile[:split_k] (include/dpdist_capi.h: dpd_set_gemm_plan)")
     a = ap.parse_args()
+    from dpdist_amd import lib as Lb
+    for item in filter(None, a.plan.split(",")):
+        f = [int(x) for x in item.split(":")]
+        Lb.check(Lb.load().dpd_set_gemm_plan(f[0], f[1], f[2] if len(f) > 2 else 1), "dpd_set_gemm_plan")
     dev = torch.device("cuda:0")
     model = DPDistModel(device=dev)
     model.load_tf_state_dict(synth.make_weights("wide"))
