@@ -55,27 +55,33 @@ def main():
             else:
                 _, a_ = planes(At, np_, False, True); _, b_ = planes(B, np_, False, True)
                 args = (np_, 1, 1, M, N, K, L.ptr(a_), M, K * M, L.ptr(b_), N, K * N)
-            for tile in (1, 2, 3, 5, 7):
+            # ring kernels 1-7; phase-staggered kernels 20-23 (one plane, BK = 64) / 24-26 (three planes, BK = 32)
+            for tile in (1, 2, 3, 5, 7) + ((20, 21, 22, 23) if np_ == 1 else (24, 25, 26)):
                 def run(args=args, tile=tile, keep=(a_, b_)):
                     C = torch.empty(M, N, device=dev)
                     L.check(lib.dpd_gemm_planes(*args, L.ptr(C), N, None, None, 0, tile, None, None, 0, L.cur_stream()), "planes")
                     return C
                 cases.append(("planes np=%d tile %d" % (np_, tile), run))
         for name, fn in cases:
-            worst, nbad = 0.0, 0
+            worst, nbad, ndiff, first = 0.0, 0, 0, None
             for it in range(a.iters):
                 if it % 3 == 0:
                     with torch.cuda.stream(side):       # perturb the memory system while the GEMM runs
                         junk.add_(1)
                 C = fn()
+                if first is None:
+                    first = C.clone()
+                elif not torch.equal(C, first):
+                    ndiff += 1
                 err = (C.double() - ref).abs().max().item()
                 lim = tol if "np=1" not in name else 0.05 * K ** 0.5
                 worst = max(worst, err)
                 nbad += err > lim
             torch.cuda.synchronize()
-            print("%-3s %-22s iters %d  worst |err| %.3e  %s" % (mode, name, a.iters, worst, "OK" if nbad == 0 else "BAD x%d" % nbad),
+            print("%-3s %-22s iters %d  worst |err| %.3e  %s  %s" % (mode, name, a.iters, worst, "OK" if nbad == 0 else "BAD x%d" % nbad,
+                                                                     "bitwise stable" if ndiff == 0 else "%d runs differ from the first" % ndiff),
                   flush=True)
-            bad += nbad
+            bad += nbad + ndiff
     print("RESULT:", "clean" if bad == 0 else "%d bad results" % bad)
     return 1 if bad else 0
 
