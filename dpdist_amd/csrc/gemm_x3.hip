@@ -55,6 +55,38 @@ __device__ __forceinline__ int chunk_of(int o, int kg) {
     return KC ? o * CPR + (kg ^ ((o / (16 / CPR)) & (CPR - 1))) : kg * BO + o;
 }
 
+// ---- "RCT" operand images (round 3): an operand whose contraction index is its ROW index, read straight from its RC plane.
+// The R8 planes exist only so that such an operand's MFMA fragment (8 consecutive k for one row/column) is one ds_read_b128; on
+// gfx950 the LDS transpose read does the same from a row-major image: ds_read_b64_tr_b16 gives every lane of a 16-lane group four
+// consecutive ROWS of its own column (measured semantics, tools/tr_read_probe.hip: output lane i, element j = element i % 4 of the
+// 8-byte piece addressed by lane i/4 + 4j of the group).  Image [BK rows (k)][BO columns] bf16, lane-linear for the LDS-DMA (a 1-KiB
+// piece = 64 / (BO/8) whole row segments); the 16-byte chunk c of row r sits in slot c ^ 2 (r & 3), chosen on the DMA's per-lane
+// SOURCE address, so that the four rows a 16-lane group reads fall on different banks.  With it the activations, the pre-activation
+// gradients and the gathered rows would need no R8 plane at all (63 MB less to write per bf16 step at B = 64).  MEASURED SLOWER and therefore
+// opt-in only (a_fmt = b_fmt = 2 of dpd_gemm_planes, tested like every other form): dW1 at B = 64 40.2 -> 47.1 us, one dW2 32.5 -> 40.8 us,
+// three planes 89.8 -> 96.4 / 54.1 -> 66.9 us (tools/tr_probe2.py) -- two LDS reads per fragment instead of one and 256-byte row
+// segments instead of fully linear 1-KiB DMA pieces cost as much as the R8 planes do.
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+
+template <int BO>
+__device__ __forceinline__ int rct_chunk(int row, int c) {
+    return row * (BO / 8) + (c ^ ((row & 3) << 1));
+}
+
+// fragment of the 32 columns starting at `o32` (multiple of 32) for the k16 step kb of a K-tile: lane (l31, half) <- rows 16 kb + 8 half + 0..7
+template <int BO>
+__device__ __forceinline__ bf16x8 rct_frag(const char* img, int o32, int kb, int lane) {
+    const int s16 = lane & 15, grp = lane >> 4;
+    const int col = o32 + 16 * (grp & 1) + 4 * (s16 & 3);                 // first column of the 8-byte piece this lane SUPPLIES
+    const int row = 16 * kb + 8 * (grp >> 1) + (s16 >> 2);                // its row (first read); +4 for the second read
+    typedef __attribute__((address_space(3))) v4i16* lp;
+    const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)((unsigned)(uintptr_t)(lds_ptr_t)img + rct_chunk<BO>(row, col >> 3) * 16 + (col & 7) * 2));
+    const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)((unsigned)(uintptr_t)(lds_ptr_t)img + rct_chunk<BO>(row + 4, col >> 3) * 16 + (col & 7) * 2));
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    const v8i16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // Epilogue shared by the plane GEMM kernels: fp32 store with bias / ReLU / gate / column sums, and -- when plane outputs are
 // requested -- the finished tile staged through the (idle) LDS ring so that the next GEMMs find their operands as bf16 planes.
 template <int BM, int BN, int NW, int TM, int TN>
@@ -125,7 +157,8 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
 
 // ABL (timing-only ablations, instantiated only with -DDPD_ABLATIONS; results are wrong by construction):
 //   1 = no LDS-DMA refill in the K loop, 2 = no barrier, 4 = no fragment reads in the loop, 8 = one MFMA per step only.
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
+// TR: operands that are not K-contiguous come as RCT images of their RC planes (above) instead of R8 planes
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0, bool TR = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
     constexpr int CPR = BK / 8, KB = BK / 16;               // chunks per row, k16 steps per K-tile
@@ -182,6 +215,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
             const int kg = slot ^ ((row / (16 / CPR)) & (CPR - 1));
             src[j] = base + (size_t)min(o0 + row, O - 1) * ld + kbeg + 8 * kg;
             step[j] = BK;
+        } else if (TR) {      // RCT image: whole row segments of the RC plane, chunk slot swizzled by the row
+            const int CH = BO / 8;
+            const int row = c * (64 / CH) + lane / CH, slot = lane % CH;
+            const int chunk = slot ^ ((row & 3) << 1);
+            src[j] = base + (size_t)(kbeg + row) * ld + min(o0 + 8 * chunk, O - 8);
+            step[j] = (long)BK * ld;
         } else {
             const int lin = c * 64 + lane;
             const int kg = lin / BO, o = lin % BO;
@@ -230,11 +269,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[buf][p][i] = *reinterpret_cast<const bf16x8*>(st + (p * PL + chunk_of<AK, BM, CPR>(wm0 + 32 * i + l31, kg)) * 16);
+                fa[buf][p][i] = (TR && !AK) ? rct_frag<BM>(st + (size_t)p * PL * 16, wm0 + 32 * i, kb, lane)
+                                            : *reinterpret_cast<const bf16x8*>(st + (p * PL + chunk_of<AK, BM, CPR>(wm0 + 32 * i + l31, kg)) * 16);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[buf][p][j] =
-                    *reinterpret_cast<const bf16x8*>(st + (p * PL + A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
+                fb[buf][p][j] = (TR && !BKC) ? rct_frag<BN>(st + (size_t)(p * PL + A_IMG) * 16, wn0 + 32 * j, kb, lane)
+                                             : *reinterpret_cast<const bf16x8*>(st + (p * PL + A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
         }
     };
     frags(0, 0, 0);
@@ -550,13 +590,13 @@ static int launch_p8(const X3Args& g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0>
+template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0, bool TR = false>
 static int launch_x3(const X3Args& g, hipStream_t s) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
     constexpr size_t ring = (size_t)NS * NP * (BM + BN) * BK * 2, stage = (size_t)BM * (BN + 4) * 4;
     constexpr size_t lds = ring > stage ? ring : stage;   // the plane epilogue stages the fp32 tile in the ring's LDS
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK, ABL>;
+    auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK, ABL, TR>;
     static LdsOptIn lds_opt;   // one per template instantiation
     if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
     const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * g.e.split_k * (g.A2 ? 2 : 1);
@@ -565,6 +605,18 @@ static int launch_x3(const X3Args& g, hipStream_t s) {
 }
 
 // tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 128x128 (8 waves of 64x32), 3 = 64x128, 4 = 128x64, 5 = 64x64
+// TN products with both operands read from their RC planes (RCT images + LDS transpose reads)
+template <int NP>
+static int launch_x3_tile_tr(int tile, const X3Args& g, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch_x3<NP, false, false, 2, 2, 2, 2, NP == 3 ? 3 : 4, 32, 0, true>(g, s);
+        case 2: return launch_x3<NP, false, false, 2, 4, 2, 1, NP == 3 ? 3 : 4, 32, 0, true>(g, s);
+        case 3: return launch_x3<NP, false, false, 2, 2, 1, 2, 4, 32, 0, true>(g, s);
+        case 5: return launch_x3<NP, false, false, 2, 2, 1, 1, 4, 32, 0, true>(g, s);
+        default: return DPD_E_UNSUPPORTED;
+    }
+}
+
 template <int NP, bool AK, bool BKC>
 static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
     switch (tile) {
@@ -601,7 +653,8 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
     }
 }
 
-// C[M,N] (fp32) = epi( op(A) op(B) ) from bf16 planes.  a_fmt/b_fmt: 0 = RC (k contiguous), 1 = R8 (k = row index).
+// C[M,N] (fp32) = epi( op(A) op(B) ) from bf16 planes.  a_fmt/b_fmt: 0 = RC (k contiguous), 1 = R8 (k = row index),
+// 2 = RC plane of an operand whose k is its ROW index (both operands: A stored [K][M], B stored [K][N]; lda / ldb = row strides).
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
             hipStream_t s, float* colsum, const X3Out* out, const uint16_t* A2, const uint16_t* B2, float* C2, int split_k, void* ws,
@@ -629,6 +682,8 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     if (epilogue == EPI_GATE && !gate && !gate16) return DPD_E_NULL;
     if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;
     if (a_fmt && b_fmt == 0) return DPD_E_UNSUPPORTED;   // (R8, RC) never occurs in the decoder
+    if ((a_fmt == 2) != (b_fmt == 2)) return DPD_E_UNSUPPORTED;   // the transpose-read form exists for TN with both operands as RC planes
+    if (a_fmt == 2 && ((M & 7) || (N & 7))) return DPD_E_UNSUPPORTED;
     X3Args g{};
     g.e.C = C; g.e.bias = bias; g.e.gate = gate; g.e.gate16 = gate ? nullptr : gate16; g.e.colsum = colsum;
     g.e.M = M; g.e.N = N; g.e.K = K; g.e.ldc = ldc; g.e.epi = epilogue;
@@ -649,7 +704,9 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
         ~ProfScope() { prof_end(on, s, fl); }
     } prof_scope{prof_begin(s), s, 2.0 * M * N * K * (A2 ? 2 : 1)};
     int rc;
-    if (np == 3) {
+    if (a_fmt == 2) {
+        rc = np == 3 ? launch_x3_tile_tr<3>(tile, g, s) : launch_x3_tile_tr<1>(tile, g, s);
+    } else if (np == 3) {
         if (!a_fmt && b_fmt) rc = launch_x3_tile<3, true, false>(tile, g, s);       // NN
         else if (!a_fmt && !b_fmt) rc = launch_x3_tile<3, true, true>(tile, g, s);  // NT
         else rc = launch_x3_tile<3, false, false>(tile, g, s);                      // TN

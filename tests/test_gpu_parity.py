@@ -546,7 +546,7 @@ def test_split_planes_reconstruct_exactly(dev):
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
-@pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
+@pytest.mark.parametrize("mode", ["NN", "NT", "TN", "TNr"])
 @pytest.mark.parametrize("np_", [3, 1])
 def test_gemm_planes(dev, np_, mode, tile):
     """Split-bf16 GEMM against fp64: the 3-plane / 6-term form must be at least as accurate as the exact-fp32 MFMA
@@ -554,6 +554,8 @@ def test_gemm_planes(dev, np_, mode, tile):
     from dpdist_amd import lib as L, ops
     if tile >= 8 and np_ == 3:
         pytest.skip("BK = 64 tiles exist for one plane only (a 3-plane stage does not fit the LDS)")
+    if mode == "TNr" and tile not in (1, 2, 3, 5):
+        pytest.skip("the transpose-read TN form (both operands as RC planes) exists for tiles 1, 2, 3, 5")
     M, N, K = 200, 328, 576 if tile >= 8 else 544   # ragged M (clamped rows), N % 8 == 0, K a whole number of K-tiles
     g = torch.Generator().manual_seed(tile * 10 + np_)
     A = torch.randn(M, K, generator=g).to(dev)
@@ -571,10 +573,15 @@ def test_gemm_planes(dev, np_, mode, tile):
         a, _ = _planes(A, np_, True, False); b, _ = _planes(Bt, np_, True, False)
         args = (np_, 0, 0, M, N, K, L.ptr(a), K, M * K, L.ptr(b), K, N * K)
         c32 = ops.gemm_f32(A, Bt, transB=True, bias=bias, epilogue=2, tile=8)
-    else:
+    elif mode == "TN":
         At = A.t().contiguous()
         _, a = _planes(At, np_, False, True); _, b = _planes(B, np_, False, True)
         args = (np_, 1, 1, M, N, K, L.ptr(a), M, K * M, L.ptr(b), N, K * N)
+        c32 = ops.gemm_f32(At, B, transA=True, bias=bias, epilogue=2, tile=8)
+    else:      # "TNr": the same product with both operands as their RC planes ([K][M], [K][N]) read through LDS transpose reads
+        At = A.t().contiguous()
+        a, _ = _planes(At, np_, True, False); b, _ = _planes(B, np_, True, False)
+        args = (np_, 2, 2, M, N, K, L.ptr(a), M, K * M, L.ptr(b), N, K * N)
         c32 = ops.gemm_f32(At, B, transA=True, bias=bias, epilogue=2, tile=8)
     L.check(lib.dpd_gemm_planes(*args, L.ptr(C), N, L.ptr(bias), None, 2, tile, None, None, 0, L.cur_stream()), "dpd_gemm_planes")
     err = (C.double() - ref).abs().max().item()

@@ -39,6 +39,12 @@ def run(mode, M, N, K, np_, tile, iters=20):
         a_rc, _ = planes(A, np_, True, False); b_rc, _ = planes(B, np_, True, False)
         args = (np_, 0, 0, M, N, K, L.ptr(a_rc), K, M * K, L.ptr(b_rc), K, N * K)
         f32 = lambda: ops.gemm_f32(A, B, transB=True, tile=8)
+    elif mode == "TR":      # TN with both operands as RC planes (LDS transpose reads)
+        A = torch.randn(K, M, generator=g).to(dev); B = torch.randn(K, N, generator=g).to(dev)
+        ref = A.double().t() @ B.double()
+        a_rc, _ = planes(A, np_, True, False); b_rc, _ = planes(B, np_, True, False)
+        args = (np_, 2, 2, M, N, K, L.ptr(a_rc), M, K * M, L.ptr(b_rc), N, K * N)
+        f32 = lambda: ops.gemm_f32(A, B, transA=True, tile=8)
     else:
         A = torch.randn(K, M, generator=g).to(dev); B = torch.randn(K, N, generator=g).to(dev)
         ref = A.double().t() @ B.double()
