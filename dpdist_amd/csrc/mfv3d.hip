@@ -106,8 +106,16 @@ __device__ __forceinline__ float slice_ssq(int tid, int gcount, float* s_red /* 
     return t;
 }
 
+#ifdef DPD_ABLATIONS
+__device__ unsigned long long g_mfv_stamps[1024 * 8];      // s_memtime milestones of thread 0 of every workgroup (tools/mfv_stamps.py)
+#define MFV_STAMP(i) do { if (threadIdx.x == 0) g_mfv_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MFV_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __restrict__ pts, float* __restrict__ fv,
                                                                  MfvConst k, int gslice, MfvFuse fu) {
+    MFV_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = k.N, G = k.G, m = k.m;
     float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][N][m]
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         }
     }
     __syncthreads();
+    MFV_STAMP(1);
     for (int e = tid; e < 3 * N; e += kFwdThreads) {              // e = a*N + n
         float S = 0.f, mz = INFINITY;
         for (int i = 0; i < m; ++i) {
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         if (!(pmax * k.w > 0.f)) atomicOr(s_bad, 1);             // also catches NaN inputs
     }
     __syncthreads();
+    MFV_STAMP(2);
     const float2* zqx = s_zq;
     const float2* zqy = s_zq + N * m;
     const float2* zqz = s_zq + 2 * N * m;
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         }
     }
     __syncthreads();
+    MFV_STAMP(3);
 
     // ---- coalesced store of the slice: fv[c][g0 + g][f], 4 consecutive f of one g per thread --------------------
     float* out = fv + ((size_t)c * G + g0) * kF;
@@ -239,8 +250,16 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         const float t = slice_ssq(tid, gcount, s_red, [&](int g, int ch) { return s_stage[g * kFP + ch]; });
         if (tid < kF) fu.ssq[((size_t)c * kSlices + sl) * kF + tid] = bad ? qnan : t;
     }
+    MFV_STAMP(4);
 }
 
+}  // namespace dpd
+#ifdef DPD_ABLATIONS
+extern "C" int dpd_debug_mfv_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dpd::g_mfv_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
+namespace dpd {
 // L2 normalisation over the Gaussian axis, per channel (:124-126), in place.  One 256-thread block per cloud.  The per-channel
 // sums are taken slice by slice in slice_ssq order and the slices added in order: the same bits as the fused form (ssq from the
 // forward kernel + scale applied by the window gather).
@@ -358,6 +377,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __r
     __syncthreads();
     for (int e = tid; e < 3 * N * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[e / m];
     __syncthreads();
+    MFV_STAMP(2);
     const float2* zqx = s_zq;
     const float2* zqy = s_zq + N * m;
     const float2* zqz = s_zq + 2 * N * m;
