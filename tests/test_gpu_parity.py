@@ -1092,6 +1092,52 @@ def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
         assert np.abs(g.cpu().numpy() - ref).max() <= bar, (np.abs(g.cpu().numpy() - ref).max(), bar)
 
 
+@pytest.mark.parametrize("dt", ["f32x3", "bf16"])
+def test_plane_step_without_fp32_copies_is_bitwise_the_step_with_them(dev, dt, monkeypatch):
+    """Plane compute types (round 3): fp32 h1 / h2 / g1 / g2 / g3 are not written at all -- layers 2/3 and the weight gradients read
+    the bf16 planes, the backward's ReLU gate is taken from the plane (EPI_GATE / gate16), g3 leaves the fused output-layer backward
+    as planes.  DPD_KEEP_F32_H=1 keeps the copies (and the separate g3 conversion launch): same planes, same GEMM results (up to the order of the
+    fp32-atomic bias-gradient sums these compute types use either way), three optimizer steps long; also through the data-parallel kernel order (single-rank RCCL group), whose weight-gradient calls differ."""
+    import torch.distributed as dist
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 32
+    batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100 + i)) for i in range(3)]
+    W0 = synth.make_weights("wide")
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29641")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for dp in (False, True):
+            outs = []
+            for keep in ("1", "0"):
+                monkeypatch.setenv("DPD_KEEP_F32_H", keep)
+                monkeypatch.setenv("DPD_FORCE_DIST", "1" if dp else "0")
+                P = DPDistParams(device=dev, compute_dtype=dt)
+                P.load_tf_state_dict(W0)
+                tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=dp)
+                assert (tr.h1 is None) == (keep == "0") and (tr.g3 is None) == (keep == "0")
+                losses = [tr.step(*b).clone() for b in batches]
+                torch.cuda.synchronize()
+                outs.append((torch.stack(losses), P.flat.detach().clone(), tr.grad.clone()))
+            assert torch.equal(outs[0][0][0], outs[1][0][0]), dp          # first step: identical weights -> identical loss bits
+            assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-6
+            # gradients of the last step: the weight matrices come from the same GEMMs on the same planes; b1 / b2 are fp32-atomic column
+            # sums in the plane compute types (order-dependent round-off from run to run, with or without the copies), which reaches the
+            # other tensors through Adam only from the second step on
+            ga, gb = outs[0][2], outs[1][2]
+            for n, (off, cnt, _) in P._segments.items():
+                a, b = ga[off:off + cnt], gb[off:off + cnt]
+                assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item()), (dp, n)
+            assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2.1e-3      # Adam: a sign flip of a ~0 gradient moves a weight by 2 lr
+            assert (outs[0][1] - outs[1][1]).abs().mean().item() <= 1e-6
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("N", [36, 100])
 @pytest.mark.parametrize("dt", ["f32x3", "bf16"])
 def test_plane_paths_on_shapes_the_plane_kernels_do_not_take(dev, dt, N):
