@@ -89,7 +89,10 @@ __device__ __forceinline__ bf16x8 rct_frag(const char* img, int o32, int kb, int
 
 // Epilogue shared by the plane GEMM kernels: fp32 store with bias / ReLU / gate / column sums, and -- when plane outputs are
 // requested -- the finished tile staged through the (idle) LDS ring so that the next GEMMs find their operands as bf16 planes.
-template <int BM, int BN, int NW, int TM, int TN>
+// NP = planes of the kernel = planes of its plane outputs (gemm_x3() checks it): compile time, so that the one-plane type converts
+// each value once instead of running the three-plane split and dropping two thirds of it (the split was most of this epilogue's
+// time: 11.4k cycles to write a 64 KB RC plane of a 256x128 tile against 9.1k for the 128 KB fp32 tile, tools/p8_stamps.py)
+template <int BM, int BN, int NW, int TM, int TN, int NP>
 __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][TN], char* smem_x3, int grp, int z, int m0, int n0,
                                             int wm0, int wn0, int tid, int l31, int half) {
     const int M = g.e.M, N = g.e.N;
@@ -120,7 +123,6 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
         }
     __syncthreads();
     constexpr int NTHR = 64 * NW;
-    const int npo = g.np_out;
     if (g.out_rc) {
         for (int t2 = tid; t2 < BM * (BN / 8); t2 += NTHR) {
             const int row = t2 / (BN / 8), cg = t2 % (BN / 8);
@@ -130,10 +132,17 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
                 const float4 x1 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg + 4);
                 const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                 uint4 w[3];
-                split_chunk(v, w);
+                if (NP == 1) {
+                    unsigned b[8];
 #pragma unroll
-                for (int q = 0; q < 3; ++q)   // compile-time plane index: w[] stays in registers
-                    if (q < npo) *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
+                    for (int j = 0; j < 8; ++j) b[j] = bf16_bits(v[j]);
+                    w[0] = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+                } else {
+                    split_chunk(v, w);
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q)   // compile-time plane index: w[] stays in registers
+                    *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
             }
         }
     }
@@ -146,10 +155,17 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = st[(8 * rg + j) * LDW + col];
                 uint4 w[3];
-                split_chunk(v, w);
+                if (NP == 1) {
+                    unsigned b[8];
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if (q < npo) *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
+                    for (int j = 0; j < 8; ++j) b[j] = bf16_bits(v[j]);
+                    w[0] = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+                } else {
+                    split_chunk(v, w);
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
             }
         }
     }
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
             if (it + 1 < nt) do_step(it + 1, 0, C1{});
         }
     }
-    x3_epilogue<BM, BN, NW, TM, TN>(g, acc, smem_x3, grp, z, m0, n0, wm0, wn0, tid, l31, half);
+    x3_epilogue<BM, BN, NW, TM, TN, NP>(g, acc, smem_x3, grp, z, m0, n0, wm0, wn0, tid, l31, half);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -572,7 +588,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
     }
     if (wgrp == 0 && !(ABL & 8)) __builtin_amdgcn_s_barrier();      // group 0 catches up: every wave has passed the same number of barriers
     P8_STAMP(3);
-    x3_epilogue<BM, BN, NW, TM, TN>(g, acc, smem_x3, grp, 0, m0, n0, wm0, wn0, tid, l31, half);
+    x3_epilogue<BM, BN, NW, TM, TN, NP>(g, acc, smem_x3, grp, 0, m0, n0, wm0, wn0, tid, l31, half);
     P8_STAMP(4);
 }
 
@@ -672,7 +688,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     }
     const bool planes_out = out && (out->rc || out->r8);
     if (!A || !B || (!C && !planes_out)) return DPD_E_NULL;
-    if (planes_out && ((out->np != 1 && out->np != 3) || (M & 7) || (N & 7) || (out->r8_rows & 7) || (out->rc && (out->ld_rc & 7))))
+    if (planes_out && (out->np != np || (M & 7) || (N & 7) || (out->r8_rows & 7) || (out->rc && (out->ld_rc & 7))))
         return DPD_E_UNSUPPORTED;
     if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
     if (np != 1 && np != 3) return DPD_E_UNSUPPORTED;
