@@ -29,7 +29,7 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # DPD_ABLATIONS=1: also compile the timing-only ablation variants of the plane GEMM (tools/x3_bench.py tile codes 100+)
-    flags = FLAGS + (["-DDPD_ABLATIONS"] if os.environ.get("DPD_ABLATIONS") == "1" else [])
+    flags = FLAGS + (["-DDPD_ABLATIONS"] if os.environ.get("DPD_ABLATIONS") == "1" else []) + os.environ.get("DPD_EXTRA_FLAGS", "").split()
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)

@@ -105,70 +105,160 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
             for (int j = 0; j < TN; ++j) store_tile(ge, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
         return;
     }
-    // Plane outputs: the finished tile is staged through the (now idle) LDS ring as fp32 [BM][BN+4] and re-read in
-    // the two chunk orientations, so that the next GEMMs find their operands as bf16 planes (no separate split pass).
-    constexpr int LDW = BN + 4;
-    float* st = reinterpret_cast<float*>(smem_x3);
-    __builtin_amdgcn_s_barrier();   // every wave is done reading the ring (all DMA pieces were waited for above)
+    // Plane outputs straight from the accumulator registers (round 3; the round-2 form staged the tile through the idle LDS ring as fp32
+    // and re-read it in both chunk orientations: two barriers, 64 ds_write_b32 and 24 LDS reads per lane).  A lane of a 32x32 accumulator
+    // tile holds ONE column and the rows (r & 3) + 8 (r >> 2) + 4 half, so after packing, dword pair g of a lane = rows 8g + 4 half + 0..3:
+    //   R8 chunks (8 consecutive rows of one column): rows 8g .. 8g+3 sit in this lane's half, 8g+4 .. 8g+7 in lane + 32: one
+    //   v_permlane32_swap per packed dword hands the lower half the chunks of the even row groups and the upper half those of the odd
+    //   ones (semantics probed in tools/permlane_probe.hip) -> one 16-byte store per pair of row groups and plane, lanes contiguous.
+    //   RC chunks (8 consecutive columns of one row) need a 16-bit transpose.  Interior tiles: every wave parks its packed dword pairs
+    //   in a private 2.25-KiB strip of the idle LDS ring (4 ds_write_b64) and takes them back through the gfx950 transpose read
+    //   (ds_read_b64_tr_b16: output lane i, element j of a 16-lane group = element i % 4 of the piece addressed by lane i/4 + 4j,
+    //   tools/tr_read_probe.hip): lane s of a group addresses column 8 (s & 3) + (s >> 2) of one four-row group, so that output lane i
+    //   receives columns 8 (i >> 2) + 0..3 of row i & 3, a second read (+4 columns) completes the 16-byte chunk -> 4 LDS writes, 4 LDS
+    //   reads and 2 stores per tile and plane, no cross-lane VALU work (the all-VALU form -- in-quad DPP transpose, then lanes 4 apart
+    //   trading row groups -- is ~100 VALU instructions per tile and plane; it stays below for the tiles that cross the matrix edge).
+    //   Strip layout: piece (column c, four-row group rg) at ((36 rg + c) * 8 bytes: writes are lane-linear, the 16 pieces of a
+    //   transpose read hit 16 different bank pairs and the neighbouring group (rg + 1, +288 bytes) the other 16.
+    // Bit-identical to converting the stored fp32 tile (tests: test_gemm_planes_fused_outputs).
+    constexpr int STRIP = 36 * 8 * 8;                      // bytes per wave and plane
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool interior = m0 + wm0 + 32 * TM <= M && n0 + wn0 + 32 * TN <= N && (!g.out_r8 || m0 + wm0 + 32 * TM <= g.r8_rows) &&
+                          !(g.ld_rc & 7) && !(N & 7);
+    if (g.out_rc) __builtin_amdgcn_s_barrier();            // every wave is done reading the ring (all DMA pieces were waited for in the K loop)
+    if (interior) {
+        const int lane = tid & 63, s16 = lane & 15, G = lane >> 4;
+        const unsigned strip = (unsigned)(uintptr_t)(lds_ptr_t)smem_x3 + wave_id * (NP * STRIP);
+        const unsigned wr_addr = strip + (half * 36 + l31) * 8;                                   // + 576 g (+ STRIP q)
+        const unsigned rd_addr = strip + (G * 36 + 8 * (s16 & 3) + (s16 >> 2)) * 8;               // + 32 (second read) + 1152 p (+ STRIP q)
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) u32x2* lds_u2;
+        typedef __attribute__((address_space(3))) v4i16* lds_v4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v[16];
+                const int grow0 = m0 + wm0 + 32 * i, gcol0 = n0 + wn0 + 32 * j;
+                tile_values(g.e, acc[i][j], grow0, gcol0 + l31, half, v);
+                put_tile(g.e, v, z, grow0, gcol0 + l31, half);
+                unsigned pk[NP][8];                              // pk[q][2g + h] = rows 8g + 4 half + 2h, + 2h + 1 of plane q
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    unsigned lo[3], hi[3];
+                    if (NP == 1) {
+                        lo[0] = bf16_bits(v[r]);
+                        hi[0] = bf16_bits(v[r + 1]);
+                    } else {
+                        split3(v[r], lo);
+                        split3(v[r + 1], hi);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) pk[q][r >> 1] = lo[q] | (hi[q] << 16);
+                }
+                if (g.out_rc) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+#pragma unroll
+                        for (int gi = 0; gi < 4; ++gi)
+                            *(lds_u2)(uintptr_t)(wr_addr + q * STRIP + 576 * gi) = u32x2{pk[q][2 * gi], pk[q][2 * gi + 1]};
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const v4i16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(rd_addr + q * STRIP + 1152 * p));
+                            const v4i16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(rd_addr + q * STRIP + 1152 * p + 32));
+                            const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+                            const int row = grow0 + 16 * p + 4 * G + (s16 & 3);
+                            *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)row * g.ld_rc + gcol0 + 8 * (s16 >> 2)) =
+                                make_uint4(ua.x, ua.y, ub.x, ub.y);
+                        }
+                    asm volatile("" ::: "memory");
+                }
+                if (g.out_r8) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q][4 * gp], pk[q][4 * gp + 2], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q][4 * gp + 1], pk[q][4 * gp + 3], false, false);
+                            const int rowg = grow0 + 8 * (2 * gp + half);
+                            *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(rowg >> 3) * N + gcol0 + l31) * 8) =
+                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float v[16];
-            const int row0 = wm0 + 32 * i, col = wn0 + 32 * j + l31;
-            tile_values(g.e, acc[i][j], m0 + row0, n0 + col, half, v);
-            put_tile(g.e, v, z, m0 + row0, n0 + col, half);
+            const int grow0 = m0 + wm0 + 32 * i, gcol0 = n0 + wn0 + 32 * j;
+            tile_values(g.e, acc[i][j], grow0, gcol0 + l31, half, v);
+            put_tile(g.e, v, z, grow0, gcol0 + l31, half);
+            unsigned pv[16][NP];                              // bf16 planes of the 16 values
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[(row0 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDW + col] = v[r];
-        }
-    __syncthreads();
-    constexpr int NTHR = 64 * NW;
-    if (g.out_rc) {
-        for (int t2 = tid; t2 < BM * (BN / 8); t2 += NTHR) {
-            const int row = t2 / (BN / 8), cg = t2 % (BN / 8);
-            const int grow = m0 + row, gcol = n0 + 8 * cg;
-            if (grow < M && gcol < N) {
-                const float4 x0 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg);
-                const float4 x1 = *reinterpret_cast<const float4*>(st + row * LDW + 8 * cg + 4);
-                const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                uint4 w[3];
+            for (int r = 0; r < 16; ++r) {
                 if (NP == 1) {
-                    unsigned b[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[j] = bf16_bits(v[j]);
-                    w[0] = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
+                    pv[r][0] = bf16_bits(v[r]);
                 } else {
-                    split_chunk(v, w);
-                }
+                    unsigned p3[3];
+                    split3(v[r], p3);
 #pragma unroll
-                for (int q = 0; q < NP; ++q)   // compile-time plane index: w[] stays in registers
-                    *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)grow * g.ld_rc + gcol) = w[q];
+                    for (int q = 0; q < NP; ++q) pv[r][q] = p3[q];
+                }
+            }
+            if (g.out_rc) {
+                // after the in-quad transpose lane 4q+j holds columns 4q..4q+3 of row 8 gi + 4 half + j (8 bytes per plane); lanes 4 apart
+                // (q even / odd) then trade row groups pairwise, so that every lane owns ONE 16-byte chunk (8 columns) per pair of row groups
+                const int jq = l31 & 3, qodd = (l31 >> 2) & 1;
+                const int col8 = gcol0 + ((l31 >> 3) << 3);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    uint2 w[4];
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi) {
+                        float a[4] = {__uint_as_float(pv[4 * gi][q]), __uint_as_float(pv[4 * gi + 1][q]), __uint_as_float(pv[4 * gi + 2][q]),
+                                      __uint_as_float(pv[4 * gi + 3][q])};     // (16-bit payloads moved as 32-bit lanes)
+                        quad_transpose4(a, l31);
+                        w[gi] = make_uint2(__float_as_uint(a[0]) | (__float_as_uint(a[1]) << 16), __float_as_uint(a[2]) | (__float_as_uint(a[3]) << 16));
+                    }
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        // even-q lanes keep row group 2 gp and receive its upper four columns from lane + 4; odd-q lanes keep 2 gp + 1
+                        // and receive its lower four columns from lane - 4
+                        const uint2 give = qodd ? w[2 * gp] : w[2 * gp + 1], keep = qodd ? w[2 * gp + 1] : w[2 * gp];
+                        const unsigned ux = (unsigned)__builtin_amdgcn_mov_dpp((int)give.x, 0x104, 0xf, 0xf, true);   // row_shl:4: from lane + 4
+                        const unsigned uy = (unsigned)__builtin_amdgcn_mov_dpp((int)give.y, 0x104, 0xf, 0xf, true);
+                        const unsigned dx = (unsigned)__builtin_amdgcn_mov_dpp((int)give.x, 0x114, 0xf, 0xf, true);   // row_shr:4: from lane - 4
+                        const unsigned dy = (unsigned)__builtin_amdgcn_mov_dpp((int)give.y, 0x114, 0xf, 0xf, true);
+                        const uint4 chunk = qodd ? make_uint4(dx, dy, keep.x, keep.y) : make_uint4(keep.x, keep.y, ux, uy);
+                        const int row = grow0 + 8 * (2 * gp + qodd) + 4 * half + jq;
+                        if (row < M && col8 < N) *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)row * g.ld_rc + col8) = chunk;
+                    }
+                }
+            }
+            if (g.out_r8) {
+                const int col = gcol0 + l31;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const int rowg = grow0 + 8 * (2 * gp + half);            // first row of the row group this lane ends up holding
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const unsigned X0 = pv[8 * gp][q] | (pv[8 * gp + 1][q] << 16), X1 = pv[8 * gp + 2][q] | (pv[8 * gp + 3][q] << 16);
+                        const unsigned Y0 = pv[8 * gp + 4][q] | (pv[8 * gp + 5][q] << 16), Y1 = pv[8 * gp + 6][q] | (pv[8 * gp + 7][q] << 16);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(X0, Y0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(X1, Y1, false, false);
+                        if (rowg < g.r8_rows && col < N)
+                            *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(rowg >> 3) * N + col) * 8) =
+                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
+                }
             }
         }
-    }
-    if (g.out_r8 && m0 < g.r8_rows) {
-        for (int t2 = tid; t2 < (BM / 8) * BN; t2 += NTHR) {
-            const int rg = t2 / BN, col = t2 % BN;
-            const int grow = m0 + 8 * rg, gcol = n0 + col;
-            if (grow < g.r8_rows && gcol < N) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = st[(8 * rg + j) * LDW + col];
-                uint4 w[3];
-                if (NP == 1) {
-                    unsigned b[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[j] = bf16_bits(v[j]);
-                    w[0] = make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
-                } else {
-                    split_chunk(v, w);
-                }
-#pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(grow / 8) * N + gcol) * 8) = w[q];
-            }
-        }
-    }
 }
 
 // ABL (timing-only ablations, instantiated only with -DDPD_ABLATIONS; results are wrong by construction):

@@ -23,3 +23,6 @@ for K in [int(k) for k in sys.argv[1:]] or [64, 1024, 2528]:
     print("K=%d OUTS=%r  (s_memtime ticks; 100 MHz => x10 ns)" % (K, outs))
     for i, n in enumerate(names):
         print("  %-18s median %8.0f   min %8.0f   max %8.0f" % (n, np.median(rel[:, i]), rel[:, i].min(), rel[:, i].max()))
+    d = np.diff(st, axis=1)           # per-workgroup phase durations (the s_memtime bases differ between XCDs: only differences within a row mean anything)
+    for i, n in enumerate(["addr setup", "first K-tile", "K loop", "epilogue"]):
+        print("  d %-16s median %8.0f   min %8.0f   max %8.0f" % (n, np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
