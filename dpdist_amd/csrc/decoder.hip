@@ -19,7 +19,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
             hipStream_t s, float* colsum, const X3Out* out = nullptr, const uint16_t* A2 = nullptr, const uint16_t* B2 = nullptr,
-            float* C2 = nullptr, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0, const uint16_t* gate16 = nullptr);
+            float* C2 = nullptr, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0, const uint16_t* gate16 = nullptr, int gate16_r8 = 0);
 int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
                    const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
                    hipStream_t s, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
@@ -62,7 +62,7 @@ static size_t plane_bytes(int dtype, int Q, int KP, int H) {
 static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                    int ldb, float* C, int ldc, const float* bias, const float* gate, int epilogue, void* ws, size_t ws_bytes,
                    Scratch scr, hipStream_t s, float* colsum = nullptr, const void* Apl = nullptr, const void* Bpl = nullptr,
-                   const X3Out* out = nullptr, const ColsumTwoStep* cs2 = nullptr, const void* gate16 = nullptr) {
+                   const X3Out* out = nullptr, const ColsumTwoStep* cs2 = nullptr, const void* gate16 = nullptr, int gate16_r8 = 0) {
     const int ra = transA ? K : M, ca = transA ? M : K;   // stored shape of A, B
     const int rb = transB ? N : K, cb = transB ? K : N;
     const bool planes_ok = dtype != 0 && !(K % 32) && !(ra & 7) && !(ca & 7) && !(rb & 7) && !(cb & 7) && !(transA && transB);
@@ -116,7 +116,7 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     if (np == 1 && g_x3_tile[op] && (g_x3_tile[op] >= 20 || !(K % 64))) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..24)
     if (np == 3 && g_x3_tile[op] >= 24 && g_x3_tile[op] <= 26) tile = g_x3_tile[op];
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
-                   out, nullptr, nullptr, nullptr, 1, nullptr, 0, (const uint16_t*)gate16);
+                   out, nullptr, nullptr, nullptr, 1, nullptr, 0, (const uint16_t*)gate16, gate16_r8);
 }
 
 // `pl` is honoured only for these shapes (everything the fused producers and the plane GEMMs assume)
@@ -980,10 +980,10 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         const bool w2 = o2.rc || o2.r8, w1 = o1.rc || o1.r8;
         if (phases & 2)
             if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2, pl->g3_rc,
-                                 pl->W3_rc, w2 ? &o2 : nullptr, nullptr, h2 ? nullptr : pl->h2_rc)) return rc;
+                                 pl->W3_rc, w2 ? &o2 : nullptr, nullptr, h2 ? nullptr : (pl->h2_r8 ? pl->h2_r8 : pl->h2_rc), pl->h2_r8 != nullptr)) return rc;
         if (phases & 4)
             if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g2, H, p->W2, H, g1, H, nullptr, h1, 3, nullptr, 0, scr, s, db1, pl->g2_rc,
-                                 pl->W2_rc, w1 ? &o1 : nullptr, nullptr, h1 ? nullptr : pl->h1_rc)) return rc;
+                                 pl->W2_rc, w1 ? &o1 : nullptr, nullptr, h1 ? nullptr : (pl->h1_r8 ? pl->h1_r8 : pl->h1_rc), pl->h1_r8 != nullptr)) return rc;
         if (dX && (phases & 4)) {
             if (int rc = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s, nullptr,
                                  pl->g1_rc, pl->W1_rc, nullptr)) return rc;

@@ -15,6 +15,7 @@ struct GemmArgs {
     const float* bias;
     const float* gate;
     const uint16_t* gate16;   // alternative to `gate` (plane GEMMs): the gating activation as a bf16 RC plane [M][ldc]; > 0 <=> non-zero, sign clear
+    int gate16_r8;            // ... or (non-zero) as its R8 plane [M/8][N][8]: a lane's four rows 8g + 4 half + 0..3 are ONE 8-byte load
     float* colsum;    // optional [N]: += column sums of the stored values (atomics; caller zeroes it)
     // deterministic bias gradients without atomics or an extra launch: a GEMM whose rows are data rows stores, per 32-row block,
     // the column sums of what it writes (colsum_part [ceil(M/32)][N]); a LATER GEMM's first-row-block waves add those partials
@@ -66,7 +67,16 @@ __device__ __forceinline__ void tile_values(const GemmArgs& g, const f32x16& acc
     const float bv = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? g.bias[col] : 0.f;
     float gv[16];
     if (epi == EPI_GATE) {
-        if (g.gate16) {      // bf16 rounding keeps the sign and never turns a positive fp32 into zero (same exponent range)
+        if (g.gate16 && g.gate16_r8) {   // 4 loads of 8 bytes per tile instead of 16 of 2 (the load ISSUE is what costs: ~16 cycles each)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const int rg = min((row0 >> 3) + gi, (g.M >> 3) - 1);
+                const uint2 b = *reinterpret_cast<const uint2*>(g.gate16 + ((size_t)rg * g.N + col) * 8 + 4 * half);
+                const unsigned e[4] = {b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[4 * gi + k] = ((e[k] & 0x7fffu) && !(e[k] >> 15)) ? 1.f : 0.f;
+            }
+        } else if (g.gate16) {      // bf16 rounding keeps the sign and never turns a positive fp32 into zero (same exponent range)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);

@@ -764,7 +764,7 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
             hipStream_t s, float* colsum, const X3Out* out, const uint16_t* A2, const uint16_t* B2, float* C2, int split_k, void* ws,
-            size_t ws_bytes, const uint16_t* gate16) {
+            size_t ws_bytes, const uint16_t* gate16, int gate16_r8) {
     if (A2 && (!B2 || !C2 || out || colsum || epilogue != EPI_NONE)) return DPD_E_UNSUPPORTED;
     // split-K (deterministic slabs in `ws` + the reduce kernel of gemm_f32.hip): plain products only (the dW shapes: K = query rows
     // is long, M x N gives too few 128x128 tiles for 256 CUs)
@@ -791,7 +791,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     if ((a_fmt == 2) != (b_fmt == 2)) return DPD_E_UNSUPPORTED;   // the transpose-read form exists for TN with both operands as RC planes
     if (a_fmt == 2 && ((M & 7) || (N & 7))) return DPD_E_UNSUPPORTED;
     X3Args g{};
-    g.e.C = C; g.e.bias = bias; g.e.gate = gate; g.e.gate16 = gate ? nullptr : gate16; g.e.colsum = colsum;
+    g.e.C = C; g.e.bias = bias; g.e.gate = gate; g.e.gate16 = gate ? nullptr : gate16; g.e.gate16_r8 = gate16_r8 && !(M & 7); g.e.colsum = colsum;
     g.e.M = M; g.e.N = N; g.e.K = K; g.e.ldc = ldc; g.e.epi = epilogue;
     g.e.split_k = 1; g.e.k_chunk = K; g.e.slab_stride = 0;
     g.A = A; g.B = B; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
@@ -916,5 +916,5 @@ extern "C" int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K
     o.rc = (uint16_t*)out_rc; o.r8 = (uint16_t*)out_r8; o.np = np; o.ld_rc = N; o.r8_rows = r8_rows;
     o.rc_plane = (long)M * N; o.r8_plane = (long)r8_rows * N;
     return dpd::gemm_x3(np, a_fmt, b_fmt, M, N, K, (const uint16_t*)A, lda, a_plane, (const uint16_t*)B, ldb, b_plane, C, ldc,
-                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0, nullptr);
+                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0, nullptr, 0);
 }
