@@ -96,6 +96,7 @@ struct AdamFuse {
     int np;
     long w_off[3];
     int w_rows[3], w_cols[3];
+    int direct[3];              // 1: no transposed copy, rows % 8 == 0, cols % 128 == 0 -> register-only plane path (one wave = 8 rows x 128 columns)
     int tile_end[3];            // cumulative tile-block counts of the three matrices (0-size matrices repeat the previous value)
     const float* partials;      // [nparts][rec] or NULL
     int nparts, rec, H, Qb;
@@ -126,6 +127,72 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
         const int rows = f.w_rows[w], cols = f.w_cols[w], tc = cols / 64;
         const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
         const size_t base = (size_t)f.w_off[w];
+        if (NP != 0 && f.direct[w]) {
+            // Planes without the LDS tile: a wave owns 8 rows x 128 columns; lane (l31, half) updates rows 4 half .. 4 half + 3 of the columns
+            // 4 l31 .. 4 l31 + 3 (float4 loads, 512 contiguous bytes per row and half-wave).  RC chunks halves (4 columns of a row) are
+            // the lane's own values; an R8 chunk (8 rows of one column) is this lane's four rows plus the four of lane +- 32: one
+            // v_permlane32_swap per packed dword gives the lower half the chunks of columns 0, 1 and the upper half those of 2, 3
+            // (same exchange as the plane GEMM epilogue, gemm_x3.hip).  35 -> 2x us at B = 64 (the 64x64 LDS-tile form ran at 4.3 TB/s).
+            const int lane = tid & 63, l31 = lane & 31, half = lane >> 5, segs = cols >> 7;
+            const int u = t * 4 + (tid >> 6);
+            if (u >= (rows >> 3) * segs) return;
+            const int rg = u / segs, c = (u % segs) * 128 + 4 * l31, row0 = 8 * rg + 4 * half;
+            float4 P[4], G[4], M[4], V[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = base + (size_t)(row0 + j) * cols + c;
+                P[j] = *reinterpret_cast<float4*>(p + o);
+                G[j] = *reinterpret_cast<const float4*>(g + o);
+                M[j] = *reinterpret_cast<float4*>(m + o);
+                V[j] = *reinterpret_cast<float4*>(v + o);
+            }
+            unsigned pv[4][4][NP ? NP : 1];      // [row j][column e][plane]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = base + (size_t)(row0 + j) * cols + c;
+                adam_one(P[j].x, G[j].x * gscale, M[j].x, V[j].x, lr_t, b1, b2, eps);
+                adam_one(P[j].y, G[j].y * gscale, M[j].y, V[j].y, lr_t, b1, b2, eps);
+                adam_one(P[j].z, G[j].z * gscale, M[j].z, V[j].z, lr_t, b1, b2, eps);
+                adam_one(P[j].w, G[j].w * gscale, M[j].w, V[j].w, lr_t, b1, b2, eps);
+                *reinterpret_cast<float4*>(p + o) = P[j];
+                *reinterpret_cast<float4*>(m + o) = M[j];
+                *reinterpret_cast<float4*>(v + o) = V[j];
+                const float x[4] = {P[j].x, P[j].y, P[j].z, P[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (NP == 1) {
+                        pv[j][e][0] = bf16_bits(x[e]);
+                    } else {
+                        unsigned p3[3];
+                        split3(x[e], p3);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) pv[j][e][q] = p3[q];
+                    }
+                }
+            }
+            const long plane = (long)rows * cols;
+            if (uint16_t* rc = f.rc[w]) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<uint2*>(rc + q * plane + (size_t)(row0 + j) * cols + c) =
+                            make_uint2(pv[j][0][q] | (pv[j][1][q] << 16), pv[j][2][q] | (pv[j][3][q] << 16));
+            }
+            if (uint16_t* r8 = f.r8[w]) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int e0 = 0; e0 < 2; ++e0) {
+                        const unsigned a0 = pv[0][e0][q] | (pv[1][e0][q] << 16), a1 = pv[2][e0][q] | (pv[3][e0][q] << 16);
+                        const unsigned b0 = pv[0][e0 + 2][q] | (pv[1][e0 + 2][q] << 16), b1_ = pv[2][e0 + 2][q] | (pv[3][e0 + 2][q] << 16);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1_, false, false);
+                        *reinterpret_cast<uint4*>(r8 + q * plane + ((size_t)rg * cols + c + e0 + 2 * half) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = tid + 256 * k, r = idx >> 4, c4 = (idx & 15) * 4;
@@ -398,7 +465,9 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
             if ((f.rc[w] || f.r8[w]) && ((fu->w_rows[w] & 7) || (((uintptr_t)f.rc[w] | (uintptr_t)f.r8[w]) & 15))) return DPD_E_UNSUPPORTED;
             if (nc && fu->w_off[w] < hi[nc - 1]) return DPD_E_DIM;
             lo[nc] = fu->w_off[w]; hi[nc] = fu->w_off[w] + cnt; ++nc;
-            tiles += ((fu->w_rows[w] + 63) / 64) * (fu->w_cols[w] / 64);
+            f.direct[w] = !fu->WT[w] && (f.rc[w] || f.r8[w]) && !(fu->w_cols[w] & 127) && getenv("DPD_ADAM_LDS_TILES") == nullptr;
+            if (f.direct[w]) tiles += ((fu->w_rows[w] / 8) * (fu->w_cols[w] / 128) + 3) / 4;
+            else tiles += ((fu->w_rows[w] + 63) / 64) * (fu->w_cols[w] / 64);
         }
         f.tile_end[w] = tiles;
     }
