@@ -104,6 +104,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_move<0x143, 0xC>(v);    // row_bcast31 into rows 2 and 3: lanes 48-63 = all four rows
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// sum over a 256-thread block (fixed order), returned in every thread; red = 4 floats of LDS
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+}
 // sum over the 32 lanes of each half-wave; valid in lanes 16-31 (lower half) and 48-63 (upper half) -- read it at lane 31 / 63
 __device__ __forceinline__ float half_sum32_hi(float v) {
     v = row_sum16(v);

@@ -138,14 +138,36 @@ static X3Out make_out(const dpd_planes* pl, void* rc, int rc_rows, void* r8, int
 }
 
 // ---- output layer: y = h3 W4 + b4 ; pred = clip(y,0,6)/3 * mask.  One wave per row. ----------------------
-__global__ __launch_bounds__(256) void out_fwd_kernel(const float* __restrict__ h3, const float* __restrict__ W4,
-                                                       const float* __restrict__ b4, const float* __restrict__ mask,
-                                                       float* __restrict__ y, float* __restrict__ pred, int Q, int H) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Q) return;
-    const float* h = h3 + (size_t)row * H;
+// the three dot products of one row with W4 [H,3] (one wave; every lane returns the full sums): ONE definition, so that every
+// kernel that evaluates the output layer produces the same bits
+// (H % 256 == 0, H <= 1024, W4 16-byte aligned: 16-byte loads of the row AND of W4 -- the 12 floats W4[k..k+3][0..2] are three float4 --
+// and the loaded row / column 0 of W4 stay in registers for a caller that goes on to the backward; same additions in the same order)
+constexpr int kOutMaxI = 4;
+struct OutRowRegs {
+    float4 h[kOutMaxI];
+    float w0[kOutMaxI][4];
+};
+__device__ __forceinline__ bool out_row_fast(const float* W4, int H) { return (H & 255) == 0 && H <= 256 * kOutMaxI && !((uintptr_t)W4 & 15); }
+
+__device__ __forceinline__ void out_row_dot(const float* __restrict__ h, const float* __restrict__ W4, int H, int lane, float (&a)[3],
+                                            OutRowRegs* keep = nullptr) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    if ((H & 255) == 0) {          // 16 bytes per lane per load: H / 256 loads in flight instead of H / 64 dependent-address ones
+    if (out_row_fast(W4, H)) {
+#pragma unroll
+        for (int i = 0; i < kOutMaxI; ++i) {
+            const int k = 4 * lane + 256 * i;
+            if (k < H) {
+                const float4 x = *reinterpret_cast<const float4*>(h + k);
+                const float4* wp = reinterpret_cast<const float4*>(W4 + (size_t)k * 3);
+                const float4 wa = wp[0], wb = wp[1], wc = wp[2];
+                a0 += x.x * wa.x; a1 += x.x * wa.y; a2 += x.x * wa.z;
+                a0 += x.y * wa.w; a1 += x.y * wb.x; a2 += x.y * wb.y;
+                a0 += x.z * wb.z; a1 += x.z * wb.w; a2 += x.z * wc.x;
+                a0 += x.w * wc.y; a1 += x.w * wc.z; a2 += x.w * wc.w;
+                if (keep) { keep->h[i] = x; keep->w0[i][0] = wa.x; keep->w0[i][1] = wa.w; keep->w0[i][2] = wb.z; keep->w0[i][3] = wc.y; }
+            }
+        }
+    } else if ((H & 255) == 0) {          // 16 bytes per lane per load: H / 256 loads in flight instead of H / 64 dependent-address ones
         for (int k = 4 * lane; k < H; k += 256) {
             const float4 x = *reinterpret_cast<const float4*>(h + k);
             const float xs[4] = {x.x, x.y, x.z, x.w};
@@ -164,11 +186,93 @@ __global__ __launch_bounds__(256) void out_fwd_kernel(const float* __restrict__ 
             a2 += x * W4[k * 3 + 2];
         }
     }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    a[0] = wave_sum(a0); a[1] = wave_sum(a1); a[2] = wave_sum(a2);
+}
+
+__global__ __launch_bounds__(256) void out_fwd_kernel(const float* __restrict__ h3, const float* __restrict__ W4,
+                                                       const float* __restrict__ b4, const float* __restrict__ mask,
+                                                       float* __restrict__ y, float* __restrict__ pred, int Q, int H) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Q) return;
+    float a[3];
+    out_row_dot(h3 + (size_t)row * H, W4, H, lane, a);
     if (lane < 3) {
-        const float v = (lane == 0 ? a0 : (lane == 1 ? a1 : a2)) + b4[lane];
+        const float v = (lane == 0 ? a[0] : (lane == 1 ? a[1] : a[2])) + b4[lane];
         y[(size_t)row * 3 + lane] = v;
         pred[(size_t)row * 3 + lane] = fminf(fmaxf(v, 0.f), 6.f) / 3.0f * mask[row];   // relu6(y)/3 (:691) * mask (:697)
+    }
+}
+
+// DPDist as a frozen loss (pcrnet-registration/iterative_PCRNet_ours.py:229-257): output layer, loss_pred and -- when g3 != NULL -- the
+// output-layer backward of d loss_pred / d pred (= gv = 0.5 / BN on channel 0 of every row, models/dpdist_and_aue.py:976-977) in ONE
+// launch instead of three (out_fwd + l1_loss + out_bwd: ~5 us each at the PCRNet batch, all launch-latency bound).  One wave per row.
+// Same values as the three-kernel chain (loss_pred within an ulp: exact fixed-point sum instead of fp32 partial sums): y / pred through
+// out_row_dot, dy = (gv * mask / 3 * [0 < y0 < 6], 0, 0), g3 = dy0 * W4[:,0] * [h3 > 0] (the chain adds two exact zeros to that).
+__global__ __launch_bounds__(256) void out_asloss_kernel(const float* __restrict__ h3, const float* __restrict__ W4,
+                                                          const float* __restrict__ b4, const float* __restrict__ mask,
+                                                          float* __restrict__ y, float* __restrict__ pred, float* __restrict__ dy,
+                                                          float* __restrict__ g3, int Q, int H, int BN, float gv,
+                                                          float* __restrict__ loss, unsigned long long* __restrict__ acc) {
+    __shared__ float s_p[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = blockIdx.x * 4 + wave;
+    float p0 = 0.f;
+    if (row < Q) {
+        const float* h = h3 + (size_t)row * H;
+        float a[3];
+        OutRowRegs rr;
+        out_row_dot(h, W4, H, lane, a, &rr);
+        const float mk = mask[row];
+        float yv[3], pv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            yv[c] = a[c] + b4[c];
+            pv[c] = fminf(fmaxf(yv[c], 0.f), 6.f) / 3.0f * mk;
+        }
+        if (lane < 3) {
+            y[(size_t)row * 3 + lane] = lane == 0 ? yv[0] : (lane == 1 ? yv[1] : yv[2]);
+            pred[(size_t)row * 3 + lane] = lane == 0 ? pv[0] : (lane == 1 ? pv[1] : pv[2]);
+        }
+        p0 = pv[0];
+        if (g3) {
+            const float d0 = (yv[0] > 0.f && yv[0] < 6.f) ? gv * mk / 3.0f : 0.f;
+            if (lane < 3) dy[(size_t)row * 3 + lane] = lane == 0 ? d0 : 0.f;
+            float* g = g3 + (size_t)row * H;
+            if (out_row_fast(W4, H)) {
+#pragma unroll
+                for (int i = 0; i < kOutMaxI; ++i) {
+                    const int k = 4 * lane + 256 * i;
+                    if (k < H) {
+                        const float4 x = rr.h[i];
+                        float4 o;
+                        o.x = x.x > 0.f ? d0 * rr.w0[i][0] : 0.f;
+                        o.y = x.y > 0.f ? d0 * rr.w0[i][1] : 0.f;
+                        o.z = x.z > 0.f ? d0 * rr.w0[i][2] : 0.f;
+                        o.w = x.w > 0.f ? d0 * rr.w0[i][3] : 0.f;
+                        *reinterpret_cast<float4*>(g + k) = o;
+                    }
+                }
+            } else {
+                for (int k = lane; k < H; k += 64) g[k] = h[k] > 0.f ? d0 * W4[k * 3] : 0.f;
+            }
+        }
+    }
+    // loss_pred = sum over ALL rows of pred[:,0] / (2 BN).  The sum is taken in 2^-32 fixed point: integer addition is associative, so
+    // the blocks can add their part in any order with ONE relaxed device-scope atomic each and still produce the same bits on every run;
+    // the block count rides in the top 16 bits of the same word, so the block that completes it needs no fence and no second look at
+    // memory (a __threadfence() per block costs an L2 write-back on this chip: this kernel took 23 us with a ticket + fence, ~6 without)
+    if (lane == 0) s_p[wave] = p0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long part = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) part += (unsigned long long)__double2ll_rn((double)s_p[w] * 4294967296.0);   // pred >= 0
+        const unsigned long long add = part + (1ull << 48);
+        const unsigned long long old = atomicAdd(acc, add);
+        if ((old >> 48) + 1 == (unsigned long long)gridDim.x) {
+            const unsigned long long total = (old + add) & ((1ull << 48) - 1);
+            loss[0] = (float)((double)total * (1.0 / 4294967296.0) / (2.0 * (double)BN));      // (:976-977)
+            atomicExch(acc, 0ull);                                                               // ready for the next launch
+        }
     }
 }
 
@@ -830,6 +934,20 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     return 0;
 }
 
+extern "C" int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
+                                      float* y, float* pred, float* loss_pred, float* dy, float* g3, float* scratch, void* stream) {
+    using namespace dpd;
+    if (!h3 || !mask || !p || !p->W4 || !p->b4 || !y || !pred || !loss_pred || !scratch) return DPD_E_NULL;
+    if (!dy != !g3) return DPD_E_NULL;
+    if (Q <= 0 || H <= 0 || BN <= 0 || Q != 2 * BN) return DPD_E_DIM;
+    if ((H & 3) || ((uintptr_t)scratch & 7) || Q > 4 * 65535 || BN > (1 << 14)) return DPD_E_UNSUPPORTED;   // 16-bit block count, 48-bit sum
+    const float gv = 0.5f * (1.0f / (float)BN) * gscale;      // = l1_loss_kernel mode 2
+    DPD_LAUNCH(out_asloss_kernel, dim3((Q + 3) / 4), dim3(256), 0, (hipStream_t)stream, h3, p->W4, p->b4, mask, y, pred, dy, g3, Q, H, BN, gv,
+               loss_pred, (unsigned long long*)scratch);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- fused window gather (DPD_F32): layer 1 reads its input rows straight from the Fisher vectors --------------------
 static int check_gather(const dpd_gather* g, int rows, size_t* a_bytes, size_t* xyz_off) {
     if (!g || !g->fv || !g->xyz || !g->rowinfo || !g->table) return DPD_E_NULL;
@@ -886,7 +1004,9 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
                                     void* stream) {
     using namespace dpd;
     const bool l1 = sg && sg->l1_labels;        // fused training loss: dpred is derived inside the output-layer kernel
-    if ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !p || !dy) return DPD_E_NULL;
+    if (phases <= 0 || phases > 31) return DPD_E_DIM;
+    // (phases without 1: the output layer was done before -- an earlier call or dpd_decoder_out_asloss -- and only g3 is read)
+    if (!p || ((phases & 1) && ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !dy))) return DPD_E_NULL;
     if ((!h1 && !(pl && pl->h1_rc)) || (!h2 && !(pl && pl->h2_rc))) return DPD_E_NULL;   // gate from the fp32 activation or its bf16 plane
     // g2 / g1 = NULL: plane compute types whose planes keep g2_rc + g2_r8 (g1_r8, and g1_rc when dX is wanted) need no fp32 copy of
     // the pre-activation gradients either (the next dH GEMM and the weight gradients read the planes; db2 / db1 come out of the

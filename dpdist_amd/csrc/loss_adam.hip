@@ -7,15 +7,6 @@
 
 namespace dpd {
 
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float s = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    return s;
-}
-
 // single block: BN rows of each direction are at most a few 10k
 __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ labels,
                                                        int BN, int mode, float gscale, float* __restrict__ loss,

@@ -15,6 +15,7 @@ dpdist_and_aue.py:36, dpdist_util.py:514-543, tf_util.py:207,217) and are create
 All arithmetic runs in the HIP kernels of dpdist_amd/csrc via ops.py; autograd is wired by `_DPDistFn`.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -226,25 +227,41 @@ class _AsLossFn(torch.autograd.Function):
         B, N, _ = pcA.shape
         pts, X, mask, vox = ops.front_end(pcA, pcB, None, m, sigma, k, P.KP)     # two launches (stack+encoder, norm+gather)
         params = P.views(flat)
-        h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype)
-        # loss_pred AND d loss_pred / d pred [Q,3] from one launch (labels only enter loss_samples, which is not used here); the
-        # upstream gradient is applied once, at the very end of the backward (everything in between is linear in dpred)
         need_grad = pcA.requires_grad or pcB.requires_grad
-        loss, dpred = ops.l1_loss(pred, mask[:B * N], mode=2 if need_grad else 0)
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
-        ctx.save_for_backward(pts, flat, mask, vox, h1, h2, h3, y, dpred if need_grad else pred)
+        ctx.fused_out = B * N <= 16384 and os.environ.get("DPD_ASLOSS_CHAIN") != "1"
+        if ctx.fused_out:
+            # output layer, loss_pred AND the output-layer backward of d loss_pred / d pred from one launch (labels only enter
+            # loss_samples, which is not used here); the upstream gradient is applied once, at the very end of the backward
+            # (everything in between is linear in it)
+            h1, h2, h3, _, _ = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype, out_layer=False)
+            _, _, loss, _, g3 = ops.out_asloss(h3, mask, params, B * N, want_grad=need_grad)
+            if need_grad:
+                ctx.save_for_backward(pts, flat, vox, h1, h2, g3)
+            return loss[0]
+        # three-launch form (very large batches; DPD_ASLOSS_CHAIN=1 for A/B timing): out_fwd, l1_loss(mode 2), out_bwd
+        h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype)
+        loss, dpred = ops.l1_loss(pred, mask[:B * N], mode=2 if need_grad else 0)
+        ctx.save_for_backward(pts, flat, vox, h1, h2, mask, h3, y, dpred if need_grad else pred)
         return loss[1]
 
     @staticmethod
     def backward(ctx, g):
         P = ctx.P
         B, N, m, k, sigma = ctx.cfg
-        pts, flat, mask, vox, h1, h2, h3, y, dpred = ctx.saved_tensors
         Q = 2 * B * N
         dt = P.compute_dtype
+        if ctx.fused_out:
+            pts, flat, vox, h1, h2, g3 = ctx.saved_tensors
+        else:
+            pts, flat, vox, h1, h2, mask, h3, y, dpred = ctx.saved_tensors
         ws = ops.workspace(Q, P.KP, P.H, flat.device, dt) if dt else None
         wT = P.transposed(flat) if dt in ("f32", 0) else None
-        _, _, _, _, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, P.views(flat), P.KP, True, dtype=dt, ws=ws, transposed=wT)
+        if ctx.fused_out:
+            _, _, _, _, dX = ops.decoder_bwd_data(None, None, None, h1, h2, None, P.views(flat), P.KP, True, dtype=dt, ws=ws, transposed=wT,
+                                                  phases=6, g3=g3)
+        else:
+            _, _, _, _, dX = ops.decoder_bwd_data(dpred, mask, y, h1, h2, h3, P.views(flat), P.KP, True, dtype=dt, ws=ws, transposed=wT)
         _, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k, want_dq=False)
         dpts = ops.mfv3d_bwd(pts, dfv, m, sigma)
         gA, gB = ops.asloss_combine(dpts, dX, g, B, N, k)           # upstream * (encoder route + query route), one launch

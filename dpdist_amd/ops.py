@@ -98,14 +98,15 @@ def _ws_args(ws):
     return (L.ptr(ws), ws.numel() * ws.element_size()) if ws is not None else (None, 0)
 
 
-def decoder_fwd(X, mask, params, H, bufs=None, dtype=0, ws=None):
-    """X [Q,KP] -> (h1,h2,h3 [Q,H], y [Q,3], pred [Q,3])   (:513-544, :691, :695-698)"""
+def decoder_fwd(X, mask, params, H, bufs=None, dtype=0, ws=None, out_layer=True):
+    """X [Q,KP] -> (h1,h2,h3 [Q,H], y [Q,3], pred [Q,3])   (:513-544, :691, :695-698); out_layer=False: y = pred = None (left to
+    out_asloss / the fused output-layer kernel of the backward)"""
     L.req(X, name="X"), L.req(mask, name="mask")
     Q, KP = X.shape
     if bufs is None:
         h1, h2, h3 = (torch.empty(Q, H, device=X.device, dtype=torch.float32) for _ in range(3))
-        y = torch.empty(Q, 3, device=X.device, dtype=torch.float32)
-        pred = torch.empty(Q, 3, device=X.device, dtype=torch.float32)
+        y = torch.empty(Q, 3, device=X.device, dtype=torch.float32) if out_layer else None
+        pred = torch.empty(Q, 3, device=X.device, dtype=torch.float32) if out_layer else None
     else:
         h1, h2, h3, y, pred = bufs
     p = L.make_params(*params)
@@ -130,15 +131,44 @@ def stack_clouds(pcA, pcB, noise=None):
     return pts, q
 
 
+_OUT_SCRATCH = {}
+
+
+def out_asloss(h3, mask, params, BN, want_grad=True, gscale=1.0):
+    """Output layer + loss_pred (+ its output-layer backward) of the as-loss mode in one launch (include/dpdist_capi.h:
+    dpd_decoder_out_asloss).  h3 [2*BN,H] -> y, pred [2*BN,3], loss_pred [1], dy [2*BN,3] | None, g3 [2*BN,H] | None"""
+    L.req(h3, name="h3"), L.req(mask, name="mask")
+    Q, H = h3.shape
+    dev = h3.device
+    f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)   # noqa: E731
+    y, pred, loss = f(Q, 3), f(Q, 3), f(1)
+    dy, g3 = (f(Q, 3), f(Q, H)) if want_grad else (None, None)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    scr = _OUT_SCRATCH.get(key)
+    if scr is None:          # the 64-bit accumulator (zero once; the kernel leaves it zero); one per stream
+        if len(_OUT_SCRATCH) > 16:
+            _OUT_SCRATCH.clear()
+        scr = _OUT_SCRATCH[key] = torch.zeros(2, device=dev, dtype=torch.float32)
+    L.check(L.load().dpd_decoder_out_asloss(L.ptr(h3), L.ptr(mask), Q, H, BN, L.make_params(*params), float(gscale), L.ptr(y), L.ptr(pred),
+                                            L.ptr(loss), L.ptr(dy), L.ptr(g3), L.ptr(scr), L.cur_stream()), "dpd_decoder_out_asloss")
+    return y, pred, loss, dy, g3
+
+
 def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None, small_grads=None, dtype=0, ws=None,
-                     transposed=None):
+                     transposed=None, phases=7, g3=None):
     """dpred [Qb,3] (first Qb rows) -> dy [Qb,3], g3,g2,g1 [Qb,H], dX [Qb,KP] or None.
-    small_grads = (db1, db2, db3, dW4, db4) tensors (or None each) to be filled by the fused epilogues."""
-    L.req(dpred, name="dpred")
-    Qb = dpred.shape[0]
+    small_grads = (db1, db2, db3, dW4, db4) tensors (or None each) to be filled by the fused epilogues.
+    phases=6 with g3 given: the output layer was done by out_asloss (dpred / y / h3 may be None)."""
+    if phases & 1:
+        L.req(dpred, name="dpred")
+    Qb = dpred.shape[0] if dpred is not None else g3.shape[0]
     H = h1.shape[1]
-    dev = dpred.device
-    if bufs is None:
+    dev = h1.device
+    if bufs is None and g3 is not None:
+        dy = None
+        g2, g1 = (torch.empty(Qb, H, device=dev, dtype=torch.float32) for _ in range(2))
+        dX = torch.empty(Qb, KP, device=dev, dtype=torch.float32) if want_dX else None
+    elif bufs is None:
         dy = torch.empty(Qb, 3, device=dev, dtype=torch.float32)
         g3, g2, g1 = (torch.empty(Qb, H, device=dev, dtype=torch.float32) for _ in range(3))
         dX = torch.empty(Qb, KP, device=dev, dtype=torch.float32) if want_dX else None
@@ -151,7 +181,7 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None,
         ws = workspace(Qb, KP, H, dev, dtype)
     L.check(L.load().dpd_decoder_bwd_data(L.ptr(dpred), L.ptr(mask), L.ptr(y), L.ptr(h1), L.ptr(h2), L.ptr(h3), Qb, KP, H,
                                           p, dtype, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), sg, *_ws_args(ws),
-                                          None, 7, L.cur_stream()), "dpd_decoder_bwd_data")
+                                          None, phases, L.cur_stream()), "dpd_decoder_bwd_data")
     return dy, g3, g2, g1, dX
 
 

@@ -269,6 +269,17 @@ size_t dpd_workspace_bytes(int Q, int KP, int H, int dtype);
 int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float gscale, float* loss,
                 float* dpred, void* stream);
 
+/* DPDist as a frozen loss (pcrnet-registration/iterative_PCRNet_ours.py:229-257; AUE splice train_multi_gpu_pc_compare_dist.py:417-431):
+ * the output layer of the decoder (utils/dpdist_util.py:691,695-698), loss_pred (:976-977) and -- when dy / g3 are given -- the
+ * output-layer backward for d loss_pred / d pred in ONE launch: replaces the tail of dpd_decoder_fwd (call it with y = pred = NULL),
+ * dpd_l1_loss(mode 2) and phase 1 of dpd_decoder_bwd_data (call it with phases = 6 and this g3).
+ *   h3 [Q,H], mask [Q], Q = 2*BN rows (AB half first), BN <= 16384;  y, pred [Q,3];  loss_pred [1] (the exact sum of pred[:,0] in
+ *   2^-32 fixed point / (2 BN): within an ulp of the fp32 means of :976-977, the same bits on every run);
+ *   dy [Q,3], g3 [Q,H] (both or neither) = the gradient of gscale * loss_pred;
+ *   scratch: 8 bytes, 8-byte aligned, ZERO before the first call (the kernel leaves it zero; one per concurrently running stream). */
+int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
+                           float* y, float* pred, float* loss_pred, float* dy, float* g3, float* scratch, void* stream);
+
 /* Host utility: CRC32C (Castagnoli, reflected, init/xorout ~0) of n bytes continuing from `crc` (0 to start); used
  * by the TensorFlow-checkpoint interchange of dpdist_amd/tf_checkpoint.py.  No device work.                 */
 uint32_t dpd_crc32c(const void* data, size_t n, uint32_t crc);

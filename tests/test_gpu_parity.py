@@ -1092,6 +1092,35 @@ def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
         assert np.abs(g.cpu().numpy() - ref).max() <= bar, (np.abs(g.cpu().numpy() - ref).max(), bar)
 
 
+@pytest.mark.parametrize("B,N,H", [(16, 64, 1024), (3, 4, 192)])
+def test_out_asloss_equals_the_three_kernel_chain(dev, B, N, H):
+    """dpd_decoder_out_asloss (output layer + loss_pred + output-layer backward of d loss_pred / d pred, one launch) against
+    out_fwd + dpd_l1_loss(mode 2) + phase 1 of dpd_decoder_bwd_data: y, pred, dy, g3 bit for bit (same dot-product code, the chain
+    only adds exact zeros), loss_pred up to the summation order; twice in a row (the arrival counter must re-arm itself)."""
+    from dpdist_amd import ops
+    g = torch.Generator().manual_seed(5)
+    Q, KP = 2 * B * N, 64
+    h1 = torch.randn(Q, H, generator=g).to(dev)
+    h3 = torch.randn(Q, H, generator=g).to(dev)
+    mask = (torch.rand(Q, generator=g) > 0.2).float().to(dev)
+    W = [torch.randn(*sh, generator=g).to(dev) * 0.05 for sh in ((KP, H), (H,), (H, H), (H,), (H, H), (H,), (H, 3), (3,))]
+    W[7] = W[7] + 1.0        # y around 1: both sides of the relu6 gate occur
+    hh3, y0, p0 = ops.decoder_fwd(torch.randn(Q, KP, generator=g).to(dev), mask, W, H)[2:]     # the forward's own output layer
+    y_ref = h3.double() @ W[6].double() + W[7].double()
+    for rep in range(2):
+        y, pred, loss, dy, g3 = ops.out_asloss(h3, mask, W, B * N)
+        assert (y.double() - y_ref).abs().max().item() <= 1e-4
+        l_ref, dpred = ops.l1_loss(pred, mask[:B * N], mode=2)
+        assert abs(loss.item() - l_ref[1].item()) <= 2e-7 * max(1.0, abs(l_ref[1].item()))
+        dy_r, g3_r, _, _, _ = ops.decoder_bwd_data(dpred, mask, y, h1, h1, h3, W, KP, False)
+        assert torch.equal(dy, dy_r)
+        assert torch.equal(g3, g3_r)
+        assert (pred - torch.clamp(y, 0.0, 6.0) / 3.0 * mask[:, None]).abs().max().item() <= 1e-6
+    # and y / pred are the bits of the forward's own output layer on the same rows
+    y2, pred2, _, _, _ = ops.out_asloss(hh3, mask, W, B * N, want_grad=False)
+    assert torch.equal(y2, y0) and torch.equal(pred2, p0)
+
+
 @pytest.mark.parametrize("dt", ["f32x3", "bf16"])
 def test_plane_step_without_fp32_copies_is_bitwise_the_step_with_them(dev, dt, monkeypatch):
     """Plane compute types (round 3): fp32 h1 / h2 / g1 / g2 / g3 are not written at all -- layers 2/3 and the weight gradients read
