@@ -316,25 +316,39 @@ __global__ __launch_bounds__(256) void patch_rows_bwd_kernel(const float* __rest
         const int g = gbeg + item / 5, part = item % 5;
         const int g0 = g / (m * m) + h, g1 = (g / m) % m + h, g2 = g % m + h;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // eight queries at a time: all eight loads are issued before the first add (a load inside the `if` made every hit a
-        // serial L2 round trip: ~16 per voxel); a query that does not cover the voxel reads the cloud's first line (L1 hit) and
-        // is dropped by a select, so the sum runs over the same values in the same order (n ascending) as before
-        for (int n0 = 0; n0 < N; n0 += 8) {
-            float4 x[8];
-            bool hit[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = min(n0 + j, N - 1);
-                const int pv = s_vox[n];
+        // Two passes per 64 queries: (1) which of them cover this voxel -- LDS reads (the same address in every lane) and compares only,
+        // a 64-bit hit mask; (2) the hits, eight at a time, all eight loads issued before the first add (a load inside an `if` made every
+        // hit a serial L2 round trip).  A query covers 5^3 of 8^3 voxels, so a thread loads ~16 window columns instead of probing 64
+        // (round 2 issued a load for every query and dropped three quarters of them by a select).  The kernel stays latency bound at the
+        // PCRNet batch (~12 us back to back, C = 32 clouds of 64 queries; a streaming plane-owner form with the voxels in LDS was 14.7).
+        // Same values added in the same order (n ascending) as before.
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            unsigned long long hm = 0;
+            const int lim = min(64, N - n0);
+            for (int j = 0; j < lim; ++j) {
+                const int pv = s_vox[n0 + j];
                 const int d0 = g0 - (pv & 255), d1 = g1 - ((pv >> 8) & 255), d2 = g2 - (pv >> 16);
-                hit[j] = n0 + j < N && (unsigned)d0 < (unsigned)k && (unsigned)d1 < (unsigned)k && (unsigned)d2 < (unsigned)k;
-                const size_t off = hit[j] ? (size_t)n * KP + ((d0 * k + d1) * k + d2) * kF + part * 4 : 0;
-                x[j] = *reinterpret_cast<const float4*>(dXc + off);
+                if ((unsigned)d0 < (unsigned)k && (unsigned)d1 < (unsigned)k && (unsigned)d2 < (unsigned)k) hm |= 1ull << j;
             }
+            while (__any(hm != 0)) {
+                float4 x[8];
+                bool hit[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc.x = hit[j] ? acc.x + x[j].x : acc.x; acc.y = hit[j] ? acc.y + x[j].y : acc.y;
-                acc.z = hit[j] ? acc.z + x[j].z : acc.z; acc.w = hit[j] ? acc.w + x[j].w : acc.w;
+                for (int j = 0; j < 8; ++j) {
+                    hit[j] = hm != 0;
+                    const int bit = hit[j] ? __ffsll((long long)hm) - 1 : 0;
+                    hm = hit[j] ? (hm & (hm - 1)) : 0;
+                    const int n = n0 + bit;
+                    const int pv = s_vox[n];
+                    const int d0 = g0 - (pv & 255), d1 = g1 - ((pv >> 8) & 255), d2 = g2 - (pv >> 16);
+                    const size_t off = hit[j] ? (size_t)n * KP + ((d0 * k + d1) * k + d2) * kF + part * 4 : 0;
+                    x[j] = *reinterpret_cast<const float4*>(dXc + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc.x = hit[j] ? acc.x + x[j].x : acc.x; acc.y = hit[j] ? acc.y + x[j].y : acc.y;
+                    acc.z = hit[j] ? acc.z + x[j].z : acc.z; acc.w = hit[j] ? acc.w + x[j].w : acc.w;
+                }
             }
         }
         *reinterpret_cast<float4*>(dfv + ((size_t)c * G + g) * kF + part * 4) = acc;
@@ -537,7 +551,7 @@ extern "C" int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, in
     if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1) || N > 8192) return DPD_E_UNSUPPORTED;
     if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
     if (dfv) {
-        const int slices = 8;
+        const int slices = (m * m * m + 50) / 51;      // <= 51 voxels x 5 channel groups = one item per thread, no ragged second pass
         DPD_LAUNCH(patch_rows_bwd_kernel, dim3(C * slices), dim3(256), (size_t)N * sizeof(int), (hipStream_t)stream,
                            dX, vox, dfv, N, m, k, KP, slices);
         DPD_CHECK_LAUNCH();
