@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeJobs J) {
 }  // namespace dpd
 
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
-    if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 12) { dpd::g_x3_tile[op - 16] = tile; return 0; }
+    if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 26) { dpd::g_x3_tile[op - 16] = tile; return 0; }
     if (op == 32 && tile >= 0 && tile <= 12 && split_k >= 1 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
     if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
