@@ -418,6 +418,12 @@ struct OutFwd {
     float* pred;    // [2*Qb, 3]
 };
 
+#ifdef DPD_ABLATIONS
+__device__ unsigned long long g_ob_stamps[1024 * 8];       // s_memtime milestones of thread 0 of every workgroup (tools/ob_stamps.py)
+#define OB_STAMP(i) do { if (threadIdx.x == 0) g_ob_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define OB_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __restrict__ dpred, const float* __restrict__ mask,
                                                               const float* __restrict__ y, const float* __restrict__ h3,
                                                               const float* __restrict__ W4, float* __restrict__ dy,
@@ -427,56 +433,86 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
     if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
         for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
     }
+    OB_STAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = H / 256;            // column groups (<= 4)
     const int P = 4 * H + kOBRec;
     constexpr int RW = kOBRows / 4;    // rows per wave
     float lsum[3] = {0.f, 0.f, 0.f};   // loss sums of this wave's rows (identical in every lane)
-    float w4[4][4][3], s3[4][4], a4[4][4][3];
+    float dsum[3] = {0.f, 0.f, 0.f};
+    float d[RW][3];
+    float4 hv[RW][4], hb[RW][4];
+    const int row0 = blockIdx.x * kOBRows + wave * RW;
+    // Every global load of the kernel is requested HERE, before anything waits: W4 above, the rows (and their BA twins) and the per-row
+    // scalars below.  Left where they were used, they made three dependent round trips (W4 -> row 0 -> row 1: 5.5k + 3.9k + 5.7k cycles
+    // of a 25k-cycle kernel at B = 32, tools/ob_stamps.py); with one workgroup per CU there is nothing else to hide them behind.
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int rr = 0; rr < RW; ++rr) {
+        const int row = min(row0 + rr, Qb - 1);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (jj < ng) {
+                hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
+                if (of.y) hb[rr][jj] = *reinterpret_cast<const float4*>(h3 + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
+            }
+        }
+    }
+    float w4[4][4][3], s3[4][4], a4[4][4][3];
+    const bool w4_vec = !((uintptr_t)W4 & 15);       // the 12 floats W4[k..k+3][0..2] of a lane's four columns are three float4 (k % 4 == 0)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (w4_vec && jj < ng) {      // 12 loads per lane instead of 48: the address unit was ~6k of this kernel's 24k cycles at B = 32
+            const float4* wp = reinterpret_cast<const float4*>(W4 + (size_t)(256 * jj + 4 * lane) * 3);
+            const float4 wa = wp[0], wb = wp[1], wc = wp[2];
+            const float w[12] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) w4[jj][e][c] = w[3 * e + c];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             s3[jj][e] = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 a4[jj][e][c] = 0.f;
-                w4[jj][e][c] = (jj < ng) ? W4[(256 * jj + 4 * lane + e) * 3 + c] : 0.f;
+                if (!(w4_vec && jj < ng)) w4[jj][e][c] = (jj < ng) ? W4[(256 * jj + 4 * lane + e) * 3 + c] : 0.f;
             }
         }
-    float dsum[3] = {0.f, 0.f, 0.f};
-    float d[RW][3];
-    float4 hv[RW][4];
-    const int row0 = blockIdx.x * kOBRows + wave * RW;
+    }
+    // the per-row scalars are requested before the row loop: behind the dot products and wave sums they were one more dependent round trip
+    float mk_a[RW], mk_b[RW], lab[RW];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int row = min(row0 + rr, Qb - 1);
+        mk_a[rr] = mask[row];
+        mk_b[rr] = of.y ? mask[Qb + row] : 0.f;
+        lab[rr] = l1.labels ? l1.labels[row] : 0.f;
+    }
+    OB_STAMP(1);
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
         const int row = min(row0 + rr, Qb - 1);
         const bool live = row0 + rr < Qb;
         float yab[3] = {0.f, 0.f, 0.f}, pab0 = 0.f, pba0 = 0.f;
         if (of.y) {                // forward of the output layer for this AB row and its BA twin (out_fwd_kernel's order)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jj < ng) hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
-            float4 hb[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jj < ng) hb[jj] = *reinterpret_cast<const float4*>(h3 + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
             float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 if (jj < ng) {
                     const float xa[4] = {hv[rr][jj].x, hv[rr][jj].y, hv[rr][jj].z, hv[rr][jj].w};
-                    const float xb[4] = {hb[jj].x, hb[jj].y, hb[jj].z, hb[jj].w};
+                    const float xb[4] = {hb[rr][jj].x, hb[rr][jj].y, hb[rr][jj].z, hb[rr][jj].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) { a[c] += xa[e] * w4[jj][e][c]; b[c] += xb[e] * w4[jj][e][c]; }
                 }
             }
+            if (rr == 0) { asm volatile("" :: "v"(a[0]), "v"(b[2])); OB_STAMP(2); }
             float yba[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { yab[c] = wave_sum(a[c]) + of.b4[c]; yba[c] = wave_sum(b[c]) + of.b4[c]; }
-            const float ma = mask[row], mb = mask[Qb + row];
+            const float ma = mk_a[rr], mb = mk_b[rr];
             float pa[3], pb[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -490,11 +526,12 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
                 of.y[(size_t)row * 3 + lane] = ya; of.y[((size_t)Qb + row) * 3 + lane] = yb;
                 of.pred[(size_t)row * 3 + lane] = qa; of.pred[((size_t)Qb + row) * 3 + lane] = qb;
             }
+            if (rr == 0) OB_STAMP(3);
         }
         float dp[3];
         if (l1.labels) {           // d mean|pred_AB[:,0] - labels| / d pred_AB (tf.abs gradient = sign), channels 1, 2 get none
             const float pab = of.y ? pab0 : l1.pred[(size_t)row * 3], pba = of.y ? pba0 : l1.pred[((size_t)Qb + row) * 3];
-            const float df = pab - l1.labels[row];
+            const float df = pab - lab[rr];
             dp[0] = ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f)) * (1.0f / (float)Qb) * l1.gscale;
             dp[1] = 0.f; dp[2] = 0.f;
             if (live) { lsum[0] += fabsf(df); lsum[1] += pab; lsum[2] += pba; }
@@ -505,15 +542,11 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float yv = of.y ? yab[c] : y[(size_t)row * 3 + c];
-            d[rr][c] = (live && yv > 0.f && yv < 6.f) ? dp[c] * mask[row] / 3.0f : 0.f;   // relu6' = 1 on (0,6)
+            d[rr][c] = (live && yv > 0.f && yv < 6.f) ? dp[c] * mk_a[rr] / 3.0f : 0.f;   // relu6' = 1 on (0,6)
             dsum[c] += d[rr][c];
         }
-        if (!of.y) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (jj < ng) hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
-        }
     }
+    OB_STAMP(4);
     uint2 wpk[RW][4][3] = {};
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
@@ -537,7 +570,10 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
                 if (gp.rc || gp.r8) {
                     unsigned pl4[4][3];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split3(gg[e], pl4[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        if (gp.np == 1) { pl4[e][0] = bf16_bits(gg[e]); pl4[e][1] = 0; pl4[e][2] = 0; }     // one plane: one conversion, not the three-plane split
+                        else split3(gg[e], pl4[e]);
+                    }
                     const int col = 256 * jj + 4 * lane;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
@@ -549,23 +585,24 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
             }
         }
     }
+    OB_STAMP(5);
     float* mine = s_acc + wave * P;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         if (jj < ng) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = 256 * jj + 4 * lane + e;
-                mine[k] = s3[jj][e];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) mine[H + k * 3 + c] = a4[jj][e][c];
-            }
+            const int k = 256 * jj + 4 * lane;          // four columns: 4 + 12 contiguous floats, 16-byte aligned (H % 256 == 0, P % 4 == 0)
+            *reinterpret_cast<float4*>(mine + k) = make_float4(s3[jj][0], s3[jj][1], s3[jj][2], s3[jj][3]);
+            float4* m4 = reinterpret_cast<float4*>(mine + H + k * 3);
+            m4[0] = make_float4(a4[jj][0][0], a4[jj][0][1], a4[jj][0][2], a4[jj][1][0]);
+            m4[1] = make_float4(a4[jj][1][1], a4[jj][1][2], a4[jj][2][0], a4[jj][2][1]);
+            m4[2] = make_float4(a4[jj][2][2], a4[jj][3][0], a4[jj][3][1], a4[jj][3][2]);
         }
     }
     if (lane < 3) mine[4 * H + lane] = (lane == 0) ? dsum[0] : ((lane == 1) ? dsum[1] : dsum[2]);
     if (lane < 3) mine[4 * H + 4 + lane] = (lane == 0) ? lsum[0] : ((lane == 1) ? lsum[1] : lsum[2]);
     if (lane == 3) { mine[4 * H + 3] = 0.f; mine[4 * H + 7] = 0.f; }
     __syncthreads();
+    OB_STAMP(6);
     float* out = scratch + (size_t)blockIdx.x * P;
     for (int i = threadIdx.x; i < 4 * H + 7; i += 256) out[i] = ((s_acc[i] + s_acc[P + i]) + s_acc[2 * P + i]) + s_acc[3 * P + i];
     if (gp.r8) {      // the block's 8 rows = one row group: column c's chunk = its 8 rows (Qb % 8 == 0 when planes are in use)
@@ -588,6 +625,7 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
                     make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
             }
     }
+    OB_STAMP(7);
 }
 
 // out[i] = sum_b scratch[b][i] in a fixed order: 16 outputs x 16 block-slices per workgroup, LDS tree at the end
@@ -792,6 +830,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(TransposeJobs J) {
 
 }  // namespace dpd
 
+#ifdef DPD_ABLATIONS
+extern "C" int dpd_debug_ob_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dpd::g_ob_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
     if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 26) { dpd::g_x3_tile[op - 16] = tile; return 0; }
     if (op == 32 && tile >= 0 && tile <= 12 && split_k >= 1 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }

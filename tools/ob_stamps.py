@@ -1,0 +1,32 @@
+"""Milestones of the fused output-layer kernel of the training step (out_bwd_fused4_kernel; s_memtime of thread 0 of every workgroup;
+ablation build: DPD_ABLATIONS=1 python -m dpdist_amd.build --force).   python tools/ob_stamps.py [B] [dtype]"""
+import ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dpdist_amd import lib as L, synth  # noqa: E402
+from dpdist_amd.model import DPDistParams  # noqa: E402
+from dpdist_amd.trainer import DPDistTrainer  # noqa: E402
+
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dt = sys.argv[2] if len(sys.argv) > 2 else "f32"
+P = DPDistParams(device=dev, compute_dtype=dt)
+P.load_tf_state_dict(synth.make_weights("wide"))
+tr = DPDistTrainer(P, B, 64)
+batch = [torch.tensor(x, device=dev) for x in synth.s2_modelnet_shaped(B, 64, 100)]
+for _ in range(5):
+    tr.step(*batch)
+torch.cuda.synchronize()
+lib = L.load()
+buf = (ctypes.c_ulonglong * (1024 * 8))()
+f = lib.dpd_debug_ob_stamps
+f.argtypes = [ctypes.c_void_p]
+assert f(buf) == 0
+n = min(1024, B * 64 // 8)
+st = np.array(buf, dtype=np.uint64).reshape(1024, 8)[:n, :8].astype(np.int64)
+d = np.diff(st, axis=1)
+names = ["zero list, W4 / per-row scalars requested", "row 0: h3 rows (AB + BA twin) arrive, dot products", "row 0: wave sums, pred, y / pred stores", "row 1 (same)", "g3 (+ RC planes), s3 / a4 sums", "slabs to LDS + barrier", "4-slab sum -> block partial, R8 image + chunks"]
+print("B=%d %s, %d workgroups; cycles per section (median / max over workgroups), total median %d" % (B, dt, n, np.median(st[:, 7] - st[:, 0])))
+for i, nm in enumerate(names):
+    print("  %-46s %7.0f / %7.0f" % (nm, np.median(d[:, i]), d[:, i].max()))
