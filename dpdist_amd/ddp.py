@@ -157,11 +157,14 @@ class _Rccl:
         L = cls.lib()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         uid = cls.UniqueId()
-        if rank == 0:
-            cls.check(L.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+        rc0 = L.ncclGetUniqueId(ctypes.byref(uid)) if rank == 0 else 0
+        # rank 0's status travels with the id: every rank takes part in the broadcast and every rank sees the same failure
+        t = torch.frombuffer(bytearray(bytes(uid) + bytes([1 if rc0 == 0 else 0])), dtype=torch.uint8).to(device)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        raw = t.cpu().numpy().tobytes()
+        if raw[128] != 1:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
+        ctypes.memmove(ctypes.byref(uid), raw[:128], 128)
         comm = ctypes.c_void_p()
         cls.check(L.ncclCommInitRank(ctypes.byref(comm), world, uid, rank), "ncclCommInitRank")
         return comm
@@ -274,8 +277,17 @@ def make_reducer(flat_grad, bounds, group=None, force=False):
     want = os.environ.get("DPD_DP_BACKEND", "rccl")
     if (dist.is_initialized() and (world > 1 or force) and flat_grad.is_cuda and want == "rccl" and dist.get_backend(group) == "nccl"
             and os.environ.get("DPD_DP_MODE", "allreduce") == "allreduce"):
+        red, err = None, None
         try:
-            return DirectRcclReducer(flat_grad, bounds, group)
+            red = DirectRcclReducer(flat_grad, bounds, group)
         except Exception as e:      # plumbing only: the torch.distributed path computes the same sums
-            sys.stderr.write("dpdist_amd.ddp: direct RCCL unavailable (%r), using torch.distributed collectives\n" % (e,))
+            err = e
+        # the choice must be the same on every rank (a rank that fell back alone would wait for collectives the others never issue)
+        ok = torch.tensor([1 if red is not None else 0], device=flat_grad.device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            return red
+        if red is not None:
+            red.close()
+        sys.stderr.write("dpdist_amd.ddp: direct RCCL unavailable on some rank (%r here), using torch.distributed collectives\n" % (err,))
     return BucketReducer(flat_grad, bounds, group, force=force)
