@@ -186,6 +186,12 @@ __global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __r
 // 40 KB of Fisher vectors as 83 MB of scattered 16-byte gathers per launch.  Measured and dropped: the cloud's Fisher vectors staged
 // in LDS with several row groups per workgroup (30.8 us: one 8-wave workgroup per CU cannot hide its own barriers), five work items
 // per lane with all gathers in flight before the first store (26.6 us), unit pairs of 8 rows per thread (39 us at 180 VGPRs).
+#ifdef DPD_ABLATIONS
+__device__ unsigned long long g_pr_stamps[1024 * 8];       // s_memtime milestones of thread 0 of every workgroup (tools/gather_stamps.py)
+#define PR_STAMP(i) do { if (threadIdx.x == 0) g_pr_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PR_STAMP(i) do { } while (0)
+#endif
 template <int NP>
 __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __restrict__ q, const float* __restrict__ fv,
                                                                  float* __restrict__ X, float* __restrict__ mask,
@@ -197,6 +203,7 @@ __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __
     uint16_t* s_img = reinterpret_cast<uint16_t*>(s_tab + KP / 4);             // [NP][8][KP] (only when R8 planes are written)
     __shared__ RowInfo s_row[8];
     __shared__ __attribute__((aligned(16))) float s_sc[8][kF];
+    PR_STAMP(0);
     const int tid = threadIdx.x;
     const int G = m * m * m, h = (k - 1) / 2;
     const int E4 = k * k * k * (kF / 4), U = KP / 4, U2 = KP / 8;            // window units; units / 8-column groups per row
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __
             vox[r] = (iy * m + ix) * m + iz;
         }
         __syncthreads();
+        PR_STAMP(1);
         const bool want_r8 = r8 && (8 * rg < r8_rows);
         // ---- pass A: wave = row ----
         {
@@ -280,8 +288,10 @@ __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __
                 }
             }
         }
+        PR_STAMP(2);
         if (!want_r8) return;                                         // uniform per workgroup
         __syncthreads();
+        PR_STAMP(3);
         // ---- pass B ----
         for (int c = tid; c < KP; c += 512) {
 #pragma unroll
@@ -293,7 +303,159 @@ __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __
                     make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
             }
         }
+        PR_STAMP(4);
     }
+}
+
+// Round 3, second form (plane compute types that keep no fp32 X): the 8 rows of a row group are 8 queries of ONE cloud (N % 8 == 0), and
+// what they gather is that cloud's 512 x 20 Fisher vector, scaled and rounded to the planes -- the same 10240 values whichever row asks.
+// So the workgroup converts the cloud's vector ONCE (40 KB of coalesced float4 loads, x * scale, bf16 / three-plane split: the values
+// the row-wise kernel computes per gathered element, so the planes keep their bits) into 20 KB of LDS per plane, and both passes read LDS:
+//   pass A (wave = row): two 8-byte LDS reads per 8-column group, one uint4 per plane to the RC plane (1 KiB per wave-instruction);
+//   pass B (R8 rows): work item = column, its 8 rows are 8 two-byte LDS reads; no LDS image of the rows, no barrier between the passes.
+// The stamps of the kernel above (tools/gather_stamps.py, B = 64, one plane: 28.6k cycles per workgroup, 9.1k of them before the first
+// gather, 13.1k in pass A at the address unit's rate for ~26 cache lines per gather instruction, 45 KB of LDS = 3 workgroups per CU =
+// 1.33 rounds for the 1024 workgroups) are what this form removes: 25 KB of LDS (4 workgroups per CU, one round), 83 MB of scattered
+// 16-byte L2 gathers become 42 MB of linear reads, 20.7 M conversions become 10.5 M.
+template <int NP>
+__global__ __launch_bounds__(512) void patch_rows_planes_lds_kernel(const float* __restrict__ q, const float* __restrict__ fv,
+                                                                    float* __restrict__ mask, int32_t* __restrict__ vox, int Q, int N,
+                                                                    int m, int k, int KP, GridAxis ax, uint16_t* __restrict__ rc,
+                                                                    long rc_plane, uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
+                                                                    const float* __restrict__ ssq, int nsl) {
+    extern __shared__ __attribute__((aligned(16))) int2 s_tab2[];             // [KP/4] unit table (as above), then the planes
+    const int U = KP / 4, U2 = KP / 8;
+    const int G = m * m * m, h = (k - 1) / 2, GF = G * kF;
+    uint16_t* s_fv = reinterpret_cast<uint16_t*>(s_tab2 + U);                // [NP][GF]
+    __shared__ RowInfo s_row[8];
+    __shared__ __attribute__((aligned(16))) float s_sc[kF];
+    __shared__ __attribute__((aligned(8))) uint16_t s_qc[3][8][4];           // planes of (q - centre, 0) of the 8 rows
+    PR_STAMP(0);
+    const int tid = threadIdx.x, rg = blockIdx.x;
+    const int cloud = (8 * rg) / N;
+    const float4* fvc = reinterpret_cast<const float4*>(fv + (size_t)cloud * GF);
+    const int nv = GF / 4;
+    // ---- everything global is requested first; the unit table is built in the shadow of those loads ----
+    constexpr int PRE = 5;                                                    // m = 8: 2560 float4 = 5 per thread
+    float4 pre[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+        const int idx = tid + 512 * i;
+        pre[i] = idx < nv ? fvc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < kF) s_sc[tid] = ssq ? fv_scale(ssq, nsl, cloud, tid) : 1.0f;
+    if (tid >= 64 && tid < 72) {
+        const int rr = tid - 64, r = 8 * rg + rr;
+        const float qx = q[(size_t)r * 3], qy = q[(size_t)r * 3 + 1], qz = q[(size_t)r * 3 + 2];
+        int ix = cell_of(ax, m, qx), iy = cell_of(ax, m, qy), iz = cell_of(ax, m, qz);
+        const bool valid = (ix >= 0) && (iy >= 0) && (iz >= 0);
+        if (!valid) { ix = 0; iy = 0; iz = 0; }
+        const float dq[4] = {qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz], 0.f};
+        s_row[rr] = RowInfo{ix, iy, iz, r / N, dq[0], dq[1], dq[2]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned p3[3];
+            split3(dq[c], p3);
+            if (NP == 1) p3[0] = bf16_bits(dq[c]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) s_qc[p][rr][c] = (uint16_t)p3[p];
+        }
+        mask[r] = valid ? 1.f : 0.f;
+        vox[r] = (iy * m + ix) * m + iz;
+    }
+    const int E4 = k * k * k * (kF / 4);
+    for (int j = tid; j < U; j += 512) {
+        int2 e = make_int2(0, (j == E4 ? 1 : 2) << 24);               // y >> 24: 0 = window unit, 1 = the q - centre unit, 2 = zero padding
+        if (j < E4) {
+            const int nb = j / 5, part = j % 5;
+            const int d0 = nb / (k * k), d1 = (nb / k) % k, d2 = nb % k;       // 0 .. k-1 (displacement + h), grid axes (y, x, z)
+            e = make_int2((((d0 - h) * m + (d1 - h)) * m + (d2 - h)) * kF + part * 4, d0 | (d1 << 8) | (d2 << 16));
+        }
+        s_tab2[j] = e;
+    }
+    __syncthreads();                                                          // scales, row info, table
+    PR_STAMP(1);
+    auto stage = [&](int idx, float4 x) {
+        const float4 sc = *reinterpret_cast<const float4*>(&s_sc[(idx % 5) * 4]);
+        const float v[4] = {x.x * sc.x, x.y * sc.y, x.z * sc.z, x.w * sc.w};
+        unsigned pl[4][3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (NP == 1) pl[c][0] = bf16_bits(v[c]);
+            else split3(v[c], pl[c]);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            *reinterpret_cast<uint2*>(s_fv + (size_t)p * GF + 4 * idx) = make_uint2(pl[0][p] | (pl[1][p] << 16), pl[2][p] | (pl[3][p] << 16));
+    };
+#pragma unroll
+    for (int i = 0; i < PRE; ++i)
+        if (tid + 512 * i < nv) stage(tid + 512 * i, pre[i]);
+    for (int idx = tid + 512 * PRE; idx < nv; idx += 512) stage(idx, fvc[idx]);      // (m > 8 only)
+    __syncthreads();
+    PR_STAMP(2);
+    const bool want_r8 = r8 && (8 * rg < r8_rows);
+    // ---- pass A: wave = row ----
+    if (rc) {
+        const int rr = tid >> 6, lane = tid & 63;
+        const RowInfo ri = s_row[rr];
+        const size_t row = (size_t)(8 * rg + rr);
+        const int own = ((ri.iy * m + ri.ix) * m + ri.iz) * kF;
+        const int by = ri.iy - h, bx = ri.ix - h, bz = ri.iz - h;
+        for (int t = lane; t < U2; t += 64) {
+            uint2 w[2][NP];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int2 e = s_tab2[2 * t + u];
+                const int kind = e.y >> 24;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) w[u][p] = make_uint2(0u, 0u);
+                if (kind == 0) {
+                    const int g0 = by + (e.y & 0xff), g1 = bx + ((e.y >> 8) & 0xff), g2 = bz + ((e.y >> 16) & 0xff);
+                    if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) w[u][p] = *reinterpret_cast<const uint2*>(s_fv + (size_t)p * GF + own + e.x);
+                    }
+                } else if (kind == 1) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) w[u][p] = *reinterpret_cast<const uint2*>(&s_qc[p][rr][0]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                *reinterpret_cast<uint4*>(rc + p * rc_plane + row * KP + 8 * t) = make_uint4(w[0][p].x, w[0][p].y, w[1][p].x, w[1][p].y);
+        }
+    }
+    PR_STAMP(3);
+    if (!want_r8) return;
+    // ---- pass B: work item = column; its 8 rows straight from the planes in LDS ----
+    for (int c = tid; c < KP; c += 512) {
+        const int2 e = s_tab2[c >> 2];
+        const int kind = e.y >> 24, sub = c & 3;
+        unsigned b[NP][8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const RowInfo ri = s_row[rr];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) b[p][rr] = 0u;
+            if (kind == 0) {
+                const int g0 = ri.iy - h + (e.y & 0xff), g1 = ri.ix - h + ((e.y >> 8) & 0xff), g2 = ri.iz - h + ((e.y >> 16) & 0xff);
+                if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m) {
+                    const int at = ((ri.iy * m + ri.ix) * m + ri.iz) * kF + e.x + sub;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) b[p][rr] = s_fv[(size_t)p * GF + at];
+                }
+            } else if (kind == 1) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) b[p][rr] = s_qc[p][rr][sub];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            *reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + c) * 8) =
+                make_uint4(b[p][0] | (b[p][1] << 16), b[p][2] | (b[p][3] << 16), b[p][4] | (b[p][5] << 16), b[p][6] | (b[p][7] << 16));
+    }
+    PR_STAMP(4);
 }
 
 // Backward as a gather (deterministic, no atomics): block (c, slice) owns a slice of the voxels of cloud c and,
@@ -506,6 +668,21 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
         if (old_form) {
             DPD_LAUNCH(patch_rows_planes_kernel, dim3((Q / 8) * 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
                        KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+        } else if (!X && !(N & 7) && !getenv("DPD_GATHER_PLANES_V2") &&
+                   (size_t)pl->np * m * m * m * kF * sizeof(uint16_t) + (size_t)(KP / 4) * sizeof(int2) <= 100 * 1024) {
+            // no fp32 rows wanted and a row group never straddles two clouds: the cloud's planes are made once per workgroup, in LDS
+            const size_t lds = (size_t)pl->np * m * m * m * kF * sizeof(uint16_t) + (size_t)(KP / 4) * sizeof(int2);
+            if (pl->np == 1) {
+                static LdsOptIn ll1;
+                if (int rc2 = ensure_dyn_lds(ll1, (const void*)patch_rows_planes_lds_kernel<1>, lds)) return rc2;
+                DPD_LAUNCH(patch_rows_planes_lds_kernel<1>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+            } else {
+                static LdsOptIn ll3;
+                if (int rc2 = ensure_dyn_lds(ll3, (const void*)patch_rows_planes_lds_kernel<3>, lds)) return rc2;
+                DPD_LAUNCH(patch_rows_planes_lds_kernel<3>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+            }
         } else {
             const size_t lds = (pl->X_r8 ? (size_t)pl->np * 8 * KP * sizeof(uint16_t) : 0) + (size_t)(KP / 4) * sizeof(int2);
             if (lds > 150 * 1024) return DPD_E_UNSUPPORTED;
@@ -543,6 +720,11 @@ extern "C" int dpd_asloss_combine(const float* dpts, const float* dX, const floa
     return 0;
 }
 
+#ifdef DPD_ABLATIONS
+extern "C" int dpd_debug_pr_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dpd::g_pr_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 extern "C" int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, int N, int m, int k, int KP, float* dq,
                                   float* dfv, void* stream) {
     using namespace dpd;
