@@ -318,20 +318,33 @@ __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __
 // 1.33 rounds for the 1024 workgroups) are what this form removes: 25 KB of LDS (4 workgroups per CU, one round), 83 MB of scattered
 // 16-byte L2 gathers become 42 MB of linear reads, 20.7 M conversions become 10.5 M.
 template <int NP>
-__global__ __launch_bounds__(512) void patch_rows_planes_lds_kernel(const float* __restrict__ q, const float* __restrict__ fv,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NP == 1 ? 8 : 4)))      // one plane: <= 64 VGPRs = 4 workgroups per CU = one round at B = 64
+void patch_rows_planes_lds_kernel(const float* __restrict__ q, const float* __restrict__ fv,
                                                                     float* __restrict__ mask, int32_t* __restrict__ vox, int Q, int N,
                                                                     int m, int k, int KP, GridAxis ax, uint16_t* __restrict__ rc,
                                                                     long rc_plane, uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
-                                                                    const float* __restrict__ ssq, int nsl) {
+                                                                    const float* __restrict__ ssq, int nsl, unsigned mg_k, unsigned mg_kk) {
     extern __shared__ __attribute__((aligned(16))) int2 s_tab2[];             // [KP/4] unit table (as above), then the planes
     const int U = KP / 4, U2 = KP / 8;
     const int G = m * m * m, h = (k - 1) / 2, GF = G * kF;
     uint16_t* s_fv = reinterpret_cast<uint16_t*>(s_tab2 + U);                // [NP][GF]
     __shared__ RowInfo s_row[8];
+    __shared__ int2 s_rb[8];                                                  // per row: {offset of its own voxel in the planes, validity bits of the displacements: axis a, d -> bit 8a + d}
     __shared__ __attribute__((aligned(16))) float s_sc[kF];
     __shared__ __attribute__((aligned(8))) uint16_t s_qc[3][8][4];           // planes of (q - centre, 0) of the 8 rows
     PR_STAMP(0);
-    const int tid = threadIdx.x, rg = blockIdx.x;
+    const int tid = threadIdx.x;
+    // Workgroups go to the 8 XCDs round robin and every XCD has its own L2: with rg = blockIdx.x the N/8 row groups of a cloud would
+    // pull its Fisher vector through 8 different L2s.  Cloud c is therefore handled on XCD c % 8 (all its row groups; the clouds that
+    // carry gradient rows -- the first half -- stay spread evenly), whenever the cloud count is a multiple of 8.
+    int rg = blockIdx.x;
+    {
+        const int rgpc = N / 8, clouds = (Q / 8) / rgpc;
+        if (!(clouds & 7)) {
+            const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+            rg = ((i / rgpc) * 8 + xcd) * rgpc + i % rgpc;
+        }
+    }
     const int cloud = (8 * rg) / N;
     const float4* fvc = reinterpret_cast<const float4*>(fv + (size_t)cloud * GF);
     const int nv = GF / 4;
@@ -352,6 +365,13 @@ __global__ __launch_bounds__(512) void patch_rows_planes_lds_kernel(const float*
         if (!valid) { ix = 0; iy = 0; iz = 0; }
         const float dq[4] = {qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz], 0.f};
         s_row[rr] = RowInfo{ix, iy, iz, r / N, dq[0], dq[1], dq[2]};
+        unsigned vb = 0;
+        for (int d = 0; d < k; ++d) {
+            if ((unsigned)(iy - h + d) < (unsigned)m) vb |= 1u << d;
+            if ((unsigned)(ix - h + d) < (unsigned)m) vb |= 1u << (8 + d);
+            if ((unsigned)(iz - h + d) < (unsigned)m) vb |= 1u << (16 + d);
+        }
+        s_rb[rr] = make_int2(((iy * m + ix) * m + iz) * kF, (int)vb);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             unsigned p3[3];
@@ -367,8 +387,12 @@ __global__ __launch_bounds__(512) void patch_rows_planes_lds_kernel(const float*
     for (int j = tid; j < U; j += 512) {
         int2 e = make_int2(0, (j == E4 ? 1 : 2) << 24);               // y >> 24: 0 = window unit, 1 = the q - centre unit, 2 = zero padding
         if (j < E4) {
-            const int nb = j / 5, part = j % 5;
-            const int d0 = nb / (k * k), d1 = (nb / k) % k, d2 = nb % k;       // 0 .. k-1 (displacement + h), grid axes (y, x, z)
+            // no integer divider on gfx950 (~35 VALU instructions per run-time division, and 32 waves per CU build this table at the same
+            // time: 11k of this kernel's first 15.6k cycles): j / 5 is a compile-time division, the two by k and k*k are multiplications
+            // by host-made reciprocals (2^16 / k rounded up; exact on 0 .. k^3 - 1, checked by the launcher)
+            const int nb = j / 5, part = j - 5 * nb;
+            const int d0 = (int)(((unsigned)nb * mg_kk) >> 16), r = nb - d0 * k * k;
+            const int d1 = (int)(((unsigned)r * mg_k) >> 16), d2 = r - d1 * k;       // 0 .. k-1 (displacement + h), grid axes (y, x, z)
             e = make_int2((((d0 - h) * m + (d1 - h)) * m + (d2 - h)) * kF + part * 4, d0 | (d1 << 8) | (d2 << 16));
         }
         s_tab2[j] = e;
@@ -398,10 +422,9 @@ __global__ __launch_bounds__(512) void patch_rows_planes_lds_kernel(const float*
     // ---- pass A: wave = row ----
     if (rc) {
         const int rr = tid >> 6, lane = tid & 63;
-        const RowInfo ri = s_row[rr];
         const size_t row = (size_t)(8 * rg + rr);
-        const int own = ((ri.iy * m + ri.ix) * m + ri.iz) * kF;
-        const int by = ri.iy - h, bx = ri.ix - h, bz = ri.iz - h;
+        const int own = s_rb[rr].x;
+        const unsigned vbits = (unsigned)s_rb[rr].y;
         for (int t = lane; t < U2; t += 64) {
             uint2 w[2][NP];
 #pragma unroll
@@ -411,8 +434,7 @@ __global__ __launch_bounds__(512) void patch_rows_planes_lds_kernel(const float*
 #pragma unroll
                 for (int p = 0; p < NP; ++p) w[u][p] = make_uint2(0u, 0u);
                 if (kind == 0) {
-                    const int g0 = by + (e.y & 0xff), g1 = bx + ((e.y >> 8) & 0xff), g2 = bz + ((e.y >> 16) & 0xff);
-                    if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m) {
+                    if ((vbits >> (e.y & 0xff)) & (vbits >> (8 + ((e.y >> 8) & 0xff))) & (vbits >> (16 + ((e.y >> 16) & 0xff))) & 1u) {
 #pragma unroll
                         for (int p = 0; p < NP; ++p) w[u][p] = *reinterpret_cast<const uint2*>(s_fv + (size_t)p * GF + own + e.x);
                     }
@@ -428,32 +450,46 @@ __global__ __launch_bounds__(512) void patch_rows_planes_lds_kernel(const float*
     }
     PR_STAMP(3);
     if (!want_r8) return;
-    // ---- pass B: work item = column; its 8 rows straight from the planes in LDS ----
-    for (int c = tid; c < KP; c += 512) {
-        const int2 e = s_tab2[c >> 2];
-        const int kind = e.y >> 24, sub = c & 3;
-        unsigned b[NP][8];
+    // ---- pass B: work item = one float4 unit (4 columns): per row ONE 8-byte LDS read gives the unit's four values; the 4 x 8 block is
+    // transposed in registers into the four R8 chunks (64 contiguous bytes per plane) ----
+    int2 rb[8];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const RowInfo ri = s_row[rr];
+    for (int rr = 0; rr < 8; ++rr) rb[rr] = s_rb[rr];
+    for (int j = tid; j < U; j += 512) {
+        const int2 e = s_tab2[j];
+        const int kind = e.y >> 24;
+        const int s0 = e.y & 0xff, s1 = 8 + ((e.y >> 8) & 0xff), s2 = 16 + ((e.y >> 16) & 0xff);
+        unsigned ok = 0;
+        if (kind == 0) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) b[p][rr] = 0u;
-            if (kind == 0) {
-                const int g0 = ri.iy - h + (e.y & 0xff), g1 = ri.ix - h + ((e.y >> 8) & 0xff), g2 = ri.iz - h + ((e.y >> 16) & 0xff);
-                if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m) {
-                    const int at = ((ri.iy * m + ri.ix) * m + ri.iz) * kF + e.x + sub;
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) b[p][rr] = s_fv[(size_t)p * GF + at];
-                }
-            } else if (kind == 1) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) b[p][rr] = s_qc[p][rr][sub];
+            for (int rr = 0; rr < 8; ++rr) {
+                const unsigned vb = (unsigned)rb[rr].y;
+                ok |= ((vb >> s0) & (vb >> s1) & (vb >> s2) & 1u) << rr;
             }
         }
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
-            *reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + c) * 8) =
-                make_uint4(b[p][0] | (b[p][1] << 16), b[p][2] | (b[p][3] << 16), b[p][4] | (b[p][5] << 16), b[p][6] | (b[p][7] << 16));
+        for (int p = 0; p < NP; ++p) {           // one plane at a time: 8 reads, 4 chunks (three planes at once spilled registers)
+            uint2 v[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                v[rr] = make_uint2(0u, 0u);
+                if (kind == 0) {
+                    if ((ok >> rr) & 1u) v[rr] = *reinterpret_cast<const uint2*>(s_fv + (size_t)p * GF + rb[rr].x + e.x);
+                } else if (kind == 1) {
+                    v[rr] = *reinterpret_cast<const uint2*>(&s_qc[p][rr][0]);
+                }
+            }
+            uint4* out = reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + 4 * j) * 8);
+            // column 0 / 1 = low / high half of .x of every row, column 2 / 3 of .y  (v_perm_b32 selects two 16-bit halves)
+#define DPD_LO(a, b) __builtin_amdgcn_perm((b), (a), 0x05040100u)
+#define DPD_HI(a, b) __builtin_amdgcn_perm((b), (a), 0x07060302u)
+            out[0] = make_uint4(DPD_LO(v[0].x, v[1].x), DPD_LO(v[2].x, v[3].x), DPD_LO(v[4].x, v[5].x), DPD_LO(v[6].x, v[7].x));
+            out[1] = make_uint4(DPD_HI(v[0].x, v[1].x), DPD_HI(v[2].x, v[3].x), DPD_HI(v[4].x, v[5].x), DPD_HI(v[6].x, v[7].x));
+            out[2] = make_uint4(DPD_LO(v[0].y, v[1].y), DPD_LO(v[2].y, v[3].y), DPD_LO(v[4].y, v[5].y), DPD_LO(v[6].y, v[7].y));
+            out[3] = make_uint4(DPD_HI(v[0].y, v[1].y), DPD_HI(v[2].y, v[3].y), DPD_HI(v[4].y, v[5].y), DPD_HI(v[6].y, v[7].y));
+#undef DPD_LO
+#undef DPD_HI
+        }
     }
     PR_STAMP(4);
 }
@@ -672,16 +708,19 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
                    (size_t)pl->np * m * m * m * kF * sizeof(uint16_t) + (size_t)(KP / 4) * sizeof(int2) <= 100 * 1024) {
             // no fp32 rows wanted and a row group never straddles two clouds: the cloud's planes are made once per workgroup, in LDS
             const size_t lds = (size_t)pl->np * m * m * m * kF * sizeof(uint16_t) + (size_t)(KP / 4) * sizeof(int2);
+            const unsigned mg_k = 65536u / k + 1, mg_kk = 65536u / (k * k) + 1;          // reciprocals for the unit table
+            for (int x = 0; x < k * k * k; ++x)
+                if ((int)((x * mg_kk) >> 16) != x / (k * k) || (int)(((x % (k * k)) * mg_k) >> 16) != (x % (k * k)) / k) return DPD_E_UNSUPPORTED;
             if (pl->np == 1) {
                 static LdsOptIn ll1;
                 if (int rc2 = ensure_dyn_lds(ll1, (const void*)patch_rows_planes_lds_kernel<1>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes_lds_kernel<1>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
-                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk);
             } else {
                 static LdsOptIn ll3;
                 if (int rc2 = ensure_dyn_lds(ll3, (const void*)patch_rows_planes_lds_kernel<3>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes_lds_kernel<3>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
-                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk);
             }
         } else {
             const size_t lds = (pl->X_r8 ? (size_t)pl->np * 8 * KP * sizeof(uint16_t) : 0) + (size_t)(KP / 4) * sizeof(int2);
