@@ -494,6 +494,101 @@ void patch_rows_planes_lds_kernel(const float* __restrict__ q, const float* __re
     PR_STAMP(4);
 }
 
+// The same form for the fp32 rows of the exact compute type (X [Q, KP], no planes): the cloud's scaled Fisher vector is staged once
+// per workgroup as fp32 (40 KB), wave = row copies 16-byte pieces out of LDS into 1-KiB contiguous stores.  Replaces five run-time
+// integer divisions and one scattered 16-byte L2 gather per float4 of patch_rows_fwd_kernel.  Same products (fv * scale), same bits.
+__global__ __launch_bounds__(512) void patch_rows_fwd_lds_kernel(const float* __restrict__ q, const float* __restrict__ fv,
+                                                                 float* __restrict__ X, float* __restrict__ mask,
+                                                                 int32_t* __restrict__ vox, int Q, int N, int m, int k, int KP,
+                                                                 GridAxis ax, const float* __restrict__ ssq, int nsl, unsigned mg_k,
+                                                                 unsigned mg_kk) {
+    extern __shared__ __attribute__((aligned(16))) int2 s_tab3[];             // [KP/4] unit table, then the scaled vector [G*kF] fp32
+    const int U = KP / 4;
+    const int G = m * m * m, h = (k - 1) / 2, GF = G * kF;
+    float* s_fv = reinterpret_cast<float*>(s_tab3 + U);
+    __shared__ int2 s_rb[8];
+    __shared__ float4 s_dq[8];
+    __shared__ __attribute__((aligned(16))) float s_sc[kF];
+    const int tid = threadIdx.x;
+    int rg = blockIdx.x;
+    {
+        const int rgpc = N / 8, clouds = (Q / 8) / rgpc;
+        if (!(clouds & 7)) {                      // cloud c on XCD c % 8 (one L2 per cloud), as in the plane form
+            const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+            rg = ((i / rgpc) * 8 + xcd) * rgpc + i % rgpc;
+        }
+    }
+    const int cloud = (8 * rg) / N;
+    const float4* fvc = reinterpret_cast<const float4*>(fv + (size_t)cloud * GF);
+    const int nv = GF / 4;
+    constexpr int PRE = 5;
+    float4 pre[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+        const int idx = tid + 512 * i;
+        pre[i] = idx < nv ? fvc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < kF) s_sc[tid] = ssq ? fv_scale(ssq, nsl, cloud, tid) : 1.0f;
+    if (tid >= 64 && tid < 72) {
+        const int rr = tid - 64, r = 8 * rg + rr;
+        const float qx = q[(size_t)r * 3], qy = q[(size_t)r * 3 + 1], qz = q[(size_t)r * 3 + 2];
+        int ix = cell_of(ax, m, qx), iy = cell_of(ax, m, qy), iz = cell_of(ax, m, qz);
+        const bool valid = (ix >= 0) && (iy >= 0) && (iz >= 0);
+        if (!valid) { ix = 0; iy = 0; iz = 0; }
+        s_dq[rr] = make_float4(qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz], 0.f);      // point_cloud - Centers (:491)
+        unsigned vb = 0;
+        for (int d = 0; d < k; ++d) {
+            if ((unsigned)(iy - h + d) < (unsigned)m) vb |= 1u << d;
+            if ((unsigned)(ix - h + d) < (unsigned)m) vb |= 1u << (8 + d);
+            if ((unsigned)(iz - h + d) < (unsigned)m) vb |= 1u << (16 + d);
+        }
+        s_rb[rr] = make_int2(((iy * m + ix) * m + iz) * kF, (int)vb);
+        mask[r] = valid ? 1.f : 0.f;
+        vox[r] = (iy * m + ix) * m + iz;
+    }
+    const int E4 = k * k * k * (kF / 4);
+    for (int j = tid; j < U; j += 512) {
+        int2 e = make_int2(0, (j == E4 ? 1 : 2) << 24);
+        if (j < E4) {
+            const int nb = j / 5, part = j - 5 * nb;
+            const int d0 = (int)(((unsigned)nb * mg_kk) >> 16), r = nb - d0 * k * k;
+            const int d1 = (int)(((unsigned)r * mg_k) >> 16), d2 = r - d1 * k;
+            e = make_int2((((d0 - h) * m + (d1 - h)) * m + (d2 - h)) * kF + part * 4, d0 | (d1 << 8) | (d2 << 16));
+        }
+        s_tab3[j] = e;
+    }
+    __syncthreads();
+    auto stage = [&](int idx, float4 x) {
+        if (ssq) {      // (without ssq the vector is already normalised: copied as it is, like the row-wise kernel)
+            const float4 sc = *reinterpret_cast<const float4*>(&s_sc[(idx % 5) * 4]);
+            x.x *= sc.x; x.y *= sc.y; x.z *= sc.z; x.w *= sc.w;
+        }
+        *reinterpret_cast<float4*>(s_fv + 4 * idx) = x;
+    };
+#pragma unroll
+    for (int i = 0; i < PRE; ++i)
+        if (tid + 512 * i < nv) stage(tid + 512 * i, pre[i]);
+    for (int idx = tid + 512 * PRE; idx < nv; idx += 512) stage(idx, fvc[idx]);
+    __syncthreads();
+    const int rr = tid >> 6, lane = tid & 63;
+    const size_t row = (size_t)(8 * rg + rr);
+    const int own = s_rb[rr].x;
+    const unsigned vbits = (unsigned)s_rb[rr].y;
+    float* xr = X + row * KP;
+    for (int j = lane; j < U; j += 64) {
+        const int2 e = s_tab3[j];
+        const int kind = e.y >> 24;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kind == 0) {
+            if ((vbits >> (e.y & 0xff)) & (vbits >> (8 + ((e.y >> 8) & 0xff))) & (vbits >> (16 + ((e.y >> 16) & 0xff))) & 1u)
+                v = *reinterpret_cast<const float4*>(s_fv + own + e.x);
+        } else if (kind == 1) {
+            v = s_dq[rr];
+        }
+        *reinterpret_cast<float4*>(xr + 4 * j) = v;
+    }
+}
+
 // Backward as a gather (deterministic, no atomics): block (c, slice) owns a slice of the voxels of cloud c and,
 // for every (voxel, float4 channel group), sums the window column of every query of the cloud that covers it.
 __global__ __launch_bounds__(256) void patch_rows_bwd_kernel(const float* __restrict__ dX, const int32_t* __restrict__ vox,
@@ -739,6 +834,21 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
         }
         DPD_CHECK_LAUNCH();
         return 0;
+    }
+    {
+        const size_t lds = (size_t)m * m * m * kF * sizeof(float) + (size_t)(KP / 4) * sizeof(int2);
+        const unsigned mg_k = 65536u / k + 1, mg_kk = 65536u / (k * k) + 1;
+        bool exact = true;
+        for (int x = 0; x < k * k * k; ++x)
+            if ((int)((x * mg_kk) >> 16) != x / (k * k) || (int)(((x % (k * k)) * mg_k) >> 16) != (x % (k * k)) / k) exact = false;
+        if (exact && !(N & 7) && !(Q & 7) && lds <= 100 * 1024 && !getenv("DPD_GATHER_ROWS_V1")) {
+            static LdsOptIn lr;
+            if (int rc2 = ensure_dyn_lds(lr, (const void*)patch_rows_fwd_lds_kernel, lds)) return rc2;
+            DPD_LAUNCH(patch_rows_fwd_lds_kernel, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k, KP,
+                       make_axis(m), ssq, kMfvSlices, mg_k, mg_kk);
+            DPD_CHECK_LAUNCH();
+            return 0;
+        }
     }
     DPD_LAUNCH(patch_rows_fwd_kernel, dim3((C * N + 1) / 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, N, m, k,
                        KP, make_axis(m), C * N, ssq, kMfvSlices);
