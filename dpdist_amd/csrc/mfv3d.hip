@@ -199,6 +199,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
                 sg_s[d] += b; sg_mx[d] = fmaxf(sg_mx[d], b); sg_mn[d] = fminf(sg_mn[d], b);
             }
         }
+        MFV_STAMP(5);
         // merge the eight point groups (lanes l, l^8, l^16, l^32 ... hold the same Gaussian)
 #pragma unroll
         for (int o = 8; o < 64; o <<= 1) {
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
                 sg_mn[d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], o, 64));
             }
         }
+        MFV_STAMP(6);
         if (live && grp == 0) {
             float v[kF];
             v[0] = pi_s * invN;                                                 // :81 reduce_mean
@@ -228,8 +230,15 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
                 v[17 + d] = sg_mn[d] * k.sig_scale;
             }
 #pragma unroll
-            for (int f = 0; f < kF; ++f) s_stage[gl * kFP + f] = pnorm(v[f]);   // power-1/2 (:119-121)
+            for (int f = 0; f < kF; ++f) s_stage[gl * kFP + f] = v[f];
         }
+    }
+    __syncthreads();
+    // power-1/2 normalisation (:119-121) by ALL threads, in place: inside the branch above only 8 lanes of 64 were alive for 20 square
+    // roots each, and four waves per SIMD queue for the same VALU: 15k of this kernel's 30k cycles (tools/mfv_stamps.py)
+    for (int e = tid; e < gcount * kF; e += kFwdThreads) {
+        float* sp = s_stage + (e / kF) * kFP + e % kF;
+        *sp = pnorm(*sp);
     }
     __syncthreads();
     MFV_STAMP(3);

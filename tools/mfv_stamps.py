@@ -18,9 +18,13 @@ f = lib.dpd_debug_mfv_stamps
 f.argtypes = [ctypes.c_void_p]
 assert f(buf) == 0
 n = min(1024, 2 * B * 4)
-st = np.array(buf, dtype=np.uint64).reshape(1024, 8)[:n, :5].astype(np.int64)
+full = np.array(buf, dtype=np.uint64).reshape(1024, 8)[:n].astype(np.int64)
+st = full[:, :5]
 d = np.diff(st, axis=1)
 names = ["tables (z, exp) + stack", "row sums S + normalise + 0/0 check", "statistics loop + merge + stage", "store + slice norms"]
 print("B=%d, %d workgroups; cycles per section (median / max over workgroups), total median %d" % (B, n, np.median(st[:, 4] - st[:, 0])))
 for i, nm in enumerate(names):
     print("  %-34s %7.0f / %7.0f" % (nm, np.median(d[:, i]), d[:, i].max()))
+if full[:, 5].max() > 0:      # finer stamps inside the statistics section (wave 0's only pass): point loop | merge | power norm + stage
+    print("  statistics section: point loop %7.0f, merge of the 8 point groups %7.0f, pnorm + stage + barrier %7.0f" % (
+        np.median(full[:, 5] - full[:, 2]), np.median(full[:, 6] - full[:, 5]), np.median(full[:, 3] - full[:, 6])))
