@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
             // Planes without the LDS tile: a wave owns 8 rows x 128 columns; lane (l31, half) updates rows 4 half .. 4 half + 3 of the columns
             // 4 l31 .. 4 l31 + 3 (float4 loads, 512 contiguous bytes per row and half-wave).  RC chunks halves (4 columns of a row) are
             // the lane's own values; an R8 chunk (8 rows of one column) is this lane's four rows plus the four of lane +- 32: one
-            // v_permlane32_swap per packed dword gives the lower half the chunks of columns 0, 1 and the upper half those of 2, 3
+            // v_permlane32_swap per packed dword gives the lower half the chunks of columns 0, 2 and the upper half those of 1, 3
             // (same exchange as the plane GEMM epilogue, gemm_x3.hip).  35 -> 2x us at B = 64 (the 64x64 LDS-tile form ran at 4.3 TB/s).
             const int lane = tid & 63, l31 = lane & 31, half = lane >> 5, segs = cols >> 7;
             const int u = t * 4 + (tid >> 6);
@@ -175,11 +175,13 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
                 for (int q = 0; q < NP; ++q)
 #pragma unroll
                     for (int e0 = 0; e0 < 2; ++e0) {
-                        const unsigned a0 = pv[0][e0][q] | (pv[1][e0][q] << 16), a1 = pv[2][e0][q] | (pv[3][e0][q] << 16);
-                        const unsigned b0 = pv[0][e0 + 2][q] | (pv[1][e0 + 2][q] << 16), b1_ = pv[2][e0 + 2][q] | (pv[3][e0 + 2][q] << 16);
+                        // (lower half-wave: column 2 e0, upper: 2 e0 + 1 -> a lane pair writes 32 contiguous bytes per store instruction)
+                        const int ca = 2 * e0, cb = 2 * e0 + 1;
+                        const unsigned a0 = pv[0][ca][q] | (pv[1][ca][q] << 16), a1 = pv[2][ca][q] | (pv[3][ca][q] << 16);
+                        const unsigned b0 = pv[0][cb][q] | (pv[1][cb][q] << 16), b1_ = pv[2][cb][q] | (pv[3][cb][q] << 16);
                         const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1_, false, false);
-                        *reinterpret_cast<uint4*>(r8 + q * plane + ((size_t)rg * cols + c + e0 + 2 * half) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        *reinterpret_cast<uint4*>(r8 + q * plane + ((size_t)rg * cols + c + 2 * e0 + half) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                     }
             }
             return;

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __
 // So the workgroup converts the cloud's vector ONCE (40 KB of coalesced float4 loads, x * scale, bf16 / three-plane split: the values
 // the row-wise kernel computes per gathered element, so the planes keep their bits) into 20 KB of LDS per plane, and both passes read LDS:
 //   pass A (wave = row): two 8-byte LDS reads per 8-column group, one uint4 per plane to the RC plane (1 KiB per wave-instruction);
-//   pass B (R8 rows): work item = column, its 8 rows are 8 two-byte LDS reads; no LDS image of the rows, no barrier between the passes.
+//   pass B (R8 rows): work item = column, its 8 rows are 8 two-byte LDS reads, lanes contiguous in memory; no LDS image of the rows, no
+//   barrier between the passes.
 // The stamps of the kernel above (tools/gather_stamps.py, B = 64, one plane: 28.6k cycles per workgroup, 9.1k of them before the first
 // gather, 13.1k in pass A at the address unit's rate for ~26 cache lines per gather instruction, 45 KB of LDS = 3 workgroups per CU =
 // 1.33 rounds for the 1024 workgroups) are what this form removes: 25 KB of LDS (4 workgroups per CU, one round), 83 MB of scattered
@@ -450,45 +451,28 @@ void patch_rows_planes_lds_kernel(const float* __restrict__ q, const float* __re
     }
     PR_STAMP(3);
     if (!want_r8) return;
-    // ---- pass B: work item = one float4 unit (4 columns): per row ONE 8-byte LDS read gives the unit's four values; the 4 x 8 block is
-    // transposed in registers into the four R8 chunks (64 contiguous bytes per plane) ----
+    // ---- pass B: work item = column: its 8 rows are 8 two-byte LDS reads, one 16-byte chunk per plane, lanes contiguous in memory (1 KiB
+    // per store instruction).  Measured against one work item per float4 unit (8-byte LDS reads, v_perm transposes, but 16-byte pieces
+    // 64 bytes apart per store instruction): kernel 20.9 -> 16.5 us at B = 64, one plane ----
     int2 rb[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) rb[rr] = s_rb[rr];
-    for (int j = tid; j < U; j += 512) {
-        const int2 e = s_tab2[j];
-        const int kind = e.y >> 24;
+    for (int c = tid; c < KP; c += 512) {
+        const int2 e = s_tab2[c >> 2];
+        const int kind = e.y >> 24, sub = c & 3;
         const int s0 = e.y & 0xff, s1 = 8 + ((e.y >> 8) & 0xff), s2 = 16 + ((e.y >> 16) & 0xff);
-        unsigned ok = 0;
-        if (kind == 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            unsigned b[8];
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
+                b[rr] = 0u;
                 const unsigned vb = (unsigned)rb[rr].y;
-                ok |= ((vb >> s0) & (vb >> s1) & (vb >> s2) & 1u) << rr;
+                if (kind == 0) { if ((vb >> s0) & (vb >> s1) & (vb >> s2) & 1u) b[rr] = s_fv[(size_t)p * GF + rb[rr].x + e.x + sub]; }
+                else if (kind == 1) b[rr] = s_qc[p][rr][sub];
             }
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {           // one plane at a time: 8 reads, 4 chunks (three planes at once spilled registers)
-            uint2 v[8];
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                v[rr] = make_uint2(0u, 0u);
-                if (kind == 0) {
-                    if ((ok >> rr) & 1u) v[rr] = *reinterpret_cast<const uint2*>(s_fv + (size_t)p * GF + rb[rr].x + e.x);
-                } else if (kind == 1) {
-                    v[rr] = *reinterpret_cast<const uint2*>(&s_qc[p][rr][0]);
-                }
-            }
-            uint4* out = reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + 4 * j) * 8);
-            // column 0 / 1 = low / high half of .x of every row, column 2 / 3 of .y  (v_perm_b32 selects two 16-bit halves)
-#define DPD_LO(a, b) __builtin_amdgcn_perm((b), (a), 0x05040100u)
-#define DPD_HI(a, b) __builtin_amdgcn_perm((b), (a), 0x07060302u)
-            out[0] = make_uint4(DPD_LO(v[0].x, v[1].x), DPD_LO(v[2].x, v[3].x), DPD_LO(v[4].x, v[5].x), DPD_LO(v[6].x, v[7].x));
-            out[1] = make_uint4(DPD_HI(v[0].x, v[1].x), DPD_HI(v[2].x, v[3].x), DPD_HI(v[4].x, v[5].x), DPD_HI(v[6].x, v[7].x));
-            out[2] = make_uint4(DPD_LO(v[0].y, v[1].y), DPD_LO(v[2].y, v[3].y), DPD_LO(v[4].y, v[5].y), DPD_LO(v[6].y, v[7].y));
-            out[3] = make_uint4(DPD_HI(v[0].y, v[1].y), DPD_HI(v[2].y, v[3].y), DPD_HI(v[4].y, v[5].y), DPD_HI(v[6].y, v[7].y));
-#undef DPD_LO
-#undef DPD_HI
+            *reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + c) * 8) =
+                make_uint4(b[0] | (b[1] << 16), b[2] | (b[3] << 16), b[4] | (b[5] << 16), b[6] | (b[7] << 16));
         }
     }
     PR_STAMP(4);
