@@ -977,6 +977,44 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     return 0;
 }
 
+// The same weight-gradient GEMMs with Adam applied in their epilogue (gemm_shared.h: AdamEpi): single-GPU steps only -- with a gradient
+// all-reduce between compute_gradients and apply_gradients the separate optimizer kernel stays.
+static int adam_epi_from(const dpd_adam_epi* ad, int pair, dpd::AdamEpi* out) {
+    if (!ad || !ad->p || !ad->m || !ad->v) return DPD_E_NULL;
+    if (pair && (!ad->p2 || !ad->m2 || !ad->v2)) return DPD_E_NULL;
+    if (((uintptr_t)ad->p | (uintptr_t)ad->m | (uintptr_t)ad->v | (uintptr_t)ad->wt | (uintptr_t)ad->p2 | (uintptr_t)ad->m2 | (uintptr_t)ad->v2 |
+         (uintptr_t)ad->wt2) & 15) return DPD_E_UNSUPPORTED;
+    *out = dpd::AdamEpi{ad->p, ad->m, ad->v, ad->wt, pair ? ad->p2 : nullptr, pair ? ad->m2 : nullptr, pair ? ad->v2 : nullptr,
+                        pair ? ad->wt2 : nullptr, ad->lr_t, ad->b1, ad->b2, ad->eps, ad->gscale};
+    return 0;
+}
+
+extern "C" int dpd_decoder_bwd_weights_adam(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout, int dtype,
+                                            float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
+                                            const float* db_partials, const dpd_adam_epi* ad, void* stream) {
+    dpd::AdamEpi e;
+    if (int rc = adam_epi_from(ad, 0, &e)) return rc;
+    if (layer < 1 || layer > 3) return DPD_E_DIM;
+    if (dtype != 0) return DPD_E_UNSUPPORTED;          // (exact fp32 for now: the plane kernels would have to write the weights' planes per group)
+    dpd::g_adam_epi = &e;
+    const int rc = dpd_decoder_bwd_weights(layer, act, lda, g, Qb, Kin, Nout, dtype, dW, db, ws, ws_bytes, pl, db_partials, stream);
+    dpd::g_adam_epi = nullptr;
+    return rc;
+}
+
+extern "C" int dpd_decoder_bwd_weights_pair_adam(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
+                                                 float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws, size_t ws_bytes,
+                                                 const dpd_planes* pl, float* dbA, const float* db_partials, const dpd_adam_epi* ad,
+                                                 void* stream) {
+    dpd::AdamEpi e;
+    if (int rc = adam_epi_from(ad, 1, &e)) return rc;
+    if (dtype != 0) return DPD_E_UNSUPPORTED;
+    dpd::g_adam_epi = &e;
+    const int rc = dpd_decoder_bwd_weights_pair(actA, gA, dWA, actB, gB, dWB, lda, Qb, Kin, Nout, dtype, ws, ws_bytes, pl, dbA, db_partials, stream);
+    dpd::g_adam_epi = nullptr;
+    return rc;
+}
+
 extern "C" int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
                                       float* y, float* pred, float* loss_pred, float* dy, float* g3, float* scratch, void* stream) {
     using namespace dpd;
@@ -1180,7 +1218,7 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
                                        int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
                                        const float* db_partials, void* stream) {
     using namespace dpd;
-    if (!dW || ((!act || !g) && !(pl && dtype != 0))) return DPD_E_NULL;   // (act / g may be NULL when their R8 planes exist: checked below)
+    if ((!dW && !(g_adam_epi && layer != 4)) || ((!act || !g) && !(pl && dtype != 0))) return DPD_E_NULL;   // (act / g may be NULL when their R8 planes exist: checked below)
     if (layer == 4 && (!db || !act || !g)) return DPD_E_NULL;
     if (layer < 1 || layer > 4 || Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
@@ -1241,7 +1279,7 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                                             float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws,
                                             size_t ws_bytes, const dpd_planes* pl, float* dbA, const float* db_partials, void* stream) {
     using namespace dpd;
-    if (!dWA || !dWB) return DPD_E_NULL;
+    if ((!dWA || !dWB) && !g_adam_epi) return DPD_E_NULL;
     if ((!actA || !actB || !gA || !gB) && !(dtype != 0 && pl && pl->h1_r8 && pl->h2_r8 && pl->g2_r8 && pl->g3_r8)) return DPD_E_NULL;
     if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;

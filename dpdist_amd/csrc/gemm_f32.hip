@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         }
     }
     GemmArgs gs = g;
-    if (grp) gs.C = g.C2;
+    if (grp) { gs.C = g.C2; gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -484,10 +484,15 @@ static double tile_eff(int M, int N, int BM, int BN, int split) {
     return (double)M * N * split / ((double)rounds * 256.0 * BM * BN);
 }
 
+thread_local const AdamEpi* g_adam_epi = nullptr;
+
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
              size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2, const ColsumTwoStep* cs2) {
-    if (!A || !B || !C) return DPD_E_NULL;
+    const AdamEpi* adam = g_adam_epi;
+    if (!A || !B || (!C && !adam)) return DPD_E_NULL;
+    if (adam && (split_k != 1 || epilogue != EPI_NONE || colsum || !adam->p || !adam->m || !adam->v || (A2 && (!adam->p2 || !adam->m2 || !adam->v2))))
+        return DPD_E_UNSUPPORTED;
     // split_k == 0: "tail split" (gemm_rs.h): whole-K tiles, only the partial last round of tiles is cut along K (needs ws for
     // (pieces - 1) slabs of M*N floats; pieces <= 4).  Silently a plain launch when it does not apply.
     bool tail_auto = false;
@@ -518,14 +523,18 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.colsum = (split_k > 1) ? nullptr : colsum;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
-    if (tail_auto && !colsum && !A2) { g.tail_split = -1; g.tail_slab = (float*)ws; }
+    if (adam) {
+        if (!(tile >= 30 && tile <= 33)) return DPD_E_UNSUPPORTED;      // instantiated for the register-streamed dW kernels only
+        g.ad = *adam;
+    }
+    if (tail_auto && !colsum && !A2 && !adam) { g.tail_split = -1; g.tail_slab = (float*)ws; }
     if (cs2) {   // deterministic bias gradients in two steps (register-streamed kernels only; rows of a partial block = 32)
         if (!(tile >= 30 && tile <= 39) || (cs2->part_out && (split_k > 1 || colsum))) return DPD_E_UNSUPPORTED;
         g.colsum_part = cs2->part_out;
         g.colsum_part_in = cs2->part_in; g.colsum_part_in2 = cs2->part_in2;
         g.colsum_b = cs2->out; g.colsum_b2 = cs2->out2; g.colsum_nparts = cs2->nparts;
     }
-    if (A2 && (!B2 || !C2 || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
+    if (A2 && (!B2 || (!C2 && !adam) || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
     if (A2 && !whole_tiles) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA / register-streamed kernels only
     if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;

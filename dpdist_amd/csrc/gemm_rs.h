@@ -71,7 +71,7 @@ __device__ __forceinline__ unsigned gather_voff(unsigned rbase, unsigned rmask, 
 
 // D = pipeline depth in K-tiles (operand register sets): the loads of K-tile t+D-1 are issued, step by step, between the
 // MFMAs of K-tile t, so every operand has D-1 whole tile times ((TM*TN*16) MFMAs x 64 cycles each) to arrive.
-template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D, int ASRC = 0>
+template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D, int ASRC = 0, bool ADAM = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
     static_assert(ASRC == 0 || D == 2, "the gather pipelines are written for two operand sets");
     static_assert(ASRC != 1 || AK, "ASRC 1 gathers a K-contiguous A (rows = queries)");
@@ -280,8 +280,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
     for (int j = 0; j < D - 1; ++j)
         if (kt + j < nt) tile(j, 0, 0, false);
 
+    if (ADAM) asm volatile("" ::: "memory");      // the tile's parameters and moments are requested AFTER the K loop (registers)
     GemmArgs gs = g;
-    if (grp) gs.C = g.C2;
+    if (grp) { gs.C = g.C2; gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
     if (g.tail_split > 1 && z > 0) {      // K piece of a tail tile: its own slab, dense [M, N]
         gs.C = g.tail_slab + (size_t)(z - 1) * g.M * g.N;
         gs.ldc = g.N;
@@ -322,9 +323,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
                     if (epi == EPI_GATE) x = (egate[i][j][r] > 0.f) ? x : 0.f;
                     v[r] = x;
                 }
-                put_tile(gs, v, zs, m0 + 32 * i, n0 + 32 * j + l31, half);
+                put_tile<ADAM>(gs, v, zs, m0 + 32 * i, n0 + 32 * j + l31, half);
             } else {
-                store_tile(gs, acc[i][j], zs, m0 + 32 * i, n0 + 32 * j + l31, half);
+                store_tile<ADAM>(gs, acc[i][j], zs, m0 + 32 * i, n0 + 32 * j + l31, half);
             }
         }
 }
@@ -368,6 +369,15 @@ static int launch_rs(const GemmArgs& g_in, hipStream_t s) {
                 nblk = first + (T - first) * pieces;
                 row0 = (first / tilesN) * BM;
             }
+        }
+    }
+    if (g.ad.p) {       // Adam epilogue: the plain TN forms of the weight gradients only (everything else has no use for it)
+        if constexpr (!AK && !BKC && ASRC == 0 && D == 2 && WC == 2) {
+            if (g.tail_split > 1 || g.split_k != 1) return DPD_E_UNSUPPORTED;
+            DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D, ASRC, true>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);
+            return (int)hipGetLastError();
+        } else {
+            return DPD_E_UNSUPPORTED;
         }
     }
     DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D, ASRC>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);

@@ -97,11 +97,6 @@ struct AdamFuse {
     long v_off[5], v_cnt[5];    // vector ranges: the complement of up to four covered intervals (three matrices + the tail)
 };
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
-    m = b1 * m + (1.0f - b1) * g;
-    v = b2 * v + (1.0f - b2) * g * g;
-    p = p - lr_t * m / (sqrtf(v) + eps);
-}
 
 // NP = number of bf16 planes written next to the update (0: none / transposed fp32 copies only): compile time, so that the one-plane
 // type converts once per value instead of running the three-plane split and discarding two thirds of it
@@ -450,7 +445,13 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
         f.WT[w] = fu->WT[w]; f.w_off[w] = fu->w_off[w]; f.w_rows[w] = fu->w_rows[w]; f.w_cols[w] = fu->w_cols[w];
         f.rc[w] = planes ? (uint16_t*)fu->W_rc[w] : nullptr;
         f.r8[w] = planes ? (uint16_t*)fu->W_r8[w] : nullptr;
-        if (fu->WT[w] || f.rc[w] || f.r8[w]) {
+        if (fu->skip_w[w]) {          // updated in the epilogue of its weight-gradient GEMM: covered, nothing to do here
+            const long cnt = (long)fu->w_rows[w] * fu->w_cols[w];
+            if (fu->w_rows[w] <= 0 || fu->w_cols[w] <= 0 || fu->w_off[w] < 0 || (size_t)(fu->w_off[w] + cnt) > n) return DPD_E_DIM;
+            if (nc && fu->w_off[w] < hi[nc - 1]) return DPD_E_DIM;
+            lo[nc] = fu->w_off[w]; hi[nc] = fu->w_off[w] + cnt; ++nc;
+            f.WT[w] = nullptr; f.rc[w] = nullptr; f.r8[w] = nullptr;
+        } else if (fu->WT[w] || f.rc[w] || f.r8[w]) {
             const long cnt = (long)fu->w_rows[w] * fu->w_cols[w];
             if (fu->w_rows[w] <= 0 || fu->w_cols[w] <= 0 || (fu->w_cols[w] & 63) || (fu->w_rows[w] & 3) || (fu->w_off[w] & 3) ||
                 fu->w_off[w] < 0 || (size_t)(fu->w_off[w] + cnt) > n || ((uintptr_t)fu->WT[w] & 15))

@@ -27,7 +27,12 @@ class SmallGrads(Structure):
 class AdamFuse(Structure):   # include/dpdist_capi.h: dpd_adam_fuse
     _fields_ = [("WT", c_void_p * 3), ("w_off", c_long * 3), ("w_rows", c_int * 3), ("w_cols", c_int * 3),
                 ("W_rc", c_void_p * 3), ("W_r8", c_void_p * 3), ("np", c_int), ("partials", c_void_p),
-                ("nparts", c_int), ("rec", c_int), ("H", c_int), ("Qb", c_int), ("tail_off", c_long), ("loss", c_void_p)]
+                ("nparts", c_int), ("rec", c_int), ("H", c_int), ("Qb", c_int), ("tail_off", c_long), ("loss", c_void_p),
+                ("skip_w", c_int * 3)]
+
+
+class AdamEpi(Structure):    # include/dpdist_capi.h: dpd_adam_epi
+    _fields_ = [(n, c_void_p) for n in ("p", "m", "v", "wt", "p2", "m2", "v2", "wt2")] + [(n, c_float) for n in ("lr_t", "b1", "b2", "eps", "gscale")]
 
 
 class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
@@ -71,6 +76,10 @@ SIGNATURES = {
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p, c_void_p]),
+    "dpd_decoder_bwd_weights_adam": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p, POINTER(AdamEpi), c_void_p]),
+    "dpd_decoder_bwd_weights_pair_adam": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p,
+                                                                                POINTER(AdamEpi), c_void_p]),
     "dpd_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "dpd_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),

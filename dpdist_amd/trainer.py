@@ -139,6 +139,32 @@ class DPDistTrainer:
             if i == 1:
                 af.partials, af.nparts, af.rec, af.H, af.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
                 af.tail_off, af.loss = seg["b3"][0], self.loss.data_ptr()
+        # Adam inside the weight-gradient GEMMs (include/dpdist_capi.h: dpd_decoder_bwd_weights*_adam): single-GPU exact-fp32 steps; the
+        # optimizer launch then only takes the biases and the output layer (descriptor [2] = [1] with the three matrices skipped).
+        # OPT-IN (DPD_ADAM_IN_DW=1): bit-identical, but measured SLOWER (0.573 vs 0.561 ms per step): the workgroups of a dW GEMM finish
+        # their K loops together, so the 112 MB of p / m / v traffic arrive as one burst at the end of each launch (+19 us on the two
+        # GEMMs) instead of hiding under the matrix cores, and the optimizer kernel only gets 18 us shorter (DESIGN.md section 3.4 h)
+        self.adam_in_dw = (self.dt == 0 and self.reducer is None and not self.fused and BN % 32 == 0
+                           and os.environ.get("DPD_ADAM_IN_DW", "0") == "1")
+        self._adam_now = None      # (lr_t) while a step that applies Adam in the dW epilogues is in flight
+        self._keep_grad = os.environ.get("DPD_KEEP_GRAD", "0") == "1"      # also store dW (the optimizer no longer reads it)
+        if self.adam_in_dw:
+            base = lambda t, n: t.data_ptr() + 4 * seg[n][0]      # noqa: E731
+            pf, mf, vf = params.flat, self.m_state, self.v_state
+            _, _, _, b1_, b2_, eps_ = self.hp
+            self._aepi1, self._aepi23 = L.AdamEpi(), L.AdamEpi()
+            e1, e2 = self._aepi1, self._aepi23
+            e1.p, e1.m, e1.v, e1.wt = base(pf, "W1p"), base(mf, "W1p"), base(vf, "W1p"), None
+            e2.p, e2.m, e2.v, e2.wt = base(pf, "W2"), base(mf, "W2"), base(vf, "W2"), self.W2T.data_ptr()
+            e2.p2, e2.m2, e2.v2, e2.wt2 = base(pf, "W3"), base(mf, "W3"), base(vf, "W3"), self.W3T.data_ptr()
+            for e in (e1, e2):
+                e.b1, e.b2, e.eps, e.gscale = b1_, b2_, eps_, 1.0
+            sk = L.AdamFuse()
+            for j, (n, rows) in enumerate((("W1p", KP), ("W2", H), ("W3", H))):
+                sk.w_off[j], sk.w_rows[j], sk.w_cols[j], sk.skip_w[j] = seg[n][0], rows, H, 1
+            sk.partials, sk.nparts, sk.rec, sk.H, sk.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
+            sk.tail_off, sk.loss = seg["b3"][0], self.loss.data_ptr()
+            self._afuse.append(sk)
         # [b3 | W4 | b4] end the flat buffer (up to 3 elements of alignment padding behind them)
         self._tail_ok = 0 <= params.numel - (seg["b3"][0] + 4 * H + 3) <= 3 and H % 256 == 0 and H <= 1024
         # hipGraph mode (single GPU): the whole step is captured once per input-buffer set and replayed; weight-derived
@@ -280,13 +306,27 @@ class DPDistTrainer:
                         "dpd_decoder_bwd_weights_gather")
                 return
             db = gv[2 * layer - 1] if (det_db and layer in (1, 2)) else None
+            if self._adam_now is not None and layer == 1:      # Adam on W1p in the epilogue; the gradient itself is not stored
+                self._aepi1.lr_t = self._adam_now
+                L.check(lib.dpd_decoder_bwd_weights_adam(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
+                                                         L.ptr(dW) if self._keep_grad else None, L.ptr(db), L.ptr(self.ws), wsb, self._planes,
+                                                         L.ptr(dbp) if db is not None else None, self._aepi1, L.cur_stream()),
+                        "dpd_decoder_bwd_weights_adam(1)")
+                return
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0) if act is not None else dW.shape[0], L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
                                                 L.ptr(dW), L.ptr(db), L.ptr(self.ws), wsb, self._planes, L.ptr(dbp) if db is not None else None,
                                                 L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
         def dw23():
-            if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
+            if BN % 32 == 0 and self._adam_now is not None:
+                self._aepi23.lr_t = self._adam_now
+                kg = self._keep_grad
+                L.check(lib.dpd_decoder_bwd_weights_pair_adam(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]) if kg else None, L.ptr(self.h2),
+                                                              L.ptr(self.g3), L.ptr(d[4]) if kg else None, P.H, BN, P.H, P.H, self.dt,
+                                                              L.ptr(self.ws), wsb, self._planes, L.ptr(gv[3]) if det_db else None, L.ptr(dbp),
+                                                              self._aepi23, L.cur_stream()), "dpd_decoder_bwd_weights_pair_adam")
+            elif BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
                 L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
                                                          L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes,
                                                          L.ptr(gv[3]) if det_db else None, L.ptr(dbp), L.cur_stream()),
@@ -351,7 +391,7 @@ class DPDistTrainer:
         self._wdirty = True
         self.P._tr_key = None
 
-    def apply_gradients(self, tail_from_partials=False):
+    def apply_gradients(self, tail_from_partials=False, matrices_done=False):
         """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
         steps compute lr_t on the host (a device-side schedule kernel of one thread costs 4.7 us per step on MI355X: launch
         latency); only the captured hipGraph step keeps the schedule on the device."""
@@ -365,9 +405,10 @@ class DPDistTrainer:
             self.reducer.wait()
             gscale = self.reducer.grad_scale
         if self.fused_adam and (self.W2T is not None or self._afuse[0].np or tail_from_partials):
+            # matrices_done: W1p / W2 / W3 (and W2T / W3T) were updated in the epilogues of their weight-gradient GEMMs with this lr_t
+            af = self._afuse[2] if matrices_done else self._afuse[1 if tail_from_partials else 0]
             L.check(L.load().dpd_adam_tf_fused(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
-                                               self.P.numel, lr_t, b1, b2, eps, gscale, self._afuse[1 if tail_from_partials else 0],
-                                               L.cur_stream()), "dpd_adam_tf_fused")
+                                               self.P.numel, lr_t, b1, b2, eps, gscale, af, L.cur_stream()), "dpd_adam_tf_fused")
             # the transposed copies / operand planes written in the same pass are already those of the new weights
             self._wdirty = self._planes is not None and not self._afuse[0].np
             self.P._tr_key = None
@@ -437,11 +478,17 @@ class DPDistTrainer:
                 self._pref_key = self._key(*prefetch)
             self._after_dw1 = launch_front
         defer = self.fused_adam and self.fuse_loss and self._tail_ok and self.reducer is None
+        in_dw = self.adam_in_dw and defer
+        if in_dw:       # lr_t of THIS step (apply_gradients recomputes the same value when it advances the step counter)
+            base_lr, decay_step, decay_rate, b1, b2, _ = self.hp
+            lr = learning_rate(self.t, base_lr, decay_step, decay_rate)
+            self._adam_now = lr * math.sqrt(1.0 - b2 ** (self.t + 1)) / (1.0 - b1 ** (self.t + 1))
         try:
             self.backward(labels.reshape(-1), defer_small=defer)
         finally:
             self._after_dw1 = None
-        self.apply_gradients(tail_from_partials=defer)
+            self._adam_now = None
+        self.apply_gradients(tail_from_partials=defer, matrices_done=in_dw)
         return self.loss
 
     # -- optimizer state <-> TF global variables ------------------------------------------------------------------

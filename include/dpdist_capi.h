@@ -326,9 +326,29 @@ typedef struct dpd_adam_fuse {
     int nparts, rec, H, Qb;
     long tail_off;
     float* loss;
+    int skip_w[3];   /* != 0: matrix w was already updated by dpd_decoder_bwd_weights*_adam: its interval is left alone */
 } dpd_adam_fuse;
 int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, float gscale,
                       const dpd_adam_fuse* fuse, void* stream);
+
+/* apply_gradients INSIDE compute_gradients (single-GPU steps; train_multi_gpu_pc_compare_dist.py:277-302 with one tower): the weight-gradient
+ * GEMM applies TF-form Adam (same expression as dpd_adam_tf, same bits) to the tile it has just produced, instead of storing it for an
+ * optimizer launch that would read it back with p, m, v: the three matrices (99.9 % of the parameters) leave the optimizer kernel, which
+ * keeps the biases and the output layer (dpd_adam_fuse.skip_w).  p / m / v: the matrix's parameters and moments, laid out like dW
+ * ([Kin, Nout], 16-byte aligned); wt: optional transposed copy [Nout, Kin] of the NEW parameters (what dpd_weights_transpose would
+ * make); *2: the second matrix of the pair call.  dW may be NULL (the gradient is then not stored at all).  DPD_F32 only in this round.
+ * Not for data-parallel steps (the all-reduce stands between the gradient and its use).                                            */
+typedef struct dpd_adam_epi {
+    float *p, *m, *v, *wt;
+    float *p2, *m2, *v2, *wt2;
+    float lr_t, b1, b2, eps, gscale;
+} dpd_adam_epi;
+int dpd_decoder_bwd_weights_adam(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout, int dtype,
+                                 float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl, const float* db_partials,
+                                 const dpd_adam_epi* ad, void* stream);
+int dpd_decoder_bwd_weights_pair_adam(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB, float* dWB,
+                                      int lda, int Qb, int Kin, int Nout, int dtype, void* ws, size_t ws_bytes, const dpd_planes* pl,
+                                      float* dbA, const float* db_partials, const dpd_adam_epi* ad, void* stream);
 
 /* The same update with the schedule kept ON THE DEVICE, so that a captured (hipGraph) training step carries no per-step host
  * parameters.  state: 8 floats, caller-owned: [0] global step (int32 bits), [1] beta1_power, [2] beta2_power (the running

@@ -1121,6 +1121,36 @@ def test_out_asloss_equals_the_three_kernel_chain(dev, B, N, H):
     assert torch.equal(y2, y0) and torch.equal(pred2, p0)
 
 
+def test_adam_in_the_weight_gradient_epilogue_is_bitwise_the_optimizer_kernel(dev, monkeypatch):
+    """Single-GPU exact-fp32 steps apply Adam to W1p / W2 / W3 inside the epilogue of their weight-gradient GEMMs
+    (dpd_decoder_bwd_weights*_adam) and leave the optimizer launch the biases and the output layer.  Same adam_one on the same
+    gradient values: parameters, both moments, the transposed copies and the losses are bit for bit those of DPD_ADAM_IN_DW=0,
+    four steps long (the schedule's lr_t changes every step), also when the gradients are stored as well (DPD_KEEP_GRAD=1)."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 32
+    batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 300 + i)) for i in range(4)]
+    W0 = synth.make_weights("wide")
+    outs = []
+    for in_dw, keep in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("DPD_ADAM_IN_DW", in_dw)
+        monkeypatch.setenv("DPD_KEEP_GRAD", keep)
+        P = DPDistParams(device=dev)
+        P.load_tf_state_dict(W0)
+        tr = DPDistTrainer(P, B, 64)
+        assert tr.adam_in_dw == (in_dw == "1")
+        losses = [tr.step(*b).clone() for b in batches]
+        torch.cuda.synchronize()
+        outs.append((P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), tr.W2T.clone(), tr.W3T.clone(), torch.stack(losses),
+                     tr.grad.clone()))
+    ref = outs[0]
+    for o in outs[1:]:
+        for a, b in zip(ref[:6], o[:6]):
+            assert torch.equal(a, b)
+    assert torch.equal(ref[6], outs[2][6])          # DPD_KEEP_GRAD=1: the stored gradients are the ones the kernel form stores
+    assert torch.equal(ref[3], P.view("W2", ref[0]).t().contiguous())     # and the transposed copy is the transpose of the new W2
+
+
 @pytest.mark.parametrize("dt", ["f32x3", "bf16"])
 def test_plane_step_without_fp32_copies_is_bitwise_the_step_with_them(dev, dt, monkeypatch):
     """Plane compute types (round 3): fp32 h1 / h2 / g1 / g2 / g3 are not written at all -- layers 2/3 and the weight gradients read
