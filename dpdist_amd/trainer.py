@@ -165,6 +165,25 @@ class DPDistTrainer:
             sk.partials, sk.nparts, sk.rec, sk.H, sk.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
             sk.tail_off, sk.loss = seg["b3"][0], self.loss.data_ptr()
             self._afuse.append(sk)
+        # Adam for W1p (55 % of the parameters) as soon as dW1 exists, on a side stream, under the dW2 + dW3 GEMM: that launch keeps the
+        # matrix cores busy and leaves most of the HBM bandwidth idle, the optimizer is the opposite (exact fp32, single GPU; the main
+        # optimizer launch then skips W1p).  DPD_ADAM_W1_EARLY=0: everything in the one launch at the end of the step.
+        self.adam_w1_early = (self.dt == 0 and self.reducer is None and not self.fused and self.W2T is not None
+                              and os.environ.get("DPD_ADAM_W1_EARLY", "1") == "1")
+        if self.adam_w1_early:
+            ew = L.AdamFuse()
+            for j, (n, rows, T) in enumerate((("W1p", KP, None), ("W2", H, self.W2T), ("W3", H, self.W3T))):
+                ew.w_off[j], ew.w_rows[j], ew.w_cols[j] = seg[n][0], rows, H
+                if T is None:
+                    ew.skip_w[j] = 1
+                else:
+                    ew.WT[j] = T.data_ptr()
+            ew.partials, ew.nparts, ew.rec, ew.H, ew.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
+            ew.tail_off, ew.loss = seg["b3"][0], self.loss.data_ptr()
+            self._afuse_w1 = ew
+            self._w1_range = (seg["W1p"][0], seg["W1p"][1])
+            self._ev_dw1 = self._ev_w1done = None
+            self._side_opt = None
         # [b3 | W4 | b4] end the flat buffer (up to 3 elements of alignment padding behind them)
         self._tail_ok = 0 <= params.numel - (seg["b3"][0] + 4 * H + 3) <= 3 and H % 256 == 0 and H <= 1024
         # hipGraph mode (single GPU): the whole step is captured once per input-buffer set and replayed; weight-derived
@@ -391,7 +410,7 @@ class DPDistTrainer:
         self._wdirty = True
         self.P._tr_key = None
 
-    def apply_gradients(self, tail_from_partials=False, matrices_done=False):
+    def apply_gradients(self, tail_from_partials=False, matrices_done=False, w1_done=False):
         """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
         steps compute lr_t on the host (a device-side schedule kernel of one thread costs 4.7 us per step on MI355X: launch
         latency); only the captured hipGraph step keeps the schedule on the device."""
@@ -406,7 +425,7 @@ class DPDistTrainer:
             gscale = self.reducer.grad_scale
         if self.fused_adam and (self.W2T is not None or self._afuse[0].np or tail_from_partials):
             # matrices_done: W1p / W2 / W3 (and W2T / W3T) were updated in the epilogues of their weight-gradient GEMMs with this lr_t
-            af = self._afuse[2] if matrices_done else self._afuse[1 if tail_from_partials else 0]
+            af = self._afuse[2] if matrices_done else (self._afuse_w1 if w1_done else self._afuse[1 if tail_from_partials else 0])
             L.check(L.load().dpd_adam_tf_fused(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                                self.P.numel, lr_t, b1, b2, eps, gscale, af, L.cur_stream()), "dpd_adam_tf_fused")
             # the transposed copies / operand planes written in the same pass are already those of the new weights
@@ -479,6 +498,30 @@ class DPDistTrainer:
             self._after_dw1 = launch_front
         defer = self.fused_adam and self.fuse_loss and self._tail_ok and self.reducer is None
         in_dw = self.adam_in_dw and defer
+        w1_early = self.adam_w1_early and defer and not in_dw
+        if w1_early:
+            if self._side_opt is None:
+                from .hipevents import LightEvent
+                self._side_opt = torch.cuda.Stream(device=self.P.flat.device)
+                self._ev_dw1, self._ev_w1done = LightEvent(system_fence=False), LightEvent(system_fence=False)
+            base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
+            lr_now = learning_rate(self.t, base_lr, decay_step, decay_rate)
+            lr_t_now = lr_now * math.sqrt(1.0 - b2 ** (self.t + 1)) / (1.0 - b1 ** (self.t + 1))
+            chained = self._after_dw1
+            main_s = torch.cuda.current_stream()
+
+            def early_w1():
+                if chained is not None:
+                    chained()
+                self._ev_dw1.record(main_s)
+                off, cnt = self._w1_range
+                with torch.cuda.stream(self._side_opt):
+                    self._ev_dw1.wait(self._side_opt)
+                    sl = slice(off, off + cnt)
+                    L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat.detach()[sl]), L.ptr(self.grad[sl]), L.ptr(self.m_state[sl]),
+                                                 L.ptr(self.v_state[sl]), cnt, lr_t_now, b1, b2, eps, 1.0, L.cur_stream()), "dpd_adam_tf(W1p)")
+                    self._ev_w1done.record(self._side_opt)
+            self._after_dw1 = early_w1
         if in_dw:       # lr_t of THIS step (apply_gradients recomputes the same value when it advances the step counter)
             base_lr, decay_step, decay_rate, b1, b2, _ = self.hp
             lr = learning_rate(self.t, base_lr, decay_step, decay_rate)
@@ -488,7 +531,9 @@ class DPDistTrainer:
         finally:
             self._after_dw1 = None
             self._adam_now = None
-        self.apply_gradients(tail_from_partials=defer, matrices_done=in_dw)
+        self.apply_gradients(tail_from_partials=defer, matrices_done=in_dw, w1_done=w1_early)
+        if w1_early:
+            self._ev_w1done.wait(torch.cuda.current_stream())      # W1p is complete before anything that follows this step
         return self.loss
 
     # -- optimizer state <-> TF global variables ------------------------------------------------------------------

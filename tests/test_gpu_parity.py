@@ -1132,13 +1132,15 @@ def test_adam_in_the_weight_gradient_epilogue_is_bitwise_the_optimizer_kernel(de
     batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 300 + i)) for i in range(4)]
     W0 = synth.make_weights("wide")
     outs = []
-    for in_dw, keep in (("0", "0"), ("1", "0"), ("1", "1")):
+    for in_dw, keep, early in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("0", "0", "1")):
+        # (the last form: Adam for W1p on a side stream right after dW1, under the dW2 + dW3 GEMM -- the default)
         monkeypatch.setenv("DPD_ADAM_IN_DW", in_dw)
         monkeypatch.setenv("DPD_KEEP_GRAD", keep)
+        monkeypatch.setenv("DPD_ADAM_W1_EARLY", early)
         P = DPDistParams(device=dev)
         P.load_tf_state_dict(W0)
         tr = DPDistTrainer(P, B, 64)
-        assert tr.adam_in_dw == (in_dw == "1")
+        assert tr.adam_in_dw == (in_dw == "1") and tr.adam_w1_early == (early == "1")
         losses = [tr.step(*b).clone() for b in batches]
         torch.cuda.synchronize()
         outs.append((P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), tr.W2T.clone(), tr.W3T.clone(), torch.stack(losses),
