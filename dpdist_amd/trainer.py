@@ -167,9 +167,11 @@ class DPDistTrainer:
             self._afuse.append(sk)
         # Adam for W1p (55 % of the parameters) as soon as dW1 exists, on a side stream, under the dW2 + dW3 GEMM: that launch keeps the
         # matrix cores busy and leaves most of the HBM bandwidth idle, the optimizer is the opposite (exact fp32, single GPU; the main
-        # optimizer launch then skips W1p).  DPD_ADAM_W1_EARLY=0: everything in the one launch at the end of the step.
+        # optimizer launch then skips W1p).  OPT-IN (DPD_ADAM_W1_EARLY=1): bit-identical, measured SLOWER (0.567 vs 0.562 ms per step) --
+        # like every two-stream form tried on this runtime (DESIGN.md section 3.4 c, h): the cross-queue hand-over and the interference
+        # with the GEMM cost more than the 13 us of optimizer time that move under it.
         self.adam_w1_early = (self.dt == 0 and self.reducer is None and not self.fused and self.W2T is not None
-                              and os.environ.get("DPD_ADAM_W1_EARLY", "1") == "1")
+                              and os.environ.get("DPD_ADAM_W1_EARLY", "0") == "1")
         if self.adam_w1_early:
             ew = L.AdamFuse()
             for j, (n, rows, T) in enumerate((("W1p", KP, None), ("W2", H, self.W2T), ("W3", H, self.W3T))):

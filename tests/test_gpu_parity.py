@@ -1133,7 +1133,7 @@ def test_adam_in_the_weight_gradient_epilogue_is_bitwise_the_optimizer_kernel(de
     W0 = synth.make_weights("wide")
     outs = []
     for in_dw, keep, early in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("0", "0", "1")):
-        # (the last form: Adam for W1p on a side stream right after dW1, under the dW2 + dW3 GEMM -- the default)
+        # (the last form: Adam for W1p on a side stream right after dW1, under the dW2 + dW3 GEMM; opt-in as well)
         monkeypatch.setenv("DPD_ADAM_IN_DW", in_dw)
         monkeypatch.setenv("DPD_KEEP_GRAD", keep)
         monkeypatch.setenv("DPD_ADAM_W1_EARLY", early)
