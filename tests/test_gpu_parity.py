@@ -1121,6 +1121,42 @@ def test_out_asloss_equals_the_three_kernel_chain(dev, B, N, H):
     assert torch.equal(y2, y0) and torch.equal(pred2, p0)
 
 
+@pytest.mark.parametrize("dt,B", [("bf16", 64), ("f32x3", 32), ("bf16", 8), ("f32", 32), ("f32", 4)])
+def test_lds_window_gather_is_bitwise_the_row_wise_kernels(dev, dt, B, monkeypatch):
+    """The window gather of round 3 stages the cloud's scaled Fisher vector once per workgroup in LDS (planes: patch_rows_planes_lds_kernel,
+    fp32 rows: patch_rows_fwd_lds_kernel).  Same products, same rounding: X / the operand planes, mask and voxel ids are bit for bit those
+    of the row-wise kernels (DPD_GATHER_PLANES_V2 / DPD_GATHER_ROWS_V1), including rows whose query lies outside the grid and windows
+    that stick out of it."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    P = DPDistParams(device=dev, compute_dtype=dt)
+    P.load_tf_state_dict(synth.make_weights("wide"))
+    tr = DPDistTrainer(P, B, 64)
+    pcA, pcB, _ = [_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100, tilt_deg=20.0)]
+    pcA[0, :3] += 5.0                     # three queries outside the grid (mask 0)
+    pcB[-1, :5] = pcB[-1, :5] * 0.0 + 0.79      # and a few in a corner cell (windows clipped on three sides)
+    tr._take_front(pcA, pcB, None)
+    buf = tr._plane_mem if tr._planes is not None else tr.X
+
+    def run(old):
+        for k in ("DPD_GATHER_PLANES_V2", "DPD_GATHER_ROWS_V1"):
+            if old:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        buf.zero_(); tr.mask.fill_(-1.0); tr.vox.fill_(-1)
+        tr._gather()
+        torch.cuda.synchronize()
+        return buf.clone(), tr.mask.clone(), tr.vox.clone()
+
+    new, old = run(False), run(True)
+    assert int((new[1] == 0).sum()) >= 3 and int((new[0] != 0).sum()) > 0
+    for a, b in zip(new, old):        # bit patterns: the cloud whose points were moved out of the grid is NaN in both (the reference's 0/0)
+        ai = a.view(torch.int32) if a.dtype == torch.float32 else a
+        bi = b.view(torch.int32) if b.dtype == torch.float32 else b
+        assert torch.equal(ai, bi)
+
+
 def test_adam_in_the_weight_gradient_epilogue_is_bitwise_the_optimizer_kernel(dev, monkeypatch):
     """Single-GPU exact-fp32 steps apply Adam to W1p / W2 / W3 inside the epilogue of their weight-gradient GEMMs
     (dpd_decoder_bwd_weights*_adam) and leave the optimizer launch the biases and the output layer.  Same adam_one on the same

@@ -27,7 +27,7 @@ n = min(1024, 2 * B * 64 // 8)
 st = np.array(buf, dtype=np.uint64).reshape(1024, 8)[:n, :5].astype(np.int64)
 st = st[st[:, 4] > st[:, 0]]            # workgroups that wrote R8 chunks (the gradient-carrying half)
 d = np.diff(st, axis=1)
-names = ["unit table, row info, barrier", "pass A: gathers, convert, RC planes, LDS image", "barrier", "pass B: R8 chunks from the LDS image"]
+names = ["loads requested, unit table, row info, barrier", "cloud vector -> planes in LDS, barrier", "pass A: RC planes (wave = row)", "pass B: R8 chunks (work item = column) + store drain"]
 print("B=%d %s, %d workgroups with R8; cycles per section (median / max), total median %d" % (B, dt, len(st), np.median(st[:, 4] - st[:, 0])))
 for i, nm in enumerate(names):
     print("  %-46s %7.0f / %7.0f" % (nm, np.median(d[:, i]), d[:, i].max()))
