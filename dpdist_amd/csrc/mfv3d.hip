@@ -648,75 +648,85 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const floa
     }
 }
 
-// Per-cloud combine (ONE workgroup per cloud, thread = Gaussian): merges the kSlices statistic records, takes the channel sums over
+// Per-cloud combine (thread = Gaussian): merges the kSlices statistic records, takes the channel sums over
 // ALL Gaussians, and turns dfv into the gradient w.r.t. the 20 raw statistics of every Gaussian.  This is the sqrt / divide heavy
 // part of the backward; it used to be repeated by both half-waves of every one of the kSlices apply workgroups (8x).  Output, in
 // place over slice 0's record of the cloud (every thread only touches its own column g): rows 0..19 = d raw statistic (tie
 // counts already divided in), rows 20..32 = the 13 global extrema the apply kernel needs for its tie tests.
-__global__ __launch_bounds__(512) void mfv3d_bwd_combine_kernel(const float* __restrict__ dfv, float* __restrict__ part, MfvConst k) {
-    __shared__ float s_chred[8 * 2 * kF];
-    __shared__ float s_ch[2 * kF];
+// (round 3) FOUR workgroups per cloud, five of the 20 statistics each: the channel sums are per statistic, so the quarters never talk to
+// each other, every thread requests 24-40 record values instead of 132 (the loads of one workgroup per cloud went through ONE CU's
+// address unit: ~17k cycles of this kernel's 18.9 us at the PCRNet batch), and 128 workgroups instead of 32 share the square roots.
+// Same expressions per statistic, same summation orders: the same bits.
+__device__ __forceinline__ constexpr bool mfv_is_sum(int f) { return f == 0 || (f >= 2 && f < 5) || (f >= 11 && f < 14); }
+__device__ __forceinline__ constexpr bool mfv_is_max(int f) { return f == 1 || (f >= 5 && f < 8) || (f >= 14 && f < 17); }
+// index of statistic f among the 13 extrema {1, 5..10, 14..19} (tie-count / extremum rows 20 + index), -1 for a sum
+__device__ __forceinline__ constexpr int mfv_tie_index(int f) { return f == 1 ? 0 : (f >= 5 && f < 11 ? f - 4 : (f >= 14 ? f - 7 : -1)); }
+
+template <int F0>
+__device__ __forceinline__ void mfv3d_bwd_combine_quarter(const float* __restrict__ dfv, float* __restrict__ part, const MfvConst& k, int c,
+                                                          float* s_chred, float* s_ch) {
+    constexpr int NF = 5;
     const int N = k.N, G = k.G;
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = tid;
     const bool live = g < G;
     const int gg = live ? g : 0;
     const float invN = 1.0f / (float)N;
-    // ---- combine the slices' records (fixed order): all 4 x 33 values are requested at once (512 threads per workgroup leave
-    // 256 registers per lane; one statistic at a time would be 33 dependent L2 round trips on a 32-workgroup grid) ------------
-    float raw[kF], cnt[13];
-    {
-        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
-        const float* pc = part + (size_t)c * kSlices * kRec * G + gg;
-        float r[kSlices][kRec];
+    const float* pc = part + (size_t)c * kSlices * kRec * G + gg;
+    float r[kSlices][NF], rt[kSlices][NF];
 #pragma unroll
-        for (int s2 = 0; s2 < kSlices; ++s2)
+    for (int s2 = 0; s2 < kSlices; ++s2)
 #pragma unroll
-            for (int i = 0; i < kRec; ++i) r[s2][i] = pc[((size_t)s2 * kRec + i) * G];
-#pragma unroll
-        for (int f = 0; f < kF; ++f) {
-            const bool is_sum = (f == 0) || (f >= 2 && f < 5) || (f >= 11 && f < 14);
-            const bool is_max = (f == 1) || (f >= 5 && f < 8) || (f >= 14 && f < 17);
-            float v = r[0][f];
-#pragma unroll
-            for (int s2 = 1; s2 < kSlices; ++s2) v = is_sum ? v + r[s2][f] : (is_max ? fmaxf(v, r[s2][f]) : fminf(v, r[s2][f]));
-            raw[f] = is_sum ? v * invN : v;
+        for (int j = 0; j < NF; ++j) {
+            constexpr int dummy = 0; (void)dummy;
+            r[s2][j] = pc[((size_t)s2 * kRec + (F0 + j)) * G];
+            rt[s2][j] = 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 13; ++i) {      // tie count of an extremum: the slices that attain it contribute theirs
-            float t = 0.f;
+    for (int s2 = 0; s2 < kSlices; ++s2)
 #pragma unroll
-            for (int s2 = 0; s2 < kSlices; ++s2) t += (r[s2][mm[i]] == raw[mm[i]]) ? r[s2][20 + i] : 0.f;
-            cnt[i] = t;
-        }
+        for (int j = 0; j < NF; ++j)
+            if (mfv_tie_index(F0 + j) >= 0) rt[s2][j] = pc[((size_t)s2 * kRec + 20 + mfv_tie_index(F0 + j)) * G];
+    float raw[NF], cnt[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int f = F0 + j;
+        float v = r[0][j];
+#pragma unroll
+        for (int s2 = 1; s2 < kSlices; ++s2) v = mfv_is_sum(f) ? v + r[s2][j] : (mfv_is_max(f) ? fmaxf(v, r[s2][j]) : fminf(v, r[s2][j]));
+        raw[j] = mfv_is_sum(f) ? v * invN : v;
+        float t = 0.f;      // tie count of an extremum: the slices that attain it contribute theirs
+#pragma unroll
+        for (int s2 = 0; s2 < kSlices; ++s2) t += (r[s2][j] == raw[j]) ? rt[s2][j] : 0.f;
+        cnt[j] = t;
     }
-    // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv -----------------------------------------------------------
+    // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv ----
     const float* df = dfv + ((size_t)c * G + gg) * kF;
-    float dr[kF];
-    {
 #pragma unroll
-        for (int f = 0; f < kF; ++f) {
-            const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
-            const float sv = pnorm(raw[f] * cst);
-            const float dy = live ? df[f] : 0.f;
-            const float a = wave_sum(live ? sv * sv : 0.f), b = wave_sum(sv * dy);
-            if (lane == 0) { s_chred[wave * 2 * kF + f] = a; s_chred[wave * 2 * kF + kF + f] = b; }
-        }
+    for (int j = 0; j < NF; ++j) {
+        const int f = F0 + j;
+        const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
+        const float sv = pnorm(raw[j] * cst);
+        const float dy = live ? df[f] : 0.f;
+        const float a = wave_sum(live ? sv * sv : 0.f), b = wave_sum(sv * dy);
+        if (lane == 0) { s_chred[wave * 2 * NF + j] = a; s_chred[wave * 2 * NF + NF + j] = b; }
     }
     __syncthreads();
-    if (tid < 2 * kF) {
+    if (tid < 2 * NF) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) t += s_chred[w * 2 * kF + tid];
+        for (int w = 0; w < 8; ++w) t += s_chred[w * 2 * NF + tid];
         s_ch[tid] = t;
     }
     __syncthreads();
+    float* out = part + (size_t)c * kSlices * kRec * G + g;      // slice 0's record of this cloud (rows F0 .. F0+4 and their extremum rows)
 #pragma unroll
-    for (int f = 0; f < kF; ++f) {
+    for (int j = 0; j < NF; ++j) {
+        const int f = F0 + j;
         const float cst = (f < 2) ? 1.0f : ((f < 11) ? k.mu_scale : k.sig_scale);
-        const float v = raw[f] * cst;
+        const float v = raw[j] * cst;
         const float sv = pnorm(v);
-        const float ss = s_ch[f], dot = s_ch[kF + f];
+        const float ss = s_ch[j], dot = s_ch[NF + j];
         const float dy = live ? df[f] : 0.f;
         float ds;
         if (ss >= 1e-12f) {
@@ -728,24 +738,27 @@ __global__ __launch_bounds__(512) void mfv3d_bwd_combine_kernel(const float* __r
         float dv = 0.f;
         if (fabsf(v) >= 1e-12f) dv = ds * 0.5f / sqrtf(fabsf(v));
         float d = dv * cst;
-        if (f == 0 || (f >= 2 && f < 5) || (f >= 11 && f < 14)) d *= invN;
-        dr[f] = live ? d : 0.f;
+        if (mfv_is_sum(f)) d *= invN;
+        d = live ? d : 0.f;
+        if (mfv_tie_index(f) >= 0) d = d / fmaxf(cnt[j], 1.f);
+        if (live) {
+            out[(size_t)f * G] = d;
+            if (mfv_tie_index(f) >= 0) out[(size_t)(20 + mfv_tie_index(f)) * G] = raw[j];
+        }
     }
-    {
-        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
-#pragma unroll
-        for (int i = 0; i < 13; ++i) dr[mm[i]] = dr[mm[i]] / fmaxf(cnt[i], 1.f);
-    }
-    if (live) {
-        float* out = part + (size_t)c * kSlices * kRec * G + g;      // slice 0's record of this cloud
-        const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
-        float ext[13];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) ext[i] = raw[mm[i]];
-#pragma unroll
-        for (int f = 0; f < kF; ++f) out[(size_t)f * G] = dr[f];
-#pragma unroll
-        for (int i = 0; i < 13; ++i) out[(size_t)(20 + i) * G] = ext[i];
+}
+
+// NOTE on in-place output: quarter q overwrites rows F0..F0+4 and the extremum rows of ITS statistics in slice 0's record, which no
+// other quarter reads (each reads only its own statistic and tie rows), so the four workgroups of a cloud need no ordering.
+__global__ __launch_bounds__(512) void mfv3d_bwd_combine_kernel(const float* __restrict__ dfv, float* __restrict__ part, MfvConst k) {
+    __shared__ float s_chred[8 * 2 * 5];
+    __shared__ float s_ch[2 * 5];
+    const int c = blockIdx.x >> 2;
+    switch (blockIdx.x & 3) {
+        case 0: mfv3d_bwd_combine_quarter<0>(dfv, part, k, c, s_chred, s_ch); break;
+        case 1: mfv3d_bwd_combine_quarter<5>(dfv, part, k, c, s_chred, s_ch); break;
+        case 2: mfv3d_bwd_combine_quarter<10>(dfv, part, k, c, s_chred, s_ch); break;
+        default: mfv3d_bwd_combine_quarter<15>(dfv, part, k, c, s_chred, s_ch); break;
     }
 }
 
@@ -901,7 +914,7 @@ extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, i
         if (int rc = set_lds(mfv3d_bwd_apply_kernel, l2)) return rc;
         DPD_LAUNCH(mfv3d_bwd_stats_kernel, dim3(C * kSlices), dim3(kFwdThreads), l1, (hipStream_t)stream, pts, (float*)ws, k, nslice);
         DPD_CHECK_LAUNCH();
-        DPD_LAUNCH(mfv3d_bwd_combine_kernel, dim3(C), dim3(512), 0, (hipStream_t)stream, dfv, (float*)ws, k);
+        DPD_LAUNCH(mfv3d_bwd_combine_kernel, dim3(C * 4), dim3(512), 0, (hipStream_t)stream, dfv, (float*)ws, k);
         DPD_CHECK_LAUNCH();
         DPD_LAUNCH(mfv3d_bwd_apply_kernel, dim3(C * kSlices), dim3(kFwdThreads), l2, (hipStream_t)stream, pts, (const float*)ws, dpts, k,
                    nslice);
