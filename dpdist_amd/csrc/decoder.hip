@@ -983,6 +983,14 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
 
 // The same weight-gradient GEMMs with Adam applied in their epilogue (gemm_shared.h: AdamEpi): single-GPU steps only -- with a gradient
 // all-reduce between compute_gradients and apply_gradients the separate optimizer kernel stays.
+extern "C" int dpd_has_adam_epilogue(void) {
+#ifdef DPD_ADAM_EPI
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 static int adam_epi_from(const dpd_adam_epi* ad, int pair, dpd::AdamEpi* out) {
     if (!ad || !ad->p || !ad->m || !ad->v) return DPD_E_NULL;
     if (pair && (!ad->p2 || !ad->m2 || !ad->v2)) return DPD_E_NULL;

@@ -379,7 +379,10 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
         }
     }
     GemmArgs gs = g;
-    if (grp) { gs.C = g.C2; gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
+    if (grp) gs.C = g.C2;
+#ifdef DPD_ADAM_EPI
+    if (grp) { gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -524,8 +527,12 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     g.colsum = (split_k > 1) ? nullptr : colsum;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
     if (adam) {
+#ifdef DPD_ADAM_EPI
         if (!(tile >= 30 && tile <= 33)) return DPD_E_UNSUPPORTED;      // instantiated for the register-streamed dW kernels only
         g.ad = *adam;
+#else
+        return DPD_E_UNSUPPORTED;       // ablation build only (gemm_shared.h)
+#endif
     }
     if (tail_auto && !colsum && !A2 && !adam) { g.tail_split = -1; g.tail_slab = (float*)ws; }
     if (cs2) {   // deterministic bias gradients in two steps (register-streamed kernels only; rows of a partial block = 32)

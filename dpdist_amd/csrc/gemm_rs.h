@@ -282,7 +282,10 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
 
     if (ADAM) asm volatile("" ::: "memory");      // the tile's parameters and moments are requested AFTER the K loop (registers)
     GemmArgs gs = g;
-    if (grp) { gs.C = g.C2; gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
+    if (grp) gs.C = g.C2;
+#ifdef DPD_ADAM_EPI
+    if (grp) { gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
+#endif
     if (g.tail_split > 1 && z > 0) {      // K piece of a tail tile: its own slab, dense [M, N]
         gs.C = g.tail_slab + (size_t)(z - 1) * g.M * g.N;
         gs.ldc = g.N;
@@ -371,6 +374,7 @@ static int launch_rs(const GemmArgs& g_in, hipStream_t s) {
             }
         }
     }
+#ifdef DPD_ADAM_EPI
     if (g.ad.p) {       // Adam epilogue: the plain TN forms of the weight gradients only (everything else has no use for it)
         if constexpr (!AK && !BKC && ASRC == 0 && D == 2 && WC == 2) {
             if (g.tail_split > 1 || g.split_k != 1) return DPD_E_UNSUPPORTED;
@@ -380,6 +384,7 @@ static int launch_rs(const GemmArgs& g_in, hipStream_t s) {
             return DPD_E_UNSUPPORTED;
         }
     }
+#endif
     DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D, ASRC>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     if (g.tail_split > 1) {

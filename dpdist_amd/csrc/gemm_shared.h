@@ -2,6 +2,13 @@
 #pragma once
 #include "common.h"
 
+// The Adam epilogue of the weight-gradient GEMMs (AdamEpi below) is a measured-and-rejected experiment (DESIGN.md section 3.4 h): it is
+// compiled only into the ablation build (DPD_ABLATIONS=1 python -m dpdist_amd.build --force) -- carrying its 88 bytes of kernel arguments
+// and its epilogue branch in every GEMM costs the default step ~1 us (0.5595 vs 0.5608 ms, A/B of the two trees on one box).
+#ifdef DPD_ABLATIONS
+#define DPD_ADAM_EPI 1
+#endif
+
 namespace dpd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -64,7 +71,9 @@ struct GemmArgs {
     float* tail_slab;
     int k_chunk;      // K range per split (multiple of BK)
     long slab_stride; // floats between split-K slabs (0 when split_k == 1)
+#ifdef DPD_ADAM_EPI
     AdamEpi ad;       // ad.p != NULL: apply Adam to the tile instead of (or besides, C != NULL) storing the gradient
+#endif
 };
 
 // host side: the Adam epilogue of the NEXT plain GEMM launched from this thread (set and cleared by dpd_decoder_bwd_weights*_adam around
@@ -166,8 +175,12 @@ __device__ __forceinline__ void put_tile(const GemmArgs& g, float (&v)[16], int 
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < g.M && col_ok) cs += v[r];
     }
+#ifdef DPD_ADAM_EPI
     AdamEpi ad = g.ad;
     if (!ADAM) ad.p = nullptr;
+#else
+    AdamEpi ad{};
+#endif
     if (Cz || ad.p) {
         const int l31 = threadIdx.x & 31;
         const int col0 = __builtin_amdgcn_readfirstlane(col_in - l31);   // first column of the tile (wave-uniform)

@@ -98,7 +98,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
     const int M = g.e.M, N = g.e.N;
     if (!g.out_rc && !g.out_r8) {
         GemmArgs ge = g.e;
-        if (grp) { ge.C = g.C2; ge.ad.p = g.e.ad.p2; ge.ad.m = g.e.ad.m2; ge.ad.v = g.e.ad.v2; ge.ad.wt = g.e.ad.wt2; }
+        if (grp) ge.C = g.C2;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -145,7 +145,7 @@ class DPDistTrainer:
         # their K loops together, so the 112 MB of p / m / v traffic arrive as one burst at the end of each launch (+19 us on the two
         # GEMMs) instead of hiding under the matrix cores, and the optimizer kernel only gets 18 us shorter (DESIGN.md section 3.4 h)
         self.adam_in_dw = (self.dt == 0 and self.reducer is None and not self.fused and BN % 32 == 0
-                           and os.environ.get("DPD_ADAM_IN_DW", "0") == "1")
+                           and os.environ.get("DPD_ADAM_IN_DW", "0") == "1" and L.load().dpd_has_adam_epilogue() == 1)
         self._adam_now = None      # (lr_t) while a step that applies Adam in the dW epilogues is in flight
         self._keep_grad = os.environ.get("DPD_KEEP_GRAD", "0") == "1"      # also store dW (the optimizer no longer reads it)
         if self.adam_in_dw:

@@ -337,7 +337,10 @@ int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t n, float lr
  * keeps the biases and the output layer (dpd_adam_fuse.skip_w).  p / m / v: the matrix's parameters and moments, laid out like dW
  * ([Kin, Nout], 16-byte aligned); wt: optional transposed copy [Nout, Kin] of the NEW parameters (what dpd_weights_transpose would
  * make); *2: the second matrix of the pair call.  dW may be NULL (the gradient is then not stored at all).  DPD_F32 only in this round.
- * Not for data-parallel steps (the all-reduce stands between the gradient and its use).                                            */
+ * Not for data-parallel steps (the all-reduce stands between the gradient and its use).  Bit-identical and measured SLOWER than the
+ * optimizer launch (DESIGN.md section 3.4 h): compiled into the ablation build only (dpd_has_adam_epilogue).                        */
+int dpd_has_adam_epilogue(void);   /* 1 in a library built with DPD_ABLATIONS (the form is a measured-and-rejected experiment: both calls
+                                     * below return DPD_E_UNSUPPORTED otherwise) */
 typedef struct dpd_adam_epi {
     float *p, *m, *v, *wt;
     float *p2, *m2, *v2, *wt2;
