@@ -200,20 +200,28 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
             }
         }
         MFV_STAMP(5);
-        // merge the eight point groups (lanes l, l^8, l^16, l^32 ... hold the same Gaussian)
+        // merge the eight point groups (lanes l, l^8, l^16, l^32 ... hold the same Gaussian).  __shfl_xor is a ds_bpermute (LDS crossbar +
+        // an address register) per value and stage: 60 of them made this merge as expensive as the point loop, and the section is VALU /
+        // issue bound (four waves per SIMD).  xor 8 is a DPP row rotate, xor 32 a v_permlane32_swap (both halves receive lower + upper),
+        // only xor 16 still goes through the crossbar (ds_swizzle, no address).  Same operands, same order: the same bits.
+        auto x8 = [](float v) { return dpp_move<0x128>(v); };                                                  // row_ror:8 = lane ^ 8
+        auto x16 = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); };   // bit mode: xor 16
+        auto sum32 = [](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                                   return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+        auto max32 = [](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                                   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); };
+        auto min32 = [](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                                   return fminf(__uint_as_float(r[0]), __uint_as_float(r[1])); };
+        pi_s += x8(pi_s); pi_s += x16(pi_s); pi_s = sum32(pi_s);
+        pi_mx = fmaxf(pi_mx, x8(pi_mx)); pi_mx = fmaxf(pi_mx, x16(pi_mx)); pi_mx = max32(pi_mx);
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
-            pi_s += __shfl_xor(pi_s, o, 64);
-            pi_mx = fmaxf(pi_mx, __shfl_xor(pi_mx, o, 64));
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                mu_s[d] += __shfl_xor(mu_s[d], o, 64);
-                sg_s[d] += __shfl_xor(sg_s[d], o, 64);
-                mu_mx[d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], o, 64));
-                mu_mn[d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], o, 64));
-                sg_mx[d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], o, 64));
-                sg_mn[d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], o, 64));
-            }
+        for (int d = 0; d < 3; ++d) {
+            mu_s[d] += x8(mu_s[d]); mu_s[d] += x16(mu_s[d]); mu_s[d] = sum32(mu_s[d]);
+            sg_s[d] += x8(sg_s[d]); sg_s[d] += x16(sg_s[d]); sg_s[d] = sum32(sg_s[d]);
+            mu_mx[d] = fmaxf(mu_mx[d], x8(mu_mx[d])); mu_mx[d] = fmaxf(mu_mx[d], x16(mu_mx[d])); mu_mx[d] = max32(mu_mx[d]);
+            mu_mn[d] = fminf(mu_mn[d], x8(mu_mn[d])); mu_mn[d] = fminf(mu_mn[d], x16(mu_mn[d])); mu_mn[d] = min32(mu_mn[d]);
+            sg_mx[d] = fmaxf(sg_mx[d], x8(sg_mx[d])); sg_mx[d] = fmaxf(sg_mx[d], x16(sg_mx[d])); sg_mx[d] = max32(sg_mx[d]);
+            sg_mn[d] = fminf(sg_mn[d], x8(sg_mn[d])); sg_mn[d] = fminf(sg_mn[d], x16(sg_mn[d])); sg_mn[d] = min32(sg_mn[d]);
         }
         MFV_STAMP(6);
         if (live && grp == 0) {
@@ -233,23 +241,22 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
             for (int f = 0; f < kF; ++f) s_stage[gl * kFP + f] = v[f];
         }
     }
-    __syncthreads();
-    // power-1/2 normalisation (:119-121) by ALL threads, in place: inside the branch above only 8 lanes of 64 were alive for 20 square
-    // roots each, and four waves per SIMD queue for the same VALU: 15k of this kernel's 30k cycles (tools/mfv_stamps.py)
-    for (int e = tid; e < gcount * kF; e += kFwdThreads) {
-        float* sp = s_stage + (e / kF) * kFP + e % kF;
-        *sp = pnorm(*sp);
-    }
+    MFV_STAMP(7);
     __syncthreads();
     MFV_STAMP(3);
 
-    // ---- coalesced store of the slice: fv[c][g0 + g][f], 4 consecutive f of one g per thread --------------------
+    // ---- power-1/2 normalisation (:119-121) and coalesced store of the slice, one pass of ALL threads: fv[c][g0 + g][f], 4 consecutive f of
+    // one g per thread.  (Inside the merge branch above only 8 lanes of 64 were alive for 20 square roots each, four waves per SIMD
+    // queueing for the same VALU: 15k of this kernel's 30k cycles, tools/mfv_stamps.py.)  The normalised values go back to the stage for
+    // the slice's sums of squares.
     float* out = fv + ((size_t)c * G + g0) * kF;
     const bool bad = *s_bad != 0;
     const float qnan = __int_as_float(0x7fc00000);
     for (int i4 = tid; i4 < gcount * kF / 4; i4 += kFwdThreads) {
         const int e = i4 * 4, g = e / kF, f = e % kF;
-        float4 o = make_float4(s_stage[g * kFP + f], s_stage[g * kFP + f + 1], s_stage[g * kFP + f + 2], s_stage[g * kFP + f + 3]);
+        float* sp = s_stage + g * kFP + f;
+        float4 o = make_float4(pnorm(sp[0]), pnorm(sp[1]), pnorm(sp[2]), pnorm(sp[3]));
+        sp[0] = o.x; sp[1] = o.y; sp[2] = o.z; sp[3] = o.w;
         if (bad) o = make_float4(qnan, qnan, qnan, qnan);   // 0/0 at :74 poisons every statistic of the cloud
         *reinterpret_cast<float4*>(out + e) = o;
     }
