@@ -30,6 +30,12 @@ struct MfvConst {
     float sig_scale; // 1/sqrt(2w)             (:109)
 };
 
+// Index arithmetic without the integer divider gfx950 does not have (~35 VALU instructions per run-time division; the table loops of
+// these kernels run three of them per entry with four waves per SIMD: 3.3k of the forward kernel's 21.7k cycles at B = 32): the usual
+// sizes (m = 8, N = 64, slices of 16 points) are powers of two, so quotients are shifts; anything else keeps the division.
+__device__ __forceinline__ int lg_or_neg(int d) { return (d > 0 && !(d & (d - 1))) ? __ffs(d) - 1 : -1; }
+__device__ __forceinline__ int qdiv(int x, int d, int lg) { return lg >= 0 ? x >> lg : x / d; }
+
 __device__ __forceinline__ void gauss_centre(const MfvConst& k, int g, float& cx, float& cy, float& cz) {
     // g = i*m*m + j*m + t  ->  (x,y,z) = (l[j], l[i], l[t])   (np.meshgrid 'xy' indexing, :47-48)
     const int m = k.m;
@@ -130,8 +136,9 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
     const float* p = pts ? pts + (size_t)c * N * 3 : (c < fu.B ? fu.pcA + (size_t)c * N * 3 : fu.pcB + (size_t)(c - fu.B) * N * 3);
     const float* nz = (!pts && fu.noise && c < fu.B) ? fu.noise + (size_t)c * N * 3 : nullptr;
     if (tid == 0) *s_bad = 0;
+    const int lg_m = lg_or_neg(m), lg_n = lg_or_neg(N);
     for (int e = tid; e < 3 * N * m; e += kFwdThreads) {
-        const int a = e / (N * m), n = (e / m) % N, i = e % m;
+        const int em = qdiv(e, m, lg_m), i = e - em * m, a = qdiv(em, N, lg_n), n = em - a * N;
         const float x = nz ? p[n * 3 + a] + nz[n * 3 + a] : p[n * 3 + a];
         const float z = (x - k.ax.c[i]) / k.sigma;               // (batch_points - batch_mu) / batch_sig  (:87)
         s_zq[e] = make_float2(z, expf(-0.5f * (z * z)));
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         s_mz[e] = mz;
     }
     __syncthreads();
-    for (int e = tid; e < 3 * N * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[e / m];
+    for (int e = tid; e < 3 * N * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[qdiv(e, m, lg_m)];
     for (int n = tid; n < N; n += kFwdThreads) {
         // the reference's 0/0: every w*p_ng == 0  <=>  the largest one is (p is monotone in -|z|^2)
         const float pmax = pdf(k, sqrtf(s_mz[n]), sqrtf(s_mz[N + n]), sqrtf(s_mz[2 * N + n]));
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         const int gl = gbase + (lane & 7);
         const bool live = gl < gcount;
         const int gg = live ? g0 + gl : 0;
-        const int i = gg / (m * m), j = (gg / m) % m, t = gg % m;   // centre (x,y,z) = (l[j], l[i], l[t])  (:47-48)
+        const int gm = qdiv(gg, m, lg_m), t = gg - gm * m, i = qdiv(gm, m, lg_m), j = gm - i * m;   // centre (x,y,z) = (l[j], l[i], l[t])  (:47-48)
         float pi_s = 0.f, pi_mx = -INFINITY;
         float mu_s[3] = {0.f, 0.f, 0.f}, mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
         float sg_s[3] = {0.f, 0.f, 0.f}, sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
@@ -568,8 +575,9 @@ constexpr int kRec = 33;   // 20 statistics + 13 tie counts
 
 __device__ __forceinline__ void build_tables(const float* p, int n0, int np_, const MfvConst& k, float2* s_zq, float* s_S, int tid) {
     const int m = k.m;
+    const int lg_m = lg_or_neg(m), lg_np = lg_or_neg(np_);
     for (int e = tid; e < 3 * np_ * m; e += kFwdThreads) {
-        const int a = e / (np_ * m), ln = (e / m) % np_, i = e % m;
+        const int em = qdiv(e, m, lg_m), i = e - em * m, a = qdiv(em, np_, lg_np), ln = em - a * np_;
         const float z = (p[(n0 + ln) * 3 + a] - k.ax.c[i]) / k.sigma;
         s_zq[e] = make_float2(z, expf(-0.5f * (z * z)));
     }
@@ -580,7 +588,7 @@ __device__ __forceinline__ void build_tables(const float* p, int n0, int np_, co
         s_S[e] = S;
     }
     __syncthreads();
-    for (int e = tid; e < 3 * np_ * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[e / m];
+    for (int e = tid; e < 3 * np_ * m; e += kFwdThreads) s_zq[e].y = s_zq[e].y / s_S[qdiv(e, m, lg_m)];
     __syncthreads();
 }
 
