@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
                                                               const float* __restrict__ y, const float* __restrict__ h3,
                                                               const float* __restrict__ W4, float* __restrict__ dy,
                                                               float* __restrict__ g3, int Qb, int H, ZeroList zl,
-                                                              float* __restrict__ scratch, L1Fuse l1, OutFwd of, G3Planes gp) {
+                                                              float* __restrict__ scratch, L1Fuse l1, OutFwd of, G3Planes gp,
+                                                              const uint16_t* __restrict__ h3b) {
     extern __shared__ float s_acc[];   // [4 waves][4H + 8]; reused at the end (gp.r8) as uint16 [np][8][H]
     if (blockIdx.x < 5 && zl.p[blockIdx.x]) {
         for (int i = threadIdx.x; i < zl.n[blockIdx.x]; i += 256) zl.p[blockIdx.x][i] = 0.f;
@@ -456,8 +457,19 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             if (jj < ng) {
-                hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
-                if (of.y) hb[rr][jj] = *reinterpret_cast<const float4*>(h3 + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
+                if (h3b) {      // layer 3's activation as one bf16 plane (DPD_BF16): 8 bytes per lane instead of 16, widened exactly
+                    const uint2 ua = *reinterpret_cast<const uint2*>(h3b + (size_t)row * H + 256 * jj + 4 * lane);
+                    hv[rr][jj] = make_float4(__uint_as_float(ua.x << 16), __uint_as_float(ua.x & 0xffff0000u), __uint_as_float(ua.y << 16),
+                                             __uint_as_float(ua.y & 0xffff0000u));
+                    if (of.y) {
+                        const uint2 ub = *reinterpret_cast<const uint2*>(h3b + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
+                        hb[rr][jj] = make_float4(__uint_as_float(ub.x << 16), __uint_as_float(ub.x & 0xffff0000u), __uint_as_float(ub.y << 16),
+                                                 __uint_as_float(ub.y & 0xffff0000u));
+                    }
+                } else {
+                    hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
+                    if (of.y) hb[rr][jj] = *reinterpret_cast<const float4*>(h3 + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
+                }
             }
         }
     }
@@ -882,7 +894,7 @@ PlaneSizes plane_sizes(int Q, int Qb, int KP, int H, int np) {
 extern "C" size_t dpd_planes_bytes(int Q, int Qb, int KP, int H, int dtype, int with_dx) {
     if (dtype != 1 && dtype != 2) return 0;
     const PlaneSizes z = plane_sizes(Q, Qb, KP, H, dtype == 1 ? 3 : 1);
-    return z.X_rc + z.X_r8 + 2 * (z.h_rc + z.h_r8) + (with_dx ? 6 : 5) * z.g + (with_dx ? 2 : 1) * z.W1 + 4 * z.W23;
+    return z.X_rc + z.X_r8 + 2 * (z.h_rc + z.h_r8) + (with_dx ? 6 : 5) * z.g + (with_dx ? 2 : 1) * z.W1 + 4 * z.W23 + (dtype == 2 ? z.h_rc : 0);
 }
 
 extern "C" int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, int H, int dtype, int with_dx, dpd_planes* out) {
@@ -903,6 +915,7 @@ extern "C" int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, 
     out->W1_r8 = take(z.W1); out->W2_r8 = take(z.W23); out->W3_r8 = take(z.W23);
     out->W2_rc = take(z.W23); out->W3_rc = take(z.W23);
     out->W1_rc = with_dx ? take(z.W1) : nullptr;
+    out->h3_rc = (dtype == 2) ? take(z.h_rc) : nullptr;
     return 0;
 }
 
@@ -950,7 +963,9 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     // y = pred = NULL: the output layer is left to dpd_decoder_bwd_data (dpd_small_grads.fwd_y).  h1 / h2 = NULL: plane compute
     // types whose planes keep h1_rc / h2_rc need no fp32 copy (the next layer, the weight gradients and the ReLU gate of the backward
     // all read the planes): 2 x Q x H x 4 bytes less to write per forward
-    if (!mask || !p || !h3 || (!y != !pred)) return DPD_E_NULL;
+    // h3 = NULL (DPD_BF16, y = pred = NULL): layer 3 leaves its activation as the bf16 plane pl->h3_rc only
+    const bool h3_plane = !h3 && pl && pl->np == 1 && pl->h3_rc && !y;
+    if (!mask || !p || (!h3 && !h3_plane) || (!y != !pred)) return DPD_E_NULL;
     if ((!h1 && !(pl && pl->h1_rc)) || (!h2 && !(pl && pl->h2_rc))) return DPD_E_NULL;
     if (pl && (pl->Q != Q || pl->Qb > Q)) return DPD_E_DIM;
     if (int rc = dpd::check_planes(pl, dtype)) return rc;
@@ -967,8 +982,9 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
                              pl->X_rc, pl->W1_r8, w1 ? &o1 : nullptr)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s, nullptr,
                              pl->h1_rc, pl->W2_r8, w2 ? &o2 : nullptr)) return rc;
+        X3Out o3 = make_out(pl, pl->h3_rc, Q, nullptr, 0, H);
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s, nullptr,
-                             pl->h2_rc, pl->W3_r8, nullptr)) return rc;
+                             pl->h2_rc, pl->W3_r8, h3_plane ? &o3 : nullptr)) return rc;
     } else {
         if (dtype != 0 && !scr.p) return DPD_E_WORKSPACE;
         if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s)) return rc;
@@ -1101,7 +1117,9 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     const bool l1 = sg && sg->l1_labels;        // fused training loss: dpred is derived inside the output-layer kernel
     if (phases <= 0 || phases > 31) return DPD_E_DIM;
     // (phases without 1: the output layer was done before -- an earlier call or dpd_decoder_out_asloss -- and only g3 is read)
-    if (!p || ((phases & 1) && ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || !h3 || !dy))) return DPD_E_NULL;
+    // h3 = NULL: the bf16 plane pl->h3_rc of dpd_decoder_fwd (DPD_BF16; only the fused output-layer kernel reads it: checked below)
+    const bool h3_plane = !h3 && pl && pl->np == 1 && pl->h3_rc;
+    if (!p || ((phases & 1) && ((!dpred && !l1) || !mask || (!y && !(sg && sg->fwd_y)) || (!h3 && !h3_plane) || !dy))) return DPD_E_NULL;
     if ((!h1 && !(pl && pl->h1_rc)) || (!h2 && !(pl && pl->h2_rc))) return DPD_E_NULL;   // gate from the fp32 activation or its bf16 plane
     // g2 / g1 = NULL: plane compute types whose planes keep g2_rc + g2_r8 (g1_r8, and g1_rc when dX is wanted) need no fp32 copy of
     // the pre-activation gradients either (the next dH GEMM and the weight gradients read the planes; db2 / db1 come out of the
@@ -1129,6 +1147,7 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     const int rec = fused4 ? 4 * H + kOBRec : 4 * H + 4;          // floats per block record
     const bool fused = (db3 || dW4 || db4 || l1) && H <= 64 * kOBMaxJ && (size_t)nblk * rec <= (size_t)Qb * H;
     if (l1 && !(fused && fused4)) return DPD_E_UNSUPPORTED;       // the caller then uses dpd_l1_loss + dpred
+    if ((phases & 1) && h3_plane && !(fused && fused4 && pl)) return DPD_E_UNSUPPORTED;
     const L1Fuse lf{l1 ? sg->l1_pred : nullptr, l1 ? sg->l1_labels : nullptr, l1 ? sg->l1_gscale : 1.0f};
     const bool ofwd = sg && (sg->fwd_y || sg->fwd_pred) && (phases & 1);   // output layer's forward inside the same pass (training step)
     if (ofwd && !(l1 && fused4 && sg->fwd_y && sg->fwd_pred && p->b4)) return DPD_E_UNSUPPORTED;
@@ -1159,7 +1178,8 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
             const size_t lds = (size_t)4 * rec * sizeof(float);      // (the R8 image of g3, np * 8 * H * 2 bytes, reuses the slabs)
             static LdsOptIn lds_opt;
             if (int rc = ensure_dyn_lds(lds_opt, (const void*)out_bwd_fused4_kernel, lds)) return rc;
-            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf, ofw, gpl);
+            DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf, ofw, gpl,
+                       h3 ? nullptr : (const uint16_t*)pl->h3_rc);
         } else {
             DPD_LAUNCH(out_bwd_fused_kernel, dim3(nblk), dim3(256), (size_t)(4 * H + 4) * sizeof(float), s, dpred, mask, y, h3,
                        p->W4, dy, g3, Qb, H, zl, part);

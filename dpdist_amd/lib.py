@@ -42,7 +42,7 @@ class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
 class Planes(Structure):     # include/dpdist_capi.h: dpd_planes
     _fields_ = [("np", c_int), ("Q", c_int), ("Qb", c_int)] + [(n, c_void_p) for n in (
         "X_rc", "X_r8", "h1_rc", "h1_r8", "h2_rc", "h2_r8", "g3_rc", "g3_r8", "g2_rc", "g2_r8", "g1_rc", "g1_r8",
-        "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc")]
+        "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc", "h3_rc")]
 
 
 # name -> (restype, argtypes); mirrors include/dpdist_capi.h one to one

@@ -280,6 +280,11 @@ class DPDistTrainer:
         Q = 2 * self.B * self.N
         skip_out = bool(skip_out and self.fuse_out and not self.fused)
         self._out_pending = skip_out
+        # DPD_BF16 training step: layer 3's activation leaves its GEMM as ONE bf16 plane and the fused output-layer kernel reads that
+        # (17 MB less to write and 33 MB less to read per step at B = 64); DPD_H3_PLANE=0 keeps the fp32 h3
+        self._h3_in_plane = bool(skip_out and self.fuse_loss and self._planes is not None and self._planes.np == 1
+                                 and self._planes.h3_rc and self._tail_ok and os.environ.get("DPD_H3_PLANE", "1") == "1")
+        h3 = None if self._h3_in_plane else self.h3
         if self._wdirty:
             self.refresh_weight_planes()
         if self.fused:
@@ -288,7 +293,7 @@ class DPDistTrainer:
                     "dpd_decoder_fwd_gather")
             return
         L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
-                                    L.ptr(self.h2), L.ptr(self.h3), None if skip_out else L.ptr(self.y),
+                                    L.ptr(self.h2), L.ptr(h3), None if skip_out else L.ptr(self.y),
                                     None if skip_out else L.ptr(self.pred), L.ptr(self.ws), self.ws.numel() * 4, self._planes, s),
                 "dpd_decoder_fwd")
 
@@ -317,7 +322,7 @@ class DPDistTrainer:
 
         def data(phases):   # db1..db3, dW4, db4 fall out of the data chain (fused epilogues / one small kernel)
             L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
-                                             L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
+                                             None if getattr(self, "_h3_in_plane", False) else L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
                                              L.ptr(self.g2), L.ptr(self.g1), None, small, L.ptr(self.ws), wsb, self._planes,
                                              phases, L.cur_stream()), "dpd_decoder_bwd_data")   # stream at CALL time (graph branches)
 

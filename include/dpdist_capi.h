@@ -193,6 +193,9 @@ struct dpd_planes {
     void *X_rc, *X_r8, *h1_rc, *h1_r8, *h2_rc, *h2_r8;
     void *g3_rc, *g3_r8, *g2_rc, *g2_r8, *g1_rc, *g1_r8;
     void *W1_r8, *W2_r8, *W3_r8, *W1_rc, *W2_rc, *W3_rc;
+    void* h3_rc;  /* DPD_BF16 only (NULL otherwise): layer 3's activation as ONE bf16 plane [Q,H] instead of fp32 -- dpd_decoder_fwd writes it when
+                   * h3 == NULL and y == NULL, the fused output-layer kernel of dpd_decoder_bwd_data (which then runs the output layer's forward
+                   * as well: dpd_small_grads.fwd_y) reads it; 2 instead of 4 bytes per element written once and read once per step */
 };
 
 /* Bytes for ALL members (with_dx: also g1_rc and W1_rc, needed only when dX is requested), and the carve-up of one

@@ -1157,6 +1157,37 @@ def test_lds_window_gather_is_bitwise_the_row_wise_kernels(dev, dt, B, monkeypat
         assert torch.equal(ai, bi)
 
 
+def test_bf16_step_with_layer3_activation_as_a_plane(dev, monkeypatch):
+    """DPD_BF16 training steps keep layer 3's activation as ONE bf16 plane (dpd_planes.h3_rc: written by the layer-3 GEMM, read by the
+    fused output-layer kernel) instead of fp32.  It rounds the output layer's input like every other activation of this compute type:
+    against the fp32-h3 form (DPD_H3_PLANE=0) the losses of five steps agree to 2e-3 relative and the weights to the bf16 bar; the
+    plane form is the one that runs by default, and evaluation-mode forwards (output layer wanted) still produce the fp32 h3."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 32
+    batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 400 + i)) for i in range(5)]
+    W0 = synth.make_weights("wide")
+    res = {}
+    for v in ("1", "0"):
+        monkeypatch.setenv("DPD_H3_PLANE", v)
+        P = DPDistParams(device=dev, compute_dtype="bf16")
+        P.load_tf_state_dict(W0)
+        tr = DPDistTrainer(P, B, 64)
+        losses = []
+        for b in batches:
+            losses.append(tr.step(*b).clone())
+            assert tr._h3_in_plane == (v == "1")
+        tr._take_front(batches[0][0], batches[0][1], None)
+        tr._decode()                                  # evaluation-style forward: fp32 h3, y, pred
+        assert not tr._h3_in_plane and torch.isfinite(tr.pred).all()
+        torch.cuda.synchronize()
+        res[v] = (torch.stack(losses).cpu().numpy(), P.flat.detach().cpu().numpy())
+    la, lb = res["1"][0], res["0"][0]
+    assert np.abs(la - lb).max() <= 2e-3 * np.abs(lb).max(), (la, lb)
+    wa, wb = res["1"][1], res["0"][1]
+    assert np.abs(wa - wb).max() <= 2e-3          # five Adam steps of 1e-4: the signs of a few tiny gradients may differ, nothing more
+
+
 def test_adam_in_the_weight_gradient_epilogue_is_bitwise_the_optimizer_kernel(dev, monkeypatch):
     """Single-GPU exact-fp32 steps apply Adam to W1p / W2 / W3 inside the epilogue of their weight-gradient GEMMs
     (dpd_decoder_bwd_weights*_adam) and leave the optimizer launch the biases and the output layer.  Same adam_one on the same
