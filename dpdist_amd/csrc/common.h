@@ -104,6 +104,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_move<0x143, 0xC>(v);    // row_bcast31 into rows 2 and 3: lanes 48-63 = all four rows
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// lane <-> lane ^ 32 combinations through v_permlane32_swap (gfx950; semantics probed in tools/permlane_probe.hip: with both operands
+// equal, result 0 holds the lower half-wave's value in every lane and result 1 the upper half-wave's): both halves receive
+// lower (op) upper, the same bits as x (op) __shfl_xor(x, 32) for a commutative op -- without the LDS crossbar and its address register
+__device__ __forceinline__ float sum_x32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float max_x32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float min_x32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 // sum over a 256-thread block (fixed order), returned in every thread; red = 4 floats of LDS
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);

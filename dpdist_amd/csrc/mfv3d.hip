@@ -428,19 +428,19 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __r
                 sg_s[d] += q.b[d]; sg_mx[d] = fmaxf(sg_mx[d], q.b[d]); sg_mn[d] = fminf(sg_mn[d], q.b[d]);
             }
         }
-        pi_s += __shfl_xor(pi_s, 32, 64);
-        pi_mx = fmaxf(pi_mx, __shfl_xor(pi_mx, 32, 64));
+        pi_s = sum_x32(pi_s);
+        pi_mx = max_x32(pi_mx);
         raw[0] = pi_s * invN; raw[1] = pi_mx;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            mu_s[d] += __shfl_xor(mu_s[d], 32, 64);
-            sg_s[d] += __shfl_xor(sg_s[d], 32, 64);
+            mu_s[d] = sum_x32(mu_s[d]);
+            sg_s[d] = sum_x32(sg_s[d]);
             raw[2 + d] = mu_s[d] * invN;
-            raw[5 + d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], 32, 64));
-            raw[8 + d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], 32, 64));
+            raw[5 + d] = max_x32(mu_mx[d]);
+            raw[8 + d] = min_x32(mu_mn[d]);
             raw[11 + d] = sg_s[d] * invN;
-            raw[14 + d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], 32, 64));
-            raw[17 + d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], 32, 64));
+            raw[14 + d] = max_x32(sg_mx[d]);
+            raw[17 + d] = min_x32(sg_mn[d]);
         }
     }
     // ---- channel sums ss_f = sum_g s^2, dot_f = sum_g s*dfv -------------------------------------------------
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_kernel(const float* __r
         const int mm[13] = {1, 5, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19};
 #pragma unroll
         for (int i = 0; i < 13; ++i) {
-            const float ctot = cnt[i] + __shfl_xor(cnt[i], 32, 64);
+            const float ctot = sum_x32(cnt[i]);
             dr[mm[i]] = dr[mm[i]] / fmaxf(ctot, 1.f);
         }
     }
@@ -626,16 +626,16 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const floa
                 sg_s[d] += q.b[d]; sg_mx[d] = fmaxf(sg_mx[d], q.b[d]); sg_mn[d] = fminf(sg_mn[d], q.b[d]);
             }
         }
-        rec[0] = pi_s + __shfl_xor(pi_s, 32, 64);            // SUMS here (the mean's 1/N is applied after the combine)
-        rec[1] = fmaxf(pi_mx, __shfl_xor(pi_mx, 32, 64));
+        rec[0] = sum_x32(pi_s);            // SUMS here (the mean's 1/N is applied after the combine)
+        rec[1] = max_x32(pi_mx);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            rec[2 + d] = mu_s[d] + __shfl_xor(mu_s[d], 32, 64);
-            rec[5 + d] = fmaxf(mu_mx[d], __shfl_xor(mu_mx[d], 32, 64));
-            rec[8 + d] = fminf(mu_mn[d], __shfl_xor(mu_mn[d], 32, 64));
-            rec[11 + d] = sg_s[d] + __shfl_xor(sg_s[d], 32, 64);
-            rec[14 + d] = fmaxf(sg_mx[d], __shfl_xor(sg_mx[d], 32, 64));
-            rec[17 + d] = fminf(sg_mn[d], __shfl_xor(sg_mn[d], 32, 64));
+            rec[2 + d] = sum_x32(mu_s[d]);
+            rec[5 + d] = max_x32(mu_mx[d]);
+            rec[8 + d] = min_x32(mu_mn[d]);
+            rec[11 + d] = sum_x32(sg_s[d]);
+            rec[14 + d] = max_x32(sg_mx[d]);
+            rec[17 + d] = min_x32(sg_mn[d]);
         }
     }
     {
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const floa
             }
         }
 #pragma unroll
-        for (int i = 0; i < 13; ++i) rec[20 + i] = cnt[i] + __shfl_xor(cnt[i], 32, 64);
+        for (int i = 0; i < 13; ++i) rec[20 + i] = sum_x32(cnt[i]);
     }
     if (live && half == 0) {
         float* out = part + ((size_t)(c * kSlices + sl) * kRec) * G + g;
