@@ -39,8 +39,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# torch is imported inside main() / the helpers that need it: the watchdog supervisor of an N > 1 run (dpdist_amd/launch.py) is this
+# same file and must start in milliseconds without touching a GPU runtime
+torch = dist = None
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
@@ -116,6 +117,7 @@ def cpu_baseline(B, N, budget_s=26.0):
       torch       oracle/restate.py on torch-CPU (oneDNN/MKL GEMMs)
     each at 1 thread and at the best of a few thread counts.  `value` = the best number of all (cores = its thread count)."""
     import numpy as np
+    import torch
     from dpdist_amd import synth
     from oracle import restate as R
     ncpu = os.cpu_count() or 1
@@ -236,6 +238,7 @@ def pmc_traffic(kernel_substr):
 def profiled_gemm_pass(L, tr, lab, warmup, steps):
     """(launches, summed GEMM ms, flops) of `steps` forward + backward passes with the library's in-stream profiler on (hipEvent pairs
     around every GEMM launch on the stream the kernels run on); best of two passes (a host stall idles the GPU and drops its clock)."""
+    import torch
     best = None
     for _pass in range(2):
         for it in range(warmup + steps):
@@ -258,16 +261,23 @@ def self_launch(n):
     flag inside one process, train_multi_gpu_pc_compare_dist.py:122-126,237-302; here: one process per GPU over RCCL, the same
     environment contract as `python -m torch.distributed.run --nproc-per-node N`).  Rank 0 prints the JSON line; the exit code
     is the first non-zero rank exit code.  Children are stopped by PID, never by pattern."""
+    import torch
     if not torch.cuda.is_available() or torch.cuda.device_count() < n:
         sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible\n" % (n, torch.cuda.device_count() if torch.cuda.is_available() else 0))
         return 2
     return spawn_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
 
 
-def spawn_ranks(n, cmd):
-    """Run `cmd` n times with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set (rendezvous on 127.0.0.1, free port)."""
+def spawn_ranks(n, cmd, timeout_s=None):
+    """Run `cmd` n times with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set (rendezvous on 127.0.0.1, free port).  Every rank of
+    bench.py supervises itself (per-phase watchdog + one retry on torch.distributed collectives: dpdist_amd/launch.py); the
+    overall limit here (DPD_SPAWN_TIMEOUT, default 1500 s) is the backstop behind that: on expiry the ranks are stopped by PID and
+    the code is 124."""
     import socket
     import subprocess
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("DPD_SPAWN_TIMEOUT", "1500"))
+    t_start = time.time()
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -289,6 +299,13 @@ def spawn_ranks(n, cmd):
                     rc = code
                     for q in procs:        # one rank died: the others would hang in the next collective
                         q.terminate()
+            if procs and time.time() - t_start > timeout_s:
+                sys.stderr.write("spawn_ranks: %d rank(s) still running after %.0f s, stopping them\n" % (len(procs), timeout_s))
+                for q in procs:
+                    q.terminate()
+                time.sleep(3.0)
+                rc = rc or 124
+                break
             time.sleep(0.05)
     finally:
         for q in procs:
@@ -319,16 +336,29 @@ def main():
         if "WORLD_SIZE" not in os.environ and a.gpus > 1:
             raise SystemExit(self_launch(a.gpus))     # plain `python bench.py --gpus N`: spawn the N ranks ourselves
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    use_dist = world > 1 or os.environ.get("DPD_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
+    from dpdist_amd import launch
+    if use_dist:
+        # N > 1: this process becomes the rank's SUPERVISOR (no torch, no GPU runtime) and re-runs this command line as the worker
+        # under a per-phase watchdog; a hang or a dead rank -> the workers are stopped by PID and the run is repeated ONCE with
+        # torch.distributed collectives (DPD_DP_BACKEND=torch).  Returns only in the worker.
+        launch.maybe_supervise(world)
+    hb = launch.Heartbeat(rank)
+    hb.beat("start:import")
+    global torch, dist
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DPDist path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("DPD_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        hb.beat("init:process group")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()
 
     from dpdist_amd import lib, synth
     from dpdist_amd.model import DPDistParams
@@ -342,7 +372,9 @@ def main():
     P = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev, compute_dtype=a.dtype)
     g = torch.Generator().manual_seed(1234)            # same random-init weights on every rank (replicated variables)
     P.reset_parameters_tf(generator=g)
+    hb.beat("reducer:communicators + start-up cross-check")   # make_reducer: librccl bind, ncclCommInitRank, known-pattern reduce
     tr = DPDistTrainer(P, B, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4)
+    hb.beat("crosscheck:passed")
     pcA, pcB, lab = synth.s2_modelnet_shaped(B, N, 100 + rank)
     pcA, pcB, lab = (torch.tensor(x, device=dev) for x in (pcA, pcB, lab))
 
@@ -364,12 +396,54 @@ def main():
     gc.collect()
     gc.disable()          # like timeit: a generation-2 collection inside a 12-30 ms timed region shows up as a 20 ms host stall
 
-    def bf16_b64(distributed, label):
+    def dp_report(trn, step_fn):
+        """What the data-parallel plumbing of trainer `trn` is and costs: backend, ranks as the communicator reports them, bytes
+        each GPU puts on the links per step, the start-up cross-check, and the EXPOSED communication = time the compute stream
+        spends waiting for collectives, from in-stream event pairs around the waits in a separate pass of the same steps."""
+        red = trn.reducer
+        if red is None or not red.active:
+            return None
+        rep = {"backend": red.backend, "fallback": hb.fallback, "attempt": hb.attempt, "mode": red.mode, "wire": red.wire,
+               "two_communicators": bool(getattr(red, "two_comms", False)), "nranks": int(red.nranks),
+               "nranks_source": "ncclCommCount" if red.backend == "rccl" else "torch.distributed.get_world_size",
+               "wire_bytes_per_gpu_per_step": red.wire_bytes_per_step, "payload_bytes_per_step": 4 * P.numel,
+               "crosscheck": red.crosscheck}
+        try:
+            red.measure = True
+            for _ in range(3):
+                step_fn()
+            red.exposure.collect_ms()
+            for _ in range(a.steps):
+                step_fn()
+            nwaits, ms = red.exposure.collect_ms()
+            red.measure = False
+            t = torch.tensor([ms], device=dev, dtype=torch.float64)
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rep["exposed_comm_us_per_step"] = round(float(t.item()) * 1e3 / a.steps, 2)
+            rep["exposed_waits_per_step"] = nwaits / float(a.steps)
+            rep["exposed_note"] = ("max over ranks of the summed in-stream time between event pairs around the compute stream's waits for "
+                                   "collectives (incl. a collective enqueued on the compute stream itself), separate pass of %d steps" % a.steps)
+        except Exception as e:
+            rep["exposed_error"] = repr(e)
+        if os.environ.get("DPD_WD_HISTORY"):
+            rep["watchdog_history"] = json.loads(os.environ["DPD_WD_HISTORY"])
+        return rep
+
+    def bf16_b64(distributed, label, mode=None):
         """BASELINE configs 3-4: the same training step in bf16 at 64 pairs per GPU, timed like the headline."""
+        hb.beat("aux:" + label[:40])
         B2 = 64
         P2 = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev, compute_dtype="bf16")
         P2.reset_parameters_tf(generator=torch.Generator().manual_seed(1234))
-        tr2 = DPDistTrainer(P2, B2, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4, distributed=distributed)
+        old_mode = os.environ.get("DPD_DP_MODE")
+        if mode is not None:
+            os.environ["DPD_DP_MODE"] = mode
+        try:
+            tr2 = DPDistTrainer(P2, B2, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4, distributed=distributed)
+        finally:
+            if mode is not None:
+                os.environ.pop("DPD_DP_MODE") if old_mode is None else os.environ.__setitem__("DPD_DP_MODE", old_mode)
         a2, b2, l2 = (torch.tensor(x, device=dev) for x in synth.s2_modelnet_shaped(B2, N, 100 + rank))
         for _ in range(a.warmup):
             tr2.step(a2, b2, l2)
@@ -390,6 +464,8 @@ def main():
         out2 = {"what": label, "dtype": "bf16", "pairs_per_gpu": B2, "global_batch": B2 * nr, "n_gpus": nr,
                 "ms_per_step": round(e2 / a.steps * 1e3, 4), "value": round(2.0 * B2 * N * nr * a.steps / e2, 1),
                 "unit": "query-points/sec", "loss_samples_last": round(float(tr2.loss.cpu()[0]), 6)}
+        if distributed:
+            out2["dp"] = dp_report(tr2, lambda: tr2.step(a2, b2, l2))
         if not distributed and not a.no_roofline and rank == 0:
             # the plane-GEMM family of THIS configuration against the dense bf16 matrix-core peak (same method as `roofline` below)
             try:
@@ -416,14 +492,23 @@ def main():
             if world > 1 or (use_dist and os.environ.get("DPD_BENCH_CFG4") == "1"):   # (the env: exercise this leg on one GPU)
                 # every rank takes part in both legs (the first has collectives)
                 c4 = bf16_b64(True, "BASELINE config 4: data-parallel bf16 step, 64 pairs per GPU, RCCL gradient all-reduce")
+                try:     # the sharded optimizer (ZeRO-1: reduce-scatter -> Adam on 1/P -> all-gather of the parameters), same step
+                    c4["zero1"] = bf16_b64(True, "config 4 with DPD_DP_MODE=zero1 (sharded Adam)", mode="zero1")
+                except Exception as e:
+                    c4["zero1"] = {"error": repr(e)}
                 c4["n1_same_run"] = bf16_b64(False, "the same step on one rank without collectives (all ranks run it concurrently)")
                 c4["scaling"] = "weak"
+                n1v = c4["n1_same_run"]["value"]
+                c4["weak_scaling_efficiency_vs_n1_same_run"] = round(c4["value"] / (c4["n_gpus"] * n1v), 4)
+                if "value" in c4["zero1"]:
+                    c4["zero1"]["weak_scaling_efficiency_vs_n1_same_run"] = round(c4["zero1"]["value"] / (c4["n_gpus"] * n1v), 4)
                 cfg34 = ("config4", c4)
             elif not use_dist:
                 cfg34 = ("config3", bf16_b64(False, "BASELINE config 3: bf16 training step, 64 pairs"))
         except Exception as e:   # never take the headline number down
             cfg34 = ("config4" if world > 1 else "config3", {"error": repr(e)})
 
+    hb.beat("aux:other compute types")
     others = None
     if rank == 0 and world == 1 and not use_dist and not a.no_other_dtypes:
         # Same step, same batch, same K steps in the other compute types of the decoder GEMMs (include/dpdist_capi.h:
@@ -466,6 +551,7 @@ def main():
     # (tools/ramp_probe.py, DPD_BENCH_TRACE=1: 0.645 -> 0.58 ms per step over the first 40 steps, every time).  The driver's
     # `--steps 20 --warmup 5` is a 15 ms measurement; without this it times the ramp, not the step.  Reported as `spinup_ms`.
     spin_ms = float(os.environ.get("DPD_BENCH_SPINUP_MS", "40"))
+    hb.beat("warmup:cold pass + spin-up")
     el_cold = None
     if spin_ms > 0 and os.environ.get("DPD_BENCH_COLD", "1") == "1":
         # the number WITHOUT the spin-up, reported next to the headline as ms_per_step_cold: the same W untimed + K timed steps, run
@@ -493,6 +579,7 @@ def main():
             torch.cuda.synchronize()
     for _ in range(a.warmup):
         tr.step(pcA, pcB, lab, prefetch=nxt)
+    hb.beat("timed:%d steps" % a.steps)
     sync()
     trace = os.environ.get("DPD_BENCH_TRACE") == "1"      # diagnostic: per-10-step times of the timed region (adds syncs)
     marks = []
@@ -511,6 +598,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     loss = tr.loss.cpu().numpy()
+    hb.beat("profile:roofline + exposed communication")
+    dp = dp_report(tr, lambda: tr.step(pcA, pcB, lab)) if use_dist else None
 
     roof = None
     if a.no_roofline:
@@ -564,6 +653,7 @@ def main():
                         "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
                         "alg_gflop_per_launch": round(alg / (launches / a.steps) / 1e9, 3),
                         "gemm_ms_per_step": round(ms.value / a.steps, 4)}
+    hb.beat("report:cpu baseline + json")
     if rank == 0:
         qps = 2.0 * B * N * world * a.steps / el
         out = {"metric": "query-points/sec (DPDist fwd+bwd)", "value": round(qps, 1), "unit": "query-points/sec",
@@ -577,6 +667,9 @@ def main():
                "ms_per_step_cold": round(el_cold / a.steps * 1e3, 4) if el_cold else None,
                "cold_note": "ms_per_step_cold = the same W + K steps timed BEFORE the %g ms device spin-up (scratch fp32 GEMMs, nothing of the "
                             "model) that precedes the headline region; the difference is the GPU's clock ramp (DESIGN.md section 5)" % spin_ms}
+        if dp is not None:
+            out["dp"] = dp
+            out["dp_backend"], out["fallback"] = dp["backend"], dp["fallback"]
         if others is not None:
             out["other_compute_types"] = others
         if cfg34:
@@ -586,21 +679,21 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(B, N)
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"error": repr(e)}
-    if use_dist:
-        torch.cuda.synchronize()
-        for t_ in [tr] + [k[0] for k in keep]:      # communicators of the direct RCCL reducers go before the process group does
-            red = getattr(t_, "reducer", None)
-            if red is not None and hasattr(red, "close"):
-                red.close()
-        dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio (flushed at exit = after anything Python printed): flush it first so that
-        # the JSON line is the LAST line of stdout
+        # the JSON line is the LAST line of stdout.  The line goes out BEFORE the tear-down: a rank that hangs in ncclCommDestroy
+        # must not take the measurement with it (the supervisor treats phase "done" as success).
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    hb.beat("done")
+    if use_dist:
+        torch.cuda.synchronize()
+        for t_ in [tr] + [k[0] for k in keep]:      # communicators of the direct RCCL reducers go before the process group does
+            t_.close()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -25,6 +25,53 @@ def shard_range(global_batch, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def _wire_bytes(bounds_calls, world, wire, mode):
+    """Bytes ONE GPU sends (= receives) per step for the given (lo, hi) calls: a ring all-reduce moves 2 (P-1)/P of the payload per
+    GPU, reduce-scatter and all-gather (P-1)/P each (so rs_ag and zero1 with an fp32 parameter gather move the same bytes as the
+    all-reduce; what zero1 saves is the replicated optimizer, and the gather half leaves the critical path of the backward)."""
+    el = 2 if wire == "bf16" else 4
+    f = (world - 1) / float(world) if world > 1 else 0.0
+    return int(sum(2 * f * (hi - lo) * el for lo, hi in bounds_calls))
+
+
+def zero_partition(lo, hi, world):
+    """zero1: [lo, hi) = `world` equal shards of a multiple of 4 elements (float4 alignment of the optimizer kernel survives) + a
+    replicated remainder of < 4*world elements that is all-reduced and updated on every rank.  Returns (main, shard)."""
+    main = (hi - lo) - (hi - lo) % (4 * world)
+    return main, main // world
+
+
+class _Exposure:
+    """In-stream timing of the places where the COMPUTE stream waits for a collective (opt-in: `reducer.measure = True`; a timing
+    event record costs the stream a few us, so this runs in a separate pass, never in a timed region)."""
+
+    def __init__(self):
+        self.measure = False
+        self._pairs = []
+
+    def begin(self):
+        if not self.measure:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def end(self, e0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self._pairs.append((e0, e1))
+
+    def collect_ms(self):
+        """(number of waits, total ms) since the last call; host sync."""
+        torch.cuda.synchronize()
+        tot = sum(a.elapsed_time(b) for a, b in self._pairs)
+        n = len(self._pairs)
+        self._pairs = []
+        return n, tot
+
+
 class BucketReducer:
     """All-reduce slices of one flat gradient buffer, asynchronously with respect to the compute stream.
 
@@ -36,12 +83,20 @@ class BucketReducer:
         rounded into a bf16 staging buffer, reduced, and written back to the fp32 gradient (fp32 master weights and Adam state;
         the cross-rank sum itself is taken in bf16, 2^-8 relative per addend) -- meant for the bf16 compute type, whose step is
         short enough (0.40 ms at 64 pairs) for the fp32 all-reduce to show.
-    mode = "allreduce" (default) | "rs_ag": reduce-scatter followed by all-gather of the same bucket (what a ring all-reduce
-        does internally, as two collectives: the scatter half can start while later buckets are still being produced and the
-        gather half of every bucket is deferred to `wait()`, i.e. to just before the optimizer).
+    mode = "allreduce" (default) | "rs_ag" | "zero1":
+        rs_ag: reduce-scatter followed by all-gather of the same bucket (what a ring all-reduce does internally, as two collectives:
+        the scatter half can start while later buckets are still being produced and the gather half of every bucket is deferred to
+        `wait()`, i.e. to just before the optimizer).
+        zero1: the optimizer is SHARDED (ZeRO stage 1): every bucket is reduce-scattered; after `wait()` this rank holds the summed
+        gradient only on `owned_ranges()` (its shard of every bucket + the replicated remainders), the trainer runs Adam on those
+        ranges only (1/P of the optimizer traffic: 150 MB -> 19 MB per step at P = 8 in the bf16 step) and `gather_params(flat)`
+        all-gathers the updated fp32 parameters.  Same wire bytes as the all-reduce; bit-identical parameters (elementwise Adam on
+        the same sums).  fp32 wire only.
     Expected exposed time on 8 x MI355X (xGMI ring, ~7 x 153 GB/s per GPU, all-reduce moves 2 (P-1)/P of the bytes per link):
     fp32 18.7 MB -> ~33 MB per GPU on the wire ~ 40-60 us, of which only the layer-1 bucket's tail (issued last) cannot hide
     under the remaining backward; bf16 halves it.  None of this could be measured here (one-GPU boxes): see DESIGN.md."""
+
+    backend = "torch"
 
     def __init__(self, flat_grad, bounds, group=None, force=False, wire=None, mode=None):
         import os
@@ -49,14 +104,38 @@ class BucketReducer:
         self.bounds = list(bounds)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # force=True issues the collectives even for a single rank (exercises the RCCL/stream plumbing on one GPU)
         self.active = dist.is_initialized() and (self.world > 1 or force)
         self.wire = wire or os.environ.get("DPD_DP_WIRE", "f32")
         self.mode = mode or os.environ.get("DPD_DP_MODE", "allreduce")
-        if self.wire not in ("f32", "bf16") or self.mode not in ("allreduce", "rs_ag"):
-            raise ValueError("wire must be f32|bf16 and mode allreduce|rs_ag, got %r / %r" % (self.wire, self.mode))
+        if self.wire not in ("f32", "bf16") or self.mode not in ("allreduce", "rs_ag", "zero1"):
+            raise ValueError("wire must be f32|bf16 and mode allreduce|rs_ag|zero1, got %r / %r" % (self.wire, self.mode))
+        if self.mode == "zero1" and self.wire != "f32":
+            raise ValueError("zero1 shards fp32 master weights: fp32 wire only")
         self._pending = []
         self._stage = {}            # bucket -> (staging buffer [padded], shard buffer) for the bf16 wire / rs_ag mode
+        self._calls = []            # (lo, hi) of this step's reduce_async calls (zero1: what owned_ranges / gather_params cover)
+        self._fresh = True
+        self.exposure = _Exposure()
+        self.crosscheck = None      # filled by make_reducer: {"ok": bool, ...}
+
+    @property
+    def measure(self):
+        return self.exposure.measure
+
+    @measure.setter
+    def measure(self, on):
+        self.exposure.measure = bool(on) and self.flat.is_cuda
+
+    @property
+    def nranks(self):
+        return self.world
+
+    @property
+    def wire_bytes_per_step(self):
+        """bytes each GPU sends per step for the schedule of the LAST step (2 (P-1)/P of the payload: module docstring)"""
+        return _wire_bytes(self._calls, self.world, self.wire, self.mode)
 
     def _staging(self, bucket, n):
         if bucket not in self._stage:
@@ -72,9 +151,23 @@ class BucketReducer:
         the current stream."""
         if not self.active:
             return
+        if self._fresh:
+            self._calls, self._fresh = [], False
         lo, hi = self.bounds[bucket], self.bounds[(bucket if upto is None else upto) + 1]
+        self._calls.append((lo, hi))
         bucket = (bucket, upto)
         g = self.flat[lo:hi]
+        if self.mode == "zero1":
+            main, shard = zero_partition(lo, hi, self.world)
+            if main:
+                if bucket not in self._stage:
+                    self._stage[bucket] = torch.empty(shard, device=self.flat.device, dtype=torch.float32)
+                out = self._stage[bucket]
+                h = dist.reduce_scatter_tensor(out, self.flat[lo:lo + main], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append((h, ("zero", self.flat[lo + self.rank * shard:lo + (self.rank + 1) * shard], out)))
+            if main < hi - lo:
+                self._pending.append((dist.all_reduce(self.flat[lo + main:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
+            return
         if self.wire == "f32" and self.mode == "allreduce":
             self._pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
             return
@@ -91,9 +184,12 @@ class BucketReducer:
         """Make the current stream (or the host, for CPU tensors) wait for every outstanding bucket; finishes the two-step
         forms (all-gather of the reduced shards, copy back into the fp32 gradient)."""
         gathers = []
+        e0 = self.exposure.begin() if self._pending else None
         for h, extra in self._pending:
             h.wait()
-            if extra is not None and extra[2] is not None:           # rs_ag: second half
+            if extra is not None and extra[0] == "zero":             # zero1: the reduced shard goes back into its place
+                extra[1].copy_(extra[2])
+            elif extra is not None and extra[2] is not None:         # rs_ag: second half
                 g, full, shard = extra
                 gathers.append((dist.all_gather_into_tensor(full, shard, group=self.group, async_op=True), g, full))
             elif extra is not None:
@@ -102,11 +198,45 @@ class BucketReducer:
         for h, g, full in gathers:
             h.wait()
             g.copy_(full[:g.numel()])
+        self.exposure.end(e0)
         self._pending = []
+        self._fresh = True
+
+    # -- zero1 -----------------------------------------------------------------------------------------------------------
+    def owned_ranges(self):
+        """zero1, after wait(): the (lo, hi) element ranges of the flat buffers whose gradient sum this rank holds and whose
+        parameters it must update: its shard of every reduce_async call + the replicated remainders."""
+        out = []
+        for lo, hi in self._calls:
+            main, shard = zero_partition(lo, hi, self.world)
+            if main:
+                out.append((lo + self.rank * shard, lo + (self.rank + 1) * shard))
+            if main < hi - lo:
+                out.append((lo + main, hi))
+        return out
+
+    def gather_params(self, flat):
+        """zero1, after the sharded optimizer: all-gather the updated shards of `flat` (same layout as the gradient buffer) on the
+        current stream."""
+        e0 = self.exposure.begin()
+        for lo, hi in self._calls:
+            main, shard = zero_partition(lo, hi, self.world)
+            if main:
+                mine = flat[lo + self.rank * shard:lo + (self.rank + 1) * shard]
+                if flat.is_cuda:
+                    dist.all_gather_into_tensor(flat[lo:lo + main], mine, group=self.group)     # in place (NCCL/RCCL)
+                else:
+                    full = torch.empty(main, dtype=flat.dtype)
+                    dist.all_gather_into_tensor(full, mine.clone(), group=self.group)
+                    flat[lo:lo + main].copy_(full)
+        self.exposure.end(e0)
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
+
+    def close(self):
+        pass
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -141,6 +271,10 @@ class _Rccl:
             L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p]
             L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            L.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+            L.ncclReduceScatter.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p]
+            L.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
             L.ncclGetErrorString.restype = ctypes.c_char_p
             L.ncclGetErrorString.argtypes = [ctypes.c_int]
         return cls._lib
@@ -169,45 +303,76 @@ class _Rccl:
         cls.check(L.ncclCommInitRank(ctypes.byref(comm), world, uid, rank), "ncclCommInitRank")
         return comm
 
+    @classmethod
+    def count(cls, comm):
+        """number of ranks as the communicator itself reports it (ncclCommCount)"""
+        import ctypes
+        n = ctypes.c_int(-1)
+        cls.check(cls.lib().ncclCommCount(comm, ctypes.byref(n)), "ncclCommCount")
+        return n.value
+
 
 class DirectRcclReducer:
-    """BucketReducer's contract (reduce_async / wait / grad_scale) with RCCL called directly.
+    """BucketReducer's contract (reduce_async / wait / grad_scale / zero1) with RCCL called directly.
 
     `torch.distributed` puts every collective on ProcessGroupNCCL's own stream and orders it with events recorded in the middle
     of the compute stream -- on this runtime a barrier packet with a system-scope release, ~20 us of idle compute stream each, and
     a cross-queue hop (~14 us) each way for the LAST bucket, which nothing hides (+52..57 us per step before a
-    single byte moves).  Here:
-      * the early buckets (everything but the last call of a step) run on a side stream behind a `hipEventDisableSystemFence` event:
-        recording it costs the compute stream ~0.3 us, the hop is paid by the side stream;
-      * the LAST bucket's all-reduce is enqueued on the COMPUTE stream itself (its own communicator): no event, no hop -- it starts
-        the moment dW1 ends and Adam follows it in stream order;
-      * `wait()` joins the side stream with one more light event (its collective finished long before: dW1 ran meanwhile).
-    wire = "f32" | "bf16" as in BucketReducer (staging copies on the stream of the collective).  One rank (force) works: RCCL's
-    single-rank all-reduce is a copy."""
+    single byte moves).  Here every collective runs on ONE side stream through ONE communicator, behind a
+    `hipEventDisableSystemFence` event: recording it costs the compute stream ~0.3 us, the hop is paid by the side stream, and
+    `wait()` joins the side stream with one more light event.
 
-    def __init__(self, flat_grad, bounds, group=None, wire=None):
+    DPD_DP_TWO_COMMS=1 (opt-in, the round-3 form): the LAST bucket's all-reduce is enqueued on the COMPUTE stream itself through a
+    second communicator -- no event, no hop: it starts the moment dW1 ends and Adam follows it in stream order (-14 us on one rank).
+    Two RCCL kernels of different communicators can then be in flight on one device; they must become co-resident on every GPU or
+    the ranks deadlock.  With <= 64 RCCL workgroups on 256 CUs they should, but no run with more than one GPU has ever shown it, so
+    the serialised form is the default until one has; `bench.py`'s watchdog falls back to torch.distributed if
+    either form hangs.
+
+    wire = "f32" | "bf16" as in BucketReducer (staging copies on the stream of the collective); mode = "allreduce" | "zero1"
+    (ncclReduceScatter in place; `gather_params` = ncclAllGather in place on the side stream).  One rank (force) works: RCCL's
+    single-rank collectives are copies."""
+
+    backend = "rccl"
+
+    def __init__(self, flat_grad, bounds, group=None, wire=None, mode=None):
         import os
         from .hipevents import LightEvent
         if not (dist.is_initialized() and flat_grad.is_cuda):
             raise RuntimeError("DirectRcclReducer needs an initialised process group and a GPU gradient buffer")
         self.flat, self.bounds, self.group = flat_grad, list(bounds), group
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.active = True
         self.wire = wire or os.environ.get("DPD_DP_WIRE", "f32")
+        self.mode = mode or os.environ.get("DPD_DP_MODE", "allreduce")
         if self.wire not in ("f32", "bf16"):
             raise ValueError("wire must be f32|bf16")
-        self.mode = "allreduce"
+        if self.mode not in ("allreduce", "zero1"):
+            raise ValueError("DirectRcclReducer: mode must be allreduce|zero1 (rs_ag lives in BucketReducer)")
+        if self.mode == "zero1" and self.wire != "f32":
+            raise ValueError("zero1 shards fp32 master weights: fp32 wire only")
+        self.two_comms = os.environ.get("DPD_DP_TWO_COMMS", "0") == "1" and self.mode == "allreduce"
         dev = flat_grad.device
         self._side = torch.cuda.Stream(device=dev)
         self._comm_side = _Rccl.new_comm(group, dev)
-        self._comm_main = _Rccl.new_comm(group, dev)
-        self._ev_fork = [LightEvent() for _ in range(4)]
+        self._comm_main = _Rccl.new_comm(group, dev) if self.two_comms else None
+        self.nranks = _Rccl.count(self._comm_side)      # as the communicator reports it, not as the environment claims
+        if self.nranks != self.world:
+            raise RuntimeError("ncclCommCount says %d ranks, the process group %d" % (self.nranks, self.world))
+        self._ev_fork = [LightEvent() for _ in range(6)]
         self._ev_join = LightEvent()
         self._nfork = 0
         self._covered = 0           # elements reduced so far in this step
         self._side_used = False
         self._stage = {}
-        self._copyback = []         # bf16 wire: (stream is_main, g, full) pending conversions back to fp32
+        self._calls, self._fresh = [], True
+        self.exposure = _Exposure()
+        self.crosscheck = None
+
+    measure = BucketReducer.measure
+    wire_bytes_per_step = BucketReducer.wire_bytes_per_step
+    owned_ranges = BucketReducer.owned_ranges
 
     def _allreduce(self, t, comm, stream):
         dt = 9 if t.dtype == torch.bfloat16 else 7          # ncclBfloat16 / ncclFloat
@@ -218,13 +383,37 @@ class DirectRcclReducer:
             self._stage[key] = torch.zeros(n, device=self.flat.device, dtype=torch.bfloat16)
         return self._stage[key]
 
+    def _fork(self, main):
+        """the side stream continues after everything enqueued on `main` so far (light event: ~0.3 us on the compute stream)"""
+        ev = self._ev_fork[self._nfork % len(self._ev_fork)]
+        self._nfork += 1
+        ev.record(main)
+        ev.wait(self._side)
+        self._side_used = True
+
     def reduce_async(self, bucket, upto=None):
+        if self._fresh:
+            self._calls, self._fresh = [], False
         lo, hi = self.bounds[bucket], self.bounds[(bucket if upto is None else upto) + 1]
+        self._calls.append((lo, hi))
         g = self.flat[lo:hi]
         self._covered += hi - lo
         last = self._covered >= self.bounds[-1] - self.bounds[0]
         main = torch.cuda.current_stream()
-        if last:
+        if self.mode == "zero1":
+            self._fork(main)
+            L = _Rccl.lib()
+            main_n, shard = zero_partition(lo, hi, self.world)
+            el = self.flat.element_size()
+            base = self.flat.data_ptr() + lo * el
+            if main_n:      # in place: the receive buffer is this rank's slice of the send buffer
+                _Rccl.check(L.ncclReduceScatter(base, base + self.rank * shard * el, shard, 7, 0, self._comm_side, self._side.cuda_stream),
+                            "ncclReduceScatter")
+            if main_n < hi - lo:
+                self._allreduce(self.flat[lo + main_n:hi], self._comm_side, self._side)
+            return
+        if last and self.two_comms:
+            e0 = self.exposure.begin()
             if self.wire == "bf16":
                 full = self._staging((lo, hi), hi - lo)
                 full.copy_(g)
@@ -232,12 +421,9 @@ class DirectRcclReducer:
                 g.copy_(full)
             else:
                 self._allreduce(g, self._comm_main, main)
+            self.exposure.end(e0)
             return
-        ev = self._ev_fork[self._nfork % len(self._ev_fork)]
-        self._nfork += 1
-        ev.record(main)
-        ev.wait(self._side)
-        self._side_used = True
+        self._fork(main)
         if self.wire == "bf16":
             full = self._staging((lo, hi), hi - lo)
             with torch.cuda.stream(self._side):
@@ -247,12 +433,32 @@ class DirectRcclReducer:
         else:
             self._allreduce(g, self._comm_side, self._side)
 
-    def wait(self):
+    def _join(self):
         if self._side_used:
+            e0 = self.exposure.begin()
             self._ev_join.record(self._side)
             self._ev_join.wait(torch.cuda.current_stream())
+            self.exposure.end(e0)
         self._side_used = False
+
+    def wait(self):
+        self._join()
         self._covered = 0
+        self._fresh = True
+
+    def gather_params(self, flat):
+        """zero1, after the sharded optimizer (enqueued on the current stream): ncclAllGather of the updated shards, in place, on the
+        side stream; the current stream continues after them."""
+        L = _Rccl.lib()
+        el = flat.element_size()
+        self._fork(torch.cuda.current_stream())
+        for lo, hi in self._calls:
+            main_n, shard = zero_partition(lo, hi, self.world)
+            if main_n:
+                base = flat.data_ptr() + lo * el
+                _Rccl.check(L.ncclAllGather(base + self.rank * shard * el, base, shard, 7, self._comm_side, self._side.cuda_stream),
+                            "ncclAllGather")
+        self._join()
 
     @property
     def grad_scale(self):
@@ -267,27 +473,108 @@ class DirectRcclReducer:
                 setattr(self, c, None)
 
 
+def crosscheck(red, group=None):
+    """Start-up self-test of a reducer: a known integer-valued pattern (exact in fp32 AND bf16 whatever the summation order: every
+    addend in [-15, 15], at most 8 x 15 per sum) goes through `red` with the trainer's call sequence (layers 2-4, then layer 1) and
+    through a plain `torch.distributed.all_reduce`; both results must equal the closed-form sum BIT FOR BIT.  The gradient buffer is
+    restored.  Returns a dict for the bench line; every rank must call it (collectives)."""
+    flat = red.flat
+    if not getattr(red, "active", False):
+        return {"ok": True, "skipped": "reducer inactive"}
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    saved = flat.clone()
+    n = flat.numel()
+    idx = torch.arange(n, device=flat.device, dtype=torch.int64)
+
+    def pat(r):
+        return ((idx * 2654435761 + r * 40503) % 31 - 15).to(torch.float32)
+
+    expect = pat(0)
+    for r in range(1, world):
+        expect += pat(r)
+    try:
+        flat.copy_(pat(rank))
+        nb = len(red.bounds) - 1
+        if nb > 1:
+            red.reduce_async(1, upto=nb - 1)
+        red.reduce_async(0)
+        red.wait()
+        if red.mode == "zero1":
+            own_ok = all(bool(torch.equal(flat[lo:hi], expect[lo:hi])) for lo, hi in red.owned_ranges())
+            red.gather_params(flat)
+        else:
+            own_ok = True
+        ref = pat(rank)
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda:
+            torch.cuda.synchronize()
+        lo, hi = red.bounds[0], red.bounds[-1]
+        ok_red = own_ok and bool(torch.equal(flat[lo:hi], expect[lo:hi]))
+        ok_ref = bool(torch.equal(ref, expect))
+        bad = int((flat[lo:hi] != expect[lo:hi]).sum()) if not ok_red else 0
+    finally:
+        flat.copy_(saved)
+    return {"ok": ok_red and ok_ref, "reducer_bitwise": ok_red, "torch_all_reduce_bitwise": ok_ref, "mismatching_elements": bad,
+            "elements": hi - lo, "backend": red.backend, "mode": red.mode, "wire": red.wire}
+
+
+def _agree(flag, device, group):
+    """MIN over the ranks of a 0/1 flag (through the process group that already works)."""
+    t = torch.tensor([1 if flag else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
 def make_reducer(flat_grad, bounds, group=None, force=False):
     """The gradient reducer of a data-parallel trainer: RCCL driven directly on GPU buffers under an NCCL/RCCL process group
-    (DPD_DP_BACKEND=torch, a DPD_DP_MODE other than allreduce, or a failure to bind librccl keep `BucketReducer`), torch.distributed
-    otherwise (gloo / CPU tensors: the tests)."""
+    (DPD_DP_BACKEND=torch, DPD_DP_MODE=rs_ag, or a failure to bind librccl keep `BucketReducer`), torch.distributed otherwise
+    (gloo / CPU tensors: the tests).
+
+    Every decision is taken by ALL ranks together, and before anything that could leave ranks in different collectives:
+      1. bind librccl (local, no communication)            -> agree (MIN)  -> all direct, or all torch.distributed
+      2. create the communicator(s)                        -> agree (MIN); a rank that fails inside ncclCommInitRank takes the others
+                                                              with it or hangs them: that case belongs to the launch watchdog
+      3. `crosscheck` (known pattern, bitwise)             -> agree (MIN)  -> direct reducer, or fall back together
+    The torch.distributed reducer runs the same cross-check and raises if IT is wrong (nothing left to fall back to)."""
     import os
     import sys
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     want = os.environ.get("DPD_DP_BACKEND", "rccl")
+    mode = os.environ.get("DPD_DP_MODE", "allreduce")
+    check = os.environ.get("DPD_DP_CROSSCHECK", "1") == "1"
     if (dist.is_initialized() and (world > 1 or force) and flat_grad.is_cuda and want == "rccl" and dist.get_backend(group) == "nccl"
-            and os.environ.get("DPD_DP_MODE", "allreduce") == "allreduce"):
-        red, err = None, None
+            and mode in ("allreduce", "zero1")):
+        err = None
         try:
-            red = DirectRcclReducer(flat_grad, bounds, group)
-        except Exception as e:      # plumbing only: the torch.distributed path computes the same sums
+            _Rccl.lib()
+        except Exception as e:
             err = e
-        # the choice must be the same on every rank (a rank that fell back alone would wait for collectives the others never issue)
-        ok = torch.tensor([1 if red is not None else 0], device=flat_grad.device, dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
-            return red
-        if red is not None:
-            red.close()
+        red = None
+        if _agree(err is None, flat_grad.device, group):
+            try:
+                red = DirectRcclReducer(flat_grad, bounds, group)
+            except Exception as e:      # plumbing only: the torch.distributed path computes the same sums
+                err = e
+            if _agree(red is not None, flat_grad.device, group):
+                if check:
+                    try:
+                        red.crosscheck = crosscheck(red, group)
+                    except Exception as e:
+                        err, red.crosscheck = e, {"ok": False, "error": repr(e)}
+                    if not _agree(red.crosscheck["ok"], flat_grad.device, group):
+                        err = err or RuntimeError("start-up cross-check failed: %r" % (red.crosscheck,))
+                        red.close()
+                        red = None
+                if red is not None:
+                    return red
+            elif red is not None:
+                red.close()
+                red = None
         sys.stderr.write("dpdist_amd.ddp: direct RCCL unavailable on some rank (%r here), using torch.distributed collectives\n" % (err,))
-    return BucketReducer(flat_grad, bounds, group, force=force)
+    red = BucketReducer(flat_grad, bounds, group, force=force)
+    if red.active and check:
+        red.crosscheck = crosscheck(red, group)
+        if not red.crosscheck["ok"]:
+            raise RuntimeError("torch.distributed gradient reducer failed its start-up cross-check: %r" % (red.crosscheck,))
+    return red

@@ -247,12 +247,14 @@ def train(argv=None):
         if epoch % F.eval_every == 0 or epoch == F.max_epoch - 1:   # :349-357
             es, ep = run_epoch(test_ds, False)
             log_string("eval mean loss: %f" % es)
+            tr.gather_optimizer_state()             # zero1: every rank takes part (Adam slots live sharded); no-op otherwise
             if rank == 0:
                 sd = tr.tf_global_variables()       # what tf.train.Saver() saves: variables, `batch`, beta powers, Adam slots
                 np.savez(os.path.join(F.log_dir, "model.ckpt.npz"), **sd)
                 write_checkpoint(os.path.join(F.log_dir, "model.ckpt"), sd)                    # saver.save(...) (:354-357)
                 with open(os.path.join(F.log_dir, "metrics.jsonl"), "a") as f:
                     f.write(json.dumps({"epoch": epoch + 1, "step": tr.t, "train_loss_samples": ls, "eval_loss_samples": es}) + "\n")
+    tr.close()                                      # RCCL communicators go before the process group does
     if world > 1:
         dist.destroy_process_group()
     return ls

@@ -79,7 +79,9 @@ class DPDistTrainer:
         self.ws = torch.empty((L.load().dpd_workspace_bytes(Q, KP, H, self.dt) + 3) // 4, device=dev, dtype=torch.float32)
         # bf16-matrix-core compute types: operand planes persist between the kernels (no conversion passes)
         self._planes = None
-        if self.dt and Q % 8 == 0 and BN % 32 == 0 and KP % 32 == 0:
+        # (the same predicate as the C side's usable_planes(): with H % 64 != 0 the library ignores the planes and needs the fp32
+        # activations, so they must be allocated)
+        if self.dt and Q % 8 == 0 and BN % 32 == 0 and KP % 32 == 0 and H % 64 == 0:
             lib = L.load()
             nbytes = lib.dpd_planes_bytes(Q, BN, KP, H, self.dt, 0)
             self._plane_mem = torch.empty(nbytes, device=dev, dtype=torch.uint8)
@@ -200,6 +202,13 @@ class DPDistTrainer:
         self._ev_front = self._ev_xfree = self._ev_fwd = None
         self.front_launches = 0    # front ends (stack + encoder + gather) enqueued so far, on either stream
         self.prefetch_hits = 0     # steps that found their front end already computed by the side stream
+
+    def close(self):
+        """Release what outlives Python's garbage collection badly: the RCCL communicators of the direct reducer must be destroyed
+        before the process group is (bench.py, tests/rccl_rank.py and train.py call this at tear-down)."""
+        red, self.reducer = self.reducer, None
+        if red is not None and hasattr(red, "close"):
+            red.close()
 
     def refresh_weight_planes(self):
         """Re-derive what is computed FROM the weights (bf16 weight planes / transposed fp32 copies) on the current stream.
@@ -430,6 +439,19 @@ class DPDistTrainer:
         if self.reducer:
             self.reducer.wait()
             gscale = self.reducer.grad_scale
+            if self.reducer.active and self.reducer.mode == "zero1":
+                # sharded optimizer (ZeRO stage 1, ddp.py): this rank holds the summed gradient of its shards only; Adam on those
+                # ranges (1/P of the 28 B per parameter), then the updated fp32 parameters are all-gathered and everything derived
+                # from the weights (operand planes / transposed copies) is refreshed lazily like after any optimizer step
+                lib = L.load()
+                pf = self.P.flat.detach()
+                for lo, hi in self.reducer.owned_ranges():
+                    L.check(lib.dpd_adam_tf(L.ptr(pf[lo:hi]), L.ptr(self.grad[lo:hi]), L.ptr(self.m_state[lo:hi]), L.ptr(self.v_state[lo:hi]),
+                                            hi - lo, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf(shard)")
+                self.reducer.gather_params(pf)
+                self._wdirty = True
+                self.P._tr_key = None
+                return
         if self.fused_adam and (self.W2T is not None or self._afuse[0].np or tail_from_partials):
             # matrices_done: W1p / W2 / W3 (and W2T / W3T) were updated in the epilogues of their weight-gradient GEMMs with this lr_t
             af = self._afuse[2] if matrices_done else (self._afuse_w1 if w1_done else self._afuse[1 if tail_from_partials else 0])
@@ -544,6 +566,15 @@ class DPDistTrainer:
         return self.loss
 
     # -- optimizer state <-> TF global variables ------------------------------------------------------------------
+    def gather_optimizer_state(self):
+        """DPD_DP_MODE=zero1: the Adam slots m / v are only current on the rank that owns a shard; all-gather them (COLLECTIVE:
+        every rank must call) so that `tf_global_variables` on any rank sees what a replicated optimizer would hold.  No-op for
+        the replicated modes."""
+        red = self.reducer
+        if red is not None and red.active and red.mode == "zero1" and red._calls:
+            red.gather_params(self.m_state)
+            red.gather_params(self.v_state)
+
     def tf_global_variables(self):
         """Everything the reference's `tf.train.Saver()` stores besides summaries (train_multi_gpu_pc_compare_dist.py:305,
         354-357): the 8 decoder variables, the global step `batch` (float scalar, :205-207), AdamOptimizer's non-slot variables

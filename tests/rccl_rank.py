@@ -13,7 +13,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def main(out_path, dtype):
+def main(out_path, dtype, mode="allreduce"):
+    os.environ["DPD_DP_MODE"] = mode           # "zero1": sharded optimizer; replicas must still end bit-identical
     rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -29,11 +30,14 @@ def main(out_path, dtype):
     P = DPDistParams(device=dev, compute_dtype=dtype)
     P.load_tf_state_dict(W0)
     tr = DPDistTrainer(P, hi - lo, base_lr=1e-3)
-    assert tr.reducer is not None and tr.reducer.active and tr.reducer.world == world
+    assert tr.reducer is not None and tr.reducer.active and tr.reducer.world == world and tr.reducer.nranks == world
+    assert tr.reducer.crosscheck["ok"], tr.reducer.crosscheck
     tr._load_batch(pcA[lo:hi].contiguous(), pcB[lo:hi].contiguous(), None)
     tr.forward()
     tr.backward(lab[lo:hi].reshape(-1).contiguous())
     tr.reducer.wait()
+    if mode == "zero1":                          # this rank holds the sums of its shards only: gather them for the comparison
+        tr.reducer.gather_params(tr.grad)
     g = tr.grad * tr.reducer.grad_scale
     # two full optimizer steps as well: replicas must stay bit-identical (same averaged gradient, same Adam)
     for _ in range(2):
@@ -55,10 +59,9 @@ def main(out_path, dtype):
         same = all(bool(torch.equal(ws[0], x)) for x in ws[1:])
         open(out_path, "w").write("%d %.6e %.6e %d" % (world, err, scale, int(same)))
     dist.barrier()
-    if hasattr(tr.reducer, "close"):
-        tr.reducer.close()
+    tr.close()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "f32")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "f32", sys.argv[3] if len(sys.argv) > 3 else "allreduce")

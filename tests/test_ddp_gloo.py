@@ -121,3 +121,131 @@ def test_make_reducer_keeps_torch_distributed_off_the_gpu():
     from dpdist_amd.ddp import BucketReducer, make_reducer
     r = make_reducer(torch.zeros(16), [0, 4, 8, 16])
     assert isinstance(r, BucketReducer) and not r.active
+
+
+def _run_wd(tmp_path, monkeypatch, **env):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out = tmp_path / "wd.json"
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("DPD_WD_LIMITS", "start=120,init=60,reducer=60,timed=4,done=10")
+    monkeypatch.delenv("DPD_BENCH_CHILD", raising=False)
+    rc = bench.spawn_ranks(2, [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "wd_rank.py"), str(out)], timeout_s=300)
+    return rc, (json.loads(out.read_text()) if out.exists() else None)
+
+
+def test_watchdog_passes_a_healthy_run_through(tmp_path, monkeypatch):
+    """dpdist_amd/launch.py: every rank supervises its worker; a healthy run is attempt 1, no fallback, and the reducer's start-up
+    cross-check (known integer pattern through the reducer and through a plain all-reduce, bitwise) is on the record."""
+    rc, res = _run_wd(tmp_path, monkeypatch)
+    assert rc == 0 and res is not None
+    assert res["world"] == 2 and res["sum"] == 3.0 and res["all_equal"]
+    assert res["fallback"] is False and res["attempt"] == 1 and res["history"] == []
+    assert res["crosscheck"]["ok"] and res["crosscheck"]["reducer_bitwise"] and res["crosscheck"]["torch_all_reduce_bitwise"]
+
+
+@pytest.mark.parametrize("who", ["1", "all"])
+def test_watchdog_falls_back_after_a_hang(tmp_path, monkeypatch, who):
+    """A rank that stops before a collective (injected: the worker of attempt 1 never leaves phase `timed`) hangs every other rank
+    in it.  The supervisors notice the missing heartbeat, stop the workers by PID and run the launch once more with
+    DPD_DP_BACKEND=torch on a fresh rendezvous; rank 0's line says so (`fallback`, the failure of attempt 1)."""
+    env = {"DPD_WD_INJECT_HANG": "timed"}
+    if who != "all":
+        env["DPD_WD_INJECT_RANK"] = who
+    rc, res = _run_wd(tmp_path, monkeypatch, **env)
+    assert rc == 0 and res is not None
+    assert res["world"] == 2 and res["sum"] == 3.0 and res["all_equal"]
+    assert res["fallback"] is True and res["attempt"] == 2 and res["backend_env"] == "torch"
+    assert len(res["history"]) == 1 and "no heartbeat" in res["history"][0]["failure"] and "timed" in res["history"][0]["failure"]
+
+
+def test_watchdog_gives_up_after_the_second_failure(tmp_path, monkeypatch, capfd):
+    """Both attempts fail (the worker dies at once): exit code 3 and rank 0's supervisor prints a JSON line with value null."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.delenv("DPD_BENCH_CHILD", raising=False)
+    script = tmp_path / "dies.py"          # (a file: the supervisor re-runs sys.argv, which `python -c` does not preserve)
+    script.write_text("import os, sys; sys.path.insert(0, %r); from dpdist_amd import launch; launch.maybe_supervise(2); sys.exit(5)\n"
+                      % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    rc = bench.spawn_ranks(2, [sys.executable, str(script)], timeout_s=120)
+    assert rc == 3
+    line = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["value"] is None and len(rec["watchdog"]) == 2 and "exited with code 5" in rec["watchdog"][0]["failure"]
+
+
+def _zero_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpdist_amd.ddp import BucketReducer, crosscheck
+    n = 4 * 1000 + 12                      # not a multiple of 4 * world in every bucket: replicated remainders exist
+    bounds = [0, 2004, 3008, n]
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-3
+
+    def grad(step, r):                     # this rank's gradient of step `step`
+        g = torch.Generator().manual_seed(1000 * step + r)
+        return torch.randn(n, generator=g)
+
+    def adam(p, g, m, v, t, scale):        # TF-form Adam, elementwise (the role of dpd_adam_tf on a range)
+        g = g * scale
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        lr_t = lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+        p.sub_(lr_t * m / (v.sqrt() + eps))
+
+    res = {}
+    for mode in ("allreduce", "zero1"):
+        p = torch.linspace(-1, 1, n)
+        m, v = torch.zeros(n), torch.zeros(n)
+        flat = torch.zeros(n)
+        red = BucketReducer(flat, bounds, mode=mode)
+        chk = crosscheck(red)
+        for t in (1, 2, 3):
+            flat.copy_(grad(t, rank))
+            red.reduce_async(1, upto=2)
+            red.reduce_async(0)
+            red.wait()
+            if mode == "zero1":
+                own = red.owned_ranges()
+                for lo, hi in own:
+                    adam(p[lo:hi], flat[lo:hi], m[lo:hi], v[lo:hi], t, red.grad_scale)
+                red.gather_params(p)
+            else:
+                adam(p, flat, m, v, t, red.grad_scale)
+        if mode == "zero1":                # the Adam slots are gathered on demand (checkpoints)
+            red.gather_params(m)
+            red.gather_params(v)
+        res[mode] = (p.clone(), m.clone(), v.clone(), chk, red.wire_bytes_per_step,
+                     sum(hi - lo for lo, hi in red.owned_ranges()) if mode == "zero1" else n)
+    if rank == 0:
+        a, z = res["allreduce"], res["zero1"]
+        out.put({"p": bool(torch.equal(a[0], z[0])), "m": bool(torch.equal(a[1], z[1])), "v": bool(torch.equal(a[2], z[2])),
+                 "chk": [a[3], z[3]], "wire": [a[4], z[4]], "owned": z[5], "n": n})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero1_sharded_optimizer_is_bitwise_the_replicated_one():
+    """DPD_DP_MODE=zero1 (ddp.py): reduce-scatter -> Adam on this rank's shards (+ the replicated remainders) -> all-gather of the
+    fp32 parameters gives, after three steps, bit for bit the parameters AND Adam slots of the replicated optimizer behind an
+    all-reduce (role of `average_gradients` + `apply_gradients`, train_multi_gpu_pc_compare_dist.py:936-990); each rank updates
+    about half of the elements; both reducers pass the start-up cross-check; same bytes on the wire."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["p"] and res["m"] and res["v"]
+    assert all(c["ok"] for c in res["chk"]) and res["chk"][1]["mode"] == "zero1"
+    assert res["wire"][0] == res["wire"][1] == 4 * res["n"]          # 2 (P-1)/P x 4 B x n at P = 2
+    assert res["n"] // 2 <= res["owned"] <= res["n"] // 2 + 3 * 8     # half of every bucket + remainders of < 4 * world elements

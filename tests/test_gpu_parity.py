@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star / SURVEY 8d): fp32, max abs err <= 1e-4 on predict
 weight set additionally max rel err <= 1e-4 on unsaturated outputs.  Integer work (voxel ids, masks) is bit exact.
 """
 import os
+import time
 
 import numpy as np
 import pytest
@@ -938,8 +939,9 @@ def test_prefetch_pipeline_is_bitwise_equivalent(dev, fused_gather, monkeypatch)
     assert (tr2.evaluate(*batches[2])[0] - l2).abs().max().item() <= 1e-7
 
 
+@pytest.mark.parametrize("mode", ["allreduce", "zero1"])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-def test_two_ranks_rccl_equals_full_batch(dev, dt, tmp_path):
+def test_two_ranks_rccl_equals_full_batch(dev, dt, mode, tmp_path):
     """Two REAL ranks over RCCL (one process per GPU, started the way `python bench.py --gpus 2` starts them): the averaged
     gradient equals the full-batch gradient, and the replicas stay bit-identical through two optimizer steps.  Skipped on a
     one-GPU box (the driver's GPU box has one)."""
@@ -948,7 +950,7 @@ def test_two_ranks_rccl_equals_full_batch(dev, dt, tmp_path):
     import sys
     import bench          # tests/conftest.py puts the repo root on sys.path
     out = tmp_path / "r0.txt"
-    rc = bench.spawn_ranks(2, [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_rank.py"), str(out), dt])
+    rc = bench.spawn_ranks(2, [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_rank.py"), str(out), dt, mode])
     assert rc == 0
     world, err, scale, same = out.read_text().split()
     assert int(world) == 2 and int(same) == 1
@@ -1007,6 +1009,116 @@ def test_data_parallel_schedule_matches_plain_backward(dev, dt, buckets, backend
             assert torch.equal(a, b), n
         else:                      # plane path: grouped 64x128 tiles vs single 64x64 tiles -> different accumulation order
             assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item()), n
+
+
+def _single_rank_group(dev, port):
+    import torch.distributed as dist
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    return own
+
+
+@pytest.mark.parametrize("backend,two,mode", [("rccl", "0", "allreduce"), ("rccl", "1", "allreduce"), ("rccl", "0", "zero1"),
+                                              ("torch", "0", "allreduce"), ("torch", "0", "zero1"), ("torch", "0", "rs_ag")])
+def test_reducer_startup_crosscheck_and_rank_count(dev, backend, two, mode, monkeypatch):
+    """ddp.make_reducer: every reducer form reduces a known integer pattern (exact in any summation order) with the trainer's call
+    sequence and must return the closed-form sum BIT FOR BIT, next to a plain torch.distributed all-reduce of the same pattern;
+    the direct reducer reports its rank count from ncclCommCount; the gradient buffer is left untouched.  (Single-rank group on a
+    one-GPU box; the same code runs first thing in every N > 1 launch.)"""
+    import torch.distributed as dist
+    from dpdist_amd import ddp
+    monkeypatch.setenv("DPD_DP_BACKEND", backend)
+    monkeypatch.setenv("DPD_DP_TWO_COMMS", two)
+    monkeypatch.setenv("DPD_DP_MODE", mode)
+    own = _single_rank_group(dev, 29641)
+    try:
+        flat = torch.randn(5000, device=dev)
+        keep = flat.clone()
+        red = ddp.make_reducer(flat, [0, 2000, 3004, 5000], force=True)
+        assert red.active and red.backend == (backend if mode != "rs_ag" else "torch") and red.mode == mode
+        assert red.crosscheck["ok"] and red.crosscheck["reducer_bitwise"] and red.crosscheck["torch_all_reduce_bitwise"]
+        assert red.crosscheck["elements"] == 5000 and red.nranks == 1 and red.wire_bytes_per_step == 0
+        assert bool(getattr(red, "two_comms", False)) == (two == "1")
+        assert torch.equal(flat, keep)
+        red.measure = True                       # exposed-communication probe: event pairs around the compute stream's waits
+        for _ in range(2):
+            red.reduce_async(1, upto=2)
+            red.reduce_async(0)
+            red.wait()
+        n, ms = red.exposure.collect_ms()
+        assert n >= 2 and 0.0 <= ms < 50.0
+        red.close()
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["rccl", "torch"])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_zero1_sharded_optimizer_step_is_bitwise_replicated_adam(dev, dt, backend, monkeypatch):
+    """DPD_DP_MODE=zero1 through the trainer: reduce-scatter, `dpd_adam_tf` on the owned ranges, all-gather of the fp32 parameters,
+    operand planes / transposed copies re-derived lazily -- after three steps parameters and Adam slots equal those of the
+    replicated optimizer behind an all-reduce bit for bit (single-rank group here; two ranks: tests/rccl_rank.py)."""
+    import torch.distributed as dist
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    monkeypatch.setenv("DPD_DP_BACKEND", backend)
+    monkeypatch.setenv("DPD_FORCE_DIST", "1")
+    B = 8
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    W0 = synth.make_weights("wide")
+    own = _single_rank_group(dev, 29643)
+    res = {}
+    try:
+        for mode in ("allreduce", "zero1"):
+            monkeypatch.setenv("DPD_DP_MODE", mode)
+            P = DPDistParams(device=dev, compute_dtype=dt)
+            P.load_tf_state_dict(W0)
+            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
+            assert tr.reducer.mode == mode and tr.reducer.backend == backend
+            losses = [tr.step(pcA, pcB, lab).clone() for _ in range(3)]
+            tr.gather_optimizer_state()
+            torch.cuda.synchronize()
+            res[mode] = (P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), torch.stack(losses))
+            tr.close()
+    finally:
+        if own:
+            dist.destroy_process_group()
+    for a, b in zip(res["allreduce"], res["zero1"]):
+        assert torch.equal(a, b)
+
+
+def test_bench_watchdog_falls_back_on_the_gpu(dev):
+    """bench.py's N > 1 skeleton on one GPU (DPD_FORCE_DIST=1): the worker of attempt 1 stops beating in the timed region (injected);
+    the supervisor stops it by PID and reruns with DPD_DP_BACKEND=torch; the JSON line carries dp_backend / fallback / the
+    watchdog's record, the start-up cross-check, ncclCommCount's rank count and the exposed-communication probe.  And
+    `--gpus 2` on a one-GPU box still ends quickly with code 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DPD_FORCE_DIST="1", DPD_WD_INJECT_HANG="timed", DPD_WD_LIMITS="timed=6", MASTER_PORT="29651")
+    for k in ("DPD_BENCH_CHILD", "DPD_DP_BACKEND", "DPD_DP_MODE", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-dtypes"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["fallback"] is True and rec["dp_backend"] == "torch" and rec["value"] > 0
+    assert rec["dp"]["crosscheck"]["ok"] and rec["dp"]["nranks"] == 1 and "exposed_comm_us_per_step" in rec["dp"]
+    assert "no heartbeat" in rec["dp"]["watchdog_history"][0]["failure"]
+    env.pop("DPD_WD_INJECT_HANG")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)       # healthy run: attempt 1, direct RCCL
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["fallback"] is False and rec["dp_backend"] == "rccl" and rec["dp"]["nranks_source"] == "ncclCommCount"
+    if torch.cuda.device_count() < 2:
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and time.time() - t0 < 120
 
 
 @pytest.mark.parametrize("wire,mode", [("bf16", "allreduce"), ("f32", "rs_ag"), ("bf16", "rs_ag")])
