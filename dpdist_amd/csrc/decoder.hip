@@ -18,8 +18,8 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
-            hipStream_t s, float* colsum, const X3Out* out = nullptr, const uint16_t* A2 = nullptr, const uint16_t* B2 = nullptr,
-            float* C2 = nullptr, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0, const uint16_t* gate16 = nullptr, int gate16_r8 = 0);
+            hipStream_t s, float* colsum, const X3Out* out = nullptr, const X3Extra* ex = nullptr, int split_k = 1, void* ws = nullptr,
+            size_t ws_bytes = 0, const uint16_t* gate16 = nullptr, int gate16_r8 = 0, void* red_cnt = nullptr, int red_cnt_words = 0);
 int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
                    const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
                    hipStream_t s, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
@@ -40,7 +40,13 @@ enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 =
 static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32, 30};
 static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 3};   // (0 = tail split, gemm_rs.h: measured no gain on dW1, 0.525 vs 0.5215 ms of GEMM per step)
 static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
-static int g_x3_pair_tile = 0, g_x3_pair_split = 1;   // plane dW2+dW3 pair: tile (0 = automatic), split-K
+// split-K of the plane weight-gradient GEMMs (K = query rows is long, M x N gives 64-160 tiles of 128x128 for 256 CUs):
+//   n > 1: n slices per output tile, reduced INSIDE the launch by the last-arriving slice in slice order (gemm_x3.hip: inlaunch_reduce;
+//          deterministic); n < -1: the round-2 form, |n| fp32 slabs + a reduce launch (A/B reference); 1: off; 0: automatic
+static int g_x3_split[OP_COUNT] = {1, 1, 1, 1, 0, 0, 1, 1, 1};
+static int g_x3_pair_tile = 0, g_x3_pair_split = 0;   // plane dW2+dW3 pair: tile (0 = automatic), split-K (as above)
+static int g_x3_trio_tile = 0, g_x3_trio_split = 1;   // plane dW1+dW2+dW3 in one launch (dpd_decoder_bwd_weights_trio): tile, split-K
+constexpr size_t kRedCntBytes = 8192;                 // arrival words of the in-launch reduction: the last 8 KiB of the base workspace
 
 // Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
 //   0  exact fp32 on the fp32 MFMA (gemm_f32.hip)
@@ -56,6 +62,17 @@ static size_t plane_bytes(int dtype, int Q, int KP, int H) {
     const size_t np = dtype == 1 ? 3 : 1;
     const size_t big = (size_t)(KP > H ? KP : H);
     return np * 2 * ((size_t)Q * big + big * H) + 256;
+}
+
+// Automatic split-K of a plane weight-gradient GEMM: enough slices that the launch has about two 128x128 workgroups per CU (their
+// 64 KiB LDS rings let two co-reside: one wave of tiles alone cannot keep the LDS-DMA ring of a CU full), each with >= 1024 deep K.
+static int x3_auto_split(int np, int tile, int M, int N, int K) {
+    if (np != 1 || tile < 1 || tile > 5) return 1;
+    const int bm = (tile == 3 || tile == 5) ? 64 : 128, bn = (tile == 4 || tile == 5) ? 64 : 128;
+    const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    int split = (int)(480 / (tiles > 0 ? tiles : 1));
+    while (split > 1 && K / split < 1024) --split;
+    return split < 1 ? 1 : (split > 4 ? 4 : split);
 }
 
 // Apl / Bpl: operand planes that already exist (else the fp32 operand is split into `scr`); out: plane outputs.
@@ -115,8 +132,22 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     if (np == 3 && tile == 2) tile = 24;
     if (np == 1 && g_x3_tile[op] && (g_x3_tile[op] >= 20 || !(K % 64))) tile = g_x3_tile[op];   // tuning override (dpd_set_gemm_plan, ops 16..24)
     if (np == 3 && g_x3_tile[op] >= 24 && g_x3_tile[op] <= 26) tile = g_x3_tile[op];
+    // plane weight gradients (TN, plain product): split-K with the reduction inside the launch when the tiles alone leave CUs idle
+    // (`ws` = the slab region of the base workspace, its last kRedCntBytes the arrival words)
+    int split = 1;
+    void* cnt = nullptr;
+    if (transA && !transB && epilogue == 0 && !colsum && !out && C && ws && ws_bytes > kRedCntBytes) {
+        split = g_x3_split[op];
+        if (split == 0) split = x3_auto_split(np, tile, M, N, K);
+        if (split > 1 && tile >= 1 && tile <= 5) cnt = (char*)ws + ws_bytes - kRedCntBytes;
+        else if (split < -1) split = -split;
+        else split = 1;
+        const int chunk = (((K + split - 1) / split) + 63) / 64 * 64;
+        if (split > 1 && chunk * (split - 1) >= K) { split = 1; cnt = nullptr; }
+    }
     return gemm_x3(np, transA, !transB, M, N, K, Ap, ca, (long)ae, Bp, cb, (long)be, C, ldc, bias, gate, epilogue, tile, s, colsum,
-                   out, nullptr, nullptr, nullptr, 1, nullptr, 0, (const uint16_t*)gate16, gate16_r8);
+                   out, nullptr, split, split > 1 ? ws : nullptr, split > 1 ? ws_bytes - kRedCntBytes : 0,
+                   (const uint16_t*)gate16, gate16_r8, cnt, (int)(kRedCntBytes / 8));
 }
 
 // `pl` is honoured only for these shapes (everything the fused producers and the plane GEMMs assume)
@@ -852,8 +883,15 @@ extern "C" int dpd_debug_ob_stamps(unsigned long long* host_out) {
 }
 #endif
 extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
-    if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 26) { dpd::g_x3_tile[op - 16] = tile; return 0; }
-    if (op == 32 && tile >= 0 && tile <= 12 && split_k >= 1 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
+    // plane GEMMs: ops 16.. = call sites, 32 = the grouped dW2 + dW3 launch; split_k: n > 1 in-launch reduction, n < -1 slabs + reduce
+    // launch, 1 off, 0 automatic (decoder.hip: g_x3_split)
+    if (op >= 16 && op < 16 + dpd::OP_COUNT && tile >= 0 && tile <= 26 && split_k >= -8 && split_k <= 8) {
+        dpd::g_x3_tile[op - 16] = tile;
+        if (op - 16 == dpd::OP_BWD_DW1 || op - 16 == dpd::OP_BWD_DW23) dpd::g_x3_split[op - 16] = split_k;
+        return 0;
+    }
+    if (op == 32 && tile >= 0 && tile <= 14 && split_k >= -4 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
+    if (op == 33 && tile >= 0 && tile <= 14 && split_k >= 1 && split_k <= 4) { dpd::g_x3_trio_tile = tile; dpd::g_x3_trio_split = split_k; return 0; }
     if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;
@@ -863,7 +901,7 @@ extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
 static size_t base_ws_bytes(int KP, int H) {
     const size_t slabs = (size_t)8 * (size_t)(KP > H ? KP : H) * H * sizeof(float);   // split-K <= 8 of the largest dW
     const size_t cols = dpd::colsum_ws_floats(H, 3) * sizeof(float);
-    return (slabs + cols + 255) / 256 * 256;
+    return (slabs + cols + 255) / 256 * 256 + dpd::kRedCntBytes;
 }
 // plane scratch = the tail of the workspace
 static dpd::Scratch scratch_of(void* ws, size_t ws_bytes, int KP, int H) {
@@ -1294,7 +1332,10 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
     ColsumTwoStep cs{};
     cs.part_in = db_partials ? db_partials + (layer == 1 ? (size_t)((Qb + 31) / 32) * Nout : 0) : nullptr;
     cs.out = db; cs.nparts = (Qb + 31) / 32;
-    if (int rc = gemm_dt(dtype, op, 1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, ws, slab_bytes, scr, s, nullptr,
+    // plane compute types: the slab region + arrival words of the base workspace serve the in-launch split-K of gemm_dt
+    const size_t base_b = base_ws_bytes(Kin > Nout ? Kin : Nout, Nout);
+    const size_t gemm_ws = dtype == 0 ? slab_bytes : ((ws && ws_bytes >= base_b) ? base_b : 0);
+    if (int rc = gemm_dt(dtype, op, 1, 0, Kin, Nout, Qb, act, lda, g, Nout, dW, Nout, nullptr, nullptr, 0, ws, gemm_ws, scr, s, nullptr,
                          apl, gpl, nullptr, free_db ? &cs : nullptr))
         return rc;
     if (!db || free_db) return 0;   // bias gradient not wanted / already produced
@@ -1330,14 +1371,36 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
             // tiles (2 x 64 x 2 workgroups, two fp32 slabs added in a fixed order) is available through dpd_set_gemm_plan(32,
             // tile, 2) and tested, but measured slower in every compute type (bf16 B=64: 0.3903 vs 0.3861 ms per step; the slab
             // traffic and the reduce launch cost more than the shorter K loop saves).
+            // Round 4: split-K with the reduction INSIDE the launch (gemm_x3.hip: inlaunch_reduce; g_x3_pair_split > 1 or automatic):
+            // 2 x 64 tiles of 128x128 x 3-4 slices = two workgroups per CU instead of one on half of them.
             const long pe = (long)Kin * Qb, ge = (long)Qb * Nout;
             int split = g_x3_pair_split, ptile = g_x3_pair_tile;
-            if (split > 1 && (Qb % (128 * split) || !ws || (size_t)2 * split * Kin * Nout * sizeof(float) > ws_bytes)) split = 1;
+            void* cnt = nullptr;
+            const size_t base_b = base_ws_bytes(Kin > Nout ? Kin : Nout, Nout);
+            const bool ws_ok = ws && ws_bytes >= base_b;
+            if (split == 0) {                                     // automatic
+                if (!ptile) ptile = pl->np == 1 ? 2 : 3;
+                split = (ws_ok && ptile <= 5) ? x3_auto_split(pl->np, ptile, 2 * Kin, Nout, Qb) : 1;
+                if (split == 1 && !g_x3_pair_tile) ptile = 3;
+            }
+            size_t slab_b = ws_bytes;
+            if (split > 1) {                                      // in-launch reduction
+                const int chunk = (((Qb + split - 1) / split) + 63) / 64 * 64;
+                if (!ws_ok || ptile > 5 || chunk * (split - 1) >= Qb) split = 1;
+                else { cnt = (char*)ws + base_b - kRedCntBytes; slab_b = base_b - kRedCntBytes; if (!ptile) ptile = 2; }
+            } else if (split < -1) {                              // slabs + reduce launch (round 2)
+                split = -split;
+                if (Qb % (128 * split) || !ws || (size_t)2 * split * Kin * Nout * sizeof(float) > ws_bytes) split = 1;
+            } else {
+                split = 1;
+            }
             if (!ptile) ptile = split > 1 ? 2 : 3;
             if (ptile >= 8 && (pl->np != 1 || Qb % (64 * split))) ptile = split > 1 ? 2 : 3;
+            X3Extra ex;
+            ex.A2 = (const uint16_t*)pl->h2_r8; ex.B2 = (const uint16_t*)pl->g3_r8; ex.C2 = dWB;
             return gemm_x3(pl->np, 1, 1, Kin, Nout, Qb, (const uint16_t*)pl->h1_r8, Kin, pe, (const uint16_t*)pl->g2_r8, Nout, ge, dWA, Nout,
-                           nullptr, nullptr, 0, ptile, (hipStream_t)stream, nullptr, nullptr, (const uint16_t*)pl->h2_r8,
-                           (const uint16_t*)pl->g3_r8, dWB, split, ws, ws_bytes);
+                           nullptr, nullptr, 0, ptile, (hipStream_t)stream, nullptr, nullptr, &ex, split, ws, slab_b, nullptr, 0, cnt,
+                           (int)(kRedCntBytes / 8));
         }
         if (int rc = gemm_dt(dtype, OP_BWD_DW23, 1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, nullptr, 0,
                              scr, (hipStream_t)stream, nullptr, have ? pl->h1_r8 : nullptr, have ? pl->g2_r8 : nullptr, nullptr)) return rc;
@@ -1351,4 +1414,39 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
     cs.part_in = db_partials; cs.out = dbA; cs.nparts = (Qb + 31) / 32;     // (layer 2 = problem A: the first half of the scratch)
     return gemm_f32(1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, 1, tile, nullptr, 0,
                     (hipStream_t)stream, nullptr, actB, gB, dWB, dbA ? &cs : nullptr);
+}
+
+// dW1, dW2 and dW3 of a plane compute type in ONE grouped launch (round 4).  Every weight-gradient GEMM of the step contracts over the
+// query rows (K = Qb = 4096 at B = 64): a workgroup's K loop takes ~27 us whatever the grid, and dW1 alone has 160 tiles of 128x128,
+// dW2 / dW3 64 each, for 256 CUs -- launched one after the other they leave 96-192 CUs idle for 27 us each time (tools/
+// overlap_probe_bf16.py: dW1 37 us, one dW 27-35 us, both on two streams 42 us).  Here the three problems share one grid (288 tiles of
+// 128x128): all operands come from the R8 planes (X / g1, h1 / g2, h2 / g3).  DPD_E_UNSUPPORTED when the planes are not all there
+// (the caller then uses dpd_decoder_bwd_weights + _pair); bias gradients are not produced here (plane types: dH epilogues).
+extern "C" int dpd_decoder_bwd_weights_trio(int Qb, int KP, int H, int dtype, float* dW1, float* dW2, float* dW3, void* ws, size_t ws_bytes,
+                                            const dpd_planes* pl, void* stream) {
+    using namespace dpd;
+    if (!dW1 || !dW2 || !dW3 || !pl) return DPD_E_NULL;
+    if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
+    if (dtype != 1 && dtype != 2) return DPD_E_UNSUPPORTED;
+    pl = usable_planes(pl, dtype, pl->Q, Qb, KP, H);
+    if (!pl) return DPD_E_UNSUPPORTED;
+    if (pl->Qb != Qb) return DPD_E_DIM;
+    if (int rc = check_planes(pl, dtype)) return rc;
+    if (!(pl->X_r8 && pl->g1_r8 && pl->h1_r8 && pl->g2_r8 && pl->h2_r8 && pl->g3_r8) || (KP & 7) || (Qb % 64)) return DPD_E_UNSUPPORTED;
+    int tile = g_x3_trio_tile ? g_x3_trio_tile : 2, split = g_x3_trio_split;
+    if (tile > 5 && (pl->np != 1 || split > 1)) tile = 2;       // the BK = 64 tiles: one plane, whole K
+    void* cnt = nullptr;
+    size_t slab_b = 0;
+    if (split > 1) {
+        const size_t base_b = base_ws_bytes(KP > H ? KP : H, H);
+        const int chunk = (((Qb + split - 1) / split) + 63) / 64 * 64;
+        if (!ws || ws_bytes < base_b || chunk * (split - 1) >= Qb) split = 1;
+        else { cnt = (char*)ws + base_b - kRedCntBytes; slab_b = base_b - kRedCntBytes; }
+    }
+    X3Extra ex;
+    ex.A2 = (const uint16_t*)pl->h1_r8; ex.B2 = (const uint16_t*)pl->g2_r8; ex.C2 = dW2; ex.M2 = H;
+    ex.A3 = (const uint16_t*)pl->h2_r8; ex.B3 = (const uint16_t*)pl->g3_r8; ex.C3 = dW3; ex.M3 = H;
+    return gemm_x3(pl->np, 1, 1, KP, H, Qb, (const uint16_t*)pl->X_r8, KP, (long)KP * Qb, (const uint16_t*)pl->g1_r8, H, (long)Qb * H, dW1, H,
+                   nullptr, nullptr, 0, tile, (hipStream_t)stream, nullptr, nullptr, &ex, split, split > 1 ? ws : nullptr, slab_b, nullptr, 0,
+                   cnt, (int)(kRedCntBytes / 8));
 }

@@ -337,6 +337,19 @@ struct X3Out {
     int ld_rc = 0, r8_rows = 0, np = 0;
 };
 
+// further problems of a grouped plain plane-GEMM launch (gemm_x3.hip): same N, K, B layout and tile; own operands, output and rows.
+// M2 / M3 = 0: the rows of problem 0.  Problems with other rows than problem 0, and a third problem, run on the ring kernels only.
+struct X3Extra {
+    const uint16_t* A2 = nullptr;
+    const uint16_t* B2 = nullptr;
+    float* C2 = nullptr;
+    int M2 = 0;
+    const uint16_t* A3 = nullptr;
+    const uint16_t* B3 = nullptr;
+    float* C3 = nullptr;
+    int M3 = 0;
+};
+
 struct SplitJob {
     const float* src;
     uint16_t* rc;

@@ -19,6 +19,8 @@
 //
 // Kernel structure = gemm_f32.hip's LDS-DMA ring: NS stages, pieces issued NS-1 K-tiles ahead, one raw s_barrier per
 // K-tile, counted vmcnt, fragments requested one k16-step ahead of their MFMAs.
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm_shared.h"
@@ -42,6 +44,22 @@ struct X3Args {
     const uint16_t* A2;
     const uint16_t* B2;
     float* C2;
+    // round 4 (ring kernel only, plain products): the grouped problems may differ in M (rows of A^T / C), and there may be three of
+    // them -- the three weight gradients of the bf16 step in ONE launch (dW1 2528 x 1024, dW2 and dW3 1024 x 1024, K = query rows):
+    // each alone leaves 96-192 of the 256 CUs idle for the 27 us its K loop takes.  0 = same as problem 0.
+    int M2, lda2;
+    long a_plane2;
+    const uint16_t* A3;
+    const uint16_t* B3;
+    float* C3;
+    int M3, lda3;
+    long a_plane3;
+    // in-launch split-K (red_cnt != NULL; e.split_k slices of e.k_chunk per output tile): every slice parks its raw accumulators in
+    // red_slab, the slice that arrives LAST at the tile's counter adds all slices in slice order and runs the normal epilogue on C
+    float* red_slab;               // [tiles (x2 grouped)][split][BM*BN] floats, accumulator-register order (lane-linear 16-byte pieces)
+    unsigned long long* red_cnt;   // [tiles (x2 grouped)] arrival words {generation : 32, arrivals : 32}
+    unsigned red_gen;              // generation of this launch: a word of another generation (workspace garbage, an aborted launch) counts as 0
+    int red_sc1;                   // != 0: slabs published by write-through (sc1) stores and read by sc1 loads, no release / acquire fence
 };
 
 template <int N>
@@ -98,7 +116,8 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
     const int M = g.e.M, N = g.e.N;
     if (!g.out_rc && !g.out_r8) {
         GemmArgs ge = g.e;
-        if (grp) ge.C = g.C2;
+        if (grp == 1) { ge.C = g.C2; if (g.M2) ge.M = g.M2; }
+        if (grp == 2) { ge.C = g.C3; ge.M = g.M3; }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -261,6 +280,100 @@ __device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][T
         }
 }
 
+// In-launch split-K reduction (cdna_hip_programming.md, "In-launch split-K reduction"; the dW GEMMs of the bf16 step: K = query rows
+// is long, M x N gives 64-160 tiles of 128x128 for 256 CUs).  One agent-scope release per slice, one agent-scope acquire per tile:
+//   every slice: raw accumulators -> its slab (plain 16-byte stores, lane-linear) -> every wave s_waitcnt vmcnt(0) -> barrier ->
+//                thread 0: release fence (agent) + the restated vmcnt(0) wait -> relaxed arrival at the tile's counter word;
+//   the slice that draws the last ticket: thread 0 acquire fence (agent) -> barrier -> all waves add the slabs of slice 0, 1, ...
+//                in THAT order (fp32 addition is not associative: a fixed order makes the result independent of who arrives last,
+//                bitwise reproducible) -> the ordinary epilogue.
+// Correct for any placement of a tile's slices over XCDs; the block-id map only makes the common placement fast (slices of a tile are
+// neighbours in the logical id, i.e. on one XCD: the reducer then finds the slabs in its own L2).
+// The arrival word carries the launch's generation: a word left by another generation (uninitialised workspace, an aborted launch)
+// counts as zero arrivals, and the last arriver leaves {generation, 0} behind so that a replay of the same captured launch starts clean.
+// Returns true in the reducing slice (acc = the sum).  `flag` = one dword of the idle LDS ring (no second __shared__ object).
+template <int NW, int TM, int TN>
+__device__ __forceinline__ bool inlaunch_reduce(const X3Args& g, f32x16 (&acc)[TM][TN], char* smem, int tile_id, int z, int tid) {
+    const int split = g.e.split_k;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int ITEM4 = NW * TM * TN * 4 * 64;                      // float4s per slice slab
+    float4* slab = reinterpret_cast<float4*>(g.red_slab) + (size_t)tile_id * split * ITEM4;
+    float4* mine = slab + (size_t)z * ITEM4 + (size_t)wave * (TM * TN * 4 * 64) + lane;
+    const bool sc1 = g.red_sc1 != 0;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, (int)((size_t)split * ITEM4 * 16), 0x00020000);
+    const unsigned voff_w = (unsigned)(wave * (TM * TN * 4 * 64) + lane) * 16u;
+    if (sc1) {      // write-through: the slab is visible to every XCD once the stores have been acknowledged (no buffer_wbl2)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u4v v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
+                                   __float_as_uint(acc[i][j][4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff_w + (unsigned)(((i * TN + j) * 4 + q) * 64) * 16u,
+                                                           (unsigned)z * (unsigned)(ITEM4 * 16), 16);
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mine[((i * TN + j) * 4 + q) * 64] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(smem);
+    if (tid == 0) {
+        if (!sc1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        unsigned long long* c = g.red_cnt + tile_id;
+        const unsigned long long gen = (unsigned long long)g.red_gen << 32;
+        unsigned long long old = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned n;
+        do {
+            n = ((old >> 32) == g.red_gen ? (unsigned)old : 0u) + 1u;
+        } while (!__hip_atomic_compare_exchange_strong(c, &old, gen | n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const bool last = n == (unsigned)split;
+        if (last) {
+            __hip_atomic_store(c, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!sc1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!*flag) return false;
+    const float4* src = slab + (size_t)wave * (TM * TN * 4 * 64) + lane;
+    for (int zz = 0; zz < split; ++zz) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v;
+                    if (sc1) {
+                        const u4v u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_w + (unsigned)(((i * TN + j) * 4 + q) * 64) * 16u,
+                                                                            (unsigned)zz * (unsigned)(ITEM4 * 16), 16);
+                        v = make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+                    } else {
+                        v = src[(size_t)zz * ITEM4 + ((i * TN + j) * 4 + q) * 64];
+                    }
+                    if (zz == 0) {
+                        acc[i][j][4 * q] = v.x; acc[i][j][4 * q + 1] = v.y; acc[i][j][4 * q + 2] = v.z; acc[i][j][4 * q + 3] = v.w;
+                    } else {
+                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                    }
+                }
+    }
+    return true;
+}
+
 // ABL (timing-only ablations, instantiated only with -DDPD_ABLATIONS; results are wrong by construction):
 //   1 = no LDS-DMA refill in the K loop, 2 = no barrier, 4 = no fragment reads in the loop, 8 = one MFMA per step only.
 // TR: operands that are not K-contiguous come as RCT images of their RC planes (above) instead of R8 planes
@@ -284,15 +397,25 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm0 = (wave / WC) * 32 * TM, wn0 = (wave % WC) * 32 * TN;
 
-    const int M = g.e.M, N = g.e.N;
-    const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
-    const int per_z = tilesM * tilesN;
-    const int sid0 = xcd_remap(blockIdx.x, per_z * g.e.split_k * (g.A2 ? 2 : 1));
-    const int grp = sid0 / (per_z * g.e.split_k);
-    const int sid = sid0 % (per_z * g.e.split_k);
-    const int z = sid / per_z, t = sid % per_z;
-    const uint16_t* gA = grp ? g.A2 : g.A;
-    const uint16_t* gB = grp ? g.B2 : g.B;
+    const int N = g.e.N;
+    const int tilesN = (N + BN - 1) / BN;
+    // up to three grouped problems (rows M0, M1, M2): block id -> (problem, tile, K slice)
+    const int Mp1 = g.A2 ? (g.M2 ? g.M2 : g.e.M) : 0, Mp2 = g.A3 ? g.M3 : 0;
+    const int nt0 = ((g.e.M + BM - 1) / BM) * tilesN, nt1 = ((Mp1 + BM - 1) / BM) * tilesN, nt2 = ((Mp2 + BM - 1) / BM) * tilesN;
+    const int SK = g.e.split_k;
+    const int sid0 = xcd_remap(blockIdx.x, (nt0 + nt1 + nt2) * SK);
+    const int grp = sid0 >= (nt0 + nt1) * SK ? 2 : (sid0 >= nt0 * SK ? 1 : 0);
+    const int per_z = grp == 0 ? nt0 : (grp == 1 ? nt1 : nt2);
+    const int tile_base = grp == 0 ? 0 : (grp == 1 ? nt0 : nt0 + nt1);
+    const int sid = sid0 - tile_base * SK;
+    const int M = grp == 0 ? g.e.M : (grp == 1 ? Mp1 : Mp2);
+    // slab split-K: slice-major (a slab is written tile after tile); in-launch reduction: tile-major, so that the slices of a tile are
+    // neighbours in the logical id and land on one XCD (a speed choice only: inlaunch_reduce is placement-independent)
+    const int z = g.red_cnt ? sid % SK : sid / per_z, t = g.red_cnt ? sid / SK : sid % per_z;
+    const uint16_t* gA = grp == 0 ? g.A : (grp == 1 ? g.A2 : g.A3);
+    const uint16_t* gB = grp == 0 ? g.B : (grp == 1 ? g.B2 : g.B3);
+    const int lda_g = grp == 0 ? g.lda : (grp == 1 ? (g.lda2 ? g.lda2 : g.lda) : g.lda3);
+    const long a_plane_g = grp == 0 ? g.a_plane : (grp == 1 ? (g.a_plane2 ? g.a_plane2 : g.a_plane) : g.a_plane3);
     const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
     const int kbeg = z * g.e.k_chunk;
     const int kend = min(g.e.K, kbeg + g.e.k_chunk);
@@ -310,8 +433,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
         const bool isA = w < PA;
         const int c = isA ? w : w - PA;
         const bool kc = isA ? AK : BKC;
-        const uint16_t* base = isA ? gA + plane * g.a_plane : gB + plane * g.b_plane;
-        const int ld = isA ? g.lda : g.ldb;
+        const uint16_t* base = isA ? gA + plane * a_plane_g : gB + plane * g.b_plane;
+        const int ld = isA ? lda_g : g.ldb;
         const int o0 = isA ? m0 : n0;
         const int O = isA ? M : N;
         const int BO = isA ? BM : BN;
@@ -441,6 +564,11 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
             do_step(it, 0, C0{});
             if (it + 1 < nt) do_step(it + 1, 0, C1{});
         }
+    }
+    if (g.red_cnt) {
+        if (!inlaunch_reduce<NW, TM, TN>(g, acc, smem_x3, tile_base + t, z, tid)) return;
+        x3_epilogue<BM, BN, NW, TM, TN, NP>(g, acc, smem_x3, grp, 0, m0, n0, wm0, wn0, tid, l31, half);
+        return;
     }
     x3_epilogue<BM, BN, NW, TM, TN, NP>(g, acc, smem_x3, grp, z, m0, n0, wm0, wn0, tid, l31, half);
 }
@@ -705,7 +833,8 @@ static int launch_x3(const X3Args& g, hipStream_t s) {
     auto kern = gemm_x3_kernel<NP, AK, BKC, WR, WC, TM, TN, NS, BK, ABL, TR>;
     static LdsOptIn lds_opt;   // one per template instantiation
     if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
-    const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * g.e.split_k * (g.A2 ? 2 : 1);
+    const int tn = (g.e.N + BN - 1) / BN;
+    const int nblk = (((g.e.M + BM - 1) / BM) + (g.A2 ? ((g.M2 ? g.M2 : g.e.M) + BM - 1) / BM : 0) + (g.A3 ? (g.M3 + BM - 1) / BM : 0)) * tn * g.e.split_k;
     DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
     return (int)hipGetLastError();
 }
@@ -739,6 +868,10 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 10: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x128, 4 waves of 64x64
         case 11: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x256, 8 waves of 64x64
         case 12: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 1, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 64x128, 4 waves of 32x64
+        // 192x128 (round 4): the tile with the smallest BM + BN (= LDS fill bytes per flop) that covers dW1 + dW2 + dW3 in at most one
+        // workgroup per CU (112 + 48 + 48 = 208 tiles): 8 waves of 96x32, BK = 64, 3 stages x 40 KiB
+        case 13: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 3, 1, 3, 64>(g, s); return DPD_E_UNSUPPORTED;
+        case 14: if (NP == 1) return launch_x3<1, AK, BKC, 4, 2, 1, 3, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x192, 8 waves of 32x96
         // phase-staggered kernels (gemm_p8_kernel; K % 32 == 0, no split-K): one plane at BK = 64, three planes at BK = 32
         case 20: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64
         case 21: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // ... group 0 waits after its MFMAs
@@ -763,16 +896,28 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
 // 2 = RC plane of an operand whose k is its ROW index (both operands: A stored [K][M], B stored [K][N]; lda / ldb = row strides).
 int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A, int lda, long a_plane, const uint16_t* B,
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
-            hipStream_t s, float* colsum, const X3Out* out, const uint16_t* A2, const uint16_t* B2, float* C2, int split_k, void* ws,
-            size_t ws_bytes, const uint16_t* gate16, int gate16_r8) {
+            hipStream_t s, float* colsum, const X3Out* out, const X3Extra* ex, int split_k, void* ws,
+            size_t ws_bytes, const uint16_t* gate16, int gate16_r8, void* red_cnt, int red_cnt_words) {
+    const uint16_t* A2 = ex ? ex->A2 : nullptr;
+    const uint16_t* B2 = ex ? ex->B2 : nullptr;
+    float* C2 = ex ? ex->C2 : nullptr;
+    const int M2 = (ex && ex->M2) ? ex->M2 : M;
+    const bool three = ex && ex->A3;
+    const bool uneven = A2 && (M2 != M || three);      // problems of different rows / a third problem: ring kernels, TN only
     if (A2 && (!B2 || !C2 || out || colsum || epilogue != EPI_NONE)) return DPD_E_UNSUPPORTED;
+    if (three && (!A2 || !ex->B3 || !ex->C3 || ex->M3 <= 0)) return DPD_E_UNSUPPORTED;
+    if (uneven && (a_fmt != 1 || b_fmt != 1 || tile < 1 || (tile > 5 && tile != 13 && tile != 14) || (M2 & 7) || (three && (ex->M3 & 7))))
+        return DPD_E_UNSUPPORTED;
+    const int nprob = A2 ? (three ? 3 : 2) : 1;
     // split-K (deterministic slabs in `ws` + the reduce kernel of gemm_f32.hip): plain products only (the dW shapes: K = query rows
     // is long, M x N gives too few 128x128 tiles for 256 CUs)
+    // red_cnt != NULL: the slices are reduced INSIDE the launch (inlaunch_reduce above; ring kernels, tiles 1-5); `ws` then holds the
+    // raw accumulator slabs of every slice (tile-padded) and red_cnt [>= tiles] arrival words of 8 bytes
     int chunk = K;
     if (split_k > 1) {
         chunk = (((K + split_k - 1) / split_k) + 63) / 64 * 64;
         if (out || colsum || epilogue != EPI_NONE || !C || chunk * (split_k - 1) >= K) return DPD_E_UNSUPPORTED;
-        if (!ws || (size_t)split_k * M * N * sizeof(float) * (A2 ? 2 : 1) > ws_bytes) return DPD_E_WORKSPACE;
+        if (!red_cnt && (uneven || !ws || (size_t)split_k * M * N * sizeof(float) * nprob > ws_bytes)) return DPD_E_WORKSPACE;
     } else {
         split_k = 1;
     }
@@ -783,7 +928,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
     if (np != 1 && np != 3) return DPD_E_UNSUPPORTED;
     if ((K % 32) || (N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return DPD_E_UNSUPPORTED;
-    if (tile >= 8 && tile <= 12 && (K % 64)) return DPD_E_UNSUPPORTED;   // BK = 64 kernels take whole 64-deep K-tiles
+    if (tile >= 8 && tile <= 14 && (K % 64)) return DPD_E_UNSUPPORTED;   // BK = 64 kernels take whole 64-deep K-tiles
     if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) && !bias) return DPD_E_NULL;
     if (epilogue == EPI_GATE && !gate && !gate16) return DPD_E_NULL;
     if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;
@@ -796,7 +941,30 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     g.e.split_k = 1; g.e.k_chunk = K; g.e.slab_stride = 0;
     g.A = A; g.B = B; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
-    if (split_k > 1) {
+    if (uneven) {      // TN on R8 planes: the row count of a problem is its A's k-group row length and (with K) its plane stride
+        g.M2 = M2; g.lda2 = M2; g.a_plane2 = (long)K * M2;
+        if (three) { g.A3 = ex->A3; g.B3 = ex->B3; g.C3 = ex->C3; g.M3 = ex->M3; g.lda3 = ex->M3; g.a_plane3 = (long)K * ex->M3; }
+    }
+    if (tile == 0) tile = 1;
+    if (split_k > 1 && red_cnt) {
+        int bm, bn;
+        switch (tile) {
+            case 1: case 2: bm = 128; bn = 128; break;
+            case 3: bm = 64; bn = 128; break;
+            case 4: bm = 128; bn = 64; break;
+            case 5: bm = 64; bn = 64; break;
+            default: return DPD_E_UNSUPPORTED;
+        }
+        const size_t tn = (size_t)((N + bn - 1) / bn);
+        const size_t tiles = ((size_t)((M + bm - 1) / bm) + (A2 ? (M2 + bm - 1) / bm : 0) + (three ? (ex->M3 + bm - 1) / bm : 0)) * tn;
+        if (!ws || tiles * split_k * bm * bn * sizeof(float) > ws_bytes) return DPD_E_WORKSPACE;
+        if (tiles > (size_t)red_cnt_words) return DPD_E_WORKSPACE;
+        static std::atomic<unsigned> generation{0x5eed0000u};
+        g.e.split_k = split_k; g.e.k_chunk = chunk;          // C / C2 / ldc stay the real output: the reducing slice stores it
+        g.red_slab = (float*)ws; g.red_cnt = (unsigned long long*)red_cnt; g.red_gen = ++generation;
+        static const int sc1_mode = [] { const char* e = getenv("DPD_RED_SC1"); return e ? atoi(e) : 1; }();
+        g.red_sc1 = sc1_mode;
+    } else if (split_k > 1) {
         g.e.split_k = split_k; g.e.k_chunk = chunk; g.e.slab_stride = (long)M * N; g.e.ldc = N;
         g.e.C = (float*)ws; g.C2 = (float*)ws + (size_t)split_k * M * N;
     }
@@ -804,11 +972,10 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
         g.out_rc = out->rc; g.out_r8 = out->r8; g.rc_plane = out->rc_plane; g.r8_plane = out->r8_plane;
         g.ld_rc = out->ld_rc; g.r8_rows = out->r8_rows; g.np_out = out->np;
     }
-    if (tile == 0) tile = 1;
     struct ProfScope {
         bool on; hipStream_t s; double fl;
         ~ProfScope() { prof_end(on, s, fl); }
-    } prof_scope{prof_begin(s), s, 2.0 * M * N * K * (A2 ? 2 : 1)};
+    } prof_scope{prof_begin(s), s, 2.0 * N * K * ((double)M + (A2 ? M2 : 0) + (three ? ex->M3 : 0))};
     int rc;
     if (a_fmt == 2) {
         rc = np == 3 ? launch_x3_tile_tr<3>(tile, g, s) : launch_x3_tile_tr<1>(tile, g, s);
@@ -821,7 +988,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
         else if (!a_fmt && !b_fmt) rc = launch_x3_tile<1, true, true>(tile, g, s);
         else rc = launch_x3_tile<1, false, false>(tile, g, s);
     }
-    if (rc || split_k == 1) return rc;
+    if (rc || split_k == 1 || red_cnt) return rc;
     if ((rc = splitk_reduce(g.e.C, split_k, (long)M * N, M, N, C, ldc, nullptr, nullptr, EPI_NONE, s))) return rc;
     if (A2) rc = splitk_reduce(g.C2, split_k, (long)M * N, M, N, C2, ldc, nullptr, nullptr, EPI_NONE, s);
     return rc;
@@ -916,5 +1083,5 @@ extern "C" int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K
     o.rc = (uint16_t*)out_rc; o.r8 = (uint16_t*)out_r8; o.np = np; o.ld_rc = N; o.r8_rows = r8_rows;
     o.rc_plane = (long)M * N; o.r8_plane = (long)r8_rows * N;
     return dpd::gemm_x3(np, a_fmt, b_fmt, M, N, K, (const uint16_t*)A, lda, a_plane, (const uint16_t*)B, ldb, b_plane, C, ldc,
-                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0, nullptr, 0);
+                        bias, gate, epilogue, tile, (hipStream_t)stream, nullptr, (out_rc || out_r8) ? &o : nullptr, nullptr, 1, nullptr, 0, nullptr, 0, nullptr, 0);
 }

@@ -76,6 +76,7 @@ SIGNATURES = {
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p, c_void_p]),
+    "dpd_decoder_bwd_weights_trio": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
     "dpd_has_adam_epilogue": (c_int, []),
     "dpd_decoder_bwd_weights_adam": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                              c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p, POINTER(AdamEpi), c_void_p]),

@@ -195,6 +195,7 @@ class DPDistTrainer:
         self.use_graph = os.environ.get("DPD_GRAPH", "0") == "1"   # opt-in: measured 4 % SLOWER than eager launches on MI355X / ROCm 7
         self._graphs, self._seen_keys, self._gstreams = {}, set(), None
         self.graph_replays = 0
+        self._trio = self._planes is not None and os.environ.get("DPD_DW_TRIO", "1") == "1"
         self._wdirty = True        # transposed copies / bf16 planes of the weights need a refresh before their next use
         self._after_dw1 = None
         self._side = None          # side stream of the prefetch pipeline (created on first use)
@@ -402,6 +403,18 @@ class DPDistTrainer:
             data(2 | 4)
         else:
             data(7 | 16 if defer_small else 7)     # 16: db3 / dW4 / db4 and the loss stay block partials (the optimizer sums them)
+        if self._trio and self._adam_now is None and not self.reducer:
+            # plane compute types: dW1 + dW2 + dW3 as ONE grouped launch (288 tiles of 128x128 for 256 CUs; apart they leave 96-192
+            # CUs idle for the ~27 us a K = 4096 loop takes: DESIGN.md section 3.5)
+            rc = lib.dpd_decoder_bwd_weights_trio(BN, P.KP, P.H, self.dt, L.ptr(d[0]), L.ptr(d[2]), L.ptr(d[4]), L.ptr(self.ws), wsb, self._planes,
+                                                  L.cur_stream())
+            if rc == 0:
+                if self._after_dw1 is not None:
+                    self._after_dw1()
+                return
+            if rc != -3:
+                L.check(rc, "dpd_decoder_bwd_weights_trio")
+            self._trio = False            # DPD_E_UNSUPPORTED: shapes / planes the grouped launch does not take
         dw(1, self.X, self.g1, d[0])
         if self._after_dw1 is not None:
             self._after_dw1()             # X / mask are free from here on: the prefetch pipeline hooks in

@@ -400,9 +400,19 @@ int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const voi
 /* Tuning knob (process-wide, never needed for correctness): GEMM tile / split-K per
  * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3, 6 / 7 bwd dH / dX with a
  * transposed weight copy, 8 bwd dW1 with the fused gather; 16 + op: one-plane (bf16) tile of gemm_x3.hip for that call site
- * (0 = automatic), 32: its grouped dW2/dW3 launch.  tile as in dpd_gemm_f32 (0 = auto); split_k only applies to ops 4, 5, 8.
- * Defaults are the measured best.                                                                                        */
+ * (0 = automatic), 32: its grouped dW2/dW3 launch, 33: the grouped dW1/dW2/dW3 launch of dpd_decoder_bwd_weights_trio.  tile as in
+ * dpd_gemm_f32 (0 = auto); split_k applies to ops 4, 5, 8 and, for the plane weight gradients (ops 20, 21, 32, 33): n > 1 = n K slices
+ * per tile reduced inside the launch (last-arriving slice, slice order: deterministic), n < -1 = |n| fp32 slabs + a reduce launch,
+ * 1 = off, 0 = automatic.  Defaults are the measured best.                                                              */
 int dpd_set_gemm_plan(int op, int tile, int split_k);
+
+/* dW1, dW2 and dW3 of a plane compute type (dtype 1 / 2) in ONE grouped launch; all operands are the R8 planes of `pl`
+ * (X / g1, h1 / g2, h2 / g3).  Same gradients as dpd_decoder_bwd_weights(1) + dpd_decoder_bwd_weights_pair up to fp32 summation
+ * order; no bias gradients (the plane compute types get them from the dH epilogues of dpd_decoder_bwd_data).  DPD_E_UNSUPPORTED
+ * when a plane is missing or a shape is not plane-shaped: the caller then makes the separate calls.
+ * Replaces TF autodiff of the three tf.nn.conv2d kernels (utils/tf_util.py:213, train_multi_gpu_pc_compare_dist.py:274-277).   */
+int dpd_decoder_bwd_weights_trio(int Qb, int KP, int H, int dtype, float* dW1, float* dW2, float* dW3, void* ws, size_t ws_bytes,
+                                 const dpd_planes* pl, void* stream);
 
 /* Opt-in profiler for the roofline measurement (bench.py): when enabled, every GEMM kernel launch is bracketed
  * by a hipEvent pair on its own stream.  dpd_prof_collect waits for them and returns the launch count and the
