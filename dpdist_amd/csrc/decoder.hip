@@ -1433,8 +1433,14 @@ extern "C" int dpd_decoder_bwd_weights_trio(int Qb, int KP, int H, int dtype, fl
     if (pl->Qb != Qb) return DPD_E_DIM;
     if (int rc = check_planes(pl, dtype)) return rc;
     if (!(pl->X_r8 && pl->g1_r8 && pl->h1_r8 && pl->g2_r8 && pl->h2_r8 && pl->g3_r8) || (KP & 7) || (Qb % 64)) return DPD_E_UNSUPPORTED;
-    int tile = g_x3_trio_tile ? g_x3_trio_tile : 2, split = g_x3_trio_split;
-    if (tile > 5 && (pl->np != 1 || split > 1)) tile = 2;       // the BK = 64 tiles: one plane, whole K
+    // Default tile (one plane): 192x128 (gemm_x3.hip tile 13).  A workgroup's K loop is bound by the LDS-DMA fill of its CU
+    // (~30 B/clk/CU for linear 1-KiB pieces), i.e. its time is ~ (BM + BN) * K * 2 B / 72 GB/s whatever else runs, and a CU that gets
+    // two tiles takes twice as long: the best tile is the one with the smallest BM + BN that still gives every CU at most ONE
+    // workgroup -- 128x128 makes 288 tiles (32 CUs get two: 58 us), 192x128 makes 112 + 48 + 48 = 208 (36 us), 256x128 144 (44 us).
+    // Measured in the bf16 step at B = 64 (profiles/r04_bf16_trio_sweep.txt): the three launches apart 71 us, grouped on 128x128
+    // tiles 67 us, on 192x128 tiles 51 us (step 0.3107 -> 0.2909 ms on that box).
+    int tile = g_x3_trio_tile ? g_x3_trio_tile : ((pl->np == 1 && !(Qb % 64)) ? 13 : 2), split = g_x3_trio_split;
+    if (tile > 5 && (pl->np != 1 || split > 1 || (Qb % 64))) tile = 2;       // the BK = 64 tiles: one plane, whole K
     void* cnt = nullptr;
     size_t slab_b = 0;
     if (split > 1) {

@@ -526,7 +526,7 @@ def _agree(flag, device, group):
     return int(t.item()) == 1
 
 
-def make_reducer(flat_grad, bounds, group=None, force=False):
+def make_reducer(flat_grad, bounds, group=None, force=False, mode=None):
     """The gradient reducer of a data-parallel trainer: RCCL driven directly on GPU buffers under an NCCL/RCCL process group
     (DPD_DP_BACKEND=torch, DPD_DP_MODE=rs_ag, or a failure to bind librccl keep `BucketReducer`), torch.distributed otherwise
     (gloo / CPU tensors: the tests).
@@ -541,7 +541,7 @@ def make_reducer(flat_grad, bounds, group=None, force=False):
     import sys
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     want = os.environ.get("DPD_DP_BACKEND", "rccl")
-    mode = os.environ.get("DPD_DP_MODE", "allreduce")
+    mode = mode or os.environ.get("DPD_DP_MODE", "allreduce")      # `mode`: a caller that cannot shard its optimizer pins "allreduce"
     check = os.environ.get("DPD_DP_CROSSCHECK", "1") == "1"
     if (dist.is_initialized() and (world > 1 or force) and flat_grad.is_cuda and want == "rccl" and dist.get_backend(group) == "nccl"
             and mode in ("allreduce", "zero1")):
@@ -553,7 +553,7 @@ def make_reducer(flat_grad, bounds, group=None, force=False):
         red = None
         if _agree(err is None, flat_grad.device, group):
             try:
-                red = DirectRcclReducer(flat_grad, bounds, group)
+                red = DirectRcclReducer(flat_grad, bounds, group, mode=mode)
             except Exception as e:      # plumbing only: the torch.distributed path computes the same sums
                 err = e
             if _agree(red is not None, flat_grad.device, group):
@@ -572,7 +572,7 @@ def make_reducer(flat_grad, bounds, group=None, force=False):
                 red.close()
                 red = None
         sys.stderr.write("dpdist_amd.ddp: direct RCCL unavailable on some rank (%r here), using torch.distributed collectives\n" % (err,))
-    red = BucketReducer(flat_grad, bounds, group, force=force)
+    red = BucketReducer(flat_grad, bounds, group, force=force, mode=mode)
     if red.active and check:
         red.crosscheck = crosscheck(red, group)
         if not red.crosscheck["ok"]:

@@ -66,7 +66,7 @@ class Heartbeat:
     def beat(self, phase):
         self.phase = phase
         if self.dir:
-            _write_atomic(os.path.join(self.dir, "rank%d.a%d" % (self.rank, self.attempt)), "%s %.3f\n" % (phase, time.time()))
+            _write_atomic(os.path.join(self.dir, "rank%d.a%d" % (self.rank, self.attempt)), "%s %.3f\n" % ("_".join(phase.split()), time.time()))
         if self._hang and phase.split(":")[0] == self._hang:
             sys.stderr.write("launch.Heartbeat: injected hang in phase %r on rank %d (attempt %d)\n" % (phase, self.rank, self.attempt))
             sys.stderr.flush()
@@ -76,8 +76,8 @@ class Heartbeat:
 
 def _read_beat(path):
     try:
-        txt = open(path).read().split()
-        return txt[0], float(txt[1])
+        txt = open(path).read().rsplit(None, 1)      # "<phase> <unix time>": the phase is everything before the last field
+        return txt[0].strip(), float(txt[1])
     except (OSError, IndexError, ValueError):
         return None, None
 

@@ -58,10 +58,48 @@ class TFAdam(torch.optim.Optimizer):
             p.grad = self.grad[off:off + k].view_as(p)
             off += k
 
+    def _inside(self, t, flat):
+        return t is not None and flat.data_ptr() <= t.data_ptr() < flat.data_ptr() + flat.numel() * 4
+
+    @torch.no_grad()
+    def _check_views(self):
+        """step() updates the FLAT buffers: a parameter or gradient that no longer lives in them (a backward with create_graph that
+        replaced p.grad, zero_grad(set_to_none=True), net.to(...), an assignment to p.data) would otherwise be updated with a stale or
+        zero gradient, silently.  Foreign gradients are copied in, foreign parameter storage is adopted and re-bound."""
+        off = 0
+        for p in self._params:
+            k = p.numel()
+            if not self._inside(p.data, self.flat):
+                self.flat[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + k].view_as(p)
+            if p.grad is None:               # TF skips variables without a gradient; the fused kernel cannot: a zero gradient still
+                self.grad[off:off + k].zero_()   # decays m / v and moves p by the remaining momentum (documented deviation)
+                p.grad = self.grad[off:off + k].view_as(p)
+            elif not self._inside(p.grad, self.grad):
+                self.grad[off:off + k].copy_(p.grad.reshape(-1))
+                p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+
+    def state_dict(self):
+        """torch's optimizer state_dict plus the flat slots and the step count (they do not live in `self.state`)."""
+        sd = super().state_dict()
+        sd["tf_adam"] = {"m": self.m.clone(), "v": self.v.clone(), "t": self.t}
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        extra = sd.pop("tf_adam", None)
+        super().load_state_dict(sd)
+        if extra is not None:
+            self.m.copy_(extra["m"])
+            self.v.copy_(extra["v"])
+            self.t = int(extra["t"])
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("TFAdam: no closure form")
+        self._check_views()
         g = self.param_groups[0]
         b1, b2 = g["beta1"], g["beta2"]
         self.t += 1

@@ -180,17 +180,70 @@ def predicted_pose_applied(source, pose):
     return transformation_quat_tensor(source, quat, pose[:, :3])
 
 
+def centroid_residual(T_pred, gt_pose, source):
+    """Where the registration leaves the SOURCE'S CENTROID, against where the ground-truth pose puts it: |T_pred c - T_ideal c| per
+    pair (T_ideal = the inverse of the pose that created the source).  The reference's translation metric compares pose vectors
+    (results_itrPCRNet_no_stop.py:112-133); with `centroid_sub=0` the clouds are not centred, so a rotation error of d radians about
+    the ORIGIN has to be compensated by a translation of ~d x |centroid| for the clouds to overlap -- the pose-space translation
+    error then mostly measures the rotation error times that lever arm (0.035 rad x 0.3 = 0.01 at 2 deg), not how far apart the
+    registered clouds are.  This is the number that says the latter.  T_pred [B,4,4]; gt_pose [B,6] (t, rx, ry, rz); source [B,N,3]."""
+    gt = np.asarray(gt_pose, dtype=np.float64)
+    Tp = np.asarray(T_pred, dtype=np.float64)
+    c = np.asarray(source, dtype=np.float64).mean(1)
+    out = np.zeros(len(gt))
+    for i in range(len(gt)):
+        R = euler_to_mat(gt[i, 3], gt[i, 4], gt[i, 5])
+        ideal = R.T @ (c[i] - gt[i, :3])                        # source = R x + t  ->  x = R^T (source - t)
+        out[i] = np.linalg.norm(Tp[i, :3, :3] @ c[i] + Tp[i, :3, 3] - ideal)
+    return out
+
+
+def flat_gradient_views(params):
+    """One flat fp32 buffer with every parameter's `.grad` as a view into it (what `optim.TFAdam` does for its own parameters): the
+    data-parallel step all-reduces that ONE buffer instead of a tensor per layer."""
+    params = [p for p in params if p.requires_grad]
+    n = sum(p.numel() for p in params)
+    flat = torch.zeros((n + 3) // 4 * 4, device=params[0].device, dtype=params[0].dtype)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    return flat
+
+
 class IterativeRegistration:
     """One training step = iterative_PCRNet_ours.py:410-470: 7 forward-only refinements (no gradient), then one step
     in which the DPDist loss of (transformed source, template) is back-propagated THROUGH the frozen DPDist path into
     the pose network; the optimizer is `tf.train.AdamOptimizer(learning_rate, name='Adam2')` (:239) = `optim.TFAdam`.
     `loss_fn(moved_source, template) -> scalar` is DPDistLoss (the reference's 'ours') or any other differentiable
-    cloud distance (the reference's Chamfer baseline, iterative_PCRNet.py)."""
+    cloud distance (the reference's Chamfer baseline, iterative_PCRNet.py).
 
-    def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None):
+    Data parallel (BASELINE config 5, "8 x MI355X DP"; the reference itself is single-GPU here, iterative_PCRNet_ours.py:196): one
+    process per GPU, every rank registers its own pairs; DPDist is FROZEN, so there is no DPDist collective at all --
+    the one exchange step is the sum all-reduce of the pose network's flat gradient (0.9 M parameters = 3.7 MB) through the same
+    reducer as the DPDist trainer (ddp.make_reducer: RCCL driven directly, start-up cross-check, torch.distributed fallback), then
+    every rank applies the same averaged gradient: replicas stay bit-identical.  `distributed=None` follows the process group."""
+
+    def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None, distributed=None, group=None):
+        import os
+        import torch.distributed as dist
         from .optim import TFAdam
         self.net, self.loss_fn, self.max_loops = pose_net, dpdist_loss, max_loops
         self.opt = optimizer if optimizer is not None else TFAdam(pose_net.parameters(), lr=lr)
+        use_dist = (dist.is_available() and dist.is_initialized()) if distributed is None else bool(distributed)
+        self.reducer = None
+        self._flat_grad = getattr(self.opt, "grad", None) if isinstance(getattr(self.opt, "grad", None), torch.Tensor) else None
+        if use_dist:
+            from .ddp import make_reducer
+            if self._flat_grad is None:
+                self._flat_grad = flat_gradient_views(pose_net.parameters())
+            self.reducer = make_reducer(self._flat_grad, [0, self._flat_grad.numel()], group,
+                                        force=os.environ.get("DPD_FORCE_DIST") == "1", mode="allreduce")
+
+    def close(self):
+        red, self.reducer = self.reducer, None
+        if red is not None:
+            red.close()
 
     def refine(self, source, template, loops):
         T = torch.eye(4, device=source.device).repeat(source.shape[0], 1, 1)
@@ -210,7 +263,19 @@ class IterativeRegistration:
         moved = predicted_pose_applied(refined_source, pose)
         loss = self.loss_fn(moved, template)                 # (mean(AB[...,0]) + mean(BA[...,0])) / 2, :248-251
         self.opt.zero_grad()
+        if self._flat_grad is not None and not hasattr(self.opt, "grad"):
+            self._flat_grad.zero_()                          # (a foreign optimizer's zero_grad may have dropped the views: rebind)
+            if any(p.grad is None for p in self.net.parameters() if p.requires_grad):
+                off = 0
+                for p in (q for q in self.net.parameters() if q.requires_grad):
+                    p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+                    off += p.numel()
         loss.backward()
+        if self.reducer is not None and self.reducer.active:
+            # the one collective of this path: mean over the ranks of the pose network's gradient (DPDist is frozen: nothing of it travels)
+            self.reducer.reduce_async(0)
+            self.reducer.wait()
+            self._flat_grad.mul_(self.reducer.grad_scale)
         return loss.detach(), pose.detach()
 
     def train_step(self, source, template):

@@ -195,7 +195,9 @@ class DPDistTrainer:
         self.use_graph = os.environ.get("DPD_GRAPH", "0") == "1"   # opt-in: measured 4 % SLOWER than eager launches on MI355X / ROCm 7
         self._graphs, self._seen_keys, self._gstreams = {}, set(), None
         self.graph_replays = 0
-        self._trio = self._planes is not None and os.environ.get("DPD_DW_TRIO", "1") == "1"
+        # one plane (bf16): dW1 + dW2 + dW3 as one grouped launch; three planes (f32x3): measured SLOWER grouped (0.557 vs 0.523 ms at B = 32:
+        # its dW1 alone runs the phase-staggered 128x128 kernel, the grouped launch needs the ring kernel), so opt-in there (DPD_DW_TRIO=1)
+        self._trio = self._planes is not None and os.environ.get("DPD_DW_TRIO", "1" if self._planes.np == 1 else "0") == "1"
         self._wdirty = True        # transposed copies / bf16 planes of the weights need a refresh before their next use
         self._after_dw1 = None
         self._side = None          # side stream of the prefetch pipeline (created on first use)

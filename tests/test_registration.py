@@ -300,3 +300,142 @@ def test_gpu_only_helpers_refuse_the_cpu():
         from dpdist_amd import hipevents
         with pytest.raises(RuntimeError):
             hipevents.LightEvent()
+
+
+# ---- BASELINE config 5's data-parallel leg: the pose network's gradient is the one thing that travels -------------------------
+def _torch_chamfer(a, b):
+    d = torch.cdist(a, b)
+    return d.min(2)[0].mean() + d.min(1)[0].mean()
+
+
+def _reg_dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from dpdist_amd.ddp import shard_range
+    from dpdist_amd.registration import IterativeRegistration
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    GB = 8
+    src, tmpl, _ = synth.registration_pairs(GB, 64, seed=5)
+    src, tmpl = torch.tensor(src), torch.tensor(tmpl)
+    lo, hi = shard_range(GB, rank, world)
+
+    def harness(distributed):
+        torch.manual_seed(0)                                   # replicated variables: the same pose network on every rank
+        net = PoseNet(keep_prob=1.0)                           # (no dropout: the full-batch comparison needs the same function)
+        return IterativeRegistration(net, _torch_chamfer, optimizer=torch.optim.SGD(net.parameters(), lr=1e-2), max_loops=3,
+                                     distributed=distributed)
+
+    reg = harness(True)
+    assert reg.reducer is not None and reg.reducer.active and reg.reducer.mode == "allreduce" and reg.reducer.crosscheck["ok"]
+    refined, _ = reg.refine(src[lo:hi], tmpl[lo:hi], 2)
+    reg.loss_and_gradients(refined, tmpl[lo:hi])               # all-reduced and scaled by 1 / world
+    g_dp = reg._flat_grad.clone()
+    for _ in range(2):                                         # two optimizer steps: replicas must stay bit-identical
+        loss, T = reg.train_step(src[lo:hi], tmpl[lo:hi])
+    w = torch.cat([p.detach().reshape(-1) for p in reg.net.parameters()])
+    ws = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    if rank == 0:
+        full = harness(False)
+        assert full.reducer is None
+        refined, _ = full.refine(src, tmpl, 2)
+        full.loss_and_gradients(refined, tmpl)
+        g_full = torch.cat([p.grad.reshape(-1) for p in full.net.parameters()])
+        out.put({"err": float((g_dp[:g_full.numel()] - g_full).abs().max()), "scale": float(g_full.abs().max()),
+                 "same": bool(all(torch.equal(ws[0], x) for x in ws[1:])), "moved": float((w - torch.cat([p.detach().reshape(-1) for p in harness(False).net.parameters()])).abs().max()),
+                 "wire": reg.reducer.wire_bytes_per_step, "n": int(g_full.numel())})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_registration_data_parallel_step_on_gloo():
+    """BASELINE config 5's data-parallel leg (registration.IterativeRegistration(distributed=True); world size 2 over gloo, a torch
+    Chamfer distance standing in for the GPU-only DPDist loss, SGD for the GPU-only TFAdam): the mean over the ranks of the pose
+    network's shard gradients equals the full-batch gradient, two optimizer steps leave the replicas bit-identical, and the only
+    bytes on the wire are the pose network's flat gradient (DPDist is frozen: no DPDist collective)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reg_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["err"] <= 1e-6 * max(1.0, res["scale"]), res
+    assert res["same"] and res["moved"] > 0
+    assert res["wire"] == 4 * ((res["n"] + 3) // 4 * 4)          # 2 (P-1)/P x 4 B x parameters at P = 2
+
+
+def test_centroid_residual_separates_lever_arm_from_misregistration():
+    """registration.centroid_residual: a pure rotation error about the origin moves an off-centre cloud although the translation
+    vector is exact; the ideal transform leaves no residual."""
+    from dpdist_amd.registration import centroid_residual, euler_to_mat
+    rng = np.random.default_rng(0)
+    src = rng.normal(size=(4, 64, 3)) * 0.05 + np.array([0.3, 0.0, 0.0])
+    gt = np.concatenate([rng.uniform(-0.01, 0.01, (4, 3)), np.radians(rng.uniform(-45, 45, (4, 3)))], 1)
+    ideal = np.tile(np.eye(4), (4, 1, 1))
+    for i in range(4):
+        R = euler_to_mat(*gt[i, 3:])
+        ideal[i, :3, :3] = R.T
+        ideal[i, :3, 3] = -R.T @ gt[i, :3]
+    assert centroid_residual(ideal, gt, src).max() < 1e-12
+    off = ideal.copy()
+    d = np.radians(2.0)
+    Rz = np.array([[math.cos(d), -math.sin(d), 0], [math.sin(d), math.cos(d), 0], [0, 0, 1]])
+    for i in range(4):
+        off[i, :3, :3] = Rz @ ideal[i, :3, :3]                 # 2 degrees of rotation error, translation vector untouched
+    r = centroid_residual(off, gt, src)
+    assert 0.005 < r.min() and r.max() < 0.02                  # ~ 0.035 rad x 0.3 lever arm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["rccl", "torch"])
+def test_registration_step_on_a_single_rank_group_is_the_plain_step(backend, monkeypatch):
+    """The data-parallel registration step through RCCL on one GPU (single-rank group, DPD_FORCE_DIST=1: the all-reduce is a copy, the
+    scale 1): config 5's B = 16 / 8-loop step gives bit for bit the pose-network gradients and the update of the plain step (whose
+    gradients test_registration_step_gradients_vs_oracle pins to the oracle); the reducer passed its start-up cross-check."""
+    import torch.distributed as dist
+    monkeypatch.setenv("DPD_DP_BACKEND", backend)
+    monkeypatch.setenv("DPD_FORCE_DIST", "1")
+    dev = torch.device("cuda:0")
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29661")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        src, tmpl, _ = synth.registration_pairs(16, 64, seed=5)
+        src, tmpl = torch.tensor(src, device=dev), torch.tensor(tmpl, device=dev)
+        res = {}
+        for mode in ("plain", "dp"):
+            from dpdist_amd.model import DPDistLoss, DPDistModel
+            from dpdist_amd.registration import IterativeRegistration
+            torch.manual_seed(3)
+            model = DPDistModel(device=dev)
+            model.load_tf_state_dict(synth.make_weights("wide"))
+            reg = IterativeRegistration(PoseNet(keep_prob=1.0).to(dev), DPDistLoss(model), lr=1e-4, max_loops=8, distributed=(mode == "dp"))
+            if mode == "dp":
+                assert reg.reducer.active and reg.reducer.backend == backend and reg.reducer.crosscheck["ok"] and reg.reducer.nranks == 1
+            else:
+                assert reg.reducer is None
+            refined, _ = reg.refine(src, tmpl, 7)
+            reg.loss_and_gradients(refined, tmpl)
+            g = reg.opt.grad.clone()
+            loss, T = reg.train_step(src, tmpl)
+            torch.cuda.synchronize()
+            res[mode] = (g, reg.opt.flat.clone(), loss.clone(), T.clone())
+            reg.close()
+        for a, b in zip(res["plain"], res["dp"]):
+            assert torch.equal(a, b)
+        assert float(res["plain"][0].abs().max()) > 0
+    finally:
+        if own:
+            dist.destroy_process_group()

@@ -25,7 +25,7 @@ def main(out_path):
     from dpdist_amd.ddp import make_reducer
     flat = torch.zeros(4096)
     red = make_reducer(flat, [0, 1024, 2048, 4096])
-    hb.beat("timed:all-reduce")
+    hb.beat("timed:all-reduce of 4096 floats")      # (phase texts may contain spaces)
     flat.fill_(rank + 1.0)
     red.reduce_async(1, upto=2)
     red.reduce_async(0)
