@@ -22,6 +22,11 @@ Extra objects on the JSON line:
   roofline     -- the fp32 MFMA GEMM kernel family (gemm_rs_kernel<...> + the LDS-ring fallback): algorithmic flops of the GEMM
                   launches of a step / their summed duration, measured with hipEvent pairs recorded in-stream around each
                   launch (library profiler, separate pass of the same K steps); peak = 157.3 TFLOP/s fp32 MFMA.
+  roofline_hbm -- the bandwidth-bound kernels (3DmFV encoder, window gather, fused output layer, optimizer, small-gradient reduction,
+                  weight copies): algorithmic HBM bytes per launch / in-stream launch duration (dpd_prof_enable(2)) as GB/s and fraction of
+                  the 8 TB/s peak, next to the PMC fabric bytes of the committed rocprofv3 summary; also inside config3 for its step.
+  dp           -- (N > 1 or DPD_FORCE_DIST=1) the data-parallel plumbing: collective backend, fallback flag and the watchdog's record,
+                  ranks as ncclCommCount reports them, start-up cross-check, bytes on the wire per GPU per step, exposed communication.
   cpu_baseline -- the CPU ports (oracle/cpu_ref.c faithful + compact, oracle/restate.py on torch-CPU), each pinned to the
                   reference's goldens, timed on this box's host cores on bounded samples (N = 1 only).
   config3      -- (N = 1) BASELINE config 3: the same step in bf16 at 64 pairs per GPU.
@@ -56,13 +61,23 @@ def gemm_flops_per_step(B, N, E3, H):
     return fwd + bwd, 3 + 2 + 3
 
 
-def gemm_bytes_per_step(B, N, KP, H):
-    """Algorithmic HBM bytes of the same GEMMs (fp32; every operand read once, every result written once; the dH GEMMs
-    also read their ReLU gate)."""
+def gemm_bytes_per_step(B, N, KP, H, dtype="f32"):
+    """Algorithmic HBM bytes of the same GEMMs: every operand read once, every result written once, in the compute type's own
+    storage -- fp32 (4 B); bf16 planes: 2 B per element per plane (f32x3: three planes); the plane types write an activation /
+    pre-activation gradient once per layout its consumers read (RC for the next layer and the dH chain, R8 for the weight gradient)
+    and read the ReLU gate as a plane; weight gradients leave as fp32 in every type."""
     Q, BN = 2 * B * N, B * N
-    fwd = 4.0 * ((Q * KP + KP * H + Q * H) + 2 * (Q * H + H * H + Q * H))
-    dh = 4.0 * 2 * (BN * H + H * H + BN * H + BN * H)
-    dw = 4.0 * ((BN * KP + BN * H + KP * H) + 2 * (BN * H + BN * H + H * H))
+    if dtype == "f32":
+        fwd = 4.0 * ((Q * KP + KP * H + Q * H) + 2 * (Q * H + H * H + Q * H))
+        dh = 4.0 * 2 * (BN * H + H * H + BN * H + BN * H)
+        dw = 4.0 * ((BN * KP + BN * H + KP * H) + 2 * (BN * H + BN * H + H * H))
+        return fwd + dh + dw
+    e = 2.0 * (3 if dtype == "f32x3" else 1)          # bytes per element of an operand (all planes)
+    h_out = e * (Q + BN) * H                          # h1 / h2: RC plane for all rows + R8 plane for the gradient rows
+    h3_out = (2.0 if dtype == "bf16" else 4.0) * Q * H
+    fwd = e * (Q * KP + KP * H) + h_out + e * (Q * H + H * H) + h_out + e * (Q * H + H * H) + h3_out
+    dh = 2 * (e * (BN * H + H * H) + e * BN * H + 2 * e * BN * H)        # g in, W in, gate in, g out in both layouts
+    dw = e * (BN * KP + BN * H) + 4.0 * KP * H + 2 * (e * (BN * H + BN * H) + 4.0 * H * H)
     return fwd + dh + dw
 
 
@@ -215,24 +230,76 @@ def cpu_baseline(B, N, budget_s=26.0):
             "cpu_model": _cpu_model(), "nproc": ncpu, "cpu_quota": quota, "variants": variants}
 
 
-def pmc_traffic(kernel_substr):
-    """Fabric-side bytes per launch of the dominant kernel family from the COMMITTED PMC summary of the same command
-    (profiles/rNN_pmc_summary.csv: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md section HBM).  bench.py cannot collect counters itself; None when no summary is in the tree."""
+def pmc_traffic(kernel_substr, suffix=""):
+    """Fabric-side bytes per launch of a kernel family from the COMMITTED PMC summary of the same command
+    (profiles/rNN_pmc_summary<suffix>.csv: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md section HBM).  bench.py cannot collect counters itself; None when no summary is in the tree.
+    kernel_substr: one substring or a tuple of alternatives; suffix: "" (f32 B=32), "_bf16_b64", "_bf16", "_f32x3"."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.csv")))
+    import re
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r*_pmc_summary%s.csv" % suffix))
+                   if re.fullmatch(r"r\d+_pmc_summary%s\.csv" % re.escape(suffix), os.path.basename(f)))
     if not files:
         return None, None
+    subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
     tot, n = 0.0, 0
     for r in csv.DictReader(open(files[-1])):
-        if kernel_substr in r["kernel"] and r["calls_in_stats"] and r["fabric_read_MB_per_launch(x2 gfx950 correction)"]:
+        if any(x in r["kernel"] for x in subs) and r["calls_in_stats"] and r["fabric_read_MB_per_launch(x2 gfx950 correction)"]:
             calls = int(r["calls_in_stats"])
             rd = float(r["fabric_read_MB_per_launch(x2 gfx950 correction)"]) * 1e6
             wr = float(r["WRITE_SIZE_KB_per_launch"] or 0) * 1024.0
             tot += calls * (rd + wr)
             n += calls
-    return (tot / n if n else None), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    return (tot / n if n else None), os.path.relpath(files[-1], root)
+
+
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E, 8 TB/s
+ACHIEVABLE_HBM_GBPS = 6300.0    # what a pure streaming kernel sustains on this chip (same guide; our Adam kernel reaches it)
+# stage tag of the library's in-stream profiler (include/dpdist_capi.h: dpd_prof_collect_stage) -> (name, kernel-name substrings in the
+# rocprofv3 summaries, what it replaces in the reference)
+HBM_STAGES = {1: ("encoder", ("mfv3d_fwd_kernel",), "get_3dmfv_tf, utils/dpdist_util.py:22-141"),
+              2: ("window_gather", ("patch_rows_",), "local_z_3d + mask + gather, utils/dpdist_util.py:434-492,911-930"),
+              3: ("output_layer_fused", ("out_bwd_fused4_kernel",), "layer 4 + relu6/3 + mask + L1 loss + their backward, :540-544,690-698,962-980"),
+              4: ("optimizer", ("adam_",), "tf.train.AdamOptimizer.apply_gradients, train_multi_gpu_pc_compare_dist.py:301"),
+              5: ("small_grads_reduce", ("small_grads_reduce",), "db3 / dW4 / db4 block partials"),
+              6: ("weight_copies", ("transpose_kernel", "split_planes_kernel"), "derived data: transposed fp32 copies / bf16 operand planes")}
+
+
+def hbm_roofline_pass(L, step_fn, warmup, steps, pmc_suffix=""):
+    """`roofline_hbm`: the bandwidth-bound kernels of the step, each against the HBM roofline -- ALGORITHMIC bytes per launch (recorded by
+    the launch site: every input read once, every output written once) / average launch duration from hipEvent pairs recorded
+    in-stream around the launch (dpd_prof_enable(2); separate pass of the same steps), as GB/s and as a fraction of the 8 TB/s peak
+    and of the 6.3 TB/s a streaming kernel sustains; next to it the fabric-side bytes per launch of the same kernel from the
+    committed rocprofv3 PMC summary (2 x FETCH_SIZE + WRITE_SIZE): traffic well above the algorithmic bytes = wasted re-reads."""
+    import torch
+    for it in range(warmup + steps):
+        if it == warmup:
+            torch.cuda.synchronize()
+            L.dpd_prof_enable(2)
+        step_fn()
+    torch.cuda.synchronize()
+    out = {}
+    for tag, (name, kerns, what) in HBM_STAGES.items():
+        ms_, by_ = ctypes.c_double(0), ctypes.c_double(0)
+        n = L.dpd_prof_collect_stage(tag, ctypes.byref(ms_), ctypes.byref(by_))
+        if n <= 0 or ms_.value <= 0:
+            continue
+        gbps = by_.value / (ms_.value * 1e-3) / 1e9
+        traffic, src = pmc_traffic(kerns, pmc_suffix)
+        out[name] = {"bound": "hbm", "kernel": " / ".join(kerns), "replaces": what, "launches_per_step": round(n / float(steps), 2),
+                     "avg_launch_us": round(ms_.value * 1e3 / n, 2), "algorithmic_bytes_per_launch": round(by_.value / n),
+                     "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                     "frac_of_achievable_6300": round(gbps / ACHIEVABLE_HBM_GBPS, 4),
+                     "traffic": round(traffic) if traffic else None, "traffic_source": src}
+    L.dpd_prof_enable(0)
+    if out:
+        tot_us = sum(v["avg_launch_us"] * v["launches_per_step"] for v in out.values())
+        out["_sum"] = {"us_per_step": round(tot_us, 1),
+                       "note": "in-stream hipEvent pairs around each launch (separate pass; an event pair costs the stream ~2 us between "
+                               "launches, not inside them); `traffic` is NOT measured in this run: committed PMC summary named in traffic_source"}
+    return out
 
 
 def profiled_gemm_pass(L, tr, lab, warmup, steps):
@@ -281,10 +348,12 @@ def spawn_ranks(n, cmd, timeout_s=None):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
+    import tempfile
+    wd_base = tempfile.mkdtemp(prefix="dpd_wd_")     # heartbeat directory of THIS launch (dpdist_amd/launch.py)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DPD_WD_DIR_BASE=wd_base)
         env.setdefault("OMP_NUM_THREADS", "8")
         procs.append(subprocess.Popen(list(cmd), env=env))
     rc = 0
@@ -310,6 +379,8 @@ def spawn_ranks(n, cmd, timeout_s=None):
     finally:
         for q in procs:
             q.kill()
+        import shutil
+        shutil.rmtree(wd_base, ignore_errors=True)
     return rc
 
 
@@ -475,14 +546,22 @@ def main():
                     n_, ms_, _ = got
                     alg2, _ = gemm_flops_per_step(B2, N, 2503, 1024)
                     ach2 = alg2 * a.steps / (ms_ * 1e-3) / 1e12
+                    tr3, tsrc3 = pmc_traffic(("gemm_p8_kernel", "gemm_x3_kernel"), "_bf16_b64")
                     out2["roofline"] = {"bound": "mfma", "kernel": "gemm_p8_kernel / gemm_x3_kernel<1,...> (v_mfma_f32_32x32x16_bf16, one bf16 plane)",
                                         "achieved": round(ach2, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(ach2 / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
+                                        "frac": round(ach2 / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": round(tr3) if tr3 else None,
+                                        "traffic_note": ("NOT measured in this run: committed PMC pass %s (2 x FETCH_SIZE + WRITE_SIZE per launch, "
+                                                         "launch-weighted over the family)" % tsrc3) if tr3 else None,
+                                        "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(B2, N, 2528, 1024, "bf16") / (n_ // a.steps)),
                                         "launches_per_step": n_ // a.steps, "avg_launch_us": round(ms_ * 1e3 / n_, 2),
                                         "gemm_ms_per_step": round(ms_ / a.steps, 4),
                                         "whole_step_frac": round(alg2 / (e2 / a.steps) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
             except Exception as e:
                 out2["roofline"] = {"error": repr(e)}
+            try:
+                out2["roofline_hbm"] = hbm_roofline_pass(L, lambda: tr2.step(a2, b2, l2), a.warmup, a.steps, "_bf16_b64")
+            except Exception as e:
+                out2["roofline_hbm"] = {"error": repr(e)}
         keep.append((tr2, P2))     # freed after the headline: a hipFree of ~1 GB idles the GPU for milliseconds (clock ramp)
         return out2
 
@@ -639,7 +718,8 @@ def main():
                 mult, peak, kern = {"f32": (1, PEAK_FP32_MFMA_TFLOPS, "gemm_rs_kernel<...> (fp32 v_mfma_f32_32x32x2, register-streamed operands, no LDS / barriers)"),
                                     "f32x3": (6, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<3,...> (6 x v_mfma_f32_32x32x16_bf16 per product, LDS-DMA ring)"),
                                     "bf16": (1, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<1,...> (v_mfma_f32_32x32x16_bf16, LDS-DMA ring)")}[a.dtype]
-                traffic, tsrc = pmc_traffic("gemm_rs_kernel") if a.dtype == "f32" else (None, None)
+                sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16"}[a.dtype] if B == 32 else ("_bf16_b64" if (a.dtype, B) == ("bf16", 64) else "_none")
+                traffic, tsrc = pmc_traffic(("gemm_rs_kernel",) if a.dtype == "f32" else ("gemm_p8_kernel", "gemm_x3_kernel"), sfx)
                 roof = {"bound": "mfma", "kernel": kern,
                         "achieved": round(ach * mult, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach * mult / peak, 4),
@@ -648,11 +728,18 @@ def main():
                                          "WRITE_SIZE runs of this command); bytes per launch at the L2's fabric side (2 x FETCH_SIZE + "
                                          "WRITE_SIZE, Infinity-Cache hits included), launch-weighted over the family" % tsrc) if traffic else
                                         "PMC passes are separate rocprofv3 runs: profiles/",
-                        "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(B, N, 2528, 1024) / (launches / a.steps)),
+                        "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(B, N, 2528, 1024, a.dtype) / (launches / a.steps)),
                         "algorithmic_tflops": round(ach, 2),
                         "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
                         "alg_gflop_per_launch": round(alg / (launches / a.steps) / 1e9, 3),
                         "gemm_ms_per_step": round(ms.value / a.steps, 4)}
+    roof_hbm = None
+    if not a.no_roofline and rank == 0 and not use_dist:
+        try:
+            sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16"}[a.dtype] if B == 32 else ("_bf16_b64" if (a.dtype, B) == ("bf16", 64) else "_none")
+            roof_hbm = hbm_roofline_pass(L, lambda: tr.step(pcA, pcB, lab), a.warmup, a.steps, sfx)
+        except Exception as e:
+            roof_hbm = {"error": repr(e)}
     hb.beat("report:cpu baseline + json")
     if rank == 0:
         qps = 2.0 * B * N * world * a.steps / el
@@ -663,7 +750,7 @@ def main():
                                       "fwd both directions + bwd AB half + Adam), S2 ModelNet-shaped clouds",
                           "pairs_per_gpu": B, "global_batch": B * world, "num_point": N, "query_points_per_step": 2 * B * N * world,
                           "parallelism": "dp%d" % world, "loss_samples_last": round(float(loss[0]), 6)},
-               "roofline": roof, "spinup_ms": spin_ms,
+               "roofline": roof, "roofline_hbm": roof_hbm, "spinup_ms": spin_ms,
                "ms_per_step_cold": round(el_cold / a.steps * 1e3, 4) if el_cold else None,
                "cold_note": "ms_per_step_cold = the same W + K steps timed BEFORE the %g ms device spin-up (scratch fp32 GEMMs, nothing of the "
                             "model) that precedes the headline region; the difference is the GPU's clock ramp (DESIGN.md section 5)" % spin_ms}

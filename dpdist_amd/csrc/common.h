@@ -51,6 +51,24 @@ inline int ensure_dyn_lds(LdsOptIn& slot, const void* kern, size_t lds) {
     return 0;
 }
 
+// In-stream stage profiler (gemm_f32.hip; dpd_prof_enable(2)): the bandwidth-bound kernels of the step bracket their launch with an
+// event pair and record their ALGORITHMIC HBM bytes (every input read once, every output written once) under a stage tag; bench.py
+// turns that into the `roofline_hbm` object of its JSON line.  Off (one branch, no lock) unless the profiler was enabled with mode 2.
+enum { DPD_STAGE_GEMM = 0, DPD_STAGE_ENCODER = 1, DPD_STAGE_GATHER = 2, DPD_STAGE_OUT_LAYER = 3, DPD_STAGE_OPTIMIZER = 4,
+       DPD_STAGE_SMALL_REDUCE = 5, DPD_STAGE_WEIGHT_COPIES = 6, DPD_STAGE_COUNT = 7 };
+bool prof_begin_stage(hipStream_t s);
+void prof_end_stage(bool on, hipStream_t s, int tag, double bytes);
+struct StageProf {
+    bool on;
+    hipStream_t s;
+    int tag;
+    double bytes;
+    StageProf(void* stream, int tag_, double bytes_) : on(prof_begin_stage((hipStream_t)stream)), s((hipStream_t)stream), tag(tag_), bytes(bytes_) {}
+    ~StageProf() { prof_end_stage(on, s, tag, bytes); }
+    StageProf(const StageProf&) = delete;
+    StageProf& operator=(const StageProf&) = delete;
+};
+
 constexpr int kWave = 64;   // CDNA wavefront
 constexpr int kNumXCD = 8;  // MI355X: 8 XCDs, block b runs on XCD b % 8 (speed only, never correctness)
 

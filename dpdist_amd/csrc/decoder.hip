@@ -970,6 +970,9 @@ extern "C" int dpd_weights_to_planes(const dpd_decoder_params* p, int KP, int H,
     add(p->W2, H, pl->W2_rc, pl->W2_r8);
     add(p->W3, H, pl->W3_rc, pl->W3_r8);
     if (!jobs.n) return 0;
+    double by = 0.0;
+    for (int t = 0; t < jobs.n; ++t) by += (double)jobs.j[t].R * H * (4.0 + pl->np * 2.0 * ((jobs.j[t].rc ? 1 : 0) + (jobs.j[t].r8 ? 1 : 0)));
+    StageProf prof(stream, DPD_STAGE_WEIGHT_COPIES, by);
     return split_planes_multi(jobs, (hipStream_t)stream);
 }
 
@@ -987,6 +990,7 @@ extern "C" int dpd_weights_transpose(const dpd_decoder_params* p, int KP, int H,
     add(p->W2, W2T, H, H);
     add(p->W3, W3T, H, H);
     if (W1pT) add(p->W1p, W1pT, KP, H);
+    StageProf prof(stream, DPD_STAGE_WEIGHT_COPIES, 8.0 * ((double)2 * H * H + (W1pT ? (double)KP * H : 0.0)));
     DPD_LAUNCH(transpose_kernel, dim3(J.blk0[J.n]), dim3(256), 0, (hipStream_t)stream, J);
     DPD_CHECK_LAUNCH();
     return 0;
@@ -1216,6 +1220,12 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
             const size_t lds = (size_t)4 * rec * sizeof(float);      // (the R8 image of g3, np * 8 * H * 2 bytes, reuses the slabs)
             static LdsOptIn lds_opt;
             if (int rc = ensure_dyn_lds(lds_opt, (const void*)out_bwd_fused4_kernel, lds)) return rc;
+            // algorithmic bytes: layer 3's activation in (the Qb gradient rows, and their Qb twins when the layer's forward runs here
+            // too; fp32 or one bf16 plane), g3 out (fp32 or both operand planes), the block partials, mask / labels / y / pred
+            const double h3_b = h3 ? 4.0 : 2.0;
+            StageProf prof(stream, DPD_STAGE_OUT_LAYER,
+                           (double)Qb * H * h3_b * (ofwd ? 2.0 : 1.0) + (g3 ? (double)Qb * H * 4.0 : 0.0) +
+                               ((gpl.rc ? 1.0 : 0.0) + (gpl.r8 ? 1.0 : 0.0)) * gpl.np * 2.0 * Qb * H + (double)nblk * rec * 4.0 + Qb * 40.0 + H * 12.0);
             DPD_LAUNCH(out_bwd_fused4_kernel, dim3(nblk), dim3(256), lds, s, dpred, mask, y, h3, p->W4, dy, g3, Qb, H, zl, part, lf, ofw, gpl,
                        h3 ? nullptr : (const uint16_t*)pl->h3_rc);
         } else {
@@ -1224,6 +1234,7 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         }
         DPD_CHECK_LAUNCH();
         if (!(phases & 16)) {   // 16: the block partials stay in the scratch (= g2, which must not be overwritten before phase 8 ran)
+            StageProf prof(stream, DPD_STAGE_SMALL_REDUCE, (double)nblk * rec * 4.0 + (4.0 * H + 3) * 4.0);
             DPD_LAUNCH(small_grads_reduce, dim3(nred), dim3(256), 0, s, (const float*)part, nblk, H, db3, dW4, db4, rec, lossp, Qb);
             DPD_CHECK_LAUNCH();
         }

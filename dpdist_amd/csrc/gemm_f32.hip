@@ -405,10 +405,12 @@ static int launch_dma(const GemmArgs& g, hipStream_t s) {
 // stream the kernel is launched on.  Off by default; costs two event records per launch when on.
 struct GemmProf {
     bool on = false;
+    int mode = 0;      // 1: GEMM launches only (dpd_prof_collect); 2: also the bandwidth-bound stages (dpd_prof_collect_stage)
     int n = 0;
     static constexpr int kMax = 8192;
     hipEvent_t ev[2 * kMax];
-    double flops[kMax];
+    double flops[kMax];   // flops (tag 0) or algorithmic HBM bytes (stage tags)
+    int tag[kMax];
     int created = 0;   // events [0, created) exist
 };
 static GemmProf g_prof;
@@ -434,6 +436,21 @@ void prof_end(bool on, hipStream_t s, double flops) {
     if (!g_prof.on) return;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
     g_prof.flops[g_prof.n] = flops;
+    g_prof.tag[g_prof.n] = DPD_STAGE_GEMM;
+    ++g_prof.n;
+}
+// stages never nest inside each other or inside a GEMM bracket (one open pair at a time: the pair of slot n)
+bool prof_begin_stage(hipStream_t s) {
+    if (!g_prof.on || g_prof.mode < 2) return false;
+    return prof_begin(s);
+}
+void prof_end_stage(bool on, hipStream_t s, int tag, double bytes) {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof.on) return;
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
+    g_prof.flops[g_prof.n] = bytes;
+    g_prof.tag[g_prof.n] = tag;
     ++g_prof.n;
 }
 
@@ -617,6 +634,7 @@ extern "C" int dpd_prof_enable(int on) {
     using dpd::g_prof;
     std::lock_guard<std::mutex> lk(dpd::g_prof_mu);
     g_prof.on = on != 0;
+    g_prof.mode = on;
     if (on) {
         g_prof.n = 0;
     } else {   // release the events (dpd_prof_collect must have been called before)
@@ -633,16 +651,41 @@ extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
     using dpd::g_prof;
     std::lock_guard<std::mutex> lk(dpd::g_prof_mu);
     double ms = 0.0, fl = 0.0;
+    int n = 0;
     for (int i = 0; i < g_prof.n; ++i) {
+        if (g_prof.tag[i] != dpd::DPD_STAGE_GEMM) continue;
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return -1;
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return -1;
         ms += t;
         fl += g_prof.flops[i];
+        ++n;
     }
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
-    return g_prof.n;
+    return n;
+}
+
+// The bandwidth-bound stages recorded since dpd_prof_enable(2): launches of stage `tag` (1 encoder, 2 window gather, 3 fused output
+// layer, 4 optimizer, 5 small-gradient reduction, 6 weight copies), their summed duration [ms] and ALGORITHMIC HBM bytes.
+extern "C" int dpd_prof_collect_stage(int tag, double* total_ms, double* total_bytes) {
+    using dpd::g_prof;
+    if (tag <= 0 || tag >= dpd::DPD_STAGE_COUNT) return DPD_E_DIM;
+    std::lock_guard<std::mutex> lk(dpd::g_prof_mu);
+    double ms = 0.0, by = 0.0;
+    int n = 0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        if (g_prof.tag[i] != tag) continue;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return -1;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return -1;
+        ms += t;
+        by += g_prof.flops[i];
+        ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_bytes) *total_bytes = by;
+    return n;
 }
 
 extern "C" int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,

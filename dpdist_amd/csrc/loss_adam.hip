@@ -423,6 +423,7 @@ extern "C" int dpd_adam_tf(float* p, const float* g, float* m, float* v, size_t 
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
+    dpd::StageProf prof(stream, dpd::DPD_STAGE_OPTIMIZER, 28.0 * (double)n);      // read p, g, m, v; write p, m, v
     DPD_LAUNCH(dpd::adam_tf_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t,
                        b1, b2, eps, gscale);
     DPD_CHECK_LAUNCH();
@@ -498,6 +499,16 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
     if (vblocks == 0 && vec_elems) vblocks = 1;
     const unsigned grid = (unsigned)(tiles + f.ntail + vblocks);
     if (grid == 0) return DPD_E_DIM;
+    // algorithmic bytes: 28 B per parameter (read p, g, m, v; write p, m, v; the matrices a weight-gradient GEMM already updated do not
+    // count), + the copies written in the same pass (transposed fp32: 4 B, bf16 operand planes: np x 2 B per layout) + the block partials
+    double by = 0.0;
+    for (int w = 0; w < 3; ++w) {
+        const double cnt = (double)fu->w_rows[w] * fu->w_cols[w];
+        if (fu->skip_w[w]) by -= 28.0 * cnt;
+        else by += cnt * ((f.WT[w] ? 4.0 : 0.0) + f.np * 2.0 * ((f.rc[w] ? 1.0 : 0.0) + (f.r8[w] ? 1.0 : 0.0)));
+    }
+    by += 28.0 * (double)n + (fu->partials ? (double)fu->nparts * fu->rec * 4.0 : 0.0);
+    StageProf prof(stream, DPD_STAGE_OPTIMIZER, by);
     if (f.np == 1) DPD_LAUNCH(adam_fused_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);
     else if (f.np == 3) DPD_LAUNCH(adam_fused_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);
     else DPD_LAUNCH(adam_fused_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, lr_t, b1, b2, eps, gscale, f);

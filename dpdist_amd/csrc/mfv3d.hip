@@ -882,6 +882,7 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     const int gslice = (k.G + kSlices - 1) / kSlices;
     const size_t lds = fwd_lds_bytes(N, m, gslice);
     if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
+    StageProf prof(stream, DPD_STAGE_ENCODER, (double)C * (N * 12.0 + k.G * 80.0));      // points in, [G,20] Fisher vector out
     DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k, gslice, MfvFuse{});
     DPD_CHECK_LAUNCH();
     DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, fv, k.G, gslice);
@@ -899,6 +900,8 @@ extern "C" int dpd_mfv3d_fwd_stacked(const float* pcA, const float* pcB, const f
     const int C = 2 * B, gslice = (k.G + kSlices - 1) / kSlices;
     const size_t lds = fwd_lds_bytes(N, m, gslice);
     if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
+    // points (+ noise) in; stacked pts / q and the [G,20] Fisher vector (+ per-slice sums of squares) out
+    StageProf prof(stream, DPD_STAGE_ENCODER, (double)C * (N * 12.0 * (noise ? 1.5 : 1.0) + N * 24.0 + k.G * 80.0 + (ssq ? kSlices * 80.0 : 0.0)));
     DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, (const float*)nullptr, fv, k, gslice,
                MfvFuse{pcA, pcB, noise, pts, q, ssq, B});
     DPD_CHECK_LAUNCH();

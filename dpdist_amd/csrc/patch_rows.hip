@@ -778,6 +778,11 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
     if (C <= 0 || N <= 0) return DPD_E_DIM;
     if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
     if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
+    // algorithmic bytes: the clouds' Fisher vectors and the query points in; the rows out -- fp32 [Q,KP] and / or bf16 planes (RC for
+    // all Q rows, R8 for the Qb rows that carry gradient) -- plus mask and voxel id per row
+    StageProf prof(stream, DPD_STAGE_GATHER,
+                   (double)C * m * m * m * kF * 4.0 + Q * 12.0 + Q * 8.0 + (X ? (double)Q * KP * 4.0 : 0.0) +
+                       (planes ? pl->np * 2.0 * KP * ((pl->X_rc ? (double)Q : 0.0) + (pl->X_r8 ? (double)pl->Qb : 0.0)) : 0.0));
     if (planes) {
         if ((pl->np != 1 && pl->np != 3) || pl->Q != Q || pl->Qb > Q || pl->Qb < 0) return DPD_E_DIM;
         static const bool old_form = getenv("DPD_GATHER_PLANES_V1") != nullptr;      // A/B reference: the round-1 kernel

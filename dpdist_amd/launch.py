@@ -106,7 +106,8 @@ def _free_port():
 
 
 def wd_dir():
-    """One directory per launch: every rank of a launch has the same parent (torchrun's agent or spawn_ranks)."""
+    """One directory per launch: every rank of a launch has the same parent (torchrun's agent: a fresh process per launch; bench.
+    spawn_ranks passes a fresh temporary directory as DPD_WD_DIR_BASE, because one parent may launch several times)."""
     d = os.environ.get("DPD_WD_DIR_BASE")
     if d is None:
         d = os.path.join("/tmp", "dpd_wd_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
@@ -141,6 +142,12 @@ def supervise(argv, rank, world, log=sys.stderr):
     Attempt 1: the environment as given.  Attempt 2 (after any rank's supervisor declared attempt 1 failed): DPD_DP_BACKEND=torch
     on a fresh rendezvous.  After a failed attempt 2, rank 0 prints a JSON line that says so (`value` null) and the code is 3."""
     d = wd_dir()
+    if world == 1:          # the only rank: nobody else reads this directory, so what an earlier launch of the same parent left is stale
+        for f in os.listdir(d):
+            try:
+                os.unlink(os.path.join(d, f))
+            except OSError:
+                pass
     lim = limits()
     t_launch = time.time()
     history = []

@@ -105,6 +105,7 @@ SIGNATURES = {
     "dpd_set_gemm_plan": (c_int, [c_int, c_int, c_int]),
     "dpd_prof_enable": (c_int, [c_int]),
     "dpd_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "dpd_prof_collect_stage": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
 }
 
 _lib = None
