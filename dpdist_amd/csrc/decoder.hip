@@ -26,6 +26,7 @@ int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_byt
 int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
                  long r8_plane, hipStream_t s);
 int split_planes_multi(SplitJobs jobs, hipStream_t s);
+extern int g_rs_xcd_band;
 
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
@@ -891,6 +892,7 @@ extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
         return 0;
     }
     if (op == 32 && tile >= 0 && tile <= 14 && split_k >= -4 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
+    if (op == 40 && tile >= 0 && tile <= 2) { dpd::g_rs_xcd_band = tile; return 0; }      // XCD-blocked tile map of the fp32 register-streamed GEMMs
     if (op == 33 && tile >= 0 && tile <= 14 && split_k >= 1 && split_k <= 4) { dpd::g_x3_trio_tile = tile; dpd::g_x3_trio_split = split_k; return 0; }
     if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;

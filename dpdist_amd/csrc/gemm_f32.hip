@@ -413,6 +413,7 @@ struct GemmProf {
     int tag[kMax];
     int created = 0;   // events [0, created) exist
 };
+int g_rs_xcd_band = 0;     // dpd_set_gemm_plan(40, mode, 1): 0 off, 1 the weight-gradient (TN) products, 2 every register-streamed GEMM
 static GemmProf g_prof;
 static std::mutex g_prof_mu;   // the profiler is process-wide (one GEMM stream at a time is the supported use); the lock keeps it memory-safe
 
@@ -552,6 +553,7 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
 #endif
     }
     if (tail_auto && !colsum && !A2 && !adam) { g.tail_split = -1; g.tail_slab = (float*)ws; }
+    g.xcd_band = (g_rs_xcd_band == 2 || (g_rs_xcd_band == 1 && transA && !transB)) ? 1 : 0;
     if (cs2) {   // deterministic bias gradients in two steps (register-streamed kernels only; rows of a partial block = 32)
         if (!(tile >= 30 && tile <= 39) || (cs2->part_out && (split_k > 1 || colsum))) return DPD_E_UNSUPPORTED;
         g.colsum_part = cs2->part_out;

