@@ -30,7 +30,11 @@ for a, b in (("bench.json", "bench.json"), ("bench_f32x3.json", "bench_f32x3.jso
              ("asloss_bench.txt", "asloss_bench.txt"), ("ramp_probe.txt", "ramp_probe.txt"), ("host_rate.txt", "host_rate.txt"),
              ("ldsdma_bw.txt", "ldsdma_bw.txt"), ("dp_single_rank.txt", "dp_single_rank.txt"), ("step_timeline.txt", "step_timeline.txt"),
              ("x3_bench_p8.txt", "x3_bench_p8.txt"), ("gather_bench.txt", "gather_bench.txt"), ("event_cost.txt", "event_cost.txt"),
-             ("launch_floor.txt", "launch_floor.txt")):
+             ("launch_floor.txt", "launch_floor.txt"), ("bf16_trio_sweep.txt", "bf16_trio_sweep.txt"), ("bf16_bwd_sweep.txt", "bf16_bwd_sweep.txt"),
+             ("bf16_plan_sweep.txt", "bf16_plan_sweep.txt"), ("trio_other_configs.txt", "trio_other_configs.txt"), ("xcd_band_ab.txt", "xcd_band_ab.txt"),
+             ("overlap_probe_bf16.txt", "overlap_probe_bf16.txt"), ("watchdog_fallback.json", "watchdog_fallback.json"),
+             ("watchdog_fallback.err", "watchdog_fallback.err"), ("bench_forced_dist_cfg4.json", "bench_forced_dist_cfg4.json"),
+             ("registration_demo.txt", "registration_demo.txt"), ("mfv_stamps.txt", "mfv_stamps.txt")):
     copy(a, b)
 
 # per-kernel stats (our kernels only), one file per compute type
