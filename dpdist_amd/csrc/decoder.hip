@@ -1093,7 +1093,7 @@ extern "C" int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q,
     if (!h3 || !mask || !p || !p->W4 || !p->b4 || !y || !pred || !loss_pred || !scratch) return DPD_E_NULL;
     if (!dy != !g3) return DPD_E_NULL;
     if (Q <= 0 || H <= 0 || BN <= 0 || Q != 2 * BN) return DPD_E_DIM;
-    if ((H & 3) || ((uintptr_t)scratch & 7) || Q > 8 * 65535 || BN > (1 << 14)) return DPD_E_UNSUPPORTED;   // 16-bit block count, 48-bit sum
+    if ((H & 3) || ((uintptr_t)scratch & 7) || Q > 8 * 65535 || BN >= (1 << 14)) return DPD_E_UNSUPPORTED;   // 16-bit block count; 48-bit sum: Q rows x at most 2.0 x 2^32 must stay below 2^48
     const float gv = 0.5f * (1.0f / (float)BN) * gscale;      // = l1_loss_kernel mode 2
     // two rows per wave: 9.9 us against 11.2 (one) and 11.9 (four) at the PCRNet batch -- the kernel is a chain of round trips (rows and
     // W4 -> wave sums -> stores -> the atomic's return), not a throughput problem

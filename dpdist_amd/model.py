@@ -229,7 +229,7 @@ class _AsLossFn(torch.autograd.Function):
         params = P.views(flat)
         need_grad = pcA.requires_grad or pcB.requires_grad
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
-        ctx.fused_out = B * N <= 16384 and os.environ.get("DPD_ASLOSS_CHAIN") != "1"
+        ctx.fused_out = B * N < 16384 and os.environ.get("DPD_ASLOSS_CHAIN") != "1"
         if ctx.fused_out:
             # output layer, loss_pred AND the output-layer backward of d loss_pred / d pred from one launch (labels only enter
             # loss_samples, which is not used here); the upstream gradient is applied once, at the very end of the backward

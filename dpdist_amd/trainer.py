@@ -122,6 +122,7 @@ class DPDistTrainer:
         # training step: the output layer's forward runs inside its fused backward (no out_fwd launch); DPD_FUSE_OUT=0 = separate
         self.fuse_out = self.fuse_loss and os.environ.get("DPD_FUSE_OUT", "1") == "1"
         self._out_pending = False
+        self._h3_in_plane = False      # set by _decode(skip_out=True) of a DPD_BF16 step, read by the backward that must follow it
         # front end in two launches (dpd_mfv3d_fwd_stacked + dpd_patch_rows_fwd_scaled) instead of four; DPD_FRONT2=0 = four
         self.front2 = not self.fused and os.environ.get("DPD_FRONT2", "1") == "1"
         self._ssq = f(C * 4 * 20)
@@ -334,7 +335,7 @@ class DPDistTrainer:
 
         def data(phases):   # db1..db3, dW4, db4 fall out of the data chain (fused epilogues / one small kernel)
             L.check(lib.dpd_decoder_bwd_data(L.ptr(self.dpred), L.ptr(self.mask), L.ptr(self.y), L.ptr(self.h1), L.ptr(self.h2),
-                                             None if getattr(self, "_h3_in_plane", False) else L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
+                                             None if self._h3_in_plane else L.ptr(self.h3), BN, P.KP, P.H, self._cparams, self.dt, L.ptr(self.dy), L.ptr(self.g3),
                                              L.ptr(self.g2), L.ptr(self.g1), None, small, L.ptr(self.ws), wsb, self._planes,
                                              phases, L.cur_stream()), "dpd_decoder_bwd_data")   # stream at CALL time (graph branches)
 
