@@ -427,6 +427,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # data-parallel steps: the optimizer runs on the collectives' stream and is joined where the next step first reads the weights
+        # (trainer.apply_gradients; this loop never reads params.flat between steps)
+        os.environ.setdefault("DPD_DP_ADAM_SIDE", "1")
         hb.beat("init:process group")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()
@@ -475,7 +478,8 @@ def main():
         if red is None or not red.active:
             return None
         rep = {"backend": red.backend, "fallback": hb.fallback, "attempt": hb.attempt, "mode": red.mode, "wire": red.wire,
-               "two_communicators": bool(getattr(red, "two_comms", False)), "nranks": int(red.nranks),
+               "two_communicators": bool(getattr(red, "two_comms", False)), "optimizer_on_collective_stream": bool(trn.adam_on_side),
+               "nranks": int(red.nranks),
                "nranks_source": "ncclCommCount" if red.backend == "rccl" else "torch.distributed.get_world_size",
                "wire_bytes_per_gpu_per_step": red.wire_bytes_per_step, "payload_bytes_per_step": 4 * P.numel,
                "crosscheck": red.crosscheck}

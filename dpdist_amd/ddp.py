@@ -202,6 +202,22 @@ class BucketReducer:
         self._pending = []
         self._fresh = True
 
+    def wait_side(self):
+        """Like wait(), but for a SIDE stream: returns a stream on which the reduced gradient is complete, without making the compute
+        stream wait (the trainer runs the optimizer there, under the next step's front end: trainer.apply_gradients).  None when
+        this reducer has no such stream (CPU tensors, inactive)."""
+        if not self.active or not self.flat.is_cuda:
+            self.wait()
+            return None
+        if getattr(self, "_opt_side", None) is None:
+            from .hipevents import LightEvent
+            self._opt_side, self._ev_side = torch.cuda.Stream(device=self.flat.device), LightEvent()
+        self._ev_side.record(torch.cuda.current_stream())
+        self._ev_side.wait(self._opt_side)
+        with torch.cuda.stream(self._opt_side):
+            self.wait()                      # Work.wait() orders the CURRENT stream (= the side stream) behind the collectives
+        return self._opt_side
+
     # -- zero1 -----------------------------------------------------------------------------------------------------------
     def owned_ranges(self):
         """zero1, after wait(): the (lo, hi) element ranges of the flat buffers whose gradient sum this rank holds and whose
@@ -445,6 +461,18 @@ class DirectRcclReducer:
         self._join()
         self._covered = 0
         self._fresh = True
+
+    def wait_side(self):
+        """The stream on which the reduced gradient is complete WITHOUT joining it into the compute stream: every collective of the
+        step was enqueued on the side stream, so whatever is enqueued there next (the optimizer) follows them in stream order -- no
+        event, no hop.  None in the two-communicator form (its last bucket ran on the compute stream): the caller then uses wait()."""
+        if self.two_comms or self.mode != "allreduce":
+            self.wait()
+            return None
+        self._side_used = False
+        self._covered = 0
+        self._fresh = True
+        return self._side
 
     def gather_params(self, flat):
         """zero1, after the sharded optimizer (enqueued on the current stream): ncclAllGather of the updated shards, in place, on the

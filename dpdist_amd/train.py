@@ -179,6 +179,7 @@ def train(argv=None):
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("DPD_DP_ADAM_SIDE", "1")      # optimizer on the collectives' stream (trainer.apply_gradients); the trainer joins it itself
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert F.batch_size % world == 0                               # :122-126
     dev_bs = F.batch_size // world

@@ -198,6 +198,10 @@ class DPDistTrainer:
         self.graph_replays = 0
         # one plane (bf16): dW1 + dW2 + dW3 as one grouped launch; three planes (f32x3): measured SLOWER grouped (0.557 vs 0.523 ms at B = 32:
         # its dW1 alone runs the phase-staggered 128x128 kernel, the grouped launch needs the ring kernel), so opt-in there (DPD_DW_TRIO=1)
+        # data-parallel steps: Adam on the collectives' stream, joined only where the weights are read next (opt-in: a caller that reads
+        # params.flat right after step() must call join_optimizer(); bench.py and dpdist_amd.train switch it on)
+        self.adam_on_side = os.environ.get("DPD_DP_ADAM_SIDE", "0") == "1"
+        self._ev_opt, self._opt_pending = None, False
         self._trio = self._planes is not None and os.environ.get("DPD_DW_TRIO", "1" if self._planes.np == 1 else "0") == "1"
         self._wdirty = True        # transposed copies / bf16 planes of the weights need a refresh before their next use
         self._after_dw1 = None
@@ -210,6 +214,7 @@ class DPDistTrainer:
     def close(self):
         """Release what outlives Python's garbage collection badly: the RCCL communicators of the direct reducer must be destroyed
         before the process group is (bench.py, tests/rccl_rank.py and train.py call this at tear-down)."""
+        self._join_optimizer()
         red, self.reducer = self.reducer, None
         if red is not None and hasattr(red, "close"):
             red.close()
@@ -217,6 +222,7 @@ class DPDistTrainer:
     def refresh_weight_planes(self):
         """Re-derive what is computed FROM the weights (bf16 weight planes / transposed fp32 copies) on the current stream.
         The trainer does this lazily before the first kernel that needs them (`_wdirty`); call it yourself only to force it."""
+        self._join_optimizer()
         self._wdirty = False
         if self._planes is not None:
             L.check(L.load().dpd_weights_to_planes(self._cparams, self.P.KP, self.P.H, self._planes, L.cur_stream()),
@@ -291,6 +297,7 @@ class DPDistTrainer:
         half of h3 once for both directions of the layer (dpd_small_grads.fwd_y); `backward` must follow."""
         lib, s, P = L.load(), L.cur_stream(), self.P
         Q = 2 * self.B * self.N
+        self._join_optimizer()          # the weights (and what is derived from them) of a side-stream optimizer step
         skip_out = bool(skip_out and self.fuse_out and not self.fused)
         self._out_pending = skip_out
         # DPD_BF16 training step: layer 3's activation leaves its GEMM as ONE bf16 plane and the fused output-layer kernel reads that
@@ -452,8 +459,18 @@ class DPDistTrainer:
         self._last_lr = lr
         lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         gscale = 1.0
+        side = None
         if self.reducer:
-            self.reducer.wait()
+            self._join_optimizer()
+            if self.adam_on_side and self.reducer.active and self.reducer.mode == "allreduce" and self.reducer.backend == "rccl":
+                # data-parallel step: the optimizer runs on the stream the collectives ran on, right behind the last one, and the
+                # compute stream is NOT joined: the next step's encoder + window gather (which do not read the weights) run meanwhile
+                # and the decoder waits for the optimizer's event (_join_optimizer) -- the tail of the last all-reduce, the cross-queue
+                # hop and Adam itself hide under ~35 us of front end.  One rank, direct RCCL (profiles/r04_dp_side_ab.txt): f32 0.5947 ->
+                # 0.5692 ms, bf16 B=64 0.3395 -> 0.3216; through torch.distributed's streams it LOSES (0.6148 -> 0.6266): direct reducer only
+                side = self.reducer.wait_side()
+            else:
+                self.reducer.wait()
             gscale = self.reducer.grad_scale
             if self.reducer.active and self.reducer.mode == "zero1":
                 # sharded optimizer (ZeRO stage 1, ddp.py): this rank holds the summed gradient of its shards only; Adam on those
@@ -468,19 +485,40 @@ class DPDistTrainer:
                 self._wdirty = True
                 self.P._tr_key = None
                 return
-        if self.fused_adam and (self.W2T is not None or self._afuse[0].np or tail_from_partials):
-            # matrices_done: W1p / W2 / W3 (and W2T / W3T) were updated in the epilogues of their weight-gradient GEMMs with this lr_t
-            af = self._afuse[2] if matrices_done else (self._afuse_w1 if w1_done else self._afuse[1 if tail_from_partials else 0])
-            L.check(L.load().dpd_adam_tf_fused(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
-                                               self.P.numel, lr_t, b1, b2, eps, gscale, af, L.cur_stream()), "dpd_adam_tf_fused")
-            # the transposed copies / operand planes written in the same pass are already those of the new weights
-            self._wdirty = self._planes is not None and not self._afuse[0].np
-            self.P._tr_key = None
-            return
-        L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
-                                     self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
-        self._wdirty = True
-        self.P._tr_key = None     # DPDistParams.transposed() keys its cache on flat._version, which a raw-pointer update never bumps
+        import contextlib
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if self.fused_adam and (self.W2T is not None or self._afuse[0].np or tail_from_partials):
+                # matrices_done: W1p / W2 / W3 (and W2T / W3T) were updated in the epilogues of their weight-gradient GEMMs with this lr_t
+                af = self._afuse[2] if matrices_done else (self._afuse_w1 if w1_done else self._afuse[1 if tail_from_partials else 0])
+                L.check(L.load().dpd_adam_tf_fused(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
+                                                   self.P.numel, lr_t, b1, b2, eps, gscale, af, L.cur_stream()), "dpd_adam_tf_fused")
+                # the transposed copies / operand planes written in the same pass are already those of the new weights
+                self._wdirty = self._planes is not None and not self._afuse[0].np
+            else:
+                L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
+                                             self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
+                self._wdirty = True
+            self.P._tr_key = None     # DPDistParams.transposed() keys its cache on flat._version, which a raw-pointer update never bumps
+            if side is not None:
+                if self._ev_opt is None:
+                    from .hipevents import LightEvent
+                    self._ev_opt = LightEvent()
+                self._ev_opt.record(side)
+                self._opt_pending = True
+
+    def _join_optimizer(self):
+        """Make the current stream wait for an optimizer step that runs on the reducer's side stream (data-parallel steps with
+        DPD_DP_ADAM_SIDE=1).  Every method of the trainer that reads the weights or the optimizer state calls this first; code that
+        reads `params.flat` directly after `step()` must call `join_optimizer()` itself."""
+        if self._opt_pending:
+            red = self.reducer
+            e0 = red.exposure.begin() if red is not None else None
+            self._ev_opt.wait(torch.cuda.current_stream())
+            if red is not None:
+                red.exposure.end(e0)
+            self._opt_pending = False
+
+    join_optimizer = _join_optimizer
 
     def _sync_dev_schedule(self):
         """Put the host's step count into the device-side schedule (before graph replays that follow eager steps / a restore)."""
@@ -586,6 +624,7 @@ class DPDistTrainer:
         """DPD_DP_MODE=zero1: the Adam slots m / v are only current on the rank that owns a shard; all-gather them (COLLECTIVE:
         every rank must call) so that `tf_global_variables` on any rank sees what a replicated optimizer would hold.  No-op for
         the replicated modes."""
+        self._join_optimizer()
         red = self.reducer
         if red is not None and red.active and red.mode == "zero1" and red._calls:
             red.gather_params(self.m_state)
@@ -597,6 +636,7 @@ class DPDistTrainer:
         `beta1_power` / `beta2_power` (TF keeps beta^(t+1) after t steps) and the slots `<variable>/Adam` (m), `<variable>/Adam_1`
         (v), all in the TF layouts.  Host sync."""
         _, _, _, b1, b2, _ = self.hp
+        self._join_optimizer()
         sd = dict(self.P.tf_state_dict())
         for suffix, flat in (("/Adam", self.m_state), ("/Adam_1", self.v_state)):
             for n, a in self.P.tf_state_dict(flat).items():
@@ -611,6 +651,7 @@ class DPDistTrainer:
         """Inverse of tf_global_variables; optimizer entries that are absent (a weights-only checkpoint) leave that part of the
         state untouched.  Returns the list of state groups that were restored."""
         _, _, _, b1, b2, _ = self.hp
+        self._join_optimizer()
         got = ["weights"]
         self.P.load_tf_state_dict(sd)
         self._wdirty = True

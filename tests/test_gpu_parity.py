@@ -1099,6 +1099,55 @@ def test_zero1_sharded_optimizer_step_is_bitwise_replicated_adam(dev, dt, backen
         assert (res["allreduce"][0] - res["zero1"][0]).abs().mean().item() <= 1e-6
 
 
+@pytest.mark.parametrize("backend", ["rccl", "torch"])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_optimizer_on_the_collective_stream_is_the_joined_step(dev, dt, backend, monkeypatch):
+    """DPD_DP_ADAM_SIDE=1: in a data-parallel step Adam runs on the stream the collectives ran on and the compute stream is joined only
+    where the next step first reads the weights (after its encoder + window gather).  Four steps on alternating batches, with a
+    memory-hungry kernel train on the compute stream in between, give the parameters, Adam slots and losses of the joined form
+    (f32: bit for bit); reading the weights through the trainer (evaluate, tf_global_variables) joins by itself."""
+    import torch.distributed as dist
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    monkeypatch.setenv("DPD_DP_BACKEND", backend)
+    monkeypatch.setenv("DPD_FORCE_DIST", "1")
+    B = 8
+    batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100 + i)) for i in range(2)]
+    W0 = synth.make_weights("wide")
+    own = _single_rank_group(dev, 29645)
+    junk = torch.empty(64 << 20, device=dev)
+    res = {}
+    try:
+        for side in ("0", "1"):
+            monkeypatch.setenv("DPD_DP_ADAM_SIDE", side)
+            P = DPDistParams(device=dev, compute_dtype=dt)
+            P.load_tf_state_dict(W0)
+            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
+            assert tr.adam_on_side == (side == "1")
+            losses = []
+            for i in range(4):
+                losses.append(tr.step(*batches[i % 2]).clone())
+                junk.add_(1.0)                       # work on the compute stream while the optimizer may still run on the side stream
+            assert tr._opt_pending == (side == "1" and backend == "rccl")      # (torch.distributed's streams: measured slower, not used)
+            ev = tr.evaluate(*batches[0])[0].clone()  # joins
+            assert not tr._opt_pending
+            sd = tr.tf_global_variables()
+            torch.cuda.synchronize()
+            res[side] = (P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), torch.stack(losses), ev, sd["batch"])
+            tr.close()
+    finally:
+        if own:
+            dist.destroy_process_group()
+    a, b = res["0"], res["1"]
+    assert a[5] == b[5] == 4
+    if dt == "f32":
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y)
+    else:       # plane types: db1 / db2 are fp32 atomics (run-to-run round-off)
+        assert torch.equal(a[3][0], b[3][0]) and (a[3] - b[3]).abs().max().item() <= 1e-5
+        assert (a[0] - b[0]).abs().max().item() <= 2.1e-3 and (a[0] - b[0]).abs().mean().item() <= 1e-6
+
+
 def test_bench_watchdog_falls_back_on_the_gpu(dev):
     """bench.py's N > 1 skeleton on one GPU (DPD_FORCE_DIST=1): the worker of attempt 1 stops beating in the timed region (injected);
     the supervisor stops it by PID and reruns with DPD_DP_BACKEND=torch; the JSON line carries dp_backend / fallback / the
