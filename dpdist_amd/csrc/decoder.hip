@@ -1168,8 +1168,10 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     // g2 / g1 = NULL: plane compute types whose planes keep g2_rc + g2_r8 (g1_r8, and g1_rc when dX is wanted) need no fp32 copy of
     // the pre-activation gradients either (the next dH GEMM and the weight gradients read the planes; db2 / db1 come out of the
     // epilogue); the block partials then need their own scratch (sg->partials)
-    if (!g2 && !(pl && pl->g2_rc && pl->g2_r8 && sg && sg->partials)) return DPD_E_NULL;
-    if (!g1 && !(pl && pl->g1_r8 && (!dX || pl->g1_rc))) return DPD_E_NULL;
+    // (phases without 1 -- the as-loss chain behind dpd_decoder_out_asloss -- has no block partials and, without weight gradients to
+    //  follow, needs only the RC planes: g2_rc for the next dH GEMM, g1_rc for dX)
+    if (!g2 && !(pl && pl->g2_rc && ((pl->g2_r8 && sg && sg->partials) || !(phases & 1)))) return DPD_E_NULL;
+    if (!g1 && !(pl && (pl->g1_r8 || pl->g1_rc) && (!dX || pl->g1_rc))) return DPD_E_NULL;
     if (l1 && (!sg->l1_pred || !sg->l1_loss)) return DPD_E_NULL;
     if (!p->W1p || !p->W2 || !p->W3 || !p->W4) return DPD_E_NULL;
     if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
@@ -1257,7 +1259,9 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     }
     // g2 = (g3 W3^T) * [h2 > 0] ;  g1 = (g2 W2^T) * [h1 > 0];  db2 / db1 = column sums, fused into the epilogue
     if (pl) {
-        if ((phases & 1) && (pl->g3_rc || pl->g3_r8) && !g3_planes_done) {   // g3 from a kernel that wrote no planes: one conversion launch for both layouts
+        // g3 from a kernel that wrote no planes (this call's unfused output layer, or -- phases without 1 and an fp32 g3 given --
+        // dpd_decoder_out_asloss): one conversion launch for the layouts the planes keep
+        if ((((phases & 1) && !g3_planes_done) || (!(phases & 1) && g3 && (phases & 2))) && (pl->g3_rc || pl->g3_r8)) {
             if (!g3) return DPD_E_NULL;
             if (int rc = split_planes(g3, Qb, H, H, pl->np, (uint16_t*)pl->g3_rc, H, (long)Qb * H, (uint16_t*)pl->g3_r8, (long)Qb * H, s))
                 return rc;

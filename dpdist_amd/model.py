@@ -225,11 +225,23 @@ class _AsLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pcA, pcB, flat, P, m, k, sigma):
         B, N, _ = pcA.shape
-        pts, X, mask, vox = ops.front_end(pcA, pcB, None, m, sigma, k, P.KP)     # two launches (stack+encoder, norm+gather)
         params = P.views(flat)
         need_grad = pcA.requires_grad or pcB.requires_grad
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
         ctx.fused_out = B * N < 16384 and os.environ.get("DPD_ASLOSS_CHAIN") != "1"
+        ctx.planes = None
+        if ctx.fused_out and ops.AsLossPlanes.usable(P, 2 * B * N, P.compute_dtype) and os.environ.get("DPD_ASLOSS_PLANES", "1") == "1":
+            # plane compute types: the rows, h1, h2 (and g3 / g2 / g1 in the backward) live as bf16 RC planes written by their producers,
+            # the frozen weights' planes are cached: no conversion launch per GEMM, no fp32 X / h1 / h2 (round 4; DPD_ASLOSS_PLANES=0 = before)
+            pl = ops.AsLossPlanes(P, flat, 2 * B * N, P.compute_dtype, pcA.device)
+            pts, mask, vox = ops.front_end_planes(pcA, pcB, m, sigma, k, pl)
+            _, _, h3, _, _ = ops.decoder_fwd(None, mask, params, P.H, dtype=P.compute_dtype, out_layer=False, planes=pl)
+            _, _, loss, _, g3 = ops.out_asloss(h3, mask, params, B * N, want_grad=need_grad)
+            if need_grad:
+                ctx.planes = pl
+                ctx.save_for_backward(pts, flat, vox, g3)
+            return loss[0]
+        pts, X, mask, vox = ops.front_end(pcA, pcB, None, m, sigma, k, P.KP)     # two launches (stack+encoder, norm+gather)
         if ctx.fused_out:
             # output layer, loss_pred AND the output-layer backward of d loss_pred / d pred from one launch (labels only enter
             # loss_samples, which is not used here); the upstream gradient is applied once, at the very end of the backward
@@ -251,6 +263,15 @@ class _AsLossFn(torch.autograd.Function):
         B, N, m, k, sigma = ctx.cfg
         Q = 2 * B * N
         dt = P.compute_dtype
+        if ctx.planes is not None:
+            pts, flat, vox, g3 = ctx.saved_tensors
+            _, _, _, _, dX = ops.decoder_bwd_data(None, None, None, None, None, None, P.views(flat), P.KP, True, dtype=dt, phases=6, g3=g3,
+                                                  planes=ctx.planes)
+            ctx.planes = None
+            _, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k, want_dq=False)
+            dpts = ops.mfv3d_bwd(pts, dfv, m, sigma)
+            gA, gB = ops.asloss_combine(dpts, dX, g, B, N, k)
+            return gA, gB, None, None, None, None, None
         if ctx.fused_out:
             pts, flat, vox, h1, h2, g3 = ctx.saved_tensors
         else:

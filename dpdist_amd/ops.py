@@ -98,24 +98,81 @@ def _ws_args(ws):
     return (L.ptr(ws), ws.numel() * ws.element_size()) if ws is not None else (None, 0)
 
 
-def decoder_fwd(X, mask, params, H, bufs=None, dtype=0, ws=None, out_layer=True):
+def decoder_fwd(X, mask, params, H, bufs=None, dtype=0, ws=None, out_layer=True, planes=None):
     """X [Q,KP] -> (h1,h2,h3 [Q,H], y [Q,3], pred [Q,3])   (:513-544, :691, :695-698); out_layer=False: y = pred = None (left to
-    out_asloss / the fused output-layer kernel of the backward)"""
-    L.req(X, name="X"), L.req(mask, name="mask")
-    Q, KP = X.shape
+    out_asloss / the fused output-layer kernel of the backward).  planes (AsLossPlanes, plane compute types): the rows come from
+    planes.X_rc (X may be None), h1 / h2 leave as bf16 planes only (returned as None), h3 stays fp32"""
+    L.req(mask, name="mask")
+    if planes is not None:
+        Q, KP = planes.Q, planes.KP
+        dev = mask.device
+    else:
+        L.req(X, name="X")
+        Q, KP = X.shape
+        dev = X.device
     if bufs is None:
-        h1, h2, h3 = (torch.empty(Q, H, device=X.device, dtype=torch.float32) for _ in range(3))
-        y = torch.empty(Q, 3, device=X.device, dtype=torch.float32) if out_layer else None
-        pred = torch.empty(Q, 3, device=X.device, dtype=torch.float32) if out_layer else None
+        h1, h2 = (None, None) if planes is not None else tuple(torch.empty(Q, H, device=dev, dtype=torch.float32) for _ in range(2))
+        h3 = torch.empty(Q, H, device=dev, dtype=torch.float32)
+        y = torch.empty(Q, 3, device=dev, dtype=torch.float32) if out_layer else None
+        pred = torch.empty(Q, 3, device=dev, dtype=torch.float32) if out_layer else None
     else:
         h1, h2, h3, y, pred = bufs
     p = L.make_params(*params)
     dtype = L.DTYPES[dtype]
-    if dtype and ws is None:
-        ws = workspace(Q, KP, H, X.device, dtype)
+    if dtype and ws is None and planes is None:
+        ws = workspace(Q, KP, H, dev, dtype)
     L.check(L.load().dpd_decoder_fwd(L.ptr(X), L.ptr(mask), Q, KP, H, p, dtype, L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(y),
-                                     L.ptr(pred), *_ws_args(ws), None, L.cur_stream()), "dpd_decoder_fwd")
+                                     L.ptr(pred), *_ws_args(ws), planes.c if planes is not None else None, L.cur_stream()), "dpd_decoder_fwd")
     return h1, h2, h3, y, pred
+
+
+class AsLossPlanes:
+    """bf16 operand planes of ONE as-loss evaluation (plane compute types f32x3 / bf16): the gathered rows, h1, h2 and the
+    pre-activation gradients live as RC planes only (there are no weight gradients to feed, so no R8 copies), allocated per call
+    (autograd may hold several evaluations); the weights are frozen, so their planes (R8 for the forward, RC for the data
+    gradients) are converted once and cached on the parameter object until its buffer changes."""
+
+    def __init__(self, P, flat, Q, dtype, device):
+        dt = L.DTYPES[dtype]
+        self.np = 3 if dt == 1 else 1
+        self.Q, self.KP, self.H = Q, P.KP, P.H
+        e = lambda rows, cols: torch.empty(self.np * rows * cols, device=device, dtype=torch.int16)   # noqa: E731
+        self.act = {"X_rc": e(Q, P.KP), "h1_rc": e(Q, P.H), "h2_rc": e(Q, P.H), "g3_rc": e(Q, P.H), "g2_rc": e(Q, P.H), "g1_rc": e(Q, P.H)}
+        key = (flat.data_ptr(), flat._version, dt)
+        cache = getattr(P, "_wplanes", None)
+        if cache is None or cache[0] != key:
+            w = {"W1_r8": e(P.KP, P.H), "W2_r8": e(P.H, P.H), "W3_r8": e(P.H, P.H), "W1_rc": e(P.KP, P.H), "W2_rc": e(P.H, P.H), "W3_rc": e(P.H, P.H)}
+            c = L.Planes()
+            c.np, c.Q, c.Qb = self.np, Q, Q
+            for n, t in w.items():
+                setattr(c, n, t.data_ptr())
+            L.check(L.load().dpd_weights_to_planes(L.make_params(*P.views(flat)), P.KP, P.H, c, L.cur_stream()), "dpd_weights_to_planes")
+            cache = P._wplanes = (key, w)
+        self.w = cache[1]
+        self.c = L.Planes()
+        self.c.np, self.c.Q, self.c.Qb = self.np, Q, Q
+        for n, t in list(self.act.items()) + list(self.w.items()):
+            setattr(self.c, n, t.data_ptr())
+
+    @staticmethod
+    def usable(P, Q, dtype):
+        return L.DTYPES[dtype] != 0 and Q % 32 == 0 and P.KP % 32 == 0 and P.H % 64 == 0
+
+
+def front_end_planes(pcA, pcB, m, sigma, k, planes):
+    """front_end for the plane compute types of the as-loss node: the window gather writes the rows straight into planes.X_rc (no fp32
+    X at all: its backward needs only dX, vox).  -> pts, mask, vox"""
+    L.req(pcA, name="pcA"), L.req(pcB, name="pcB")
+    B, N, _ = pcA.shape
+    dev, lib, s = pcA.device, L.load(), L.cur_stream()
+    f = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)   # noqa: E731
+    pts, q, fv, ssq = f(2 * B, N, 3), f(2 * B, N, 3), f(2 * B, m ** 3, F), f(2 * B, 4, F)
+    mask, vox = f(2 * B * N), torch.empty(2 * B * N, device=dev, dtype=torch.int32)
+    L.check(lib.dpd_mfv3d_fwd_stacked(L.ptr(pcA), L.ptr(pcB), None, B, N, m, float(sigma), L.ptr(pts), L.ptr(q), L.ptr(fv), L.ptr(ssq), s),
+            "dpd_mfv3d_fwd_stacked")
+    L.check(lib.dpd_patch_rows_fwd_scaled(L.ptr(q), L.ptr(fv), L.ptr(ssq), 2 * B, N, m, k, planes.KP, None, L.ptr(mask), L.ptr(vox),
+                                          planes.c, s), "dpd_patch_rows_fwd_scaled")
+    return pts, mask, vox
 
 
 def stack_clouds(pcA, pcB, noise=None):
@@ -155,18 +212,19 @@ def out_asloss(h3, mask, params, BN, want_grad=True, gscale=1.0):
 
 
 def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None, small_grads=None, dtype=0, ws=None,
-                     transposed=None, phases=7, g3=None):
+                     transposed=None, phases=7, g3=None, planes=None):
     """dpred [Qb,3] (first Qb rows) -> dy [Qb,3], g3,g2,g1 [Qb,H], dX [Qb,KP] or None.
     small_grads = (db1, db2, db3, dW4, db4) tensors (or None each) to be filled by the fused epilogues.
     phases=6 with g3 given: the output layer was done by out_asloss (dpred / y / h3 may be None)."""
     if phases & 1:
         L.req(dpred, name="dpred")
     Qb = dpred.shape[0] if dpred is not None else g3.shape[0]
-    H = h1.shape[1]
-    dev = h1.device
+    H = h1.shape[1] if h1 is not None else planes.H
+    dev = h1.device if h1 is not None else g3.device
     if bufs is None and g3 is not None:
         dy = None
-        g2, g1 = (torch.empty(Qb, H, device=dev, dtype=torch.float32) for _ in range(2))
+        # (planes: g2 / g1 travel as RC planes only)
+        g2, g1 = (None, None) if planes is not None else tuple(torch.empty(Qb, H, device=dev, dtype=torch.float32) for _ in range(2))
         dX = torch.empty(Qb, KP, device=dev, dtype=torch.float32) if want_dX else None
     elif bufs is None:
         dy = torch.empty(Qb, 3, device=dev, dtype=torch.float32)
@@ -177,11 +235,11 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None,
     p = L.make_params(*params, *(transposed if transposed is not None else ()))
     sg = L.make_small_grads(*small_grads) if small_grads is not None else None
     dtype = L.DTYPES[dtype]
-    if dtype and ws is None:
+    if dtype and ws is None and planes is None:
         ws = workspace(Qb, KP, H, dev, dtype)
     L.check(L.load().dpd_decoder_bwd_data(L.ptr(dpred), L.ptr(mask), L.ptr(y), L.ptr(h1), L.ptr(h2), L.ptr(h3), Qb, KP, H,
                                           p, dtype, L.ptr(dy), L.ptr(g3), L.ptr(g2), L.ptr(g1), L.ptr(dX), sg, *_ws_args(ws),
-                                          None, phases, L.cur_stream()), "dpd_decoder_bwd_data")
+                                          planes.c if planes is not None else None, phases, L.cur_stream()), "dpd_decoder_bwd_data")
     return dy, g3, g2, g1, dX
 
 

@@ -1261,6 +1261,57 @@ def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
         assert np.abs(g.cpu().numpy() - ref).max() <= bar, (np.abs(g.cpu().numpy() - ref).max(), bar)
 
 
+@pytest.mark.parametrize("dt", ["f32x3", "bf16"])
+def test_as_loss_node_on_persistent_planes(dev, dt, golden_dir, monkeypatch):
+    """The as-loss node of the plane compute types (round 4): rows / h1 / h2 / g3 / g2 / g1 as bf16 RC planes written by their
+    producers, the frozen weights' planes cached on the parameter object -- against the round-3 form that converted both operands of
+    every GEMM (DPD_ASLOSS_PLANES=0): same loss and input gradients (the planes hold the same bits); f32x3 also against the oracle's
+    float64 autograd at the bars of the exact type; two evaluations may be alive before either backward runs; a change of the
+    weights re-derives the cached weight planes."""
+    from dpdist_amd import model as M
+    from oracle import restate as R
+    d = _g(golden_dir, "path_bwd_s2_wide.npz")
+    B = 16
+    pcA, pcB, _ = synth.s2_modelnet_shaped(B, 64, 100)
+    res = {}
+    for planes in ("0", "1"):
+        monkeypatch.setenv("DPD_ASLOSS_PLANES", planes)
+        mod = _model(dev, "wide")
+        mod.params_.compute_dtype = dt
+        fn = M.DPDistLoss(mod)
+        a1, b1 = _cu(pcA, dev).requires_grad_(True), _cu(pcB, dev).requires_grad_(True)
+        a2, b2 = _cu(pcB, dev).requires_grad_(True), _cu(pcA, dev).requires_grad_(True)
+        l1 = fn(a1, b1)
+        l2 = fn(a2, b2)                                   # a second evaluation before the first backward
+        g1 = torch.autograd.grad(l1 * 2.0, [a1, b1])
+        g2 = torch.autograd.grad(l2, [a2, b2])
+        res[planes] = (l1.detach().clone(), l2.detach().clone(), g1, g2)
+        if planes == "1":
+            assert getattr(mod.params_, "_wplanes", None) is not None
+            key0 = mod.params_._wplanes[0]
+            with torch.no_grad():
+                mod.params_.flat.mul_(1.0)                # bumps the version: the cached weight planes must be re-derived
+            fn(a1, b1)
+            assert mod.params_._wplanes[0] != key0
+    tol = 1e-6 if dt == "f32x3" else 1e-5
+    for x, y in ((res["0"][0], res["1"][0]), (res["0"][1], res["1"][1])):
+        assert abs(x.item() - y.item()) <= tol
+    for ga, gb in zip(res["0"][2] + res["0"][3], res["1"][2] + res["1"][3]):
+        assert (ga - gb).abs().max().item() <= tol * max(1.0, ga.abs().max().item())
+    # against the oracle (float64 autograd of the same loss)
+    W = R.as_torch_weights(synth.make_weights("wide"), torch.float64)
+    a3 = torch.tensor(pcA, dtype=torch.float64, requires_grad=True)
+    b3 = torch.tensor(pcB, dtype=torch.float64, requires_grad=True)
+    ps3, _ = R.get_model(a3, b3, W)
+    _, lp3 = R.get_loss(ps3, torch.ones(B, 64, dtype=torch.float64))
+    g64 = torch.autograd.grad(lp3 * 2.0, [a3, b3])
+    assert abs(res["1"][0].item() - lp3.item()) <= (2e-5 if dt == "f32x3" else 3e-3)
+    for g, ref in zip(res["1"][2], g64):
+        scale = max(1.0, ref.abs().max().item())
+        err = (g.double().cpu() - ref).abs().max().item()
+        assert err <= (2e-3 if dt == "f32x3" else 5e-2) * scale, (err, scale)       # piecewise-smooth loss: gate flips move single entries
+
+
 @pytest.mark.parametrize("B,N,H", [(16, 64, 1024), (3, 4, 192)])
 def test_out_asloss_equals_the_three_kernel_chain(dev, B, N, H):
     """dpd_decoder_out_asloss (output layer + loss_pred + output-layer backward of d loss_pred / d pred, one launch) against
