@@ -84,6 +84,18 @@ class DPDistParams(nn.Module):
     def views(self, flat=None):
         return [self.view(n, flat) for n in ("W1p", "b1", "W2", "b2", "W3", "b3", "W4", "b4")]
 
+    def cparams(self, flat=None):
+        """The C-ABI pointer block of the 8 variables inside `flat` (include/dpdist_capi.h: dpd_decoder_params), cached per buffer
+        address: building the eight views costs the host ~80 us per call, which is what bounds the as-loss node of the plane compute
+        types at the registration batch."""
+        from . import lib as L
+        src = self.flat if flat is None else flat
+        key = src.data_ptr()
+        c = getattr(self, "_cparams_cache", None)
+        if c is None or c[0] != key:
+            c = self._cparams_cache = (key, L.make_params(*self.views(src)))
+        return c[1]
+
     def transposed(self, flat=None):
         """(W2T, W3T, W1pT): transposed copies for the fp32 backward data GEMMs (include/dpdist_capi.h:
         dpd_weights_transpose), cached until the parameter buffer changes (frozen weights in as-loss mode: one launch)."""
@@ -225,7 +237,6 @@ class _AsLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pcA, pcB, flat, P, m, k, sigma):
         B, N, _ = pcA.shape
-        params = P.views(flat)
         need_grad = pcA.requires_grad or pcB.requires_grad
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
         ctx.fused_out = B * N < 16384 and os.environ.get("DPD_ASLOSS_CHAIN") != "1"
@@ -233,14 +244,16 @@ class _AsLossFn(torch.autograd.Function):
         if ctx.fused_out and ops.AsLossPlanes.usable(P, 2 * B * N, P.compute_dtype) and os.environ.get("DPD_ASLOSS_PLANES", "1") == "1":
             # plane compute types: the rows, h1, h2 (and g3 / g2 / g1 in the backward) live as bf16 RC planes written by their producers,
             # the frozen weights' planes are cached: no conversion launch per GEMM, no fp32 X / h1 / h2 (round 4; DPD_ASLOSS_PLANES=0 = before)
+            cp = P.cparams(flat)
             pl = ops.AsLossPlanes(P, flat, 2 * B * N, P.compute_dtype, pcA.device)
             pts, mask, vox = ops.front_end_planes(pcA, pcB, m, sigma, k, pl)
-            _, _, h3, _, _ = ops.decoder_fwd(None, mask, params, P.H, dtype=P.compute_dtype, out_layer=False, planes=pl)
-            _, _, loss, _, g3 = ops.out_asloss(h3, mask, params, B * N, want_grad=need_grad)
+            _, _, h3, _, _ = ops.decoder_fwd(None, mask, cp, P.H, dtype=P.compute_dtype, out_layer=False, planes=pl)
+            _, _, loss, _, g3 = ops.out_asloss(h3, mask, cp, B * N, want_grad=need_grad)
             if need_grad:
                 ctx.planes = pl
                 ctx.save_for_backward(pts, flat, vox, g3)
             return loss[0]
+        params = P.views(flat)
         pts, X, mask, vox = ops.front_end(pcA, pcB, None, m, sigma, k, P.KP)     # two launches (stack+encoder, norm+gather)
         if ctx.fused_out:
             # output layer, loss_pred AND the output-layer backward of d loss_pred / d pred from one launch (labels only enter
@@ -265,7 +278,7 @@ class _AsLossFn(torch.autograd.Function):
         dt = P.compute_dtype
         if ctx.planes is not None:
             pts, flat, vox, g3 = ctx.saved_tensors
-            _, _, _, _, dX = ops.decoder_bwd_data(None, None, None, None, None, None, P.views(flat), P.KP, True, dtype=dt, phases=6, g3=g3,
+            _, _, _, _, dX = ops.decoder_bwd_data(None, None, None, None, None, None, P.cparams(flat), P.KP, True, dtype=dt, phases=6, g3=g3,
                                                   planes=ctx.planes)
             ctx.planes = None
             _, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k, want_dq=False)

@@ -117,7 +117,7 @@ def decoder_fwd(X, mask, params, H, bufs=None, dtype=0, ws=None, out_layer=True,
         pred = torch.empty(Q, 3, device=dev, dtype=torch.float32) if out_layer else None
     else:
         h1, h2, h3, y, pred = bufs
-    p = L.make_params(*params)
+    p = params if isinstance(params, L.DecoderParams) else L.make_params(*params)
     dtype = L.DTYPES[dtype]
     if dtype and ws is None and planes is None:
         ws = workspace(Q, KP, H, dev, dtype)
@@ -137,7 +137,13 @@ class AsLossPlanes:
         self.np = 3 if dt == 1 else 1
         self.Q, self.KP, self.H = Q, P.KP, P.H
         e = lambda rows, cols: torch.empty(self.np * rows * cols, device=device, dtype=torch.int16)   # noqa: E731
-        self.act = {"X_rc": e(Q, P.KP), "h1_rc": e(Q, P.H), "h2_rc": e(Q, P.H), "g3_rc": e(Q, P.H), "g2_rc": e(Q, P.H), "g1_rc": e(Q, P.H)}
+        # one allocation for the six activation / gradient planes (the host, not the GPU, bounds this node at small batches)
+        sizes = (("X_rc", Q * P.KP), ("h1_rc", Q * P.H), ("h2_rc", Q * P.H), ("g3_rc", Q * P.H), ("g2_rc", Q * P.H), ("g1_rc", Q * P.H))
+        self.arena = torch.empty(self.np * sum(n for _, n in sizes), device=device, dtype=torch.int16)
+        base, off, self.act = self.arena.data_ptr(), 0, {}
+        for n, cnt in sizes:
+            self.act[n] = base + 2 * off
+            off += self.np * cnt
         key = (flat.data_ptr(), flat._version, dt)
         cache = getattr(P, "_wplanes", None)
         if cache is None or cache[0] != key:
@@ -151,7 +157,9 @@ class AsLossPlanes:
         self.w = cache[1]
         self.c = L.Planes()
         self.c.np, self.c.Q, self.c.Qb = self.np, Q, Q
-        for n, t in list(self.act.items()) + list(self.w.items()):
+        for n, ptr_ in self.act.items():
+            setattr(self.c, n, ptr_)
+        for n, t in self.w.items():
             setattr(self.c, n, t.data_ptr())
 
     @staticmethod
@@ -206,7 +214,7 @@ def out_asloss(h3, mask, params, BN, want_grad=True, gscale=1.0):
         if len(_OUT_SCRATCH) > 16:
             _OUT_SCRATCH.clear()
         scr = _OUT_SCRATCH[key] = torch.zeros(2, device=dev, dtype=torch.float32)
-    L.check(L.load().dpd_decoder_out_asloss(L.ptr(h3), L.ptr(mask), Q, H, BN, L.make_params(*params), float(gscale), L.ptr(y), L.ptr(pred),
+    L.check(L.load().dpd_decoder_out_asloss(L.ptr(h3), L.ptr(mask), Q, H, BN, params if isinstance(params, L.DecoderParams) else L.make_params(*params), float(gscale), L.ptr(y), L.ptr(pred),
                                             L.ptr(loss), L.ptr(dy), L.ptr(g3), L.ptr(scr), L.cur_stream()), "dpd_decoder_out_asloss")
     return y, pred, loss, dy, g3
 
@@ -232,7 +240,7 @@ def decoder_bwd_data(dpred, mask, y, h1, h2, h3, params, KP, want_dX, bufs=None,
         dX = torch.empty(Qb, KP, device=dev, dtype=torch.float32) if want_dX else None
     else:
         dy, g3, g2, g1, dX = bufs
-    p = L.make_params(*params, *(transposed if transposed is not None else ()))
+    p = params if isinstance(params, L.DecoderParams) else L.make_params(*params, *(transposed if transposed is not None else ()))
     sg = L.make_small_grads(*small_grads) if small_grads is not None else None
     dtype = L.DTYPES[dtype]
     if dtype and ws is None and planes is None:
