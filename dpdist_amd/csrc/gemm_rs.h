@@ -437,6 +437,10 @@ static int launch_rs_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 35: return launch_rs<AK, BKC, 1, 2, 2, 2, 3>(g, s);   //  64x128, 3 operand sets
         case 36: return launch_rs<AK, BKC, 1, 1, 2, 2, 3>(g, s);   //  64x64,  3 operand sets
         case 37: return launch_rs<AK, BKC, 2, 2, 2, 4, 2>(g, s);   // 128x256, 8 waves (2 per SIMD)
+        // round 4: two-wave workgroups of 32x32 wave tiles -- finer tiles for grids that leave a partial wave of 64x64 workgroups
+        // (dW1: 640 tiles = 2.5 per CU; as 32x64 tiles 1264 = 4.94 per CU of six resident)
+        case 38: return launch_rs<AK, BKC, 1, 1, 1, 2, 2>(g, s);   //  32x64,  2 waves of 32x32
+        case 39: return launch_rs<AK, BKC, 1, 1, 2, 1, 2>(g, s);   //  64x32,  2 waves of 32x32
         default: return DPD_E_UNSUPPORTED;
     }
 }
