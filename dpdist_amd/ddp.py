@@ -533,6 +533,8 @@ def crosscheck(red, group=None):
             red.gather_params(flat)
         else:
             own_ok = True
+        if flat.is_cuda:
+            torch.cuda.synchronize()      # never two communicators' kernels in flight at once (the reducer's and the process group's)
         ref = pat(rank)
         dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=group)
         if flat.is_cuda:
