@@ -237,6 +237,7 @@ def train(argv=None):
             cur = nxt
         ds.reset()
         if world > 1:
+            tr.join_optimizer()              # the side stream's collectives + Adam are ordered before the process group's all-reduce
             dist.all_reduce(sums)
             sums /= world
         return (sums / max(n, 1)).tolist()
