@@ -84,6 +84,12 @@ class DPDistParams(nn.Module):
     def views(self, flat=None):
         return [self.view(n, flat) for n in ("W1p", "b1", "W2", "b2", "W3", "b3", "W4", "b4")]
 
+    def invalidate_derived(self):
+        """Drop what is cached FROM the parameter values (transposed fp32 copies, bf16 weight planes of the as-loss node).  Callers that
+        update `flat` through raw device pointers (the trainer's Adam kernels never bump `flat._version`) must call this."""
+        self._tr_key = None
+        self._wplanes = None
+
     def cparams(self, flat=None):
         """The C-ABI pointer block of the 8 variables inside `flat` (include/dpdist_capi.h: dpd_decoder_params), cached per buffer
         address: building the eight views costs the host ~80 us per call, which is what bounds the as-loss node of the plane compute

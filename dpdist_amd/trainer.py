@@ -447,7 +447,7 @@ class DPDistTrainer:
         L.check(L.load().dpd_adam_tf_dev(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                          self.P.numel, L.ptr(self.opt_state), b1, b2, eps, 1.0, L.cur_stream()), "dpd_adam_tf_dev")
         self._wdirty = True
-        self.P._tr_key = None
+        self.P.invalidate_derived()
 
     def apply_gradients(self, tail_from_partials=False, matrices_done=False, w1_done=False):
         """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
@@ -483,7 +483,7 @@ class DPDistTrainer:
                                             hi - lo, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf(shard)")
                 self.reducer.gather_params(pf)
                 self._wdirty = True
-                self.P._tr_key = None
+                self.P.invalidate_derived()
                 return
         import contextlib
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -498,7 +498,7 @@ class DPDistTrainer:
                 L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                              self.P.numel, lr_t, b1, b2, eps, gscale, L.cur_stream()), "dpd_adam_tf")
                 self._wdirty = True
-            self.P._tr_key = None     # DPDistParams.transposed() keys its cache on flat._version, which a raw-pointer update never bumps
+            self.P.invalidate_derived()     # DPDistParams.transposed() keys its cache on flat._version, which a raw-pointer update never bumps
             if side is not None:
                 if self._ev_opt is None:
                     from .hipevents import LightEvent
@@ -692,7 +692,7 @@ class DPDistTrainer:
         self.graph_replays += 1
         self.front_launches += 1
         self._wdirty = True            # the replay ends with Adam: derived buffers are one step behind the weights
-        self.P._tr_key = None
+        self.P.invalidate_derived()
         return self.loss
 
     def _capture(self, pcA, pcB, labels, noise):
