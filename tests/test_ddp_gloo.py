@@ -249,3 +249,48 @@ def test_zero1_sharded_optimizer_is_bitwise_the_replicated_one():
     assert all(c["ok"] for c in res["chk"]) and res["chk"][1]["mode"] == "zero1"
     assert res["wire"][0] == res["wire"][1] == 4 * res["n"]          # 2 (P-1)/P x 4 B x n at P = 2
     assert res["n"] // 2 <= res["owned"] <= res["n"] // 2 + 3 * 8     # half of every bucket + remainders of < 4 * world elements
+
+
+def test_zero_partition_and_wire_bytes():
+    """ddp.zero_partition: `world` equal shards of a multiple of four elements + a replicated remainder of < 4 * world; the shards and
+    remainders of the real bucket layout cover every parameter exactly once over the ranks; ddp._wire_bytes = 2 (P - 1) / P x payload."""
+    from dpdist_amd.ddp import BucketReducer, _wire_bytes, zero_partition
+    from dpdist_amd.model import DPDistParams
+    for world in (1, 2, 3, 8):
+        for lo, hi in ((0, 2589696), (2589696, 3639296), (3639296, 4692996), (0, 5), (8, 8 + 4 * world + 3)):
+            main, shard = zero_partition(lo, hi, world)
+            assert main % (4 * world) == 0 and shard * world == main and 0 <= (hi - lo) - main < 4 * world
+    P = DPDistParams(device="cpu", init=None)
+    world = 8
+    seen = torch.zeros(P.numel, dtype=torch.int32)
+    for rank in range(world):
+        red = BucketReducer(torch.zeros(P.numel), P.bucket_bounds, mode="zero1")
+        red.world, red.rank = world, rank                       # (no process group: the partition is pure arithmetic)
+        red._calls = [(P.bucket_bounds[1], P.bucket_bounds[3]), (P.bucket_bounds[0], P.bucket_bounds[1])]
+        for lo, hi in red.owned_ranges():
+            seen[lo:hi] += 1
+    lo2, hi2 = P.bucket_bounds[1], P.bucket_bounds[3]
+    main2, _ = zero_partition(lo2, hi2, world)
+    expect = torch.ones(P.numel, dtype=torch.int32)
+    expect[lo2 + main2:hi2] = world                              # the replicated remainder is updated on every rank
+    main0, _ = zero_partition(P.bucket_bounds[0], P.bucket_bounds[1], world)
+    expect[P.bucket_bounds[0] + main0:P.bucket_bounds[1]] = world
+    assert torch.equal(seen, expect)
+    assert _wire_bytes([(0, 1000)], 8, "f32", "allreduce") == int(2 * 7 / 8 * 4000)
+    assert _wire_bytes([(0, 1000)], 8, "bf16", "allreduce") == int(2 * 7 / 8 * 2000)
+    assert _wire_bytes([(0, 1000)], 1, "f32", "zero1") == 0
+
+
+def test_watchdog_limits_and_heartbeat_file(tmp_path, monkeypatch):
+    """launch.limits honours DPD_WD_LIMITS; a heartbeat's phase text may contain spaces (the supervisor reads '<phase> <time>')."""
+    from dpdist_amd import launch
+    monkeypatch.setenv("DPD_WD_LIMITS", "timed=7, init=11")
+    lim = launch.limits()
+    assert lim["timed"] == 7.0 and lim["init"] == 11.0 and lim["start"] == launch.LIMITS["start"]
+    monkeypatch.setenv("DPD_WD_DIR", str(tmp_path))
+    monkeypatch.delenv("DPD_WD_INJECT_HANG", raising=False)
+    hb = launch.Heartbeat(rank=3)
+    hb.beat("timed:20 steps of the headline")
+    phase, t = launch._read_beat(str(tmp_path / "rank3.a1"))
+    assert phase == "timed:20_steps_of_the_headline" and abs(t - __import__("time").time()) < 5
+    assert launch._read_beat(str(tmp_path / "missing")) == (None, None)

@@ -56,7 +56,8 @@ def main():
                 _, a_ = planes(At, np_, False, True); _, b_ = planes(B, np_, False, True)
                 args = (np_, 1, 1, M, N, K, L.ptr(a_), M, K * M, L.ptr(b_), N, K * N)
             # ring kernels 1-7; phase-staggered kernels 20-23 (one plane, BK = 64) / 24-26 (three planes, BK = 32)
-            for tile in (1, 2, 3, 5, 7) + ((20, 21, 22, 23) if np_ == 1 else (24, 25, 26)):
+            # (13 / 14: the 192x128 / 128x192 BK = 64 ring tiles of round 4: one plane, K % 64 == 0)
+            for tile in (1, 2, 3, 5, 7) + ((20, 21, 22, 23) + ((13, 14) if K % 64 == 0 else ()) if np_ == 1 else (24, 25, 26)):
                 def run(args=args, tile=tile, keep=(a_, b_)):
                     C = torch.empty(M, N, device=dev)
                     L.check(lib.dpd_gemm_planes(*args, L.ptr(C), N, None, None, 0, tile, None, None, 0, L.cur_stream()), "planes")
@@ -82,6 +83,47 @@ def main():
                                                                      "bitwise stable" if ndiff == 0 else "%d runs differ from the first" % ndiff),
                   flush=True)
             bad += nbad + ndiff
+    # round 4: the weight gradients of the plane compute types as they run in the step -- grouped dW1 + dW2 + dW3 launch (192x128 and
+    # 128x128 tiles) and the in-launch split-K (arrival counters, last-arriver reduction) -- repeated under the same memory pressure:
+    # every run must reproduce the first bit for bit and agree with the separate whole-K launches
+    from dpdist_amd import synth
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 64
+    pcA, pcB, lab = (torch.tensor(x, device=dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    base = None
+    for name, env, plans in (("apart, whole K", "0", ((20, 0, 1), (32, 3, 1))), ("grouped 192x128", "1", ((33, 13, 1),)), ("grouped 128x128", "1", ((33, 2, 1),)),
+                             ("grouped 128x128 split-K 2 in launch", "1", ((33, 2, 2),)), ("apart, dW1 split-K 3 + pair split-K 2 in launch", "0", ((20, 2, 3), (32, 2, 2)))):
+        os.environ["DPD_DW_TRIO"] = env
+        for op, tile, split in plans:
+            ops.set_gemm_plan(op, tile, split)
+        P = DPDistParams(device=dev, compute_dtype="bf16")
+        P.load_tf_state_dict(synth.make_weights("wide"))
+        tr = DPDistTrainer(P, B, distributed=False)
+        first, ndiff = None, 0
+        for it in range(max(20, a.iters // 4)):
+            if it % 2 == 0:
+                with torch.cuda.stream(side):
+                    junk.add_(1)
+            tr._take_front(pcA, pcB, None)
+            tr._decode()
+            tr.backward(lab.reshape(-1))
+            g = torch.cat([P.view(n, tr.grad).reshape(-1) for n in ("W1p", "W2", "W3")]).clone()
+            if first is None:
+                first = g
+            elif not torch.equal(g, first):
+                ndiff += 1
+        torch.cuda.synchronize()
+        if base is None:
+            base = first
+        rel = ((first - base).abs().max() / base.abs().max()).item()
+        ok = ndiff == 0 and rel <= 4e-6
+        print("bf16 B=64 weight gradients, %-48s %d runs: %s, vs apart max rel diff %.1e  %s" % (name, max(20, a.iters // 4), "bitwise stable" if ndiff == 0 else
+              "%d runs differ" % ndiff, rel, "OK" if ok else "BAD"), flush=True)
+        bad += 0 if ok else 1
+        for op, tile, split in plans:
+            ops.set_gemm_plan(op, 0, 1 if op == 33 else 0)
+    os.environ.pop("DPD_DW_TRIO", None)
     print("RESULT:", "clean" if bad == 0 else "%d bad results" % bad)
     return 1 if bad else 0
 
