@@ -891,9 +891,9 @@ extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
         if (op - 16 == dpd::OP_BWD_DW1 || op - 16 == dpd::OP_BWD_DW23) dpd::g_x3_split[op - 16] = split_k;
         return 0;
     }
-    if (op == 32 && tile >= 0 && tile <= 14 && split_k >= -4 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
+    if (op == 32 && tile >= 0 && tile <= 16 && split_k >= -4 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
     if (op == 40 && tile >= 0 && tile <= 2) { dpd::g_rs_xcd_band = tile; return 0; }      // XCD-blocked tile map of the fp32 register-streamed GEMMs
-    if (op == 33 && tile >= 0 && tile <= 14 && split_k >= 1 && split_k <= 4) { dpd::g_x3_trio_tile = tile; dpd::g_x3_trio_split = split_k; return 0; }
+    if (op == 33 && tile >= 0 && tile <= 16 && split_k >= 1 && split_k <= 4) { dpd::g_x3_trio_tile = tile; dpd::g_x3_trio_split = split_k; return 0; }
     if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;

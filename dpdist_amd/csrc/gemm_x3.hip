@@ -872,6 +872,11 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         // workgroup per CU (112 + 48 + 48 = 208 tiles): 8 waves of 96x32, BK = 64, 3 stages x 40 KiB
         case 13: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 3, 1, 3, 64>(g, s); return DPD_E_UNSUPPORTED;
         case 14: if (NP == 1) return launch_x3<1, AK, BKC, 4, 2, 1, 3, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x192, 8 waves of 32x96
+        // the same tiles on FOUR waves of 96x64 / 64x96 (one per SIMD): 5 fragment reads per 6 MFMAs instead of 4 per 3 -- 37 % less LDS read traffic.
+        // Measured SLOWER in the grouped weight-gradient launch (0.2877 vs 0.2792 ms per bf16 step at B = 64): the second wave per SIMD is worth more
+        // than the fragment traffic; kept selectable (dpd_set_gemm_plan(33, 15 | 16, 1)) and tested
+        case 15: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 3, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 192x128, 4 waves of 96x64
+        case 16: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 3, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x192, 4 waves of 64x96
         // phase-staggered kernels (gemm_p8_kernel; K % 32 == 0, no split-K): one plane at BK = 64, three planes at BK = 32
         case 20: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64
         case 21: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // ... group 0 waits after its MFMAs
@@ -906,7 +911,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     const bool uneven = A2 && (M2 != M || three);      // problems of different rows / a third problem: ring kernels, TN only
     if (A2 && (!B2 || !C2 || out || colsum || epilogue != EPI_NONE)) return DPD_E_UNSUPPORTED;
     if (three && (!A2 || !ex->B3 || !ex->C3 || ex->M3 <= 0)) return DPD_E_UNSUPPORTED;
-    if (uneven && (a_fmt != 1 || b_fmt != 1 || tile < 1 || (tile > 5 && tile != 13 && tile != 14) || (M2 & 7) || (three && (ex->M3 & 7))))
+    if (uneven && (a_fmt != 1 || b_fmt != 1 || tile < 1 || (tile > 5 && (tile < 13 || tile > 16)) || (M2 & 7) || (three && (ex->M3 & 7))))
         return DPD_E_UNSUPPORTED;
     const int nprob = A2 ? (three ? 3 : 2) : 1;
     // split-K (deterministic slabs in `ws` + the reduce kernel of gemm_f32.hip): plain products only (the dW shapes: K = query rows
@@ -928,7 +933,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
     if (np != 1 && np != 3) return DPD_E_UNSUPPORTED;
     if ((K % 32) || (N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return DPD_E_UNSUPPORTED;
-    if (tile >= 8 && tile <= 14 && (K % 64)) return DPD_E_UNSUPPORTED;   // BK = 64 kernels take whole 64-deep K-tiles
+    if (tile >= 8 && tile <= 16 && (K % 64)) return DPD_E_UNSUPPORTED;   // BK = 64 kernels take whole 64-deep K-tiles
     if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) && !bias) return DPD_E_NULL;
     if (epilogue == EPI_GATE && !gate && !gate16) return DPD_E_NULL;
     if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;

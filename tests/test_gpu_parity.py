@@ -546,7 +546,7 @@ def test_split_planes_reconstruct_exactly(dev):
     assert torch.equal(r8_as_rc, rc)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN", "TNr"])
 @pytest.mark.parametrize("np_", [3, 1])
 def test_gemm_planes(dev, np_, mode, tile):
