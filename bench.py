@@ -505,8 +505,18 @@ def main():
             rep["watchdog_history"] = json.loads(os.environ["DPD_WD_HISTORY"])
         return rep
 
-    def bf16_b64(distributed, label, mode=None):
-        """BASELINE configs 3-4: the same training step in bf16 at 64 pairs per GPU, timed like the headline."""
+    def bf16_b64(distributed, label, mode=None, env=None):
+        """BASELINE configs 3-4: the same training step in bf16 at 64 pairs per GPU, timed like the headline.  env: environment switches
+        that hold for the whole leg (the trainer reads DPD_DP_SCHEDULE at every backward)."""
+        saved = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            return _bf16_b64(distributed, label, mode)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+    def _bf16_b64(distributed, label, mode=None):
         hb.beat("aux:" + label[:40])
         B2 = 64
         P2 = DPDistParams(k=5, mlp=(1024, 1024, 1024), device=dev, compute_dtype="bf16")
@@ -579,12 +589,18 @@ def main():
                     c4["zero1"] = bf16_b64(True, "config 4 with DPD_DP_MODE=zero1 (sharded Adam)", mode="zero1")
                 except Exception as e:
                     c4["zero1"] = {"error": repr(e)}
+                try:     # the single-GPU launch order with ONE grouped weight-gradient launch and ONE all-reduce behind it (DPD_DP_SCHEDULE=grouped)
+                    c4["grouped_schedule"] = bf16_b64(True, "config 4 with DPD_DP_SCHEDULE=grouped (one dW launch, one all-reduce)",
+                                                      env={"DPD_DP_SCHEDULE": "grouped"})
+                except Exception as e:
+                    c4["grouped_schedule"] = {"error": repr(e)}
                 c4["n1_same_run"] = bf16_b64(False, "the same step on one rank without collectives (all ranks run it concurrently)")
                 c4["scaling"] = "weak"
                 n1v = c4["n1_same_run"]["value"]
                 c4["weak_scaling_efficiency_vs_n1_same_run"] = round(c4["value"] / (c4["n_gpus"] * n1v), 4)
-                if "value" in c4["zero1"]:
-                    c4["zero1"]["weak_scaling_efficiency_vs_n1_same_run"] = round(c4["zero1"]["value"] / (c4["n_gpus"] * n1v), 4)
+                for leg in ("zero1", "grouped_schedule"):
+                    if "value" in c4[leg]:
+                        c4[leg]["weak_scaling_efficiency_vs_n1_same_run"] = round(c4[leg]["value"] / (c4["n_gpus"] * n1v), 4)
                 cfg34 = ("config4", c4)
             elif not use_dist:
                 cfg34 = ("config3", bf16_b64(False, "BASELINE config 3: bf16 training step, 64 pairs"))

@@ -381,6 +381,18 @@ class DPDistTrainer:
                 dw(2, self.h1, self.g2, d[2])
                 dw(3, self.h2, self.g3, d[4])
 
+        if self.reducer and self._trio and self._adam_now is None and os.environ.get("DPD_DP_SCHEDULE", "early") == "grouped":
+            # DPD_DP_SCHEDULE=grouped (plane compute types, opt-in until an 8-GPU run has compared them): the single-GPU order -- data chain,
+            # then dW1 + dW2 + dW3 as ONE grouped launch (20 us less GEMM time at B = 64 than the three early launches) -- and the whole
+            # gradient as ONE all-reduce behind it; with the optimizer on the collectives' stream its tail overlaps the next front end
+            data(7)
+            rc = lib.dpd_decoder_bwd_weights_trio(BN, P.KP, P.H, self.dt, L.ptr(d[0]), L.ptr(d[2]), L.ptr(d[4]), L.ptr(self.ws), wsb, self._planes,
+                                                  L.cur_stream())
+            L.check(rc, "dpd_decoder_bwd_weights_trio")
+            if self._after_dw1 is not None:
+                self._after_dw1()
+            self.reducer.reduce_async(0, upto=len(P.bucket_bounds) - 2)
+            return
         if self.reducer and os.environ.get("DPD_DP_SCHEDULE", "early") == "early":
             # Data-parallel schedule: every weight gradient is produced as early as its inputs exist, smallest bucket first,
             # so that the all-reduces (serial on the RCCL stream) start ~250 us before the backward ends instead of after dW1:

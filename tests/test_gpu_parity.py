@@ -1148,6 +1148,46 @@ def test_optimizer_on_the_collective_stream_is_the_joined_step(dev, dt, backend,
         assert (a[0] - b[0]).abs().max().item() <= 2.1e-3 and (a[0] - b[0]).abs().mean().item() <= 1e-6
 
 
+@pytest.mark.parametrize("backend", ["rccl", "torch"])
+def test_grouped_data_parallel_schedule_matches_the_early_one(dev, backend, monkeypatch):
+    """DPD_DP_SCHEDULE=grouped (bf16): data chain, ONE grouped dW1 + dW2 + dW3 launch, ONE all-reduce of the whole gradient -- against
+    the default early schedule (three weight-gradient launches, two collectives): the same reduced gradients up to fp32 summation
+    order / the atomics' round-off of the bias gradients, the same three training steps."""
+    import torch.distributed as dist
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    monkeypatch.setenv("DPD_DP_BACKEND", backend)
+    monkeypatch.setenv("DPD_FORCE_DIST", "1")
+    B = 32
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    own = _single_rank_group(dev, 29647)
+    res = {}
+    try:
+        for sched in ("early", "grouped"):
+            monkeypatch.setenv("DPD_DP_SCHEDULE", sched)
+            P = DPDistParams(device=dev, compute_dtype="bf16")
+            P.load_tf_state_dict(synth.make_weights("wide"))
+            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
+            tr._take_front(pcA, pcB, None)
+            tr._decode(skip_out=True)
+            tr.backward(lab.reshape(-1))
+            tr.reducer.wait()
+            torch.cuda.synchronize()
+            g = tr.grad.clone()
+            assert len(tr.reducer._calls) == (2 if sched == "early" else 1)
+            losses = torch.stack([tr.step(pcA, pcB, lab).clone() for _ in range(3)])
+            tr.join_optimizer()
+            torch.cuda.synchronize()
+            res[sched] = (g, losses)
+            tr.close()
+    finally:
+        if own:
+            dist.destroy_process_group()
+    a, b = res["early"][0], res["grouped"][0]
+    assert (a - b).abs().max().item() <= 4e-6 * a.abs().max().item()
+    assert (res["early"][1] - res["grouped"][1]).abs().max().item() <= 2e-3
+
+
 def test_bench_watchdog_falls_back_on_the_gpu(dev):
     """bench.py's N > 1 skeleton on one GPU (DPD_FORCE_DIST=1): the worker of attempt 1 stops beating in the timed region (injected);
     the supervisor stops it by PID and reruns with DPD_DP_BACKEND=torch; the JSON line carries dp_backend / fallback / the
