@@ -202,6 +202,8 @@ class DPDistTrainer:
         # params.flat right after step() must call join_optimizer(); bench.py and dpdist_amd.train switch it on)
         self.adam_on_side = os.environ.get("DPD_DP_ADAM_SIDE", "0") == "1"
         self._ev_opt, self._opt_pending = None, False
+        if not hasattr(self, "_side_opt"):
+            self._side_opt = None
         self._trio = self._planes is not None and os.environ.get("DPD_DW_TRIO", "1" if self._planes.np == 1 else "0") == "1"
         self._wdirty = True        # transposed copies / bf16 planes of the weights need a refresh before their next use
         self._after_dw1 = None
@@ -461,7 +463,7 @@ class DPDistTrainer:
         self._wdirty = True
         self.P.invalidate_derived()
 
-    def apply_gradients(self, tail_from_partials=False, matrices_done=False, w1_done=False):
+    def apply_gradients(self, tail_from_partials=False, matrices_done=False, w1_done=False, side_stream=None):
         """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
         steps compute lr_t on the host (a device-side schedule kernel of one thread costs 4.7 us per step on MI355X: launch
         latency); only the captured hipGraph step keeps the schedule on the device."""
@@ -471,7 +473,7 @@ class DPDistTrainer:
         self._last_lr = lr
         lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         gscale = 1.0
-        side = None
+        side = side_stream          # (single-GPU experiment DPD_ADAM_SIDE=1: the caller has ordered this stream behind the backward)
         if self.reducer:
             self._join_optimizer()
             if self.adam_on_side and self.reducer.active and self.reducer.mode == "allreduce" and self.reducer.backend == "rccl":
@@ -591,7 +593,11 @@ class DPDistTrainer:
                     self._ev_front.record(self._side)
                 self._pref_key = self._key(*prefetch)
             self._after_dw1 = launch_front
-        defer = self.fused_adam and self.fuse_loss and self._tail_ok and self.reducer is None
+        # DPD_ADAM_SIDE=1 (single GPU, opt-in experiment): the optimizer on a side stream under the NEXT step's encoder + window gather, joined at the
+        # decoder (what DPD_DP_ADAM_SIDE does behind the collectives).  The loss must then come from the small-gradient reduction on the compute
+        # stream (no deferral into the optimizer launch): callers read it right after step()
+        side_single = self.reducer is None and not self.use_graph and os.environ.get("DPD_ADAM_SIDE", "0") == "1"
+        defer = self.fused_adam and self.fuse_loss and self._tail_ok and self.reducer is None and not side_single
         in_dw = self.adam_in_dw and defer
         w1_early = self.adam_w1_early and defer and not in_dw
         if w1_early:
@@ -626,7 +632,17 @@ class DPDistTrainer:
         finally:
             self._after_dw1 = None
             self._adam_now = None
-        self.apply_gradients(tail_from_partials=defer, matrices_done=in_dw, w1_done=w1_early)
+        sstream = None
+        if side_single:
+            if self._side_opt is None:
+                from .hipevents import LightEvent
+                self._side_opt = torch.cuda.Stream(device=self.P.flat.device)
+                self._ev_dw1, self._ev_w1done = LightEvent(system_fence=False), LightEvent(system_fence=False)
+            self._join_optimizer()
+            self._ev_dw1.record(torch.cuda.current_stream())
+            self._ev_dw1.wait(self._side_opt)
+            sstream = self._side_opt
+        self.apply_gradients(tail_from_partials=defer, matrices_done=in_dw, w1_done=w1_early, side_stream=sstream)
         if w1_early:
             self._ev_w1done.wait(torch.cuda.current_stream())      # W1p is complete before anything that follows this step
         return self.loss
