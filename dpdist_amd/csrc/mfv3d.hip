@@ -12,6 +12,8 @@
 //   lane>>3 <-> one eighth of the points, 20 running statistics (sum/max/min) in registers, the eight point groups merged with
 //   three __shfl_xor; power-1/2 values staged through LDS and written with coalesced float4 stores; a second small kernel
 //   applies the per-channel L2 norm over the Gaussian axis.  Backward: sliced over the POINTS (two launches) or one launch.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dpd {
@@ -274,6 +276,202 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_fwd_kernel(const float* __r
         if (tid < kF) fu.ssq[((size_t)c * kSlices + sl) * kF + tid] = bad ? qnan : t;
     }
     MFV_STAMP(4);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 4: the same forward with less VALU work per (Gaussian, point) pair -- the statistics section of the kernel above is
+// VALU-issue bound (tools/mfv_stamps.py, profiles/r04_mfv_stamps.txt: 11k of 20.6k cycles at B = 32, 12-16k at B = 64 where two
+// workgroups share a CU's VALUs), and of its ~90 instructions per Gaussian and point group half were the merge of the eight point groups.
+//   * lanes: lane & 15 <-> Gaussian (16 per wave), lane >> 4 <-> a QUARTER of the points: two merge stages (xor 16, xor 32) for 16
+//     Gaussians instead of three for 8 -- a third of the merge work per Gaussian; 512-thread workgroups (8 waves x 16 Gaussians = the
+//     slice of 128), so a CU holds the same number of waves as before;
+//   * points in PAIRS on the packed fp32 VALU (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of products and running sums per
+//     instruction): the tables hold {z(n), z(n+1), q(n), q(n+1)} as one float4 per axis entry (one ds_read_b128 per axis and pair);
+//     max / min have no packed form and stay scalar.
+// Same expressions per element as the kernel above (Q = (qx qy) qz, (Q - w) / den, Q z, Q (z z - 1)); the running SUMS are taken over
+// even and odd points separately and over four groups instead of eight, i.e. in another order: the statistics differ from the kernel
+// above in the last bits (both are within the oracle bars; DPD_MFV_V1=1 selects the old kernel).  Needs N % 8 == 0.
+// dynamic LDS (floats): zq4[3*(N/2)*m*4] | S[3*N] | minz2[3*N] | stage[slice*21] | flag | red[8*20]    (same size as above)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kFwd2Threads = 512;
+typedef float mfv_f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* __restrict__ pts, float* __restrict__ fv, MfvConst k, int gslice,
+                                                                  MfvFuse fu) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = k.N, G = k.G, m = k.m, NP = N >> 1;
+    float* s_t = sm;                                // [3][N/2][m][4] = {z(2p), z(2p+1), q(2p), q(2p+1)}
+    float* s_S = sm + 6 * N * m;                    // [3][N]
+    float* s_mz = s_S + 3 * N;                      // [3][N] min_i z^2
+    float* s_stage = s_mz + 3 * N;                  // [gslice][21]
+    int* s_bad = reinterpret_cast<int*>(s_stage + gslice * kFP);
+    auto slot = [&](int a, int n, int i) { return ((a * NP + (n >> 1)) * m + i) * 4 + (n & 1); };    // z; q at + 2
+
+    const int tid = threadIdx.x, c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
+    const int g0 = sl * gslice, gcount = max(0, min(G, g0 + gslice) - g0);
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* p = pts ? pts + (size_t)c * N * 3 : (c < fu.B ? fu.pcA + (size_t)c * N * 3 : fu.pcB + (size_t)(c - fu.B) * N * 3);
+    const float* nz = (!pts && fu.noise && c < fu.B) ? fu.noise + (size_t)c * N * 3 : nullptr;
+    if (tid == 0) *s_bad = 0;
+    const int lg_m = lg_or_neg(m), lg_n = lg_or_neg(N);
+    // m == 8 (the reference's grid) and whole passes: the 8 entries (a, n, 0..7) of a point and axis sit in 8 consecutive lanes, so the row sum S,
+    // the normalised q = e / S and min_i z^2 come out of three DPP steps in registers -- no second pass over the table, no barrier in between
+    const bool dpp8 = m == 8 && (3 * N * m) % kFwd2Threads == 0;
+    if (dpp8) {
+        for (int e = tid; e < 3 * N * m; e += kFwd2Threads) {
+            const int em = e >> 3, i = e & 7, a = qdiv(em, N, lg_n), n = em - a * N;
+            const float x = nz ? p[n * 3 + a] + nz[n * 3 + a] : p[n * 3 + a];
+            const float z = (x - k.ax.c[i]) / k.sigma;               // (batch_points - batch_mu) / batch_sig  (:87)
+            const float ex = expf(-0.5f * (z * z));
+            float S = ex, mz = z * z, bad = (z != z) ? 1.f : 0.f;
+            S += dpp_move<0xB1>(S); mz = fminf(mz, dpp_move<0xB1>(mz)); bad += dpp_move<0xB1>(bad);        // quad_perm [1,0,3,2]
+            S += dpp_move<0x4E>(S); mz = fminf(mz, dpp_move<0x4E>(mz)); bad += dpp_move<0x4E>(bad);        // quad_perm [2,3,0,1]
+            S += dpp_move<0x141>(S); mz = fminf(mz, dpp_move<0x141>(mz)); bad += dpp_move<0x141>(bad);     // row_half_mirror: the other quad of the 8
+            const int o = slot(a, n, i);
+            s_t[o] = z;
+            s_t[o + 2] = ex / S;
+            if (i == 0) s_mz[em] = bad > 0.f ? __int_as_float(0x7fc00000) : mz;
+        }
+    } else {
+        for (int e = tid; e < 3 * N * m; e += kFwd2Threads) {
+            const int em = qdiv(e, m, lg_m), i = e - em * m, a = qdiv(em, N, lg_n), n = em - a * N;
+            const float x = nz ? p[n * 3 + a] + nz[n * 3 + a] : p[n * 3 + a];
+            const float z = (x - k.ax.c[i]) / k.sigma;               // (batch_points - batch_mu) / batch_sig  (:87)
+            const int o = slot(a, n, i);
+            s_t[o] = z;
+            s_t[o + 2] = expf(-0.5f * (z * z));
+        }
+    }
+    if (!pts && sl == 0) {      // the stacked tensors the rest of the step reads
+        const int twin = c < fu.B ? c + fu.B : c - fu.B;
+        for (int e = tid; e < 3 * N; e += kFwd2Threads) {
+            const float raw = p[e];
+            if (fu.pts_out) fu.pts_out[(size_t)c * N * 3 + e] = nz ? raw + nz[e] : raw;
+            if (fu.q_out) fu.q_out[(size_t)twin * N * 3 + e] = raw;
+        }
+    }
+    __syncthreads();
+    if (!dpp8) {
+        for (int e = tid; e < 3 * N; e += kFwd2Threads) {             // e = a*N + n
+            const int a = qdiv(e, N, lg_n), n = e - a * N;
+            float S = 0.f, mz = INFINITY;
+            for (int i = 0; i < m; ++i) {
+                const int o = slot(a, n, i);
+                const float zz = s_t[o];
+                S += s_t[o + 2];
+                mz = fminf(mz, zz * zz);
+                if (zz != zz) mz = zz;
+            }
+            s_S[e] = S;
+            s_mz[e] = mz;
+        }
+        __syncthreads();
+        for (int e = tid; e < 3 * N * m; e += kFwd2Threads) {
+            const int em = qdiv(e, m, lg_m), i = e - em * m, a = qdiv(em, N, lg_n), n = em - a * N;
+            const int o = slot(a, n, i) + 2;
+            s_t[o] = s_t[o] / s_S[em];
+        }
+    }
+    for (int n = tid; n < N; n += kFwd2Threads) {
+        const float pmax = pdf(k, sqrtf(s_mz[n]), sqrtf(s_mz[N + n]), sqrtf(s_mz[2 * N + n]));
+        if (!(pmax * k.w > 0.f)) atomicOr(s_bad, 1);             // the reference's 0/0 (also catches NaN inputs)
+    }
+    __syncthreads();
+    const float4* tx = reinterpret_cast<const float4*>(s_t);
+    const float4* ty = tx + NP * m;
+    const float4* tz = tx + 2 * NP * m;
+
+    const float invN = 1.0f / (float)N;
+    const float inv_dpi = 1.0f / k.dpi_den;
+    const int grp = lane >> 4;                      // quarter of the points
+    const int ppg = NP >> 2;                        // point pairs per group (N % 8 == 0)
+    const mfv_f2 w2 = {k.w, k.w}, inv2 = {inv_dpi, inv_dpi}, one2 = {1.0f, 1.0f};
+    for (int gbase = wave * 16; gbase < gcount; gbase += (kFwd2Threads / 64) * 16) {
+        const int gl = gbase + (lane & 15);
+        const bool live = gl < gcount;
+        const int gg = live ? g0 + gl : 0;
+        const int gm = qdiv(gg, m, lg_m), t = gg - gm * m, i = qdiv(gm, m, lg_m), j = gm - i * m;   // centre (x,y,z) = (l[j], l[i], l[t])  (:47-48)
+        mfv_f2 pi_s2 = {0.f, 0.f}, mu_s2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, sg_s2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        float pi_mx = -INFINITY;
+        float mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
+        float sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
+        for (int pp = grp * ppg; pp < (grp + 1) * ppg; ++pp) {
+            const float4 vx = tx[pp * m + j], vy = ty[pp * m + i], vz = tz[pp * m + t];
+            const mfv_f2 z[3] = {{vx.x, vx.y}, {vy.x, vy.y}, {vz.x, vz.y}};
+            const mfv_f2 qx = {vx.z, vx.w}, qy = {vy.z, vy.w}, qz = {vz.z, vz.w};
+            const mfv_f2 Q = (qx * qy) * qz;                                   // :73-74, factorised
+            const mfv_f2 dpi = (Q - w2) * inv2;                                // :78
+            pi_s2 += dpi;
+            pi_mx = fmaxf(fmaxf(pi_mx, dpi.x), dpi.y);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const mfv_f2 a = Q * z[d];                                      // :87
+                const mfv_f2 b = Q * (z[d] * z[d] - one2);                      // :100
+                mu_s2[d] += a; sg_s2[d] += b;
+                mu_mx[d] = fmaxf(fmaxf(mu_mx[d], a.x), a.y); mu_mn[d] = fminf(fminf(mu_mn[d], a.x), a.y);
+                sg_mx[d] = fmaxf(fmaxf(sg_mx[d], b.x), b.y); sg_mn[d] = fminf(fminf(sg_mn[d], b.x), b.y);
+            }
+        }
+        float pi_s = pi_s2.x + pi_s2.y, mu_s[3], sg_s[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mu_s[d] = mu_s2[d].x + mu_s2[d].y; sg_s[d] = sg_s2[d].x + sg_s2[d].y; }
+        // merge the four point groups (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same Gaussian): xor 16 through ds_swizzle, xor 32 as a
+        // v_permlane32_swap (both halves receive lower + upper)
+        auto x16 = [](float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); };
+        auto sum32 = [](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                                   return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+        auto max32 = [](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                                   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); };
+        auto min32 = [](float v) { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                                   return fminf(__uint_as_float(r[0]), __uint_as_float(r[1])); };
+        pi_s += x16(pi_s); pi_s = sum32(pi_s);
+        pi_mx = fmaxf(pi_mx, x16(pi_mx)); pi_mx = max32(pi_mx);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            mu_s[d] += x16(mu_s[d]); mu_s[d] = sum32(mu_s[d]);
+            sg_s[d] += x16(sg_s[d]); sg_s[d] = sum32(sg_s[d]);
+            mu_mx[d] = fmaxf(mu_mx[d], x16(mu_mx[d])); mu_mx[d] = max32(mu_mx[d]);
+            mu_mn[d] = fminf(mu_mn[d], x16(mu_mn[d])); mu_mn[d] = min32(mu_mn[d]);
+            sg_mx[d] = fmaxf(sg_mx[d], x16(sg_mx[d])); sg_mx[d] = max32(sg_mx[d]);
+            sg_mn[d] = fminf(sg_mn[d], x16(sg_mn[d])); sg_mn[d] = min32(sg_mn[d]);
+        }
+        if (live && grp == 0) {
+            float v[kF];
+            v[0] = pi_s * invN;                                                 // :81 reduce_mean
+            v[1] = pi_mx;                                                       // :80
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {                                       // :89-98, :102-109
+                v[2 + d] = (mu_s[d] * invN) * k.mu_scale;
+                v[5 + d] = mu_mx[d] * k.mu_scale;
+                v[8 + d] = mu_mn[d] * k.mu_scale;
+                v[11 + d] = (sg_s[d] * invN) * k.sig_scale;
+                v[14 + d] = sg_mx[d] * k.sig_scale;
+                v[17 + d] = sg_mn[d] * k.sig_scale;
+            }
+#pragma unroll
+            for (int f = 0; f < kF; ++f) s_stage[gl * kFP + f] = v[f];
+        }
+    }
+    __syncthreads();
+    // power-1/2 normalisation (:119-121) + coalesced store + the slice's sums of squares: as in mfv3d_fwd_kernel
+    float* out = fv + ((size_t)c * G + g0) * kF;
+    const bool bad = *s_bad != 0;
+    const float qnan = __int_as_float(0x7fc00000);
+    for (int i4 = tid; i4 < gcount * kF / 4; i4 += kFwd2Threads) {
+        const int e = i4 * 4, g = e / kF, f = e % kF;
+        float* sp = s_stage + g * kFP + f;
+        float4 o = make_float4(pnorm(sp[0]), pnorm(sp[1]), pnorm(sp[2]), pnorm(sp[3]));
+        sp[0] = o.x; sp[1] = o.y; sp[2] = o.z; sp[3] = o.w;
+        if (bad) o = make_float4(qnan, qnan, qnan, qnan);
+        *reinterpret_cast<float4*>(out + e) = o;
+    }
+    if (fu.ssq) {
+        float* s_red = reinterpret_cast<float*>(s_bad) + 4;  // [8][20] partials
+        __syncthreads();
+        const float t = slice_ssq(tid, gcount, s_red, [&](int g, int ch) { return s_stage[g * kFP + ch]; });
+        if (tid < kF) fu.ssq[((size_t)c * kSlices + sl) * kF + tid] = bad ? qnan : t;
+    }
 }
 
 }  // namespace dpd
@@ -873,6 +1071,12 @@ static int set_lds(K kern, size_t lds) {
 
 }  // namespace dpd
 
+// round-4 forward kernel (pairs of points on the packed VALU, four point groups): N % 8 == 0; DPD_MFV_V1=1 keeps the round-3 kernel
+static bool use_fwd2(int N) {
+    static const bool v1 = getenv("DPD_MFV_V1") != nullptr;
+    return !v1 && N >= 8 && !(N & 7);
+}
+
 extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma, float* fv, void* stream) {
     using namespace dpd;
     if (!pts || !fv) return DPD_E_NULL;
@@ -881,9 +1085,14 @@ extern "C" int dpd_mfv3d_fwd(const float* pts, int C, int N, int m, float sigma,
     if (int rc = make_const(N, m, sigma, k)) return rc;
     const int gslice = (k.G + kSlices - 1) / kSlices;
     const size_t lds = fwd_lds_bytes(N, m, gslice);
-    if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
     StageProf prof(stream, DPD_STAGE_ENCODER, (double)C * (N * 12.0 + k.G * 80.0));      // points in, [G,20] Fisher vector out
-    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k, gslice, MfvFuse{});
+    if (use_fwd2(N)) {
+        if (int rc = set_lds(mfv3d_fwd2_kernel, lds)) return rc;
+        DPD_LAUNCH(mfv3d_fwd2_kernel, dim3(C * kSlices), dim3(kFwd2Threads), lds, (hipStream_t)stream, pts, fv, k, gslice, MfvFuse{});
+    } else {
+        if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
+        DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, fv, k, gslice, MfvFuse{});
+    }
     DPD_CHECK_LAUNCH();
     DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, fv, k.G, gslice);
     DPD_CHECK_LAUNCH();
@@ -899,11 +1108,17 @@ extern "C" int dpd_mfv3d_fwd_stacked(const float* pcA, const float* pcB, const f
     if (int rc = make_const(N, m, sigma, k)) return rc;
     const int C = 2 * B, gslice = (k.G + kSlices - 1) / kSlices;
     const size_t lds = fwd_lds_bytes(N, m, gslice);
-    if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
     // points (+ noise) in; stacked pts / q and the [G,20] Fisher vector (+ per-slice sums of squares) out
     StageProf prof(stream, DPD_STAGE_ENCODER, (double)C * (N * 12.0 * (noise ? 1.5 : 1.0) + N * 24.0 + k.G * 80.0 + (ssq ? kSlices * 80.0 : 0.0)));
-    DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, (const float*)nullptr, fv, k, gslice,
-               MfvFuse{pcA, pcB, noise, pts, q, ssq, B});
+    if (use_fwd2(N)) {
+        if (int rc = set_lds(mfv3d_fwd2_kernel, lds)) return rc;
+        DPD_LAUNCH(mfv3d_fwd2_kernel, dim3(C * kSlices), dim3(kFwd2Threads), lds, (hipStream_t)stream, (const float*)nullptr, fv, k, gslice,
+                   MfvFuse{pcA, pcB, noise, pts, q, ssq, B});
+    } else {
+        if (int rc = set_lds(mfv3d_fwd_kernel, lds)) return rc;
+        DPD_LAUNCH(mfv3d_fwd_kernel, dim3(C * kSlices), dim3(kFwdThreads), lds, (hipStream_t)stream, (const float*)nullptr, fv, k, gslice,
+                   MfvFuse{pcA, pcB, noise, pts, q, ssq, B});
+    }
     DPD_CHECK_LAUNCH();
     if (!ssq) {
         DPD_LAUNCH(mfv3d_norm_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, fv, k.G, gslice);
