@@ -104,13 +104,26 @@ __device__ __forceinline__ float slice_ssq(int tid, int gcount, float* s_red /* 
         const int part = tid / kF, ch = tid % kF;
         float ss = 0.f;
         const int g1 = min(gcount, (part + 1) * per);
-        for (int g = part * per; g < g1; ++g) { const float x = val(g, ch); ss += x * x; }
+        // eight loads in flight, then the SAME additions in the same order (a padded 0 * 0 adds an exact zero): the sequential form was a
+        // chain of 16 dependent LDS round trips (1.6k of the forward kernel's 16k cycles, tools/mfv_stamps.py)
+        for (int g = part * per; g < g1; g += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (g + u < g1) ? val(g + u, ch) : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ss += x[u] * x[u];
+        }
         s_red[part * kF + ch] = ss;
     }
     __syncthreads();
     float t = 0.f;
-    if (tid < kF)
-        for (int part = 0; part < 8; ++part) t += s_red[part * kF + tid];
+    if (tid < kF) {
+        float x[8];
+#pragma unroll
+        for (int part = 0; part < 8; ++part) x[part] = s_red[part * kF + tid];
+#pragma unroll
+        for (int part = 0; part < 8; ++part) t += x[part];
+    }
     return t;
 }
 
@@ -299,6 +312,7 @@ typedef float mfv_f2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* __restrict__ pts, float* __restrict__ fv, MfvConst k, int gslice,
                                                                   MfvFuse fu) {
+    MFV_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = k.N, G = k.G, m = k.m, NP = N >> 1;
     float* s_t = sm;                                // [3][N/2][m][4] = {z(2p), z(2p+1), q(2p), q(2p+1)}
@@ -319,6 +333,7 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
     // the normalised q = e / S and min_i z^2 come out of three DPP steps in registers -- no second pass over the table, no barrier in between
     const bool dpp8 = m == 8 && (3 * N * m) % kFwd2Threads == 0;
     if (dpp8) {
+#pragma unroll 3
         for (int e = tid; e < 3 * N * m; e += kFwd2Threads) {
             const int em = e >> 3, i = e & 7, a = qdiv(em, N, lg_n), n = em - a * N;
             const float x = nz ? p[n * 3 + a] + nz[n * 3 + a] : p[n * 3 + a];
@@ -352,6 +367,7 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
         }
     }
     __syncthreads();
+    MFV_STAMP(1);
     if (!dpp8) {
         for (int e = tid; e < 3 * N; e += kFwd2Threads) {             // e = a*N + n
             const int a = qdiv(e, N, lg_n), n = e - a * N;
@@ -378,6 +394,7 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
         if (!(pmax * k.w > 0.f)) atomicOr(s_bad, 1);             // the reference's 0/0 (also catches NaN inputs)
     }
     __syncthreads();
+    MFV_STAMP(2);
     const float4* tx = reinterpret_cast<const float4*>(s_t);
     const float4* ty = tx + NP * m;
     const float4* tz = tx + 2 * NP * m;
@@ -396,8 +413,20 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
         float pi_mx = -INFINITY;
         float mu_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mu_mn[3] = {INFINITY, INFINITY, INFINITY};
         float sg_mx[3] = {-INFINITY, -INFINITY, -INFINITY}, sg_mn[3] = {INFINITY, INFINITY, INFINITY};
-        for (int pp = grp * ppg; pp < (grp + 1) * ppg; ++pp) {
-            const float4 vx = tx[pp * m + j], vy = ty[pp * m + i], vz = tz[pp * m + t];
+        // four pairs per trip with their twelve table reads requested up front: with two waves per SIMD nothing else hides the LDS latency
+        // (3.3k cycles for eight pairs before: tools/mfv_stamps.py); a partial last trip re-reads its last valid pair and skips the update
+        const int pp_end = (grp + 1) * ppg;
+        for (int pp0 = grp * ppg; pp0 < pp_end; pp0 += 4) {
+          float4 lx[4], ly[4], lz[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+              const int pq = min(pp0 + u, pp_end - 1);
+              lx[u] = tx[pq * m + j]; ly[u] = ty[pq * m + i]; lz[u] = tz[pq * m + t];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (pp0 + u >= pp_end) break;
+            const float4 vx = lx[u], vy = ly[u], vz = lz[u];
             const mfv_f2 z[3] = {{vx.x, vx.y}, {vy.x, vy.y}, {vz.x, vz.y}};
             const mfv_f2 qx = {vx.z, vx.w}, qy = {vy.z, vy.w}, qz = {vz.z, vz.w};
             const mfv_f2 Q = (qx * qy) * qz;                                   // :73-74, factorised
@@ -412,7 +441,9 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
                 mu_mx[d] = fmaxf(fmaxf(mu_mx[d], a.x), a.y); mu_mn[d] = fminf(fminf(mu_mn[d], a.x), a.y);
                 sg_mx[d] = fmaxf(fmaxf(sg_mx[d], b.x), b.y); sg_mn[d] = fminf(fminf(sg_mn[d], b.x), b.y);
             }
+          }
         }
+        MFV_STAMP(5);
         float pi_s = pi_s2.x + pi_s2.y, mu_s[3], sg_s[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) { mu_s[d] = mu_s2[d].x + mu_s2[d].y; sg_s[d] = sg_s2[d].x + sg_s2[d].y; }
@@ -436,6 +467,7 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
             sg_mx[d] = fmaxf(sg_mx[d], x16(sg_mx[d])); sg_mx[d] = max32(sg_mx[d]);
             sg_mn[d] = fminf(sg_mn[d], x16(sg_mn[d])); sg_mn[d] = min32(sg_mn[d]);
         }
+        MFV_STAMP(6);
         if (live && grp == 0) {
             float v[kF];
             v[0] = pi_s * invN;                                                 // :81 reduce_mean
@@ -453,7 +485,9 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
             for (int f = 0; f < kF; ++f) s_stage[gl * kFP + f] = v[f];
         }
     }
+    MFV_STAMP(7);
     __syncthreads();
+    MFV_STAMP(3);
     // power-1/2 normalisation (:119-121) + coalesced store + the slice's sums of squares: as in mfv3d_fwd_kernel
     float* out = fv + ((size_t)c * G + g0) * kF;
     const bool bad = *s_bad != 0;
@@ -472,6 +506,7 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
         const float t = slice_ssq(tid, gcount, s_red, [&](int g, int ch) { return s_stage[g * kFP + ch]; });
         if (tid < kF) fu.ssq[((size_t)c * kSlices + sl) * kF + tid] = bad ? qnan : t;
     }
+    MFV_STAMP(4);
 }
 
 }  // namespace dpd
