@@ -26,5 +26,5 @@ print("B=%d, %d workgroups; cycles per section (median / max over workgroups), t
 for i, nm in enumerate(names):
     print("  %-34s %7.0f / %7.0f" % (nm, np.median(d[:, i]), d[:, i].max()))
 if full[:, 5].max() > 0:      # finer stamps inside the statistics section (wave 0's only pass): point loop | merge | power norm + stage
-    print("  statistics section: point loop %7.0f, merge of the 8 point groups %7.0f, scale + stage %7.0f, barrier + power norm + barrier %7.0f" % (
+    print("  statistics section: point loop %7.0f, merge of the point groups %7.0f, scale + stage %7.0f, barrier + power norm + barrier %7.0f" % (
         np.median(full[:, 5] - full[:, 2]), np.median(full[:, 6] - full[:, 5]), np.median(full[:, 7] - full[:, 6]), np.median(full[:, 3] - full[:, 7])))
