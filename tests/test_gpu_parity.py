@@ -1737,6 +1737,29 @@ def test_plane_weight_gradients_in_one_grouped_launch(dev, dt, B, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(1, 64), (3, 64), (5, 32), (4, 100), (2, 200)])
+def test_bf16_step_on_odd_batch_shapes(dev, B, N):
+    """The bf16 training step at shapes where the round-4 grouped weight-gradient launch does or does not apply (query rows not a
+    multiple of 64 -> the separate launches; not a multiple of 32 -> no planes at all): three steps track the exact-fp32 trainer."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, N, 100))
+    out = {}
+    for dt in ("f32", "bf16"):
+        P = DPDistParams(device=dev, compute_dtype=dt)
+        P.load_tf_state_dict(synth.make_weights("wide"))
+        tr = DPDistTrainer(P, B, num_point=N, base_lr=1e-3, distributed=False)
+        losses = torch.stack([tr.step(pcA, pcB, lab).clone() for _ in range(3)])
+        torch.cuda.synchronize()
+        out[dt] = (losses, tr._trio, tr._planes is not None)
+    assert torch.isfinite(out["bf16"][0]).all()
+    assert (out["bf16"][0] - out["f32"][0]).abs().max().item() <= 3e-2
+    BN = B * N
+    assert out["bf16"][2] == (BN % 32 == 0 and (2 * BN) % 8 == 0)
+    assert out["bf16"][1] == (out["bf16"][2] and BN % 64 == 0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [32, 64])
 @pytest.mark.parametrize("dt", ["f32x3", "bf16"])
 def test_plane_weight_gradient_split_k_in_launch(dev, dt, B):
