@@ -501,6 +501,19 @@ def main():
                                    "collectives (incl. a collective enqueued on the compute stream itself), separate pass of %d steps" % a.steps)
         except Exception as e:
             rep["exposed_error"] = repr(e)
+        try:      # replicated variables must have stayed bit-identical over the ranks (same averaged gradient, same Adam): two checksums per rank
+            trn.join_optimizer()
+            w = trn.P.flat.detach()
+            chk = torch.stack([w.double().sum(), w.double().abs().sum(), trn.m_state.double().sum(), trn.v_state.double().sum()])
+            if red.mode == "zero1":
+                chk = chk[:2]         # the Adam slots live sharded
+            allc = [torch.empty_like(chk) for _ in range(world)] if use_dist else [chk]
+            if use_dist:
+                torch.cuda.synchronize()
+                dist.all_gather(allc, chk)
+            rep["replicas_bit_identical"] = bool(all(torch.equal(allc[0], x) for x in allc[1:])) and bool(torch.isfinite(chk).all())
+        except Exception as e:
+            rep["replicas_check_error"] = repr(e)
         if os.environ.get("DPD_WD_HISTORY"):
             rep["watchdog_history"] = json.loads(os.environ["DPD_WD_HISTORY"])
         return rep
