@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdpdist_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_x3.hip", "mfv3d.hip", "patch_rows.hip", "decoder.hip", "loss_adam.hip", "chamfer.hip", "host_util.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_x3.hip", "gemm_p8.hip", "mfv3d.hip", "patch_rows.hip", "decoder.hip", "loss_adam.hip", "chamfer.hip", "asloss.hip", "host_util.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -33,11 +33,19 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    # an object is reused when it is newer than its source, every header and this file, and was built with the same flags
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "dpdist_capi.h"),
+                                                                                       os.path.abspath(__file__)]
+    stamp = os.path.join(HERE, "build", "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and same_flags and os.path.exists(obj) and all(os.path.getmtime(d) < os.path.getmtime(obj)
+                                                                    for d in headers + [os.path.join(CSRC, src)]):
+            continue
         cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -45,6 +53,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed on %s" % src)
         if verbose and out.strip():
             sys.stderr.write(out.decode())
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     if verbose:

@@ -47,6 +47,21 @@ static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf
 static int g_x3_split[OP_COUNT] = {1, 1, 1, 1, 0, 0, 1, 1, 1};
 static int g_x3_pair_tile = 0, g_x3_pair_split = 0;   // plane dW2+dW3 pair: tile (0 = automatic), split-K (as above)
 static int g_x3_trio_tile = 0, g_x3_trio_split = 1;   // plane dW1+dW2+dW3 in one launch (dpd_decoder_bwd_weights_trio): tile, split-K
+// chained persistent launches of the one-plane compute type (gemm_x3.hip: gemm_chain): 0 = off, 1 = automatic, 21 / 23 = force that tile
+// default OFF: measured slower than the separate launches (round 5, DESIGN.md 3.6: +11 us per chain at B = 64 -- a hand-off costs what a kernel
+// boundary costs on this chip, and the tiles themselves take as long inside the persistent launch as apart)
+static int g_chain_fwd = 0, g_chain_bwd = 0;
+static unsigned long long* g_chain_stamps = nullptr;  // dpd_set_chain_stamps (debug)
+// tile of a chained launch over `rows` x H outputs, or 0: the 256x128 tile when it gives every CU a workgroup (B = 64: 8192 rows), else
+// the 128x128 tile when THAT does (the data-gradient chain at B = 64, the forward at B = 32)
+static int chain_tile(int mode, int rows, int H, int r8_rows) {
+    if (mode == 0) return 0;
+    auto ok = [&](int bm) { return !(rows % bm) && !(H % 128) && !(r8_rows % bm); };
+    if (mode == 21 || mode == 23) return ok(mode == 21 ? 256 : 128) ? mode : 0;
+    if (ok(256) && (long)(rows / 256) * (H / 128) >= 224) return 21;
+    if (ok(128) && (long)(rows / 128) * (H / 128) >= 200) return 23;
+    return 0;
+}
 constexpr size_t kRedCntBytes = 8192;                 // arrival words of the in-launch reduction: the last 8 KiB of the base workspace
 
 // Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
@@ -74,6 +89,18 @@ static int x3_auto_split(int np, int tile, int M, int N, int K) {
     int split = (int)(480 / (tiles > 0 ? tiles : 1));
     while (split > 1 && K / split < 1024) --split;
     return split < 1 ? 1 : (split > 4 ? 4 : split);
+}
+
+// In-launch split-K parks the raw accumulators of every slice in TILE-PADDED slabs (gemm_x3.hip: tiles * split * bm * bn floats): the largest
+// split <= `split` whose slabs fit `slab_bytes` for problems of rows[0 .. nprob) x N (with small H the base workspace holds
+// fewer slabs than the automatic split asked for, and the call failed with DPD_E_WORKSPACE instead of running unsplit)
+static int x3_fit_split(int tile, int split, const int* rows, int nprob, int N, size_t slab_bytes) {
+    if (split <= 1 || tile < 1 || tile > 5) return split;
+    const int bm = (tile == 3 || tile == 5) ? 64 : 128, bn = (tile == 4 || tile == 5) ? 64 : 128;
+    size_t tiles = 0;
+    for (int i = 0; i < nprob; ++i) tiles += (size_t)((rows[i] + bm - 1) / bm) * ((N + bn - 1) / bn);
+    while (split > 1 && (tiles * split * bm * bn * sizeof(float) > slab_bytes || tiles > kRedCntBytes / 8)) --split;
+    return split;
 }
 
 // Apl / Bpl: operand planes that already exist (else the fp32 operand is split into `scr`); out: plane outputs.
@@ -140,6 +167,7 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
     if (transA && !transB && epilogue == 0 && !colsum && !out && C && ws && ws_bytes > kRedCntBytes) {
         split = g_x3_split[op];
         if (split == 0) split = x3_auto_split(np, tile, M, N, K);
+        if (split > 1 && tile >= 1 && tile <= 5) split = x3_fit_split(tile, split, &M, 1, N, ws_bytes - kRedCntBytes);
         if (split > 1 && tile >= 1 && tile <= 5) cnt = (char*)ws + ws_bytes - kRedCntBytes;
         else if (split < -1) split = -split;
         else split = 1;
@@ -893,6 +921,7 @@ extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
     }
     if (op == 32 && tile >= 0 && tile <= 16 && split_k >= -4 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
     if (op == 40 && tile >= 0 && tile <= 2) { dpd::g_rs_xcd_band = tile; return 0; }      // XCD-blocked tile map of the fp32 register-streamed GEMMs
+    if ((op == 48 || op == 49) && (tile == 0 || tile == 1 || tile == 21 || tile == 23)) { (op == 48 ? dpd::g_chain_fwd : dpd::g_chain_bwd) = tile; return 0; }
     if (op == 33 && tile >= 0 && tile <= 16 && split_k >= 1 && split_k <= 4) { dpd::g_x3_trio_tile = tile; dpd::g_x3_trio_split = split_k; return 0; }
     if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
@@ -934,7 +963,8 @@ PlaneSizes plane_sizes(int Q, int Qb, int KP, int H, int np) {
 extern "C" size_t dpd_planes_bytes(int Q, int Qb, int KP, int H, int dtype, int with_dx) {
     if (dtype != 1 && dtype != 2) return 0;
     const PlaneSizes z = plane_sizes(Q, Qb, KP, H, dtype == 1 ? 3 : 1);
-    return z.X_rc + z.X_r8 + 2 * (z.h_rc + z.h_r8) + (with_dx ? 6 : 5) * z.g + (with_dx ? 2 : 1) * z.W1 + 4 * z.W23 + (dtype == 2 ? z.h_rc : 0);
+    return z.X_rc + z.X_r8 + 2 * (z.h_rc + z.h_r8) + (with_dx ? 6 : 5) * z.g + (with_dx ? 2 : 1) * z.W1 + 4 * z.W23 + (dtype == 2 ? z.h_rc : 0) +
+           DPD_SYNC_BYTES;
 }
 
 extern "C" int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, int H, int dtype, int with_dx, dpd_planes* out) {
@@ -956,6 +986,28 @@ extern "C" int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, 
     out->W2_rc = take(z.W23); out->W3_rc = take(z.W23);
     out->W1_rc = with_dx ? take(z.W1) : nullptr;
     out->h3_rc = (dtype == 2) ? take(z.h_rc) : nullptr;
+    out->sync = take(DPD_SYNC_BYTES);      // zeroed by dpd_planes_sync_reset / every dpd_patch_rows_fwd* given these planes
+    return 0;
+}
+
+extern "C" int dpd_planes_sync_reset(const dpd_planes* pl, void* stream) {
+    if (!pl) return DPD_E_NULL;
+    if (!pl->sync) return 0;
+    DPD_HIP(hipMemsetAsync(pl->sync, 0, DPD_SYNC_BYTES, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int dpd_planes_sync_status(const dpd_planes* pl, void* stream) {
+    if (!pl) return DPD_E_NULL;
+    if (!pl->sync) return 0;
+    unsigned err = 0;
+    DPD_HIP(hipMemcpyAsync(&err, (const unsigned*)pl->sync + 9, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DPD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return (int)(err & 0x7fffffffu);
+}
+
+extern "C" int dpd_set_chain_stamps(void* device_buf) {
+    dpd::g_chain_stamps = (unsigned long long*)device_buf;
     return 0;
 }
 
@@ -1022,6 +1074,29 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     if (pl) {   // operands from / results to the persistent planes (no conversion passes)
         X3Out o1 = make_out(pl, pl->h1_rc, Q, pl->h1_r8, pl->Qb, H), o2 = make_out(pl, pl->h2_rc, Q, pl->h2_r8, pl->Qb, H);
         const bool w1 = o1.rc || o1.r8, w2 = o2.rc || o2.r8;
+        // one plane, no fp32 copies of h1 / h2 wanted, whole tiles: layers 1 -> 2 -> 3 as ONE persistent launch (gemm_x3.hip: gemm_chain_kernel),
+        // bitwise the three launches below
+        const int ctile = (pl->np == 1 && pl->sync && !h1 && !h2 && pl->X_rc && pl->h1_rc && pl->h2_rc && pl->W1_r8 && pl->W2_r8 && pl->W3_r8 &&
+                           !(KP % 32) && (h3 || h3_plane))
+                              ? chain_tile(g_chain_fwd, Q, H, (pl->h1_r8 || pl->h2_r8) ? pl->Qb : 0) : 0;
+        if (ctile) {
+            ChainStage cs[3];
+            const uint16_t* a_in[3] = {(const uint16_t*)pl->X_rc, (const uint16_t*)pl->h1_rc, (const uint16_t*)pl->h2_rc};
+            const uint16_t* w_in[3] = {(const uint16_t*)pl->W1_r8, (const uint16_t*)pl->W2_r8, (const uint16_t*)pl->W3_r8};
+            const float* b_in[3] = {p->b1, p->b2, p->b3};
+            for (int i = 0; i < 3; ++i) {
+                cs[i].A = a_in[i]; cs[i].lda = i ? H : KP; cs[i].B = w_in[i]; cs[i].ldb = H; cs[i].b_fmt = 1; cs[i].K = i ? H : KP;
+                cs[i].bias = b_in[i]; cs[i].epilogue = EPI_BIAS_RELU;
+            }
+            cs[0].out = o1; cs[1].out = o2;
+            if (h3_plane) cs[2].out = make_out(pl, pl->h3_rc, Q, nullptr, 0, H);
+            else { cs[2].C = h3; cs[2].ldc = H; }
+            const int rc = gemm_chain(3, cs, Q, H, ctile, (unsigned*)pl->sync, g_chain_stamps, s);
+            if (rc != DPD_E_UNSUPPORTED) {
+                if (rc) return rc;
+                goto out_layer;
+            }
+        }
         if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s, nullptr,
                              pl->X_rc, pl->W1_r8, w1 ? &o1 : nullptr)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s, nullptr,
@@ -1035,6 +1110,7 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
     }
+out_layer:
     if (!y) return 0;
     DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
     DPD_CHECK_LAUNCH();
@@ -1268,6 +1344,27 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         }
         X3Out o2 = make_out(pl, pl->g2_rc, Qb, pl->g2_r8, Qb, H), o1 = make_out(pl, dX ? pl->g1_rc : nullptr, Qb, pl->g1_r8, Qb, H);
         const bool w2 = o2.rc || o2.r8, w1 = o1.rc || o1.r8;
+        // one plane, both dH GEMMs wanted, no fp32 copies of g2 / g1: g3 -> g2 -> g1 as ONE persistent launch, bitwise the two launches below
+        const int ctile = ((phases & 6) == 6 && pl->np == 1 && pl->sync && !g2 && !g1 && !h2 && !h1 && pl->g3_rc && pl->g2_rc && w1 && pl->W3_rc &&
+                           pl->W2_rc && (pl->h2_r8 || pl->h2_rc) && (pl->h1_r8 || pl->h1_rc))
+                              ? chain_tile(g_chain_bwd, Qb, H, Qb) : 0;
+        if (ctile) {
+            ChainStage cs[2];
+            cs[0].A = (const uint16_t*)pl->g3_rc; cs[0].B = (const uint16_t*)pl->W3_rc; cs[0].out = o2; cs[0].colsum = db2;
+            cs[0].gate16 = (const uint16_t*)(pl->h2_r8 ? pl->h2_r8 : pl->h2_rc); cs[0].gate16_r8 = pl->h2_r8 != nullptr;
+            cs[1].A = (const uint16_t*)pl->g2_rc; cs[1].B = (const uint16_t*)pl->W2_rc; cs[1].out = o1; cs[1].colsum = db1;
+            cs[1].gate16 = (const uint16_t*)(pl->h1_r8 ? pl->h1_r8 : pl->h1_rc); cs[1].gate16_r8 = pl->h1_r8 != nullptr;
+            for (int i = 0; i < 2; ++i) { cs[i].lda = H; cs[i].ldb = H; cs[i].b_fmt = 0; cs[i].K = H; cs[i].epilogue = EPI_GATE; }
+            const int rc = gemm_chain(2, cs, Qb, H, ctile, (unsigned*)pl->sync, g_chain_stamps, s);
+            if (rc != DPD_E_UNSUPPORTED) {
+                if (rc) return rc;
+                phases &= ~6;
+                if (dX)
+                    if (int rc2 = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s, nullptr,
+                                          pl->g1_rc, pl->W1_rc, nullptr)) return rc2;
+                return 0;
+            }
+        }
         if (phases & 2)
             if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2, pl->g3_rc,
                                  pl->W3_rc, w2 ? &o2 : nullptr, nullptr, h2 ? nullptr : (pl->h2_r8 ? pl->h2_r8 : pl->h2_rc), pl->h2_r8 != nullptr)) return rc;
@@ -1401,6 +1498,11 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                 if (split == 1 && !g_x3_pair_tile) ptile = 3;
             }
             size_t slab_b = ws_bytes;
+            if (split > 1 && ws_ok) {                             // ... with no more slices than the slab region holds (tile-padded)
+                const int rows2[2] = {Kin, Kin};
+                split = x3_fit_split(ptile ? ptile : 2, split, rows2, 2, Nout, base_b - kRedCntBytes);
+                if (split == 1 && !g_x3_pair_tile) ptile = 3;
+            }
             if (split > 1) {                                      // in-launch reduction
                 const int chunk = (((Qb + split - 1) / split) + 63) / 64 * 64;
                 if (!ws_ok || ptile > 5 || chunk * (split - 1) >= Qb) split = 1;
@@ -1462,8 +1564,10 @@ extern "C" int dpd_decoder_bwd_weights_trio(int Qb, int KP, int H, int dtype, fl
     size_t slab_b = 0;
     if (split > 1) {
         const size_t base_b = base_ws_bytes(KP > H ? KP : H, H);
+        const int rows3[3] = {KP, H, H};
+        if (ws && ws_bytes >= base_b) split = x3_fit_split(tile, split, rows3, 3, H, base_b - kRedCntBytes);
         const int chunk = (((Qb + split - 1) / split) + 63) / 64 * 64;
-        if (!ws || ws_bytes < base_b || chunk * (split - 1) >= Qb) split = 1;
+        if (split <= 1 || !ws || ws_bytes < base_b || chunk * (split - 1) >= Qb) split = 1;
         else { cnt = (char*)ws + base_b - kRedCntBytes; slab_b = base_b - kRedCntBytes; }
     }
     X3Extra ex;

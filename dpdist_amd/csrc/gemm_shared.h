@@ -351,6 +351,24 @@ struct X3Extra {
     int M3 = 0;
 };
 
+// one GEMM of a chained persistent launch (gemm_x3.hip: gemm_chain): C / planes [M, N] = epi(A B) with A an RC plane [M][lda] (k contiguous;
+// for every stage but the first it IS the previous stage's out.rc) and B as R8 planes (b_fmt 1: [K/8][N][8], forward) or RC planes
+// (b_fmt 0: [N][K], the data gradients); one bf16 plane
+struct ChainStage {
+    const uint16_t* A = nullptr;
+    int lda = 0;
+    const uint16_t* B = nullptr;
+    int ldb = 0, b_fmt = 1, K = 0;
+    const float* bias = nullptr;
+    const uint16_t* gate16 = nullptr;
+    int gate16_r8 = 0, epilogue = 0;
+    float* colsum = nullptr;
+    X3Out out;
+    float* C = nullptr;      // fp32 result: last stage only
+    int ldc = 0;
+};
+int gemm_chain(int nst, const ChainStage* st, int M, int N, int tile, unsigned* sync, unsigned long long* stamps, hipStream_t s);
+
 struct SplitJob {
     const float* src;
     uint16_t* rc;

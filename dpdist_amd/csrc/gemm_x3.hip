@@ -19,266 +19,9 @@
 //
 // Kernel structure = gemm_f32.hip's LDS-DMA ring: NS stages, pieces issued NS-1 K-tiles ahead, one raw s_barrier per
 // K-tile, counted vmcnt, fragments requested one k16-step ahead of their MFMAs.
-#include <atomic>
-#include <cstdlib>
-#include <type_traits>
-
-#include "gemm_shared.h"
+#include "gemm_x3.h"
 
 namespace dpd {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct X3Args {
-    GemmArgs e;           // epilogue view: C, bias, gate, colsum, M, N, K, ldc, epi, split (A/B/lda/ldb unused)
-    const uint16_t* A;    // plane 0 of A
-    const uint16_t* B;
-    long a_plane, b_plane;   // elements between planes
-    int lda, ldb;            // RC: row stride (elements); R8: entries per k-group row
-    // optional plane outputs of C (np_out planes each), written by the LDS-staged epilogue:
-    uint16_t* out_rc;        // RC planes [np_out][M][ld_rc]   (C is the k-contiguous operand of the next GEMM)
-    uint16_t* out_r8;        // R8 planes [np_out][r8_rows/8][N][8], rows < r8_rows only (C as a k = row operand)
-    long rc_plane, r8_plane;
-    int ld_rc, r8_rows, np_out;
-    // optional second problem of identical shape and layout (grouped launch): blocks [per_z, 2*per_z)
-    const uint16_t* A2;
-    const uint16_t* B2;
-    float* C2;
-    // round 4 (ring kernel only, plain products): the grouped problems may differ in M (rows of A^T / C), and there may be three of
-    // them -- the three weight gradients of the bf16 step in ONE launch (dW1 2528 x 1024, dW2 and dW3 1024 x 1024, K = query rows):
-    // each alone leaves 96-192 of the 256 CUs idle for the 27 us its K loop takes.  0 = same as problem 0.
-    int M2, lda2;
-    long a_plane2;
-    const uint16_t* A3;
-    const uint16_t* B3;
-    float* C3;
-    int M3, lda3;
-    long a_plane3;
-    // in-launch split-K (red_cnt != NULL; e.split_k slices of e.k_chunk per output tile): every slice parks its raw accumulators in
-    // red_slab, the slice that arrives LAST at the tile's counter adds all slices in slice order and runs the normal epilogue on C
-    float* red_slab;               // [tiles (x2 grouped)][split][BM*BN] floats, accumulator-register order (lane-linear 16-byte pieces)
-    unsigned long long* red_cnt;   // [tiles (x2 grouped)] arrival words {generation : 32, arrivals : 32}
-    unsigned red_gen;              // generation of this launch: a word of another generation (workspace garbage, an aborted launch) counts as 0
-    int red_sc1;                   // != 0: slabs published by write-through (sc1) stores and read by sc1 loads, no release / acquire fence
-};
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// chunk index inside an operand-plane image
-template <bool KC, int BO, int CPR>
-__device__ __forceinline__ int chunk_of(int o, int kg) {
-    return KC ? o * CPR + (kg ^ ((o / (16 / CPR)) & (CPR - 1))) : kg * BO + o;
-}
-
-// ---- "RCT" operand images (round 3): an operand whose contraction index is its ROW index, read straight from its RC plane.
-// The R8 planes exist only so that such an operand's MFMA fragment (8 consecutive k for one row/column) is one ds_read_b128; on
-// gfx950 the LDS transpose read does the same from a row-major image: ds_read_b64_tr_b16 gives every lane of a 16-lane group four
-// consecutive ROWS of its own column (measured semantics, tools/tr_read_probe.hip: output lane i, element j = element i % 4 of the
-// 8-byte piece addressed by lane i/4 + 4j of the group).  Image [BK rows (k)][BO columns] bf16, lane-linear for the LDS-DMA (a 1-KiB
-// piece = 64 / (BO/8) whole row segments); the 16-byte chunk c of row r sits in slot c ^ 2 (r & 3), chosen on the DMA's per-lane
-// SOURCE address, so that the four rows a 16-lane group reads fall on different banks.  With it the activations, the pre-activation
-// gradients and the gathered rows would need no R8 plane at all (63 MB less to write per bf16 step at B = 64).  MEASURED SLOWER and therefore
-// opt-in only (a_fmt = b_fmt = 2 of dpd_gemm_planes, tested like every other form): dW1 at B = 64 40.2 -> 47.1 us, one dW2 32.5 -> 40.8 us,
-// three planes 89.8 -> 96.4 / 54.1 -> 66.9 us (tools/tr_probe2.py) -- two LDS reads per fragment instead of one and 256-byte row
-// segments instead of fully linear 1-KiB DMA pieces cost as much as the R8 planes do.
-typedef short v4i16 __attribute__((ext_vector_type(4)));
-
-template <int BO>
-__device__ __forceinline__ int rct_chunk(int row, int c) {
-    return row * (BO / 8) + (c ^ ((row & 3) << 1));
-}
-
-// fragment of the 32 columns starting at `o32` (multiple of 32) for the k16 step kb of a K-tile: lane (l31, half) <- rows 16 kb + 8 half + 0..7
-template <int BO>
-__device__ __forceinline__ bf16x8 rct_frag(const char* img, int o32, int kb, int lane) {
-    const int s16 = lane & 15, grp = lane >> 4;
-    const int col = o32 + 16 * (grp & 1) + 4 * (s16 & 3);                 // first column of the 8-byte piece this lane SUPPLIES
-    const int row = 16 * kb + 8 * (grp >> 1) + (s16 >> 2);                // its row (first read); +4 for the second read
-    typedef __attribute__((address_space(3))) v4i16* lp;
-    const v4i16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)((unsigned)(uintptr_t)(lds_ptr_t)img + rct_chunk<BO>(row, col >> 3) * 16 + (col & 7) * 2));
-    const v4i16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)((unsigned)(uintptr_t)(lds_ptr_t)img + rct_chunk<BO>(row + 4, col >> 3) * 16 + (col & 7) * 2));
-    typedef short v8i16 __attribute__((ext_vector_type(8)));
-    const v8i16 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-// Epilogue shared by the plane GEMM kernels: fp32 store with bias / ReLU / gate / column sums, and -- when plane outputs are
-// requested -- the finished tile staged through the (idle) LDS ring so that the next GEMMs find their operands as bf16 planes.
-// NP = planes of the kernel = planes of its plane outputs (gemm_x3() checks it): compile time, so that the one-plane type converts
-// each value once instead of running the three-plane split and dropping two thirds of it (the split was most of this epilogue's
-// time: 11.4k cycles to write a 64 KB RC plane of a 256x128 tile against 9.1k for the 128 KB fp32 tile, tools/p8_stamps.py)
-template <int BM, int BN, int NW, int TM, int TN, int NP>
-__device__ __forceinline__ void x3_epilogue(const X3Args& g, f32x16 (&acc)[TM][TN], char* smem_x3, int grp, int z, int m0, int n0,
-                                            int wm0, int wn0, int tid, int l31, int half) {
-    const int M = g.e.M, N = g.e.N;
-    if (!g.out_rc && !g.out_r8) {
-        GemmArgs ge = g.e;
-        if (grp == 1) { ge.C = g.C2; if (g.M2) ge.M = g.M2; }
-        if (grp == 2) { ge.C = g.C3; ge.M = g.M3; }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) store_tile(ge, acc[i][j], z, m0 + wm0 + 32 * i, n0 + wn0 + 32 * j + l31, half);
-        return;
-    }
-    // Plane outputs straight from the accumulator registers (round 3; the round-2 form staged the tile through the idle LDS ring as fp32
-    // and re-read it in both chunk orientations: two barriers, 64 ds_write_b32 and 24 LDS reads per lane).  A lane of a 32x32 accumulator
-    // tile holds ONE column and the rows (r & 3) + 8 (r >> 2) + 4 half, so after packing, dword pair g of a lane = rows 8g + 4 half + 0..3:
-    //   R8 chunks (8 consecutive rows of one column): rows 8g .. 8g+3 sit in this lane's half, 8g+4 .. 8g+7 in lane + 32: one
-    //   v_permlane32_swap per packed dword hands the lower half the chunks of the even row groups and the upper half those of the odd
-    //   ones (semantics probed in tools/permlane_probe.hip) -> one 16-byte store per pair of row groups and plane, lanes contiguous.
-    //   RC chunks (8 consecutive columns of one row) need a 16-bit transpose.  Interior tiles: every wave parks its packed dword pairs
-    //   in a private 2.25-KiB strip of the idle LDS ring (4 ds_write_b64) and takes them back through the gfx950 transpose read
-    //   (ds_read_b64_tr_b16: output lane i, element j of a 16-lane group = element i % 4 of the piece addressed by lane i/4 + 4j,
-    //   tools/tr_read_probe.hip): lane s of a group addresses column 8 (s & 3) + (s >> 2) of one four-row group, so that output lane i
-    //   receives columns 8 (i >> 2) + 0..3 of row i & 3, a second read (+4 columns) completes the 16-byte chunk -> 4 LDS writes, 4 LDS
-    //   reads and 2 stores per tile and plane, no cross-lane VALU work (the all-VALU form -- in-quad DPP transpose, then lanes 4 apart
-    //   trading row groups -- is ~100 VALU instructions per tile and plane; it stays below for the tiles that cross the matrix edge).
-    //   Strip layout: piece (column c, four-row group rg) at ((36 rg + c) * 8 bytes: writes are lane-linear, the 16 pieces of a
-    //   transpose read hit 16 different bank pairs and the neighbouring group (rg + 1, +288 bytes) the other 16.
-    // Bit-identical to converting the stored fp32 tile (tests: test_gemm_planes_fused_outputs).
-    constexpr int STRIP = 36 * 8 * 8;                      // bytes per wave and plane
-    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool interior = m0 + wm0 + 32 * TM <= M && n0 + wn0 + 32 * TN <= N && (!g.out_r8 || m0 + wm0 + 32 * TM <= g.r8_rows) &&
-                          !(g.ld_rc & 7) && !(N & 7);
-    if (g.out_rc) __builtin_amdgcn_s_barrier();            // every wave is done reading the ring (all DMA pieces were waited for in the K loop)
-    if (interior) {
-        const int lane = tid & 63, s16 = lane & 15, G = lane >> 4;
-        const unsigned strip = (unsigned)(uintptr_t)(lds_ptr_t)smem_x3 + wave_id * (NP * STRIP);
-        const unsigned wr_addr = strip + (half * 36 + l31) * 8;                                   // + 576 g (+ STRIP q)
-        const unsigned rd_addr = strip + (G * 36 + 8 * (s16 & 3) + (s16 >> 2)) * 8;               // + 32 (second read) + 1152 p (+ STRIP q)
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(3))) u32x2* lds_u2;
-        typedef __attribute__((address_space(3))) v4i16* lds_v4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float v[16];
-                const int grow0 = m0 + wm0 + 32 * i, gcol0 = n0 + wn0 + 32 * j;
-                tile_values(g.e, acc[i][j], grow0, gcol0 + l31, half, v);
-                put_tile(g.e, v, z, grow0, gcol0 + l31, half);
-                unsigned pk[NP][8];                              // pk[q][2g + h] = rows 8g + 4 half + 2h, + 2h + 1 of plane q
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    unsigned lo[3], hi[3];
-                    if (NP == 1) {
-                        lo[0] = bf16_bits(v[r]);
-                        hi[0] = bf16_bits(v[r + 1]);
-                    } else {
-                        split3(v[r], lo);
-                        split3(v[r + 1], hi);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) pk[q][r >> 1] = lo[q] | (hi[q] << 16);
-                }
-                if (g.out_rc) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-#pragma unroll
-                        for (int gi = 0; gi < 4; ++gi)
-                            *(lds_u2)(uintptr_t)(wr_addr + q * STRIP + 576 * gi) = u32x2{pk[q][2 * gi], pk[q][2 * gi + 1]};
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-#pragma unroll
-                        for (int p = 0; p < 2; ++p) {
-                            const v4i16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(rd_addr + q * STRIP + 1152 * p));
-                            const v4i16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(uintptr_t)(rd_addr + q * STRIP + 1152 * p + 32));
-                            const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
-                            const int row = grow0 + 16 * p + 4 * G + (s16 & 3);
-                            *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)row * g.ld_rc + gcol0 + 8 * (s16 >> 2)) =
-                                make_uint4(ua.x, ua.y, ub.x, ub.y);
-                        }
-                    asm volatile("" ::: "memory");
-                }
-                if (g.out_r8) {
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp)
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) {
-                            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[q][4 * gp], pk[q][4 * gp + 2], false, false);
-                            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[q][4 * gp + 1], pk[q][4 * gp + 3], false, false);
-                            const int rowg = grow0 + 8 * (2 * gp + half);
-                            *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(rowg >> 3) * N + gcol0 + l31) * 8) =
-                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        }
-                }
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float v[16];
-            const int grow0 = m0 + wm0 + 32 * i, gcol0 = n0 + wn0 + 32 * j;
-            tile_values(g.e, acc[i][j], grow0, gcol0 + l31, half, v);
-            put_tile(g.e, v, z, grow0, gcol0 + l31, half);
-            unsigned pv[16][NP];                              // bf16 planes of the 16 values
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (NP == 1) {
-                    pv[r][0] = bf16_bits(v[r]);
-                } else {
-                    unsigned p3[3];
-                    split3(v[r], p3);
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) pv[r][q] = p3[q];
-                }
-            }
-            if (g.out_rc) {
-                // after the in-quad transpose lane 4q+j holds columns 4q..4q+3 of row 8 gi + 4 half + j (8 bytes per plane); lanes 4 apart
-                // (q even / odd) then trade row groups pairwise, so that every lane owns ONE 16-byte chunk (8 columns) per pair of row groups
-                const int jq = l31 & 3, qodd = (l31 >> 2) & 1;
-                const int col8 = gcol0 + ((l31 >> 3) << 3);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    uint2 w[4];
-#pragma unroll
-                    for (int gi = 0; gi < 4; ++gi) {
-                        float a[4] = {__uint_as_float(pv[4 * gi][q]), __uint_as_float(pv[4 * gi + 1][q]), __uint_as_float(pv[4 * gi + 2][q]),
-                                      __uint_as_float(pv[4 * gi + 3][q])};     // (16-bit payloads moved as 32-bit lanes)
-                        quad_transpose4(a, l31);
-                        w[gi] = make_uint2(__float_as_uint(a[0]) | (__float_as_uint(a[1]) << 16), __float_as_uint(a[2]) | (__float_as_uint(a[3]) << 16));
-                    }
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        // even-q lanes keep row group 2 gp and receive its upper four columns from lane + 4; odd-q lanes keep 2 gp + 1
-                        // and receive its lower four columns from lane - 4
-                        const uint2 give = qodd ? w[2 * gp] : w[2 * gp + 1], keep = qodd ? w[2 * gp + 1] : w[2 * gp];
-                        const unsigned ux = (unsigned)__builtin_amdgcn_mov_dpp((int)give.x, 0x104, 0xf, 0xf, true);   // row_shl:4: from lane + 4
-                        const unsigned uy = (unsigned)__builtin_amdgcn_mov_dpp((int)give.y, 0x104, 0xf, 0xf, true);
-                        const unsigned dx = (unsigned)__builtin_amdgcn_mov_dpp((int)give.x, 0x114, 0xf, 0xf, true);   // row_shr:4: from lane - 4
-                        const unsigned dy = (unsigned)__builtin_amdgcn_mov_dpp((int)give.y, 0x114, 0xf, 0xf, true);
-                        const uint4 chunk = qodd ? make_uint4(dx, dy, keep.x, keep.y) : make_uint4(keep.x, keep.y, ux, uy);
-                        const int row = grow0 + 8 * (2 * gp + qodd) + 4 * half + jq;
-                        if (row < M && col8 < N) *reinterpret_cast<uint4*>(g.out_rc + q * g.rc_plane + (size_t)row * g.ld_rc + col8) = chunk;
-                    }
-                }
-            }
-            if (g.out_r8) {
-                const int col = gcol0 + l31;
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    const int rowg = grow0 + 8 * (2 * gp + half);            // first row of the row group this lane ends up holding
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) {
-                        const unsigned X0 = pv[8 * gp][q] | (pv[8 * gp + 1][q] << 16), X1 = pv[8 * gp + 2][q] | (pv[8 * gp + 3][q] << 16);
-                        const unsigned Y0 = pv[8 * gp + 4][q] | (pv[8 * gp + 5][q] << 16), Y1 = pv[8 * gp + 6][q] | (pv[8 * gp + 7][q] << 16);
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(X0, Y0, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(X1, Y1, false, false);
-                        if (rowg < g.r8_rows && col < N)
-                            *reinterpret_cast<uint4*>(g.out_r8 + q * g.r8_plane + ((size_t)(rowg >> 3) * N + col) * 8) =
-                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    }
-                }
-            }
-        }
-}
 
 // In-launch split-K reduction (cdna_hip_programming.md, "In-launch split-K reduction"; the dW GEMMs of the bf16 step: K = query rows
 // is long, M x N gives 64-160 tiles of 128x128 for 256 CUs).  One agent-scope release per slice, one agent-scope acquire per tile:
@@ -573,257 +316,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_x3_kernel(X3Args g) {
     x3_epilogue<BM, BN, NW, TM, TN, NP>(g, acc, smem_x3, grp, z, m0, n0, wm0, wn0, tid, l31, half);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// gemm_p8_kernel: one bf16 plane, BK = 64, phase-staggered schedule (the "8-phase" structure of the CDNA4 guide, section 5,
-// re-derived for this library's chunked plane layouts and 32x32x16 MFMAs).
-//
-// The lock-step ring kernel above is additive: every wave issues its LDS-DMA pieces, then its fragment reads, then its MFMAs,
-// and all eight waves do each of these at the same time (MFMA 25 us + DMA issue 16 us + fragment reads 7 us on
-// the layer-1 shape).  Here the workgroup is two GROUPS of NW/2 waves (waves w and w + NW/2 share a SIMD) that run the same
-// program ONE BARRIER APART, so that on every SIMD one wave is inside its MFMA cluster (at raised priority) while the other
-// issues ds_reads and DMA pieces:
-//
-//     K-tile t = phases 2t (k16 steps 0,1) and 2t+1 (steps 2,3); stage = t % 3 (three whole K-tiles of LDS).
-//     phase p of a wave:   LOAD(p): fragment reads of phase p; DMA pieces: p = 2t   -> second half of this wave's pieces of K-tile t+1
-//                                                                          p = 2t+1 -> first half of K-tile t+2;
-//                                   odd p: s_waitcnt vmcnt(first half of t+2 stays in flight)  => my pieces of K-tile t+1 landed
-//                          s_barrier (B1)    MFMA(p): TM*TN*2 MFMAs, s_setprio 1    s_barrier (B2)
-//     group 1 executes one extra barrier before phase 0 and group 0 one after the last phase: between two consecutive
-//     workgroup barriers one group is in LOAD, the other in MFMA.
-//
-// Hazards (global barrier index: group 0 passes 2p / 2p+1 around MFMA(p), group 1 passes 2p+1 / 2p+2):
-//   RAW  K-tile t+1 is read from LOAD(2t+2) on.  Every wave waits for its own pieces of t+1 before ITS B1(2t+1) (index 4t+2 for
-//        group 0, 4t+3 for group 1); group 0's LOAD(2t+2) starts after index 4t+3, group 1's after 4t+4: behind both.
-//   WAR  K-tile t+2 goes to stage (t+2)%3 = (t-1)%3, last read in LOAD(2t-1), whose reads have returned before that wave's
-//        MFMA(2t-1) ends (the MFMAs consume them), i.e. before index 4t-1 (group 0) / 4t (group 1).  The first pieces of t+2 are
-//        issued in LOAD(2t+1): after index 4t+1 (group 0) / 4t+2 (group 1): behind both.
-// K % 64 == 32 (the decoder's 2528): the lanes whose chunk lies beyond K in the last K-tile fetch a zero chunk instead.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) const unsigned g_zero_chunk[4] = {0u, 0u, 0u, 0u};
-#ifdef DPD_ABLATIONS
-// ABL & 32: wave 0 of every workgroup leaves s_memtime stamps at the kernel's milestones (tools/p8_stamps.py)
-__device__ unsigned long long g_p8_stamps[1024 * 8];
-#define P8_STAMP(i) do { if ((ABL & 32) && tid == 0) g_p8_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define P8_STAMP(i) do { } while (0)
-#endif
-
-// ABL (timing-only, -DDPD_ABLATIONS): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no stagger, 16 = no setprio
-// NP planes (1: BK = 64, two k16 steps per phase; 3: BK = 32, one k16 step = six MFMA terms per phase): a K-tile is 48 KiB of LDS for
-// a 256x128 (NP = 1) or 128x128 (NP = 3) tile either way.
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
-__global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
-    constexpr int BK = NP == 1 ? 64 : 32, NS = 3, CPR = BK / 8, KS = BK / 32;   // KS = k16 steps per phase (half a K-tile)
-    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, NW = WR * WC;
-    constexpr int A_IMG = BM * CPR, B_IMG = BN * CPR, PL = A_IMG + B_IMG, STAGE = NP * PL;   // chunks of 16 B
-    constexpr int PA = A_IMG / 64, PB = B_IMG / 64;                            // 1-KiB pieces per plane image
-    constexpr int PPW = NP * (PA + PB) / NW, HP = PPW / 2;                     // pieces per wave per K-tile / per phase
-    static_assert((NP * (PA + PB)) % NW == 0 && PPW % 2 == 0, "piece split");
-    static_assert(NW % 2 == 0, "two wave groups");
-    static_assert(AK || BM % 64 == 0, "R8 images need 64-row pieces");
-    static_assert(BKC || BN % 64 == 0, "R8 images need 64-row pieces");
-    static_assert(NS * STAGE * 16 <= 160 * 1024, "LDS");
-    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
-
-    const int tid = threadIdx.x;
-    P8_STAMP(0);
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wgrp = __builtin_amdgcn_readfirstlane(wave / (NW / 2));          // 0: waves 0..NW/2-1, 1: the rest
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm0 = (wave / WC) * 32 * TM, wn0 = (wave % WC) * 32 * TN;
-
-    const int M = g.e.M, N = g.e.N;
-    const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
-    const int per_z = tilesM * tilesN;
-    const int sid0 = xcd_remap(blockIdx.x, per_z * (g.A2 ? 2 : 1));
-    const int grp = sid0 / per_z;
-    const int t0 = sid0 % per_z;
-    const uint16_t* gA = grp ? g.A2 : g.A;
-    const uint16_t* gB = grp ? g.B2 : g.B;
-    const int m0 = (t0 / tilesN) * BM, n0 = (t0 % tilesN) * BN;
-    const int K = g.e.K;
-    const int nt = (K + BK - 1) / BK;
-    const int tail_groups = (K % BK) / 8;      // != 0: the last K-tile has this many valid k-groups (K % 8 == 0)
-    const bool ktail = tail_groups != 0;
-
-    const uint16_t* src[PPW];
-    long step[PPW];
-    unsigned dst[PPW];
-    unsigned tail_ok = 0;                      // bit j: this lane's chunk of piece j is inside K in the tail K-tile
-    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem_x3;
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-        const int p = wave + j * NW;
-        const int plane = p / (PA + PB), w = p % (PA + PB);
-        const bool isA = w < PA;
-        const int c = isA ? w : w - PA;
-        const bool kc = isA ? AK : BKC;
-        const uint16_t* base = isA ? gA + plane * g.a_plane : gB + plane * g.b_plane;
-        const int ld = isA ? g.lda : g.ldb;
-        const int o0 = isA ? m0 : n0;
-        const int O = isA ? M : N;
-        const int BO = isA ? BM : BN;
-        dst[j] = lds_base + (unsigned)(plane * PL + (isA ? 0 : A_IMG) + c * 64) * 16u;
-        int kg;
-        if (kc) {
-            const int row = c * (64 / CPR) + lane / CPR, slot = lane % CPR;
-            kg = slot ^ ((row / (16 / CPR)) & (CPR - 1));
-            src[j] = base + (size_t)min(o0 + row, O - 1) * ld + 8 * kg;
-            step[j] = BK;
-        } else {
-            const int lin = c * 64 + lane;
-            kg = lin / BO;
-            const int o = lin % BO;
-            src[j] = base + ((size_t)kg * ld + min(o0 + o, O - 1)) * 8;
-            step[j] = (long)CPR * ld * 8;
-        }
-        tail_ok |= (kg < tail_groups ? 1u : 0u) << j;
-    }
-    // pieces [j0, j0 + cnt) of K-tile `tile` into stage `stage`; every piece is issued exactly once per K-tile, in K-tile order
-    auto issue = [&](int tile, int stage, auto j0c, auto cntc) {
-        constexpr int j0 = decltype(j0c)::value, cnt = decltype(cntc)::value;
-        const bool tail = ktail && tile == nt - 1;
-#pragma unroll
-        for (int j = j0; j < j0 + cnt; ++j) {
-            const void* sp = src[j];
-            if (tail && !((tail_ok >> j) & 1u)) sp = g_zero_chunk;
-            dma_piece(sp, dst[j] + (unsigned)(stage * STAGE) * 16u);
-            src[j] += step[j];
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using IH = std::integral_constant<int, HP>;
-    using IP = std::integral_constant<int, PPW>;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // prologue: K-tiles 0 and 1 whole; K-tile 0 landed and visible before anybody's LOAD(0)
-    P8_STAMP(1);
-    issue(0, 0, I0{}, IP{});
-    if (nt > 1) {
-        issue(1, 1, I0{}, IP{});
-        wait_vm<PPW>();
-    } else {
-        wait_vm<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    P8_STAMP(2);
-    if (wgrp == 1 && !(ABL & 8)) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
-
-    bf16x8 fa[KS][NP][TM], fb[KS][NP][TN];
-    auto phase = [&](int t, auto stc, auto hc) {
-        constexpr int st = decltype(stc)::value, h = decltype(hc)::value;
-        const char* sbase = smem_x3 + (size_t)st * STAGE * 16;
-        // ---- LOAD(p) ----
-#pragma unroll
-        for (int s2 = 0; s2 < ((ABL & 4) ? (t == 0 && h == 0 ? KS : 0) : KS); ++s2) {
-            const int kg = 2 * (KS * h + s2) + half;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[s2][p][i] = *reinterpret_cast<const bf16x8*>(sbase + (p * PL + chunk_of<AK, BM, CPR>(wm0 + 32 * i + l31, kg)) * 16);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[s2][p][j] =
-                        *reinterpret_cast<const bf16x8*>(sbase + (p * PL + A_IMG + chunk_of<BKC, BN, CPR>(wn0 + 32 * j + l31, kg)) * 16);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (ABL & 1) {
-        } else if (h == 0) {
-            if (t >= 1 && t + 1 < nt) issue(t + 1, (st + 1) % NS, IH{}, IH{});
-        } else {
-            if (t + 2 < nt) issue(t + 2, (st + 2) % NS, I0{}, IH{});
-            if (!LATE_WAIT || wgrp == 1) {
-                if (t + 1 < nt) {
-                    if (t + 2 < nt) wait_vm<HP>();
-                    else wait_vm<0>();
-                }
-            }
-        }
-        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                  // B1
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMA(p) ----
-        if (!(ABL & 16)) __builtin_amdgcn_s_setprio(1);
-        if (NP == 3) {      // lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi, small terms first (same order as gemm_x3_kernel)
-            constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2)
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][ta[q] < NP ? ta[q] : 0][i], fb[s2][tb[q] < NP ? tb[q] : 0][j],
-                                                                                acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < KS; ++s2)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0][i], fb[s2][0][j], acc[i][j], 0, 0, 0);
-        }
-        if (!(ABL & 16)) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (LATE_WAIT && h == 1 && wgrp == 0 && !(ABL & 1)) {        // group 0's B2 is the barrier group 1 waits before: one MFMA cluster more to land
-            if (t + 1 < nt) {
-                if (t + 2 < nt) wait_vm<HP>();
-                else wait_vm<0>();
-            }
-        }
-        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                  // B2
-    };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    using C2 = std::integral_constant<int, 2>;
-    int t = 0;
-    for (; t + 3 <= nt; t += 3) {
-        phase(t, C0{}, C0{});
-        phase(t, C0{}, C1{});
-        phase(t + 1, C1{}, C0{});
-        phase(t + 1, C1{}, C1{});
-        phase(t + 2, C2{}, C0{});
-        phase(t + 2, C2{}, C1{});
-    }
-    if (t < nt) {
-        phase(t, C0{}, C0{});
-        phase(t, C0{}, C1{});
-        if (t + 1 < nt) {
-            phase(t + 1, C1{}, C0{});
-            phase(t + 1, C1{}, C1{});
-        }
-    }
-    if (wgrp == 0 && !(ABL & 8)) __builtin_amdgcn_s_barrier();      // group 0 catches up: every wave has passed the same number of barriers
-    P8_STAMP(3);
-    x3_epilogue<BM, BN, NW, TM, TN, NP>(g, acc, smem_x3, grp, 0, m0, n0, wm0, wn0, tid, l31, half);
-    P8_STAMP(4);
-}
-
-template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
-static int launch_p8(const X3Args& g, hipStream_t s) {
-    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN, BK = NP == 1 ? 64 : 32;
-    constexpr size_t ring = (size_t)3 * NP * (BM + BN) * BK * 2, stage = (size_t)BM * (BN + 4) * 4;
-    constexpr size_t lds = ring > stage ? ring : stage;
-    static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = gemm_p8_kernel<NP, AK, BKC, WR, WC, TM, TN, LATE_WAIT, ABL>;
-    static LdsOptIn lds_opt;
-    if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
-    const int nblk = ((g.e.M + BM - 1) / BM) * ((g.e.N + BN - 1) / BN) * (g.A2 ? 2 : 1);
-    DPD_LAUNCH(kern, dim3(nblk), dim3(64 * WR * WC), lds, s, g);
-    return (int)hipGetLastError();
-}
-
 template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, int NS, int BK, int ABL = 0, bool TR = false>
 static int launch_x3(const X3Args& g, hipStream_t s) {
     constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
@@ -877,18 +369,12 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         // than the fragment traffic; kept selectable (dpd_set_gemm_plan(33, 15 | 16, 1)) and tested
         case 15: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 3, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 192x128, 4 waves of 96x64
         case 16: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 3, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x192, 4 waves of 64x96
-        // phase-staggered kernels (gemm_p8_kernel; K % 32 == 0, no split-K): one plane at BK = 64, three planes at BK = 32
-        case 20: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64
-        case 21: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // ... group 0 waits after its MFMAs
-        case 22: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 2, 4, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x256, 8 waves of 64x64
-        case 23: if (NP == 1 && g.e.split_k == 1) return launch_p8<1, AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 32x64
-        case 24: if (NP == 3 && g.e.split_k == 1) return launch_p8<3, AK, BKC, 4, 2, 1, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // 128x128, 8 waves of 32x64, 3 planes
-        case 25: if (NP == 3 && g.e.split_k == 1) return launch_p8<3, AK, BKC, 2, 4, 2, 1, true>(g, s); return DPD_E_UNSUPPORTED;    // 128x128, 8 waves of 64x32, 3 planes
-        case 26: if (NP == 3 && g.e.split_k == 1) return launch_p8<3, AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 24 with both groups waiting before B1
+        // phase-staggered kernels (gemm_p8.hip; K % 32 == 0, no split-K): one plane at BK = 64 (20..23), three planes at BK = 32 (24..26)
+        case 20: case 21: case 22: case 23: case 24: case 25: case 26:
+            return g.e.split_k == 1 ? launch_p8_code(NP, AK, BKC, tile, g, s) : DPD_E_UNSUPPORTED;
 #ifdef DPD_ABLATIONS
-#define DPD_P8_ABL(code) case 200 + code: if (NP == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true, code>(g, s); return DPD_E_UNSUPPORTED;
-        DPD_P8_ABL(32) DPD_P8_ABL(1) DPD_P8_ABL(2) DPD_P8_ABL(3) DPD_P8_ABL(4) DPD_P8_ABL(5) DPD_P8_ABL(7) DPD_P8_ABL(8) DPD_P8_ABL(16) DPD_P8_ABL(24)
-#undef DPD_P8_ABL
+        case 232: case 201: case 202: case 203: case 204: case 205: case 207: case 208: case 216: case 224:
+            return launch_p8_code(NP, AK, BKC, tile, g, s);
 #define DPD_X3_ABL(code) case 100 + code: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 1, 4, 32, code>(g, s); return DPD_E_UNSUPPORTED;
         DPD_X3_ABL(1) DPD_X3_ABL(2) DPD_X3_ABL(3) DPD_X3_ABL(4) DPD_X3_ABL(5) DPD_X3_ABL(7) DPD_X3_ABL(8) DPD_X3_ABL(9) DPD_X3_ABL(12) DPD_X3_ABL(13) DPD_X3_ABL(15)
 #undef DPD_X3_ABL
@@ -1069,11 +555,6 @@ int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, i
 
 }  // namespace dpd
 
-#ifdef DPD_ABLATIONS
-extern "C" int dpd_debug_p8_stamps(unsigned long long* host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dpd::g_p8_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 // ---- C ABI (building blocks; the decoder entry points use them when dtype != 0) -----------------------------
 extern "C" int dpd_split_planes(const float* src, int R, int C, int ld, int np, void* rc, int ld_rc, long rc_plane, void* r8,

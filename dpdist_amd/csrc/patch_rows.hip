@@ -192,13 +192,21 @@ __device__ unsigned long long g_pr_stamps[1024 * 8];       // s_memtime mileston
 #else
 #define PR_STAMP(i) do { } while (0)
 #endif
+// The producer of X_rc also zeroes the ticket / arrival words of the chained decoder launches that consume it (dpd_planes.sync, DPD_SYNC_BYTES):
+// block 0, a few stores; the kernel boundary publishes them
+__device__ __forceinline__ void zero_sync_words(unsigned* __restrict__ w) {
+    if (w && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < DPD_SYNC_BYTES / 4; i += blockDim.x) w[i] = 0u;
+}
+
 template <int NP>
 __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __restrict__ q, const float* __restrict__ fv,
                                                                  float* __restrict__ X, float* __restrict__ mask,
                                                                  int32_t* __restrict__ vox, int Q, int N, int m, int k, int KP,
                                                                  GridAxis ax, uint16_t* __restrict__ rc, long rc_plane,
                                                                  uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
-                                                                 const float* __restrict__ ssq, int nsl) {
+                                                                 const float* __restrict__ ssq, int nsl, unsigned* __restrict__ sync_zero) {
+    zero_sync_words(sync_zero);
     extern __shared__ __attribute__((aligned(16))) int2 s_tab[];               // [KP/4] per float4 unit: {offset in floats from the row's voxel, d0 | d1<<8 | d2<<16 | kind<<24}
     uint16_t* s_img = reinterpret_cast<uint16_t*>(s_tab + KP / 4);             // [NP][8][KP] (only when R8 planes are written)
     __shared__ RowInfo s_row[8];
@@ -324,7 +332,9 @@ void patch_rows_planes_lds_kernel(const float* __restrict__ q, const float* __re
                                                                     float* __restrict__ mask, int32_t* __restrict__ vox, int Q, int N,
                                                                     int m, int k, int KP, GridAxis ax, uint16_t* __restrict__ rc,
                                                                     long rc_plane, uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
-                                                                    const float* __restrict__ ssq, int nsl, unsigned mg_k, unsigned mg_kk) {
+                                                                    const float* __restrict__ ssq, int nsl, unsigned mg_k, unsigned mg_kk,
+                                                                    unsigned* __restrict__ sync_zero) {
+    zero_sync_words(sync_zero);
     extern __shared__ __attribute__((aligned(16))) int2 s_tab2[];             // [KP/4] unit table (as above), then the planes
     const int U = KP / 4, U2 = KP / 8;
     const int G = m * m * m, h = (k - 1) / 2, GF = G * kF;
@@ -787,6 +797,7 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
         if ((pl->np != 1 && pl->np != 3) || pl->Q != Q || pl->Qb > Q || pl->Qb < 0) return DPD_E_DIM;
         static const bool old_form = getenv("DPD_GATHER_PLANES_V1") != nullptr;      // A/B reference: the round-1 kernel
         if (old_form) {
+            if (pl->sync) DPD_HIP(hipMemsetAsync(pl->sync, 0, DPD_SYNC_BYTES, (hipStream_t)stream));
             DPD_LAUNCH(patch_rows_planes_kernel, dim3((Q / 8) * 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
                        KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
         } else if (!X && !(N & 7) && !getenv("DPD_GATHER_PLANES_V2") &&
@@ -800,12 +811,14 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
                 static LdsOptIn ll1;
                 if (int rc2 = ensure_dyn_lds(ll1, (const void*)patch_rows_planes_lds_kernel<1>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes_lds_kernel<1>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
-                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk);
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk,
+                           (unsigned*)pl->sync);
             } else {
                 static LdsOptIn ll3;
                 if (int rc2 = ensure_dyn_lds(ll3, (const void*)patch_rows_planes_lds_kernel<3>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes_lds_kernel<3>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
-                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk);
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk,
+                           (unsigned*)pl->sync);
             }
         } else {
             const size_t lds = (pl->X_r8 ? (size_t)pl->np * 8 * KP * sizeof(uint16_t) : 0) + (size_t)(KP / 4) * sizeof(int2);
@@ -814,12 +827,14 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
                 static LdsOptIn lo1;
                 if (int rc2 = ensure_dyn_lds(lo1, (const void*)patch_rows_planes3_kernel<1>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes3_kernel<1>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
-                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices,
+                           (unsigned*)pl->sync);
             } else {
                 static LdsOptIn lo3;
                 if (int rc2 = ensure_dyn_lds(lo3, (const void*)patch_rows_planes3_kernel<3>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes3_kernel<3>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
-                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
+                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices,
+                           (unsigned*)pl->sync);
             }
         }
         DPD_CHECK_LAUNCH();

@@ -42,7 +42,15 @@ class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
 class Planes(Structure):     # include/dpdist_capi.h: dpd_planes
     _fields_ = [("np", c_int), ("Q", c_int), ("Qb", c_int)] + [(n, c_void_p) for n in (
         "X_rc", "X_r8", "h1_rc", "h1_r8", "h2_rc", "h2_r8", "g3_rc", "g3_r8", "g2_rc", "g2_r8", "g1_rc", "g1_r8",
-        "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc", "h3_rc")]
+        "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc", "h3_rc", "sync")]
+
+
+class AsLoss(Structure):     # include/dpdist_capi.h: dpd_asloss (the as-loss engine; driven by dpdist_amd/asloss.py)
+    _fields_ = ([(n, c_int) for n in ("B", "N", "m", "k", "KP", "H", "dtype")] + [("sigma", c_float)] +
+                [(n, c_void_p) for n in ("pts", "q", "fv", "ssq", "mask", "vox", "X", "h1", "h2", "h3", "y", "pred", "dy", "g3", "g2", "g1",
+                                         "dX", "dfv", "dpts", "W2T", "W3T", "W1pT", "scratch")] +
+                [("mfv_ws", c_void_p), ("mfv_ws_bytes", c_size_t), ("ws", c_void_p), ("ws_bytes", c_size_t),
+                 ("planes", Planes), ("params", DecoderParams)])
 
 
 # name -> (restype, argtypes); mirrors include/dpdist_capi.h one to one
@@ -88,6 +96,16 @@ SIGNATURES = {
     "dpd_planes_bytes": (c_size_t, [c_int] * 6),
     "dpd_planes_carve": (c_int, [c_void_p, c_size_t] + [c_int] * 6 + [POINTER(Planes)]),
     "dpd_weights_to_planes": (c_int, [POINTER(DecoderParams), c_int, c_int, POINTER(Planes), c_void_p]),
+    "dpd_asloss_bytes": (c_size_t, [c_int] * 6),
+    "dpd_asloss_carve": (c_int, [c_void_p, c_size_t] + [c_int] * 6 + [c_float, POINTER(AsLoss)]),
+    "dpd_asloss_init": (c_int, [POINTER(AsLoss), c_void_p]),
+    "dpd_asloss_set_weights": (c_int, [POINTER(AsLoss), POINTER(DecoderParams), c_void_p]),
+    "dpd_asloss_forward": (c_int, [POINTER(AsLoss), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "dpd_asloss_backward": (c_int, [POINTER(AsLoss), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dpd_asloss_forward_backward": (c_int, [POINTER(AsLoss), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dpd_planes_sync_reset": (c_int, [POINTER(Planes), c_void_p]),
+    "dpd_planes_sync_status": (c_int, [POINTER(Planes), c_void_p]),
+    "dpd_set_chain_stamps": (c_int, [c_void_p]),
     "dpd_weights_transpose": (c_int, [POINTER(DecoderParams), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dpd_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p]),

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops
+from . import asloss, lib as L, ops
 
 TF_NAME = "pc_compare/dpdist_local/mapper_conv%d/%s"
 F = 20
@@ -89,6 +89,9 @@ class DPDistParams(nn.Module):
         update `flat` through raw device pointers (the trainer's Adam kernels never bump `flat._version`) must call this."""
         self._tr_key = None
         self._wplanes = None
+        for engines in self.__dict__.get("_asloss_engines", {}).values():      # the as-loss engines re-derive their weight copies
+            for e in engines:
+                e._wkey = None
 
     def cparams(self, flat=None):
         """The C-ABI pointer block of the 8 variables inside `flat` (include/dpdist_capi.h: dpd_decoder_params), cached per buffer
@@ -247,6 +250,17 @@ class _AsLossFn(torch.autograd.Function):
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
         ctx.fused_out = B * N < 16384 and os.environ.get("DPD_ASLOSS_CHAIN") != "1"
         ctx.planes = None
+        ctx.engine = None
+        # round 5: the whole evaluation behind ONE foreign call per direction on an engine's persistent buffers (dpdist_amd/asloss.py:
+        # same kernels, same bits; DPD_ASLOSS_ENGINE=0 = the entry-by-entry path below)
+        eng = asloss.acquire(P, flat, B, N, m, k, sigma, pcA.device) if ctx.fused_out else None
+        if eng is not None:
+            L.req(pcA, name="pcA", shape=(B, N, 3)), L.req(pcB, name="pcB", shape=(B, N, 3))
+            loss = eng.forward(pcA, pcB, need_grad)
+            if need_grad:
+                ctx.engine, ctx.engine_version = eng, eng.version
+                eng.hold(ctx)
+            return loss[0]
         if ctx.fused_out and ops.AsLossPlanes.usable(P, 2 * B * N, P.compute_dtype) and os.environ.get("DPD_ASLOSS_PLANES", "1") == "1":
             # plane compute types: the rows, h1, h2 (and g3 / g2 / g1 in the backward) live as bf16 RC planes written by their producers,
             # the frozen weights' planes are cached: no conversion launch per GEMM, no fp32 X / h1 / h2 (round 4; DPD_ASLOSS_PLANES=0 = before)
@@ -282,11 +296,19 @@ class _AsLossFn(torch.autograd.Function):
         B, N, m, k, sigma = ctx.cfg
         Q = 2 * B * N
         dt = P.compute_dtype
+        if ctx.engine is not None:
+            eng = ctx.engine
+            if eng.version != ctx.engine_version:
+                raise RuntimeError("DPDist as-loss node: its engine's buffers have been re-used by a later evaluation (a second backward after "
+                                   "the first one released them); set DPD_ASLOSS_ENGINE=0 for graphs that are differentiated repeatedly")
+            gA, gB = eng.backward(g)
+            eng.release()
+            return gA, gB, None, None, None, None, None
         if ctx.planes is not None:
             pts, flat, vox, g3 = ctx.saved_tensors
             _, _, _, _, dX = ops.decoder_bwd_data(None, None, None, None, None, None, P.cparams(flat), P.KP, True, dtype=dt, phases=6, g3=g3,
                                                   planes=ctx.planes)
-            ctx.planes = None
+            # (ctx.planes stays: a second backward through this node -- retain_graph -- recomputes g2 / g1 from the saved g3 and the intact h planes)
             _, dfv = ops.patch_rows_bwd(dX, vox, 2 * B, N, m, k, want_dq=False)
             dpts = ops.mfv3d_bwd(pts, dfv, m, sigma)
             gA, gB = ops.asloss_combine(dpts, dX, g, B, N, k)

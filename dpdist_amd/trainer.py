@@ -87,6 +87,9 @@ class DPDistTrainer:
             self._plane_mem = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             self._planes = L.Planes()
             L.check(lib.dpd_planes_carve(L.ptr(self._plane_mem), nbytes, Q, BN, KP, H, self.dt, 0, self._planes), "dpd_planes_carve")
+            # ticket / arrival words of the chained decoder launches (dpd_planes.sync): zero once here; the window gather re-zeroes them
+            # every step and every chained launch leaves them zero
+            L.check(lib.dpd_planes_sync_reset(self._planes, L.cur_stream()), "dpd_planes_sync_reset")
         # Plane compute types: layer 2/3, the weight gradients and the ReLU gate of the backward all read h1 / h2 from their bf16
         # planes, so the fp32 copies are not written at all (2 x 33.5 MB per forward at B = 64); DPD_KEEP_F32_H=1 keeps them
         if self._planes is None or os.environ.get("DPD_KEEP_F32_H", "0") == "1":

@@ -196,7 +196,21 @@ struct dpd_planes {
     void* h3_rc;  /* DPD_BF16 only (NULL otherwise): layer 3's activation as ONE bf16 plane [Q,H] instead of fp32 -- dpd_decoder_fwd writes it when
                    * h3 == NULL and y == NULL, the fused output-layer kernel of dpd_decoder_bwd_data (which then runs the output layer's forward
                    * as well: dpd_small_grads.fwd_y) reads it; 2 instead of 4 bytes per element written once and read once per step */
+    void* sync;   /* optional (NULL = never chain), DPD_SYNC_BYTES: ticket / arrival words of the CHAINED launches -- with it (and np == 1, whole
+                   * 128- or 256-row tiles, no fp32 copies of the intermediate results requested, and dpd_set_gemm_plan(48 / 49, 1, 0): opt-in)
+                   * dpd_decoder_fwd runs layers 1 -> 2 -> 3 and dpd_decoder_bwd_data (phases 2 | 4 together) the chain g3 -> g2 -> g1 as ONE
+                   * persistent launch each, bitwise the separate launches.  The words must be ZERO when such a launch starts and every launch leaves them zero; they are zeroed by
+                   * dpd_planes_sync_reset and by every dpd_patch_rows_fwd* that is given these planes (the producer of X_rc), so a caller that
+                   * follows the producer table above never sees a dirty word.  dpd_planes_sync_status reports a poll that gave up.            */
 };
+#define DPD_SYNC_BYTES 4096
+/* zero pl->sync on `stream` (no-op without sync words); call once after dpd_planes_carve when X_rc is not produced by dpd_patch_rows_fwd* */
+int dpd_planes_sync_reset(const dpd_planes* pl, void* stream);
+/* synchronises `stream` and returns the sticky error word of the chained launches (0 = every hand-off completed; bit 0 = a poll gave up
+ * after DPD_CHAIN_SPIN_LIMIT rounds and its tile was computed from incomplete rows), or a negative DPD_E_* / positive hipError_t        */
+int dpd_planes_sync_status(const dpd_planes* pl, void* stream);
+/* debug / measurement: s_memtime stamps of the chained launches' workgroups into `device_buf` ([256][4][8] uint64, NULL = off; process-wide) */
+int dpd_set_chain_stamps(void* device_buf);
 
 /* Bytes for ALL members (with_dx: also g1_rc and W1_rc, needed only when dX is requested), and the carve-up of one
  * caller buffer of that size into the members (host-side pointer arithmetic only).                          */
@@ -282,6 +296,49 @@ int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float 
  *   scratch: 8 bytes, 8-byte aligned, ZERO before the first call (the kernel leaves it zero; one per concurrently running stream). */
 int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
                            float* y, float* pred, float* loss_pred, float* dy, float* g3, float* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DPDist-as-a-loss ENGINE (round 5): the whole as-loss evaluation -- the reference's spliced graph
+ *   input1, input2 -> pc_compare/output1, output2 -> (mean(output1[...,0]) + mean(output2[...,0])) / 2
+ * (pcrnet-registration/iterative_PCRNet_ours.py:229-257, train_multi_gpu_pc_compare_dist.py:427-453) and its gradient w.r.t. the two
+ * clouds -- behind ONE entry point per direction, on buffers sized once for a fixed (B, N).  Same kernels, same order and same bits as
+ * calling dpd_mfv3d_fwd_stacked, dpd_patch_rows_fwd_scaled, dpd_decoder_fwd, dpd_decoder_out_asloss | dpd_decoder_bwd_data (phases 6),
+ * dpd_patch_rows_bwd, dpd_mfv3d_bwd, dpd_asloss_combine one by one; what it removes is the host: ~30 buffer allocations and a dozen
+ * foreign-function calls per evaluation bound the registration loop at its batch of 16 (8 evaluations per training step).
+ * All members point into ONE caller-owned allocation (dpd_asloss_bytes / dpd_asloss_carve: host-side pointer arithmetic only); the
+ * DPDist weights are frozen in this mode: dpd_asloss_set_weights derives what the compute type needs from them (transposed fp32
+ * copies or bf16 operand planes) ONCE and keeps the caller's parameter pointers -- call it again after the weights change.
+ * B*N < 16384, N <= 4096, H % 64 == 0; one engine per concurrently running stream.                                               */
+typedef struct dpd_asloss {
+    int B, N, m, k, KP, H, dtype;      /* dtype: enum dpd_dtype */
+    float sigma;
+    float *pts, *q, *fv, *ssq, *mask;  /* front end: [2B,N,3] x2, [2B,m^3,20], [2B,DPD_MFV_SLICES,20], [Q] */
+    int32_t* vox;                      /* [Q] */
+    float *X, *h1, *h2;                /* DPD_F32 only (NULL otherwise: the plane types keep them as bf16 planes) [Q,KP], [Q,H] x2 */
+    float *h3, *y, *pred, *dy, *g3;    /* [Q,H], [Q,3] x3, [Q,H] */
+    float *g2, *g1;                    /* DPD_F32 only */
+    float *dX, *dfv, *dpts;            /* [Q,KP], [2B,m^3,20], [2B,N,3] */
+    float *W2T, *W3T, *W1pT;           /* DPD_F32 only: transposed weight copies (dpd_asloss_set_weights) */
+    float* scratch;                    /* 8 bytes for dpd_decoder_out_asloss: zeroed by dpd_asloss_init */
+    void* mfv_ws; size_t mfv_ws_bytes; /* dpd_mfv3d_bwd_workspace_bytes(2B, m) */
+    void* ws; size_t ws_bytes;         /* dpd_workspace_bytes(Q, KP, H, dtype) */
+    dpd_planes planes;                 /* plane compute types: X, h1, h2, g3, g2, g1 as RC planes, the weights' R8 + RC planes, sync words */
+    dpd_decoder_params params;         /* filled by dpd_asloss_set_weights */
+} dpd_asloss;
+size_t dpd_asloss_bytes(int B, int N, int m, int k, int H, int dtype);
+int dpd_asloss_carve(void* mem, size_t bytes, int B, int N, int m, int k, int H, int dtype, float sigma, dpd_asloss* out);
+/* zero what must be zero before the first evaluation (the loss accumulator, the planes' sync words): once, on `stream` */
+int dpd_asloss_init(const dpd_asloss* e, void* stream);
+/* `e` is updated (its params member); p's W*T members are ignored (the engine owns its own transposed copies) */
+int dpd_asloss_set_weights(dpd_asloss* e, const dpd_decoder_params* p, void* stream);
+/* pcA, pcB [B,N,3] -> loss [1] (loss_pred, utils/dpdist_util.py:976-979).  want_grad != 0 also leaves what dpd_asloss_backward needs
+ * (the output-layer backward runs inside the same launch as the output layer).                                                    */
+int dpd_asloss_forward(const dpd_asloss* e, const float* pcA, const float* pcB, int want_grad, float* loss, void* stream);
+/* gradient of upstream * loss w.r.t. pcA / pcB -> gA, gB [B,N,3]; upstream = DEVICE scalar (NULL = 1).  Needs the state of the last
+ * dpd_asloss_forward(want_grad = 1) on this engine; may be called more than once for it.                                           */
+int dpd_asloss_backward(const dpd_asloss* e, const float* upstream, float* gA, float* gB, void* stream);
+/* both directions with upstream = 1 (callers without an autograd engine in between) */
+int dpd_asloss_forward_backward(const dpd_asloss* e, const float* pcA, const float* pcB, float* loss, float* gA, float* gB, void* stream);
 
 /* Host utility: CRC32C (Castagnoli, reflected, init/xorout ~0) of n bytes continuing from `crc` (0 to start); used
  * by the TensorFlow-checkpoint interchange of dpdist_amd/tf_checkpoint.py.  No device work.                 */
@@ -403,7 +460,10 @@ int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const voi
  * (0 = automatic), 32: its grouped dW2/dW3 launch, 33: the grouped dW1/dW2/dW3 launch of dpd_decoder_bwd_weights_trio.  tile as in
  * dpd_gemm_f32 (0 = auto); split_k applies to ops 4, 5, 8 and, for the plane weight gradients (ops 20, 21, 32, 33): n > 1 = n K slices
  * per tile reduced inside the launch (last-arriving slice, slice order: deterministic), n < -1 = |n| fp32 slabs + a reduce launch,
- * 1 = off, 0 = automatic.  Defaults are the measured best.                                                              */
+ * 1 = off, 0 = automatic.  op 48 / 49: the chained persistent launch of the one-plane forward (layers 1 -> 2 -> 3) / data-gradient chain
+ * (g3 -> g2 -> g1), see dpd_planes.sync: tile 0 = off (separate launches; the default: measured faster), 1 = automatic, 21 / 23 = force the
+ * 256x128 / 128x128 tile.
+ * Defaults are the measured best.                                                                                        */
 int dpd_set_gemm_plan(int op, int tile, int split_k);
 
 /* dW1, dW2 and dW3 of a plane compute type (dtype 1 / 2) in ONE grouped launch; all operands are the R8 planes of `pl`

@@ -2029,3 +2029,225 @@ def test_gemm_tail_split(dev, shape):
         assert same.any() and not same.all()                # the whole-K rows are bitwise the plain result, the tail rows are re-associated
         first_cut = int((~same).nonzero()[0])
         assert same[:first_cut].all() and first_cut % 64 == 0
+
+
+# ------------------------------------------------------------------------------------------------ chained persistent launches (round 5)
+def _chain_run(tr, pcA, pcB, lab, reps=1):
+    outs = []
+    for _ in range(reps):
+        tr._take_front(pcA, pcB, None)
+        tr._decode(skip_out=True)
+        tr.backward(lab.reshape(-1))
+        torch.cuda.synchronize()
+        outs.append((tr._plane_mem[:-4096].clone(), tr.grad.clone(), tr.loss.clone()))
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,tile", [(64, 21), (32, 23), (64, 23), (128, 21)])
+def test_chained_decoder_launches_are_bitwise_the_separate_launches(dev, B, tile):
+    """gemm_chain_kernel: layers 1 -> 2 -> 3 of the bf16 forward and the data-gradient chain g3 -> g2 -> g1 as ONE persistent launch each
+    (ticket queues, per-band arrival words, write-through plane stores) against the same GEMMs launched apart: every operand plane
+    (X, h1, h2, h3, g3, g2, g1: the whole plane allocation) bit for bit, under an uneven memory load on a second stream, five times over;
+    the ticket / arrival words are left zero and no poll gave up."""
+    from dpdist_amd import lib as L, ops
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    res = {}
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device=dev, dtype=torch.float32)
+    try:
+        for name, mode in (("apart", 0), ("chained", tile)):
+            ops.set_gemm_plan(48, mode, 0)
+            ops.set_gemm_plan(49, mode, 0)
+            P = DPDistParams(device=dev, compute_dtype="bf16")
+            P.load_tf_state_dict(synth.make_weights("wide"))
+            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+            if name == "chained":
+                with torch.cuda.stream(side):      # uneven load: a bandwidth hog that comes and goes while the chained launches run
+                    for i in range(40):
+                        junk[: (8 << 20) * (1 + i % 5)].mul_(1.0001)
+            res[name] = _chain_run(tr, pcA, pcB, lab, reps=5 if name == "chained" else 1)
+            side.synchronize()
+            if name == "chained":
+                assert L.load().dpd_planes_sync_status(tr._planes, L.cur_stream()) == 0
+                words = tr._plane_mem[-4096:].view(torch.int32)
+                assert int(words.abs().sum().item()) == 0, words.nonzero().flatten().tolist()
+    finally:
+        ops.set_gemm_plan(48, 0, 0)
+        ops.set_gemm_plan(49, 0, 0)
+    ref = res["apart"][0]
+    for i, got in enumerate(res["chained"]):
+        assert torch.equal(got[0], ref[0]), (i, int((got[0] != ref[0]).sum().item()))
+        assert torch.equal(got[2], ref[2]), i
+        # weight gradients: the same operand planes feed the same grouped launch; only the bias sums of the dH epilogues are fp32 atomics
+        assert (got[1] - ref[1]).abs().max().item() <= 2e-6 * ref[1].abs().max().item() + 1e-9
+
+
+@pytest.mark.gpu
+def test_chained_launch_reports_dirty_sync_words(dev):
+    """The ticket / arrival words must be zero at launch: garbage there is reported (the launch ends, dpd_planes_sync_status or the words
+    say so) instead of hanging, and dpd_planes_sync_reset (or the next window gather) makes the planes usable again."""
+    from dpdist_amd import lib as L, ops
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    B = 64
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    P = DPDistParams(device=dev, compute_dtype="bf16")
+    P.load_tf_state_dict(synth.make_weights("wide"))
+    tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+    ref = _chain_run(tr, pcA, pcB, lab)[0]                            # (separate launches: the default)
+    ops.set_gemm_plan(48, 1, 0)
+    ops.set_gemm_plan(49, 1, 0)
+    try:
+        _dirty_words_case(tr, pcA, pcB, lab, ref, L)
+    finally:
+        ops.set_gemm_plan(48, 0, 0)
+        ops.set_gemm_plan(49, 0, 0)
+
+
+def _dirty_words_case(tr, pcA, pcB, lab, ref, L):
+    tr._take_front(pcA, pcB, None)
+    tr._plane_mem[-4096:].view(torch.int32)[:256:32] = 1 << 30     # every ticket queue looks exhausted: no tile is computed
+    tr._plane_mem[: 1 << 20] = 0                                      # (poison a piece of what the forward should have rewritten)
+    tr._decode(skip_out=True)
+    torch.cuda.synchronize()
+    words = tr._plane_mem[-4096:].view(torch.int32)
+    assert int(words[:256].abs().sum().item()) == 0                   # the last workgroup out still cleans up
+    got = _chain_run(tr, pcA, pcB, lab)[0]                            # the next step (its gather zeroes the words) is right again
+    assert torch.equal(got[0], ref[0])
+    assert L.load().dpd_planes_sync_status(tr._planes, L.cur_stream()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ the headline workload's backward (round 5)
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [32, 64])
+@pytest.mark.parametrize("dt", ["f32", "f32x3"])
+def test_training_step_at_the_bench_shape_vs_oracle(dev, dt, B):
+    """ONE DPDistTrainer.step at the shape bench.py times (B = 32: BASELINE's metric; B = 64: configs 3-4's rows), S2 clouds of bench.py's
+    seed, `wide` weights, against the oracle's float64 autograd (train_multi_gpu_pc_compare_dist.py:274-302: loss_samples, the gradients of
+    the 8 variables, tf.train.AdamOptimizer): losses, every gradient tensor (norm, 16 x 16 corners, row and column sums, and the WHOLE tensor
+    elementwise) and the post-Adam weights.  Here BN = 2048 / 4096 rows carry gradient, i.e. the weight-gradient plan, its tile rounds and
+    the deterministic bias sums run as they do in the benchmark (the older step tests stop at B = 4)."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer, learning_rate
+    from oracle import restate as R
+    pcA, pcB, lab = synth.s2_modelnet_shaped(B, 64, 100)
+    W0 = synth.make_weights("wide")
+    P = DPDistParams(device=dev, compute_dtype=dt)
+    P.load_tf_state_dict(W0)
+    tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+    loss = tr.step(_cu(pcA, dev), _cu(pcB, dev), _cu(lab, dev)).cpu().numpy()
+    grads = P.tf_state_dict(tr.grad)
+    after = P.tf_state_dict()
+    torch.set_num_threads(8)
+    Wt = {n: torch.tensor(a, dtype=torch.float64, requires_grad=True) for n, a in W0.items()}
+    pred, _ = R.get_model(torch.tensor(pcA, dtype=torch.float64), torch.tensor(pcB, dtype=torch.float64), Wt)
+    ls, lp = R.get_loss(pred, torch.tensor(lab, dtype=torch.float64))
+    assert abs(loss[0] - ls.item()) <= 2e-5 and abs(loss[1] - lp.item()) <= 2e-5, (loss, ls.item(), lp.item())
+    names = sorted(Wt)
+    gs = torch.autograd.grad(ls, [Wt[n] for n in names])
+    for n, g in zip(names, gs):
+        ref = g.numpy()
+        got = grads[n].astype(np.float64)
+        r2, g2 = (ref.reshape(-1, ref.shape[-1]), got.reshape(-1, got.shape[-1])) if ref.ndim == 4 else (ref, got)
+        nrm = float(np.sqrt((r2 ** 2).sum()))
+        tol = 2e-4 * max(1.0, nrm)                       # the bar of test_weight_gradients_golden
+        assert abs(np.sqrt((g2 ** 2).sum()) - nrm) <= tol, (n, nrm)
+        # elementwise: fp32 sums of BN = 2048 / 4096 products per entry against float64
+        assert np.abs(g2 - r2).max() <= 1e-5 * max(1.0, np.abs(r2).max()) + 2e-6, (n, np.abs(g2 - r2).max(), np.abs(r2).max())
+        if ref.ndim == 4:
+            assert np.abs(g2[:16, :16] - r2[:16, :16]).max() <= tol and np.abs(g2[-16:, -16:] - r2[-16:, -16:]).max() <= tol, n
+            assert np.abs(g2.sum(0) - r2.sum(0)).max() <= tol * 30 and np.abs(g2.sum(1) - r2.sum(1)).max() <= tol * 30, n
+        # tf.train.AdamOptimizer's first step, in float64.  Its update lr * g / (|g| + 3.2e-7) is steep around g = 0 (layer 1's gradients are
+        # ~1e-4 here), so the optimizer is pinned on the gradient the GPU produced (itself pinned elementwise above) to fp32 rounding of the
+        # parameter; against the oracle's own gradient only the step size is bounded
+        p = Wt[n].detach().numpy().copy()
+        R.adam_tf_step(p, got, np.zeros_like(p), np.zeros_like(p), 1, learning_rate(0, 1e-3))
+        assert np.abs(after[n] - p).max() <= 3e-7 * max(1.0, np.abs(p).max()), (n, np.abs(after[n] - p).max())
+        p = Wt[n].detach().numpy().copy()
+        R.adam_tf_step(p, ref, np.zeros_like(p), np.zeros_like(p), 1, learning_rate(0, 1e-3))
+        assert np.abs(after[n] - p).max() <= 2.1e-3, n          # (at most the two steps apart of a sign flip at g ~ 0)
+
+
+# ------------------------------------------------------------------------------------------------ as-loss engine (round 5)
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "f32x3", "bf16"])
+def test_as_loss_engine_is_bitwise_the_entry_by_entry_node(dev, dt, monkeypatch):
+    """dpd_asloss_forward / dpd_asloss_backward (ONE foreign call per direction on an engine's persistent buffers) against the autograd
+    node that drives the C ABI entry by entry (DPD_ASLOSS_ENGINE=0): loss and both input gradients BIT FOR BIT at the registration
+    batch; forward-only evaluations under no_grad; several evaluations alive before their backwards (each holds its own engine, the
+    fifth falls back to the allocating path); a node dropped without a backward frees its engine; a second backward through the same
+    node works while its engine has not been re-used and raises once it has."""
+    import gc
+    from dpdist_amd import asloss, model as M
+    B = 16
+    pcA, pcB, _ = synth.s2_modelnet_shaped(B, 64, 100)
+    res = {}
+    for eng in ("0", "1"):
+        monkeypatch.setenv("DPD_ASLOSS_ENGINE", eng)
+        mod = _model(dev, "wide")
+        mod.params_.compute_dtype = dt
+        fn = M.DPDistLoss(mod)
+        a1, b1 = _cu(pcA, dev).requires_grad_(True), _cu(pcB, dev).requires_grad_(True)
+        a2, b2 = _cu(pcB, dev).requires_grad_(True), _cu(pcA, dev).requires_grad_(True)
+        with torch.no_grad():
+            l0 = fn(a1, b1).clone()
+        l1 = fn(a1, b1)
+        l2 = fn(a2, b2)                                   # a second evaluation before the first backward
+        g1 = torch.autograd.grad(l1 * 2.0, [a1, b1])
+        g2 = torch.autograd.grad(l2, [a2, b2])
+        res[eng] = (l0, l1.detach().clone(), l2.detach().clone(), g1, g2)
+        if eng == "1":
+            pool = mod.params_._asloss_engines
+            engines = next(iter(pool.values()))
+            assert len(engines) == 2 and not any(e.busy for e in engines)
+            # five evaluations alive: four engines, the fifth on the allocating path -- and all five gradients are right
+            live = [fn(a1, b1) for _ in range(5)]
+            assert len(engines) == asloss.MAX_ENGINES and all(e.busy for e in engines)
+            for lv in live:
+                g = torch.autograd.grad(lv * 2.0, [a1, b1])
+                assert torch.equal(g[0], g1[0]) and torch.equal(g[1], g1[1])
+            assert not any(e.busy for e in engines)
+            # a node dropped without a backward gives its engine back
+            lv = fn(a1, b1)
+            assert sum(e.busy for e in engines) == 1
+            del lv
+            gc.collect()
+            assert not any(e.busy for e in engines)
+            # retain_graph: a second backward through the same node while its engine still holds that evaluation ...
+            lv = fn(a1, b1)
+            ga = torch.autograd.grad(lv * 2.0, [a1, b1], retain_graph=True)
+            gb = torch.autograd.grad(lv * 2.0, [a1, b1], retain_graph=True)
+            assert torch.equal(ga[0], gb[0]) and torch.equal(ga[0], g1[0])
+            # ... and a clear error once a later evaluation has taken the engine over
+            fn(a2, b2).backward()
+            with pytest.raises(RuntimeError, match="re-used"):
+                torch.autograd.grad(lv * 2.0, [a1, b1])
+    for x, y in zip(res["0"][:3], res["1"][:3]):
+        assert torch.equal(x, y), (x.item(), y.item())
+    for ga, gb in zip(res["0"][3] + res["0"][4], res["1"][3] + res["1"][4]):
+        assert torch.equal(ga, gb), (ga - gb).abs().max().item()
+
+
+@pytest.mark.gpu
+def test_as_loss_engine_c_entry_forward_backward(dev):
+    """dpd_asloss_forward_backward straight through the C ABI (no autograd in between): the same loss and gradients as the autograd
+    node, at a batch whose rows are not plane-shaped for the bf16 type (the engine then carves the exact type's buffers)."""
+    from dpdist_amd import asloss, lib as L, model as M
+    for dt, B, N in (("f32", 16, 64), ("bf16", 3, 36)):
+        pcA, pcB, _ = synth.s2_modelnet_shaped(B, N, 7)
+        mod = _model(dev, "wide")
+        mod.params_.compute_dtype = dt
+        a, b = _cu(pcA, dev).requires_grad_(True), _cu(pcB, dev).requires_grad_(True)
+        loss = M.DPDistLoss(mod)(a, b)
+        gA, gB = torch.autograd.grad(loss, [a, b])
+        P = mod.params_
+        e = asloss.Engine(P, B, N, 8, 5, mod.sigma if hasattr(mod, "sigma") else 0.125, dev)
+        e.set_weights(P, P.flat)
+        out = torch.empty(1, device=dev)
+        g1, g2 = torch.empty(B, N, 3, device=dev), torch.empty(B, N, 3, device=dev)
+        L.check(asloss._lib().dpd_asloss_forward_backward(e.c, L.ptr(a.detach()), L.ptr(b.detach()), L.ptr(out), L.ptr(g1), L.ptr(g2),
+                                                          L.cur_stream()), "dpd_asloss_forward_backward")
+        assert torch.equal(out[0], loss.detach()) and torch.equal(g1, gA) and torch.equal(g2, gB), dt

@@ -44,17 +44,29 @@ def main():
         loss.backward()
         return loss
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        l = step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    print(json.dumps({"mode": "as-loss (fwd + bwd to inputs)", "batch": a.batch, "dtype": a.dtype, "ms_per_step": round(el / a.steps * 1e3, 4),
-                      "query_points_per_sec": round(2 * a.batch * 64 * a.steps / el, 1), "loss_pred": round(float(l), 6),
-                      "grad_norm": round(float(src.grad.norm()), 6)}))
+    def fwd_only():        # the seven no-gradient refinements of a registration step (iterative_PCRNet_ours.py:414-441)
+        with torch.no_grad():
+            return loss_fn(src, tmpl)
+
+    def run(fn):
+        for _ in range(a.warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            l = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, l
+
+    engine = os.environ.get("DPD_ASLOSS_ENGINE", "1") == "1"
+    el, l = run(step)
+    print(json.dumps({"mode": "as-loss (fwd + bwd to inputs)", "engine": engine, "batch": a.batch, "dtype": a.dtype,
+                      "ms_per_step": round(el / a.steps * 1e3, 4), "query_points_per_sec": round(2 * a.batch * 64 * a.steps / el, 1),
+                      "loss_pred": round(float(l), 6), "grad_norm": round(float(src.grad.norm()), 6)}))
+    el, l = run(fwd_only)
+    print(json.dumps({"mode": "as-loss (forward only, no_grad)", "engine": engine, "batch": a.batch, "dtype": a.dtype,
+                      "ms_per_step": round(el / a.steps * 1e3, 4), "query_points_per_sec": round(2 * a.batch * 64 * a.steps / el, 1),
+                      "loss_pred": round(float(l), 6)}))
 
 
 if __name__ == "__main__":
