@@ -259,7 +259,7 @@ PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E, 8 TB/s
 ACHIEVABLE_HBM_GBPS = 6300.0    # what a pure streaming kernel sustains on this chip (same guide; our Adam kernel reaches it)
 # stage tag of the library's in-stream profiler (include/dpdist_capi.h: dpd_prof_collect_stage) -> (name, kernel-name substrings in the
 # rocprofv3 summaries, what it replaces in the reference)
-HBM_STAGES = {1: ("encoder", ("mfv3d_fwd_kernel",), "get_3dmfv_tf, utils/dpdist_util.py:22-141"),
+HBM_STAGES = {1: ("encoder", ("mfv3d_fwd", "mfv3d_norm_kernel"), "get_3dmfv_tf, utils/dpdist_util.py:22-141"),
               2: ("window_gather", ("patch_rows_",), "local_z_3d + mask + gather, utils/dpdist_util.py:434-492,911-930"),
               3: ("output_layer_fused", ("out_bwd_fused4_kernel",), "layer 4 + relu6/3 + mask + L1 loss + their backward, :540-544,690-698,962-980"),
               4: ("optimizer", ("adam_",), "tf.train.AdamOptimizer.apply_gradients, train_multi_gpu_pc_compare_dist.py:301"),
@@ -293,6 +293,14 @@ def hbm_roofline_pass(L, step_fn, warmup, steps, pmc_suffix=""):
                      "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
                      "frac_of_achievable_6300": round(gbps / ACHIEVABLE_HBM_GBPS, 4),
                      "traffic": round(traffic) if traffic else None, "traffic_source": src}
+        if name == "encoder":
+            # 2.8-5.6 MB in 9-13 us: not a bandwidth kernel.  s_memtime stamps (profiles/r04_mfv_stamps.txt, B = 32): 20.6k cycles per
+            # workgroup = tables 3.0k + row sums 2.8k + statistics loop / merge / power norm 11.0k (VALU issue: max / min statistics have no
+            # packed form, four waves per SIMD share the VALU) + store 3.8k -- three dependent latency chains, no section waits on HBM
+            out[name].update({"bound": "latency", "frac": None, "frac_of_achievable_6300": None,
+                              "bound_note": "VALU-issue / latency bound: ~53 % of a workgroup's cycles are the statistics loop + merge + power "
+                                            "normalisation on the VALU, the rest table set-up and an LDS-staged store (profiles/r04_mfv_stamps.txt); "
+                                            "`achieved` GB/s is reported for completeness, the HBM roofline is not its yardstick"})
     L.dpd_prof_enable(0)
     if out:
         tot_us = sum(v["avg_launch_us"] * v["launches_per_step"] for v in out.values())
@@ -723,6 +731,7 @@ def main():
         # and the kernels of the next ~25 ms run slower -- seen once as frac 0.765 next to an unaffected headline.
         tr._load_batch(pcA, pcB, None)
         best = None
+        best_nn = (0, 0.0)
         for _pass in range(2):
             for it in range(a.warmup + a.steps):   # W unprofiled iterations (first launches load code objects, create events)
                 if it == a.warmup:
@@ -737,9 +746,12 @@ def main():
             if rank == 0:
                 ms_, fl_ = ctypes.c_double(0), ctypes.c_double(0)
                 n_ = L.dpd_prof_collect(ctypes.byref(ms_), ctypes.byref(fl_))
+                ms0, fl0 = ctypes.c_double(0), ctypes.c_double(0)
+                n0 = L.dpd_prof_collect_form(0, ctypes.byref(ms0), ctypes.byref(fl0))      # NN / NT launches: forward layers + data gradients
                 L.dpd_prof_enable(0)
                 if n_ > 0 and ms_.value > 0 and (best is None or ms_.value < best[1].value):
                     best = (n_, ms_, fl_)
+                    best_nn = (n0, ms0.value)
         gc.enable()
         if rank == 0:
             n, ms, fl = best if best else (0, ctypes.c_double(0), ctypes.c_double(0))
@@ -766,6 +778,17 @@ def main():
                         "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
                         "alg_gflop_per_launch": round(alg / (launches / a.steps) / 1e9, 3),
                         "gemm_ms_per_step": round(ms.value / a.steps, 4)}
+                # the DOMINANT kernel alone (the family above also holds the weight-gradient kernel): the forward layers and the data
+                # gradients are one kernel in f32 (gemm_rs_kernel<true, false, ...>, NN products on transposed weight copies)
+                n0, ms0 = best_nn
+                if n0 > 0 and ms0 > 0:
+                    Qr, BNr = 2 * B * N, B * N
+                    alg_nn = 2.0 * Qr * (2503 * 1024 + 2 * 1024 * 1024) + 2.0 * BNr * (2 * 1024 * 1024)
+                    ach_nn = alg_nn * a.steps / (ms0 * 1e-3) / 1e12
+                    roof["dominant_kernel_frac"] = round(ach_nn * mult / peak, 4)
+                    roof["dominant_kernel"] = {"what": "forward layers 1-3 + data gradients g3->g2->g1 (NN / NT products)",
+                                               "launches_per_step": n0 // a.steps, "avg_launch_us": round(ms0 * 1e3 / n0, 2),
+                                               "achieved": round(ach_nn * mult, 2), "unit": "TFLOP/s"}
     roof_hbm = None
     if not a.no_roofline and rank == 0 and not use_dist:
         try:

@@ -67,7 +67,7 @@ class Engine:
             L.check(_lib().dpd_asloss_set_weights(self.c, p, L.cur_stream()), "dpd_asloss_set_weights")
             self._wkey = key
             if self.c.dtype != 0:       # the parameter object's record of "weight planes derived for this buffer / version" (model.py)
-                P._wplanes = (key + (self.c.dtype,), self)
+                P._wplanes = (key + (self.c.dtype, "engine"), None)     # (never equal to an AsLossPlanes key: that path keeps its own planes)
 
     def forward(self, pcA, pcB, want_grad):
         loss = torch.empty(1, device=self.device, dtype=torch.float32)

@@ -411,6 +411,7 @@ struct GemmProf {
     hipEvent_t ev[2 * kMax];
     double flops[kMax];   // flops (tag 0) or algorithmic HBM bytes (stage tags)
     int tag[kMax];
+    signed char form[kMax];   // GEMM launches: 0 = NN / NT, 1 = TN (dpd_prof_collect_form)
     int created = 0;   // events [0, created) exist
 };
 int g_rs_xcd_band = 0;     // dpd_set_gemm_plan(40, mode, 1): 0 off, 1 the weight-gradient (TN) products, 2 every register-streamed GEMM
@@ -431,13 +432,14 @@ bool prof_begin(hipStream_t s) {
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n], s);
     return true;
 }
-void prof_end(bool on, hipStream_t s, double flops) {
+void prof_end(bool on, hipStream_t s, double flops, int form) {
     if (!on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof.on) return;
     (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s);
     g_prof.flops[g_prof.n] = flops;
     g_prof.tag[g_prof.n] = DPD_STAGE_GEMM;
+    g_prof.form[g_prof.n] = (signed char)form;
     ++g_prof.n;
 }
 // stages never nest inside each other or inside a GEMM bracket (one open pair at a time: the pair of slot n)
@@ -574,9 +576,9 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     }
     // profiler bracket: the GEMM kernel AND, with split-K, its reduce kernel (both belong to this GEMM)
     struct ProfScope {
-        bool on; hipStream_t s; double fl;
-        ~ProfScope() { prof_end(on, s, fl); }
-    } prof_scope{prof_begin(s), s, 2.0 * M * N * K};
+        bool on; hipStream_t s; double fl; int form;
+        ~ProfScope() { prof_end(on, s, fl, form); }
+    } prof_scope{prof_begin(s), s, 2.0 * M * N * K, transA ? 1 : 0};
     int rc;
     if (!transA && !transB) rc = launch_tile<true, false>(tile, g, s);       // NN: A[M,K], B[K,N]
     else if (!transA && transB) rc = launch_tile<true, true>(tile, g, s);    // NT: A[M,K], B[N,K]
@@ -615,9 +617,9 @@ int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_byt
         g.split_k = split_k; g.k_chunk = chunk; g.C = (float*)ws; g.ldc = N; g.slab_stride = (long)M * N; g.epi = EPI_NONE;
     }
     struct ProfScope {
-        bool on; hipStream_t s; double fl;
-        ~ProfScope() { prof_end(on, s, fl); }
-    } prof_scope{prof_begin(s), s, 2.0 * M * N * K};
+        bool on; hipStream_t s; double fl; int form;
+        ~ProfScope() { prof_end(on, s, fl, form); }
+    } prof_scope{prof_begin(s), s, 2.0 * M * N * K, which == 2 ? 1 : 0};
     if (int rc = which == 1 ? launch_rs_gather_fwd(tile, g, s) : launch_rs_gather_dw(tile, g, s)) return rc;
     if (split_k > 1) {
         const long total4 = (long)M * N / 4;
@@ -649,13 +651,13 @@ extern "C" int dpd_prof_enable(int on) {
 
 // Synchronises with the recorded events; returns the number of GEMM launches seen since dpd_prof_enable(1) and
 // fills total milliseconds / total (padded-shape) flops 2*M*N*K of those launches.
-extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
+static int prof_collect_gemm(int form, double* total_ms, double* total_flops) {
     using dpd::g_prof;
     std::lock_guard<std::mutex> lk(dpd::g_prof_mu);
     double ms = 0.0, fl = 0.0;
     int n = 0;
     for (int i = 0; i < g_prof.n; ++i) {
-        if (g_prof.tag[i] != dpd::DPD_STAGE_GEMM) continue;
+        if (g_prof.tag[i] != dpd::DPD_STAGE_GEMM || (form >= 0 && g_prof.form[i] != form)) continue;
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return -1;
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return -1;
@@ -666,6 +668,12 @@ extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) {
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
     return n;
+}
+extern "C" int dpd_prof_collect(double* total_ms, double* total_flops) { return prof_collect_gemm(-1, total_ms, total_flops); }
+// the same for the launches of ONE product form: 0 = NN / NT (forward layers and data gradients: one kernel family), 1 = TN (weight gradients)
+extern "C" int dpd_prof_collect_form(int form, double* total_ms, double* total_flops) {
+    if (form < 0 || form > 1) return DPD_E_DIM;
+    return prof_collect_gemm(form, total_ms, total_flops);
 }
 
 // The bandwidth-bound stages recorded since dpd_prof_enable(2): launches of stage `tag` (1 encoder, 2 window gather, 3 fused output

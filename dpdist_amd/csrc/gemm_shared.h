@@ -384,6 +384,7 @@ struct SplitJobs {
 
 // in-stream GEMM profiler (gemm_f32.hip): event pair around one GEMM (kernel + split-K reduce)
 bool prof_begin(hipStream_t s);
-void prof_end(bool on, hipStream_t s, double flops);
+// form: 0 = the contraction runs along A's rows (NN / NT: the forward and data-gradient products), 1 = TN (weight gradients)
+void prof_end(bool on, hipStream_t s, double flops, int form = 0);
 
 }  // namespace dpd

@@ -464,9 +464,9 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
         g.ld_rc = out->ld_rc; g.r8_rows = out->r8_rows; g.np_out = out->np;
     }
     struct ProfScope {
-        bool on; hipStream_t s; double fl;
-        ~ProfScope() { prof_end(on, s, fl); }
-    } prof_scope{prof_begin(s), s, 2.0 * N * K * ((double)M + (A2 ? M2 : 0) + (three ? ex->M3 : 0))};
+        bool on; hipStream_t s; double fl; int form;
+        ~ProfScope() { prof_end(on, s, fl, form); }
+    } prof_scope{prof_begin(s), s, 2.0 * N * K * ((double)M + (A2 ? M2 : 0) + (three ? ex->M3 : 0)), a_fmt ? 1 : 0};
     int rc;
     if (a_fmt == 2) {
         rc = np == 3 ? launch_x3_tile_tr<3>(tile, g, s) : launch_x3_tile_tr<1>(tile, g, s);

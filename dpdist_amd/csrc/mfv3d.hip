@@ -333,7 +333,9 @@ __global__ __launch_bounds__(kFwd2Threads) void mfv3d_fwd2_kernel(const float* _
     // the normalised q = e / S and min_i z^2 come out of three DPP steps in registers -- no second pass over the table, no barrier in between
     const bool dpp8 = m == 8 && (3 * N * m) % kFwd2Threads == 0;
     if (dpp8) {
-#pragma unroll 3
+        // (no unroll pragma: the trip count is a run-time value and the body holds convergent DPP operations, so hipcc cannot peel a
+        //  remainder -- a requested `unroll 3` was silently refused with a -Wpass-failed warning.  Three iterations at N = 64, 3.0k of the
+        //  workgroup's 20.6k cycles (profiles/r04_mfv_stamps.txt): not where this kernel's time goes)
         for (int e = tid; e < 3 * N * m; e += kFwd2Threads) {
             const int em = e >> 3, i = e & 7, a = qdiv(em, N, lg_n), n = em - a * N;
             const float x = nz ? p[n * 3 + a] + nz[n * 3 + a] : p[n * 3 + a];

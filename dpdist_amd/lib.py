@@ -122,6 +122,7 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dpd_set_gemm_plan": (c_int, [c_int, c_int, c_int]),
     "dpd_prof_enable": (c_int, [c_int]),
+    "dpd_prof_collect_form": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "dpd_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "dpd_prof_collect_stage": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
 }

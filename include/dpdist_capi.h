@@ -479,6 +479,9 @@ int dpd_decoder_bwd_weights_trio(int Qb, int KP, int H, int dtype, float* dW1, f
  * summed durations [ms] / flops (2*M*N*K as launched) since dpd_prof_enable(1).                              */
 int dpd_prof_enable(int on);
 int dpd_prof_collect(double* total_ms, double* total_flops);
+/* the same for ONE product form: 0 = NN / NT (forward layers and data gradients -- in DPD_F32 one kernel, the step's dominant one),
+ * 1 = TN (weight gradients)                                                                                               */
+int dpd_prof_collect_form(int form, double* total_ms, double* total_flops);
 /* dpd_prof_enable(2) additionally brackets the bandwidth-bound kernels of the step and records their ALGORITHMIC HBM bytes (every
  * input read once, every output written once) by stage: 1 3DmFV encoder, 2 window gather, 3 fused output layer (+ loss + its backward),
  * 4 optimizer, 5 small-gradient reduction, 6 weight copies (transposes / operand planes).  Returns the launches of that stage since
