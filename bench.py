@@ -466,8 +466,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    headline_sched = None
     if use_dist:
         dist.barrier()
+        hb.beat("aux:schedule of the headline step")
+        headline_sched = tr.select_dp_schedule(pcA, pcB, lab)      # collective; parameters and Adam state are restored afterwards
 
     keep = []
     try:                  # a descheduled launcher thread idles the GPU within a millisecond (shared host): ask for priority
@@ -551,6 +554,10 @@ def main():
             if mode is not None:
                 os.environ.pop("DPD_DP_MODE") if old_mode is None else os.environ.__setitem__("DPD_DP_MODE", old_mode)
         a2, b2, l2 = (torch.tensor(x, device=dev) for x in synth.s2_modelnet_shaped(B2, N, 100 + rank))
+        sched = None
+        if distributed:      # the order of the data-parallel backward: measured here, decided by all ranks together (unless DPD_DP_SCHEDULE pins it)
+            hb.beat("aux:schedule " + label[:30])
+            sched = tr2.select_dp_schedule(a2, b2, l2)
         for _ in range(a.warmup):
             tr2.step(a2, b2, l2)
         e2 = float("inf")
@@ -572,6 +579,7 @@ def main():
                 "unit": "query-points/sec", "loss_samples_last": round(float(tr2.loss.cpu()[0]), 6)}
         if distributed:
             out2["dp"] = dp_report(tr2, lambda: tr2.step(a2, b2, l2))
+            out2["dp"]["schedule"] = sched
         if not distributed and not a.no_roofline and rank == 0:
             # the plane-GEMM family of THIS configuration against the dense bf16 matrix-core peak (same method as `roofline` below)
             try:
@@ -605,7 +613,15 @@ def main():
         try:
             if world > 1 or (use_dist and os.environ.get("DPD_BENCH_CFG4") == "1"):   # (the env: exercise this leg on one GPU)
                 # every rank takes part in both legs (the first has collectives)
-                c4 = bf16_b64(True, "BASELINE config 4: data-parallel bf16 step, 64 pairs per GPU, RCCL gradient all-reduce")
+                # the headline leg runs the schedule that WON the start-up measurement (dp.schedule: candidates_ms, MAX over ranks); the
+                # pinned legs below are the record of what each candidate does over the full K steps
+                c4 = bf16_b64(True, "BASELINE config 4: data-parallel bf16 step, 64 pairs per GPU, RCCL gradient all-reduce, "
+                                    "backward order chosen by measurement at start-up")
+                try:
+                    c4["early_schedule"] = bf16_b64(True, "config 4 with DPD_DP_SCHEDULE=early (separate dW launches, buckets reduced under the backward)",
+                                                    env={"DPD_DP_SCHEDULE": "early"})
+                except Exception as e:
+                    c4["early_schedule"] = {"error": repr(e)}
                 try:     # the sharded optimizer (ZeRO-1: reduce-scatter -> Adam on 1/P -> all-gather of the parameters), same step
                     c4["zero1"] = bf16_b64(True, "config 4 with DPD_DP_MODE=zero1 (sharded Adam)", mode="zero1")
                 except Exception as e:
@@ -619,7 +635,9 @@ def main():
                 c4["scaling"] = "weak"
                 n1v = c4["n1_same_run"]["value"]
                 c4["weak_scaling_efficiency_vs_n1_same_run"] = round(c4["value"] / (c4["n_gpus"] * n1v), 4)
-                for leg in ("zero1", "grouped_schedule"):
+                if c4["n_gpus"] == 1:
+                    c4["scaling_note"] = "ONE rank: the efficiency above is the cost of the data-parallel plumbing only; nothing crossed a link"
+                for leg in ("zero1", "grouped_schedule", "early_schedule"):
                     if "value" in c4[leg]:
                         c4[leg]["weak_scaling_efficiency_vs_n1_same_run"] = round(c4[leg]["value"] / (c4["n_gpus"] * n1v), 4)
                 cfg34 = ("config4", c4)
@@ -720,6 +738,8 @@ def main():
     loss = tr.loss.cpu().numpy()
     hb.beat("profile:roofline + exposed communication")
     dp = dp_report(tr, lambda: tr.step(pcA, pcB, lab)) if use_dist else None
+    if dp is not None:
+        dp["schedule"] = headline_sched
 
     roof = None
     if a.no_roofline:

@@ -503,7 +503,7 @@ class DirectRcclReducer:
 
 def crosscheck(red, group=None):
     """Start-up self-test of a reducer: a known integer-valued pattern (exact in fp32 AND bf16 whatever the summation order: every
-    addend in [-15, 15], at most 8 x 15 per sum) goes through `red` with the trainer's call sequence (layers 2-4, then layer 1) and
+    addend in [-amp, amp] with world x amp <= 256) goes through `red` with the trainer's call sequence (layers 2-4, then layer 1) and
     through a plain `torch.distributed.all_reduce`; both results must equal the closed-form sum BIT FOR BIT.  The gradient buffer is
     restored.  Returns a dict for the bench line; every rank must call it (collectives)."""
     flat = red.flat
@@ -515,8 +515,12 @@ def crosscheck(red, group=None):
     n = flat.numel()
     idx = torch.arange(n, device=flat.device, dtype=torch.int64)
 
+    # |addend| <= amp with world * amp <= 256: every partial sum is then an integer of magnitude <= 256, exact in bf16 (8 significant bits)
+    # as well as in fp32 (the fixed amplitude of 15 was only exact up to 17 ranks on the bf16 wire)
+    amp = max(1, min(15, 256 // max(1, world)))
+
     def pat(r):
-        return ((idx * 2654435761 + r * 40503) % 31 - 15).to(torch.float32)
+        return ((idx * 2654435761 + r * 40503) % (2 * amp + 1) - amp).to(torch.float32)
 
     expect = pat(0)
     for r in range(1, world):
@@ -547,6 +551,37 @@ def crosscheck(red, group=None):
         flat.copy_(saved)
     return {"ok": ok_red and ok_ref, "reducer_bitwise": ok_red, "torch_all_reduce_bitwise": ok_ref, "mismatching_elements": bad,
             "elements": hi - lo, "backend": red.backend, "mode": red.mode, "wire": red.wire}
+
+
+def select_schedule(candidates, time_fn, device, group=None):
+    """Pick the data-parallel schedule by MEASUREMENT, on all ranks together (the agree-then-act pattern of make_reducer): every rank
+    times every candidate in the same order with `time_fn(name) -> milliseconds per step` (which runs real steps, collectives included,
+    so the ranks stay in lock step), the per-candidate times are all-reduced with MAX (a step is as slow as its slowest rank), and every
+    rank takes the candidate with the smallest maximum -- the same one everywhere, whatever each rank measured locally; ties go to the
+    earlier candidate.  Returns (choice, {name: max-over-ranks ms}).  A candidate whose time_fn raises on ANY rank is dropped on every
+    rank (its time becomes +inf through the MAX)."""
+    cands = list(candidates)
+    if not cands:
+        raise ValueError("no schedule candidates")
+    ms = []
+    for c in cands:
+        try:
+            ms.append(float(time_fn(c)))
+        except Exception:
+            ms.append(float("inf"))
+    t = torch.tensor(ms, device=device, dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            tc = t.cpu()
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX, group=group)
+            t = tc
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    vals = [float(x) for x in t.tolist()]
+    best = min(range(len(cands)), key=lambda i: (vals[i], i))
+    if vals[best] == float("inf"):
+        raise RuntimeError("every data-parallel schedule candidate failed on some rank: %r" % (cands,))
+    return cands[best], {c: (round(v, 4) if v != float("inf") else None) for c, v in zip(cands, vals)}
 
 
 def _agree(flag, device, group):

@@ -148,6 +148,14 @@ def supervise(argv, rank, world, log=sys.stderr):
                 os.unlink(os.path.join(d, f))
             except OSError:
                 pass
+    else:                   # a directory name can repeat (PID and port reuse): markers of a launch long gone must not decide this one.  The ranks
+        for f in os.listdir(d):    # of one launch start within seconds of each other, so nothing of THIS launch is two minutes old yet
+            if f.split(".")[0] in ("fail", "port", "ok"):
+                try:
+                    if os.path.getmtime(os.path.join(d, f)) < time.time() - 120.0:
+                        os.unlink(os.path.join(d, f))
+                except OSError:
+                    pass
     lim = limits()
     t_launch = time.time()
     history = []
@@ -179,7 +187,21 @@ def supervise(argv, rank, world, log=sys.stderr):
             _stop(child)
             raise
         if why == 0:
+            _write_atomic(os.path.join(d, "ok.%d.r%d" % (attempt, rank)), "%.3f\n" % time.time())
             return 0
+        # Some rank's supervisor has already returned 0 for this attempt (its worker reached "done"): that rank will not take part in a
+        # retry, which would then block in rendezvous until the init limit.  If rank 0 is among the finished, its JSON line is
+        # out and a late failure elsewhere (report / profile / tear-down phases) cannot take it back: stop here.
+        finished = [f for f in os.listdir(d) if f.startswith("ok.%d." % attempt)]
+        if finished:
+            _stop(child)
+            log.write("launch watchdog (attempt %d): %s after rank(s) %s had finished -> no retry\n" %
+                      (attempt, why if why is not None else "another rank failed", ",".join(sorted(f.rsplit("r", 1)[-1] for f in finished))))
+            log.flush()
+            if "ok.%d.r0" % attempt in finished:
+                return 0
+            history.append({"attempt": attempt, "failure": str(why), "after_s": round(time.time() - t_launch, 1), "no_retry": "ranks had finished"})
+            break
         if why is not None:
             try:
                 fd = os.open(fail_file, os.O_CREAT | os.O_EXCL | os.O_WRONLY)

@@ -218,10 +218,18 @@ def train(argv=None):
                 noise = cu((np.random.randn(F.batch_size, N, 3) * F.add_noise).astype(np.float32)[lo:hi])
             yield cu(pcA[lo:hi].copy()), cu(pcB[lo:hi].copy()), cu(lab[lo:hi].copy()), noise
 
+    sched_done = [world == 1]
+
     def run_epoch(ds, training):
         sums, n = torch.zeros(2, device=dev), 0
         it = batches(ds, training)
         cur = next(it, None)
+        if training and not sched_done[0] and cur is not None:
+            # data-parallel runs: the order of the backward (early / grouped / late) is measured on the first batch by all ranks together;
+            # weights, Adam slots and the global step are restored afterwards (DPDistTrainer.select_dp_schedule)
+            info = tr.select_dp_schedule(cur[0], cur[1], cur[2])
+            log_string("data-parallel schedule: %s" % (info,))
+            sched_done[0] = True
         while cur is not None:
             nxt = next(it, None)                                   # composed one batch ahead (host work overlaps the GPU step)
             a, b, l, noise = cur

@@ -208,6 +208,13 @@ class DPDistTrainer:
         if not hasattr(self, "_side_opt"):
             self._side_opt = None
         self._trio = self._planes is not None and os.environ.get("DPD_DW_TRIO", "1" if self._planes.np == 1 else "0") == "1"
+        # order of a DATA-PARALLEL backward (see `backward`): "early" = every weight gradient as soon as its inputs exist, buckets
+        # all-reduced under the rest of the backward; "grouped" = the single-GPU launch order (ONE grouped dW1 + dW2 + dW3 launch: 20 us
+        # less GEMM time at bf16 B = 64) and ONE all-reduce behind it; "late" = plain order, collectives after dW1 (A/B reference).
+        # DPD_DP_SCHEDULE pins it; otherwise `select_dp_schedule` MEASURES the candidates at start-up (all ranks together) and the
+        # initial value is only what runs until then
+        self.dp_schedule = os.environ.get("DPD_DP_SCHEDULE", "early")
+        self.dp_schedule_info = {"schedule": self.dp_schedule, "source": "DPD_DP_SCHEDULE" if "DPD_DP_SCHEDULE" in os.environ else "default"}
         self._wdirty = True        # transposed copies / bf16 planes of the weights need a refresh before their next use
         self._after_dw1 = None
         self._side = None          # side stream of the prefetch pipeline (created on first use)
@@ -386,19 +393,24 @@ class DPDistTrainer:
                 dw(2, self.h1, self.g2, d[2])
                 dw(3, self.h2, self.g3, d[4])
 
-        if self.reducer and self._trio and self._adam_now is None and os.environ.get("DPD_DP_SCHEDULE", "early") == "grouped":
+        if self.reducer and self._trio and self._adam_now is None and self.dp_schedule == "grouped":
             # DPD_DP_SCHEDULE=grouped (plane compute types, opt-in until an 8-GPU run has compared them): the single-GPU order -- data chain,
             # then dW1 + dW2 + dW3 as ONE grouped launch (20 us less GEMM time at B = 64 than the three early launches) -- and the whole
             # gradient as ONE all-reduce behind it; with the optimizer on the collectives' stream its tail overlaps the next front end
             data(7)
             rc = lib.dpd_decoder_bwd_weights_trio(BN, P.KP, P.H, self.dt, L.ptr(d[0]), L.ptr(d[2]), L.ptr(d[4]), L.ptr(self.ws), wsb, self._planes,
                                                   L.cur_stream())
-            L.check(rc, "dpd_decoder_bwd_weights_trio")
+            if rc == -3:        # DPD_E_UNSUPPORTED (a shape / plane set the grouped launch does not take; every rank sees the same shapes): the
+                self._trio = False                                  # separate launches, like the single-GPU path below, from now on
+                dw(1, self.X, self.g1, d[0])
+                dw23()
+            else:
+                L.check(rc, "dpd_decoder_bwd_weights_trio")
             if self._after_dw1 is not None:
                 self._after_dw1()
             self.reducer.reduce_async(0, upto=len(P.bucket_bounds) - 2)
             return
-        if self.reducer and os.environ.get("DPD_DP_SCHEDULE", "early") == "early":
+        if self.reducer and self.dp_schedule in ("early", "grouped"):      # ("grouped" without the grouped launch = "early")
             # Data-parallel schedule: every weight gradient is produced as early as its inputs exist, smallest bucket first,
             # so that the all-reduces (serial on the RCCL stream) start ~250 us before the backward ends instead of after dW1:
             #   output layer -> dW3 -> [bucket 2: W3,b3,W4,b4] -> g2 -> dW2 -> [bucket 1: W2,b2] -> g1 -> dW1 -> [bucket 0]
@@ -649,6 +661,70 @@ class DPDistTrainer:
         if w1_early:
             self._ev_w1done.wait(torch.cuda.current_stream())      # W1p is complete before anything that follows this step
         return self.loss
+
+    def dp_schedule_candidates(self):
+        c = ["early"]
+        if self._trio:
+            c.append("grouped")
+        c.append("late")
+        return c
+
+    def select_dp_schedule(self, pcA, pcB, labels, candidates=None, steps=20, warmup=5, spinup=40):
+        """Decide the data-parallel backward order by measurement: every candidate runs `warmup` + `steps` real training
+        steps on this batch -- collectives, optimizer and all -- timed between synchronisations; the times are MAX-reduced over the ranks
+        and every rank takes the same winner (ddp.select_schedule).  The parameters, the Adam slots and the step counter are restored
+        after every candidate, so the training run that follows starts from where it was.  COLLECTIVE: every rank must call it, with its
+        own shard.  A schedule pinned through DPD_DP_SCHEDULE is kept (and reported).  Returns the dict that bench.py / train.py put
+        into their `dp` record."""
+        import time
+        from . import ddp
+        if self.reducer is None or not getattr(self.reducer, "active", False):
+            self.dp_schedule_info = {"schedule": self.dp_schedule, "source": "no collectives: nothing to choose"}
+            return self.dp_schedule_info
+        if "DPD_DP_SCHEDULE" in os.environ:
+            return self.dp_schedule_info
+        cands = list(candidates) if candidates is not None else self.dp_schedule_candidates()
+        self._join_optimizer()
+        torch.cuda.synchronize()
+        keep = (self.P.flat.detach().clone(), self.m_state.clone(), self.v_state.clone(), self.t)
+
+        def restore():
+            self._join_optimizer()
+            torch.cuda.synchronize()
+            self.P.flat.detach().copy_(keep[0])
+            self.m_state.copy_(keep[1])
+            self.v_state.copy_(keep[2])
+            self.t = keep[3]
+            self._wdirty = True
+            self.P.invalidate_derived()
+
+        def time_fn(name):
+            self.dp_schedule = name
+            try:
+                for _ in range(warmup):
+                    self.step(pcA, pcB, labels)
+                self._join_optimizer()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.step(pcA, pcB, labels)
+                self._join_optimizer()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / steps * 1e3
+            finally:
+                restore()
+
+        group = getattr(self.reducer, "group", None)
+        try:        # the chip needs ~25 ms of sustained work to reach its steady clock (DESIGN.md section 5): without this the FIRST candidate
+            for _ in range(spinup):      # would be timed on the ramp and lose to the ones after it
+                self.step(pcA, pcB, labels)
+        finally:
+            restore()
+        choice, table = ddp.select_schedule(cands, time_fn, self.P.flat.device, group)
+        self.dp_schedule = choice
+        self.dp_schedule_info = {"schedule": choice, "source": "measured at start-up: %d steps per candidate after a %d-step spin-up, MAX over ranks" % (steps, spinup),
+                                 "candidates_ms": table}
+        return self.dp_schedule_info
 
     # -- optimizer state <-> TF global variables ------------------------------------------------------------------
     def gather_optimizer_state(self):

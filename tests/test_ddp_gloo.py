@@ -294,3 +294,53 @@ def test_watchdog_limits_and_heartbeat_file(tmp_path, monkeypatch):
     phase, t = launch._read_beat(str(tmp_path / "rank3.a1"))
     assert phase == "timed:20_steps_of_the_headline" and abs(t - __import__("time").time()) < 5
     assert launch._read_beat(str(tmp_path / "missing")) == (None, None)
+
+
+def _sched_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpdist_amd.ddp import select_schedule
+    calls = []
+    # the ranks DISAGREE locally: rank 0 measures "early" fastest, rank 1 "grouped"; a step is as slow as its slowest rank
+    local = {0: {"early": 0.30, "grouped": 0.33, "late": 0.40}, 1: {"early": 0.36, "grouped": 0.31, "late": 0.41}}[rank]
+
+    def time_fn(name):
+        calls.append(name)
+        dist.barrier()                      # (a real candidate runs steps with collectives: every rank must be inside the same one)
+        return local[name]
+
+    choice, table = select_schedule(["early", "grouped", "late"], time_fn, torch.device("cpu"))
+    # a candidate that fails on ONE rank is dropped on every rank
+    def flaky(name):
+        dist.barrier()
+        if name == "grouped" and rank == 1:
+            raise RuntimeError("unsupported here")
+        return local[name]
+    choice2, table2 = select_schedule(["early", "grouped"], flaky, torch.device("cpu"))
+    # a tie goes to the earlier candidate on every rank
+    choice3, _ = select_schedule(["a", "b"], lambda n: (dist.barrier(), 1.0)[1], torch.device("cpu"))
+    out.put((rank, choice, table, calls, choice2, table2, choice3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_schedule_selection_is_the_same_on_every_rank():
+    """ddp.select_schedule (the start-up choice of the data-parallel backward order, DPDistTrainer.select_dp_schedule): both ranks time
+    every candidate in the same order, the MAX over ranks decides, and both ranks take the same winner although each one alone would
+    have chosen differently."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sched_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, choice, table, calls, choice2, table2, choice3 in got:
+        assert calls == ["early", "grouped", "late"]
+        assert choice == "grouped"                      # max(0.33, 0.31) = 0.33 < max(0.30, 0.36) = 0.36
+        assert table == {"early": 0.36, "grouped": 0.33, "late": 0.41}
+        assert choice2 == "early" and table2 == {"early": 0.36, "grouped": None}
+        assert choice3 == "a"

@@ -2267,3 +2267,51 @@ def test_as_loss_engine_c_entry_forward_backward(dev):
         L.check(asloss._lib().dpd_asloss_forward_backward(e.c, L.ptr(a.detach()), L.ptr(b.detach()), L.ptr(out), L.ptr(g1), L.ptr(g2),
                                                           L.cur_stream()), "dpd_asloss_forward_backward")
         assert torch.equal(out[0], loss.detach()) and torch.equal(g1, gA) and torch.equal(g2, gB), dt
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel schedule by measurement (round 5)
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_data_parallel_schedule_is_selected_by_measurement(dev, dt, monkeypatch):
+    """DPDistTrainer.select_dp_schedule on a single-rank RCCL group: every candidate (early / grouped when the grouped weight-gradient
+    launch exists / late) is timed over real steps with the reducer in the loop, the winner becomes the trainer's order, the record holds
+    every candidate's time -- and the parameters, Adam slots and step counter are BIT FOR BIT what they were, so the training run that
+    follows is the run that would have happened without the measurement.  DPD_DP_SCHEDULE still pins the order."""
+    import torch.distributed as dist
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    monkeypatch.setenv("DPD_DP_BACKEND", "rccl")
+    monkeypatch.setenv("DPD_FORCE_DIST", "1")
+    monkeypatch.delenv("DPD_DP_SCHEDULE", raising=False)
+    B = 32
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    own = _single_rank_group(dev, 29653)
+    try:
+        P = DPDistParams(device=dev, compute_dtype=dt)
+        P.load_tf_state_dict(synth.make_weights("wide"))
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
+        for _ in range(2):
+            tr.step(pcA, pcB, lab)
+        tr.join_optimizer()
+        torch.cuda.synchronize()
+        before = (P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), tr.t)
+        info = tr.select_dp_schedule(pcA, pcB, lab, steps=4, warmup=1)
+        tr.join_optimizer()
+        torch.cuda.synchronize()
+        cands = ["early", "grouped", "late"] if dt == "bf16" else ["early", "late"]
+        assert sorted(info["candidates_ms"]) == sorted(cands) and all(v and v > 0 for v in info["candidates_ms"].values())
+        assert info["schedule"] == tr.dp_schedule and info["schedule"] == min(cands, key=lambda c: (info["candidates_ms"][c], cands.index(c)))
+        assert torch.equal(P.flat.detach(), before[0]) and torch.equal(tr.m_state, before[1]) and torch.equal(tr.v_state, before[2])
+        assert tr.t == before[3]
+        l1 = tr.step(pcA, pcB, lab).clone()
+        assert torch.isfinite(l1).all()
+        tr.close()
+        # pinned by the environment: nothing is measured
+        monkeypatch.setenv("DPD_DP_SCHEDULE", "late")
+        tr2 = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
+        info2 = tr2.select_dp_schedule(pcA, pcB, lab)
+        assert info2["schedule"] == "late" and "candidates_ms" not in info2 and tr2.dp_schedule == "late"
+        tr2.close()
+    finally:
+        if own:
+            dist.destroy_process_group()
