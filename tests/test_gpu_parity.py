@@ -2315,3 +2315,31 @@ def test_data_parallel_schedule_is_selected_by_measurement(dev, dt, monkeypatch)
     finally:
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [32, 64])
+def test_plane_weight_gradient_pair_on_a_narrow_decoder(dev, B, monkeypatch):
+    """with a narrow decoder (H = 64) and >= 2048 gradient rows the automatic in-launch split-K of the grouped dW2 + dW3 launch
+    asked for more tile-padded slab space than the base workspace holds and the call failed with DPD_E_WORKSPACE.  The split is now fitted
+    to the slab region (down to no split at all): the separate-launch backward (DPD_DW_TRIO=0: dW1, then the pair) runs and its weight
+    gradients agree with the exact-fp32 trainer's to bf16 accuracy."""
+    from dpdist_amd.model import DPDistParams
+    from dpdist_amd.trainer import DPDistTrainer
+    monkeypatch.setenv("DPD_DW_TRIO", "0")
+    mlp = (64, 64, 64)
+    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
+    grads = {}
+    for dt in ("f32", "bf16"):
+        P = DPDistParams(mlp=mlp, device=dev, compute_dtype=dt)
+        P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        tr._take_front(pcA, pcB, None)
+        tr._decode()
+        tr.backward(lab.reshape(-1))
+        torch.cuda.synchronize()
+        grads[dt] = {n: P.view(n, tr.grad).clone() for n in ("W1p", "W2", "W3")}
+    for n in ("W1p", "W2", "W3"):
+        a, b = grads["bf16"][n].double().flatten(), grads["f32"][n].double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        assert cos >= 0.995 and abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0) <= 0.03, (n, cos)

@@ -70,9 +70,16 @@ python $R/tools/event_cost.py > $OUT/event_cost.txt 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 $R/tools/launch_floor.hip -o /tmp/launch_floor 2>/dev/null && /tmp/launch_floor > $OUT/launch_floor.txt 2>&1
 python $R/tools/determinism_check.py f32 > $OUT/determinism.txt 2>&1
 { for b in 16 32; do for dt in f32 f32x3 bf16; do python $R/tools/asloss_bench.py --batch $b --dtype $dt | tail -1; done; done; } > $OUT/asloss_bench.txt 2>/dev/null
+# round 5: the chained persistent decoder launches against the separate launches (A/B + stamps), the as-loss engine on / off, the
+# registration loop's step rate with and without it
+{ python $R/tools/chain_bench.py 64 100; python $R/tools/chain_bench.py 32 100; } 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt
+{ for b in 16 32; do for dt in f32 f32x3 bf16; do for e in 0 1; do DPD_ASLOSS_ENGINE=$e python $R/tools/asloss_bench.py --batch $b --dtype $dt | grep mode; done; done; done; } > $OUT/asloss_engine_ab.txt 2>/dev/null
+{ for e in 0 1; do echo "== DPD_ASLOSS_ENGINE=$e"; ( cd $R; DPD_ASLOSS_ENGINE=$e timeout 600 python tools/registration_demo.py --loss ours --dp_steps 1500 --reg_steps 1500 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read())['pcrnet_ours']; print(json.dumps({k: d[k] for k in ('train_s','host_gen_s','steps','pairs_per_s','rot_err_median_deg') if k in d}), 'gpu+host ms per registration step (8 DPDist evaluations):', round((d['train_s']-d['host_gen_s'])/d['steps']*1e3,3))" ); done; } > $OUT/registration_engine_ab.txt 2>&1
+[ "${SWEEPS:-1}" = "0" ] || {
 # round 4: the bf16 backward -- weight gradients apart / grouped / split-K in the launch, dH || dW on two streams, tile plans
 ( cd $R; tools/bf16_trio_sweep.sh $OUT/bf16_trio_sweep.txt; PLANS="20:0:1,32:3:1 20:2:2,32:3:1 20:2:3,32:3:1 20:0:1,32:2:2 20:2:-3,32:3:1" SC1S="1 0" DPD_DW_TRIO=0 tools/bf16_bwd_sweep.sh $OUT/bf16_bwd_sweep.txt; tools/bf16_plan_sweep.sh $OUT/bf16_plan_sweep.txt; tools/trio_b32.sh $OUT/trio_other_configs.txt; tools/xcd_band_ab.sh $OUT/xcd_band_ab.txt ) > /dev/null 2>&1
 python $R/tools/overlap_probe_bf16.py > $OUT/overlap_probe_bf16.txt 2>/dev/null
+}
 python $R/tools/ramp_probe.py > $OUT/ramp_probe.txt 2>/dev/null
 { python $R/tools/host_rate.py f32 32; python $R/tools/host_rate.py bf16 64; } > $OUT/host_rate.txt 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 $R/tools/ldsdma_bw.hip -o /tmp/ldsdma_bw 2>/dev/null && /tmp/ldsdma_bw > $OUT/ldsdma_bw.txt 2>&1
@@ -80,7 +87,7 @@ hipcc --offload-arch=gfx950 -O3 $R/tools/ldsdma_bw.hip -o /tmp/ldsdma_bw 2>/dev/
     env $e MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes --no-roofline 2>/dev/null | tail -1 | line "$e" ; done; } > $OUT/dp_single_rank.txt 2>&1
 # the N > 1 skeleton on one GPU: watchdog -> fallback (injected hang), and the healthy forced-distributed line with its `dp` object
 ( cd $R; DPD_FORCE_DIST=1 DPD_WD_INJECT_HANG=timed DPD_WD_LIMITS=timed=8 MASTER_PORT=29531 $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes 2> $OUT/watchdog_fallback.err | tail -1 > $OUT/watchdog_fallback.json
-  DPD_FORCE_DIST=1 DPD_BENCH_CFG4=1 MASTER_PORT=29533 $B --steps 50 --warmup 10 $NOCPU 2>/dev/null | tail -1 > $OUT/bench_forced_dist_cfg4.json )
+  DPD_FORCE_DIST=1 DPD_BENCH_CFG4=1 DPD_DP_ADAM_SIDE=1 MASTER_PORT=29533 $B --steps 50 --warmup 10 $NOCPU 2>/dev/null | tail -1 > $OUT/bench_forced_dist_cfg4.json )
 # row f2 / config 5 with the data-parallel plumbing on (single rank): DPDist trained, frozen, pose network registered
 ( cd $R; DPD_FORCE_DIST=1 MASTER_PORT=29535 timeout 900 python tools/registration_demo.py --loss ours 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/registration_demo.txt )
 python $R/tools/summarize_profiles.py $TAG

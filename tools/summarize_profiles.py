@@ -34,7 +34,8 @@ for a, b in (("bench.json", "bench.json"), ("bench_f32x3.json", "bench_f32x3.jso
              ("bf16_plan_sweep.txt", "bf16_plan_sweep.txt"), ("trio_other_configs.txt", "trio_other_configs.txt"), ("xcd_band_ab.txt", "xcd_band_ab.txt"),
              ("overlap_probe_bf16.txt", "overlap_probe_bf16.txt"), ("watchdog_fallback.json", "watchdog_fallback.json"),
              ("watchdog_fallback.err", "watchdog_fallback.err"), ("bench_forced_dist_cfg4.json", "bench_forced_dist_cfg4.json"),
-             ("registration_demo.txt", "registration_demo.txt"), ("mfv_stamps.txt", "mfv_stamps.txt")):
+             ("registration_demo.txt", "registration_demo.txt"), ("mfv_stamps.txt", "mfv_stamps.txt"), ("chain_bench.txt", "chain_bench.txt"),
+             ("asloss_engine_ab.txt", "asloss_engine_ab.txt"), ("registration_engine_ab.txt", "registration_engine_ab.txt")):
     copy(a, b)
 
 # per-kernel stats (our kernels only), one file per compute type
