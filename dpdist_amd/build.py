@@ -25,11 +25,13 @@ def _stale():
 
 
 def build(force=False, verbose=True):
-    if not force and not _stale():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # DPD_ABLATIONS=1: also compile the timing-only ablation variants of the plane GEMM (tools/x3_bench.py tile codes 100+)
     flags = FLAGS + (["-DDPD_ABLATIONS"] if os.environ.get("DPD_ABLATIONS") == "1" else []) + os.environ.get("DPD_EXTRA_FLAGS", "").split()
+    stamp0 = os.path.join(HERE, "build", "flags.txt")
+    flags_changed = os.path.exists(stamp0) and open(stamp0).read() != " ".join(flags)
+    if not force and not flags_changed and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)

@@ -140,3 +140,73 @@ def test_synth_is_deterministic_and_shaped():
     assert np.abs(a1).max() <= 1.0        # inside the Gaussian grid's cube
     pcA, pcB = synth.s1_random_patches(32, 64, 0)
     assert np.isin(pcB, synth.BOUNDARY_SET).mean() > 0.01
+
+
+@pytest.mark.parametrize("B,N,H,dt", [(16, 64, 1024, 0), (16, 64, 1024, 1), (16, 64, 1024, 2), (3, 36, 192, 2), (32, 64, 64, 0)])
+def test_asloss_engine_carve_is_a_partition_of_the_callers_buffer(lib, B, N, H, dt):
+    """dpd_asloss_bytes / dpd_asloss_carve are host-side pointer arithmetic (no device call): every member lies inside the caller's
+    allocation, 256-byte aligned, no two members overlap, the plane compute types get planes exactly for plane-shaped rows, and shapes the
+    engine does not take are refused before anything is touched."""
+    import ctypes
+    from dpdist_amd import lib as L
+    n = lib.dpd_asloss_bytes(B, N, 8, 5, H, dt)
+    assert n > 0
+    base = 1 << 30                                          # any 256-byte aligned "device address": nothing is dereferenced
+    e = L.AsLoss()
+    assert lib.dpd_asloss_carve(ctypes.c_void_p(base), n, B, N, 8, 5, H, dt, 0.125, e) == 0
+    assert (e.B, e.N, e.m, e.k, e.KP, e.H, e.dtype) == (B, N, 8, 5, 2528, H, dt) and abs(e.sigma - 0.125) < 1e-7
+    Q, KP = 2 * B * N, 2528
+    planes = dt != 0 and Q % 32 == 0 and H % 64 == 0
+    f4 = 4
+    want = {"pts": 2 * B * N * 3 * f4, "q": 2 * B * N * 3 * f4, "fv": 2 * B * 512 * 20 * f4, "ssq": 2 * B * 4 * 20 * f4, "mask": Q * f4,
+            "vox": Q * 4, "h3": Q * H * f4, "y": Q * 3 * f4, "pred": Q * 3 * f4, "dy": Q * 3 * f4, "g3": Q * H * f4, "dX": Q * KP * f4,
+            "dfv": 2 * B * 512 * 20 * f4, "dpts": 2 * B * N * 3 * f4, "scratch": 8, "mfv_ws": e.mfv_ws_bytes, "ws": e.ws_bytes}
+    if planes:
+        np_ = 3 if dt == 1 else 1
+        assert e.planes.np == np_ and e.planes.Q == Q and e.planes.Qb == Q and not e.X and not e.h1 and not e.W2T
+        spans = dict(want)
+        pl = e.planes
+        for name, size in (("X_rc", np_ * 2 * Q * KP), ("h1_rc", np_ * 2 * Q * H), ("h2_rc", np_ * 2 * Q * H), ("g3_rc", np_ * 2 * Q * H),
+                           ("g2_rc", np_ * 2 * Q * H), ("g1_rc", np_ * 2 * Q * H), ("W1_r8", np_ * 2 * KP * H), ("W1_rc", np_ * 2 * KP * H),
+                           ("W2_r8", np_ * 2 * H * H), ("W3_r8", np_ * 2 * H * H), ("W2_rc", np_ * 2 * H * H), ("W3_rc", np_ * 2 * H * H),
+                           ("sync", 4096)):
+            spans["planes." + name] = size
+        assert not pl.X_r8 and not pl.h1_r8 and not pl.g3_r8          # as-loss mode feeds no weight gradients: RC planes only
+    else:
+        assert e.planes.np == 0 and not e.planes.X_rc
+        spans = dict(want, X=Q * KP * f4, h1=Q * H * f4, h2=Q * H * f4, g2=Q * H * f4, g1=Q * H * f4, W2T=H * H * f4, W3T=H * H * f4,
+                     W1pT=H * KP * f4)
+    iv = []
+    for name, size in spans.items():
+        ptr = getattr(e.planes, name[7:]) if name.startswith("planes.") else getattr(e, name)
+        assert ptr and ptr % 256 == 0 and base <= ptr and ptr + size <= base + n, name
+        iv.append((ptr, ptr + size, name))
+    iv.sort()
+    for (a0, a1, na), (b0, b1, nb) in zip(iv, iv[1:]):
+        assert a1 <= b0, (na, nb)
+    # refused: too small a buffer, a misaligned one, B * N beyond the fused output kernel, an even window, H not a multiple of 64
+    assert lib.dpd_asloss_carve(ctypes.c_void_p(base), n - 1, B, N, 8, 5, H, dt, 0.125, e) == -4
+    assert lib.dpd_asloss_carve(ctypes.c_void_p(base + 16), n, B, N, 8, 5, H, dt, 0.125, e) == -3
+    assert lib.dpd_asloss_bytes(256, 64, 8, 5, H, dt) == 0 and lib.dpd_asloss_bytes(B, N, 8, 4, H, dt) == 0
+    assert lib.dpd_asloss_bytes(B, N, 8, 5, H + 8, dt) == 0
+    assert lib.dpd_asloss_forward(None, None, None, 0, None, None) == -1 and lib.dpd_asloss_backward(None, None, None, None, None) == -1
+    e2 = L.AsLoss()                                            # carved but without weights: refused before any launch
+    assert lib.dpd_asloss_carve(ctypes.c_void_p(base), n, B, N, 8, 5, H, dt, 0.125, e2) == 0
+    assert lib.dpd_asloss_forward(e2, ctypes.c_void_p(base), ctypes.c_void_p(base), 0, ctypes.c_void_p(base), None) == -1
+
+
+def test_schedule_selection_single_process():
+    """ddp.select_schedule without a process group: the smallest time wins, ties go to the earlier candidate, a failing candidate is
+    dropped, and all failing is an error."""
+    from dpdist_amd.ddp import select_schedule
+    t = {"early": 0.33, "grouped": 0.29, "late": 0.31}
+    assert select_schedule(["early", "grouped", "late"], t.__getitem__, torch.device("cpu")) == ("grouped", t)
+    assert select_schedule(["a", "b"], lambda n: 1.0, torch.device("cpu"))[0] == "a"
+
+    def flaky(n):
+        if n == "grouped":
+            raise RuntimeError("no")
+        return t[n]
+    assert select_schedule(["early", "grouped"], flaky, torch.device("cpu")) == ("early", {"early": 0.33, "grouped": None})
+    with pytest.raises(RuntimeError):
+        select_schedule(["grouped"], flaky, torch.device("cpu"))
