@@ -511,22 +511,43 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
     // Every global load of the kernel is requested HERE, before anything waits: W4 above, the rows (and their BA twins) and the per-row
     // scalars below.  Left where they were used, they made three dependent round trips (W4 -> row 0 -> row 1: 5.5k + 3.9k + 5.7k cycles
     // of a 25k-cycle kernel at B = 32, tools/ob_stamps.py); with one workgroup per CU there is nothing else to hide them behind.
-#pragma unroll
-    for (int rr = 0; rr < RW; ++rr) {
-        const int row = min(row0 + rr, Qb - 1);
+    static_assert(RW == 2, "the lane-pair exchanges below assume two rows per wave");
+    const bool odd = lane & 1;
+    // exchange a 64-bit value with lane ^ 1 (DPP quad_perm [1,0,3,2])
+    auto swap_pair = [](uint2 v) {
+        return make_uint2((unsigned)__builtin_amdgcn_mov_dpp((int)v.x, 0xB1, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)v.y, 0xB1, 0xf, 0xf, true));
+    };
+    auto widen = [](uint2 u) {
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    };
+    if (h3b) {
+        // layer 3's activation as one bf16 plane (DPD_BF16), widened exactly.  A lane's four columns of one row are 8 bytes, and 8-byte
+        // accesses run at ~0.6 of the 16-byte rate (round 5: this load phase was 12k of the kernel's 37k cycles at B = 64): the lanes
+        // 2p / 2p + 1 therefore load 16 bytes -- the eight columns of BOTH lanes -- of row 0 / row 1 and hand each other the half that
+        // belongs to the partner.  Same values in the same registers as two 8-byte loads per lane.
+        const int rsel = min(row0 + (odd ? 1 : 0), Qb - 1);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             if (jj < ng) {
-                if (h3b) {      // layer 3's activation as one bf16 plane (DPD_BF16): 8 bytes per lane instead of 16, widened exactly
-                    const uint2 ua = *reinterpret_cast<const uint2*>(h3b + (size_t)row * H + 256 * jj + 4 * lane);
-                    hv[rr][jj] = make_float4(__uint_as_float(ua.x << 16), __uint_as_float(ua.x & 0xffff0000u), __uint_as_float(ua.y << 16),
-                                             __uint_as_float(ua.y & 0xffff0000u));
-                    if (of.y) {
-                        const uint2 ub = *reinterpret_cast<const uint2*>(h3b + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
-                        hb[rr][jj] = make_float4(__uint_as_float(ub.x << 16), __uint_as_float(ub.x & 0xffff0000u), __uint_as_float(ub.y << 16),
-                                                 __uint_as_float(ub.y & 0xffff0000u));
-                    }
-                } else {
+                const uint4 va = *reinterpret_cast<const uint4*>(h3b + (size_t)rsel * H + 256 * jj + 8 * (lane >> 1));
+                const uint2 ra = swap_pair(odd ? make_uint2(va.x, va.y) : make_uint2(va.z, va.w));
+                hv[0][jj] = widen(odd ? ra : make_uint2(va.x, va.y));
+                hv[1][jj] = widen(odd ? make_uint2(va.z, va.w) : ra);
+                if (of.y) {
+                    const uint4 vb = *reinterpret_cast<const uint4*>(h3b + ((size_t)Qb + rsel) * H + 256 * jj + 8 * (lane >> 1));
+                    const uint2 rb = swap_pair(odd ? make_uint2(vb.x, vb.y) : make_uint2(vb.z, vb.w));
+                    hb[0][jj] = widen(odd ? rb : make_uint2(vb.x, vb.y));
+                    hb[1][jj] = widen(odd ? make_uint2(vb.z, vb.w) : rb);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int row = min(row0 + rr, Qb - 1);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (jj < ng) {
                     hv[rr][jj] = *reinterpret_cast<const float4*>(h3 + (size_t)row * H + 256 * jj + 4 * lane);
                     if (of.y) hb[rr][jj] = *reinterpret_cast<const float4*>(h3 + ((size_t)Qb + row) * H + 256 * jj + 4 * lane);
                 }
@@ -655,7 +676,25 @@ __global__ __launch_bounds__(256) void out_bwd_fused4_kernel(const float* __rest
                     for (int q = 0; q < 3; ++q) {
                         const uint2 w = make_uint2(pl4[0][q] | (pl4[1][q] << 16), pl4[2][q] | (pl4[3][q] << 16));
                         wpk[rr][jj][q] = w;      // kept in registers: the LDS image for the R8 chunks reuses the slabs once they are summed
-                        if (gp.rc && q < gp.np) *reinterpret_cast<uint2*>(gp.rc + q * gp.plane + (size_t)row * H + col) = w;
+                    }
+                    (void)col;
+                }
+            }
+        }
+    }
+    if (gp.rc) {
+        // RC planes: lane 2p stores the eight columns of lanes 2p / 2p + 1 of row 0, lane 2p + 1 those of row 1 -- one 16-byte store per
+        // lane, column group and plane instead of two 8-byte ones (the planes exist only for whole 8-row blocks: both rows are valid)
+        uint16_t* rcp = gp.rc + (size_t)(row0 + (odd ? 1 : 0)) * H + 8 * (lane >> 1);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (jj < ng) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (q < gp.np) {
+                        const uint2 got = swap_pair(odd ? wpk[0][jj][q] : wpk[1][jj][q]);
+                        const uint2 lo = odd ? got : wpk[0][jj][q], hi = odd ? wpk[1][jj][q] : got;
+                        *reinterpret_cast<uint4*>(rcp + q * gp.plane + 256 * jj) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                     }
                 }
             }
