@@ -439,3 +439,36 @@ def test_registration_step_on_a_single_rank_group_is_the_plain_step(backend, mon
     finally:
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(monkeypatch):
+    """Twelve training steps of the iterative registration at the reference's workload (batch 16, 8 loops, dropout on: 7 no-gradient
+    evaluations + 1 differentiated one per step) with DPDist evaluated through the as-loss engine (dpd_asloss_forward / _backward) and
+    through the entry-by-entry autograd node: the pose network ends up bit for bit the same, and the same again on a second run."""
+    import hashlib
+    from dpdist_amd.model import DPDistLoss, DPDistModel
+    from dpdist_amd.registration import IterativeRegistration
+    dev = torch.device("cuda:0")
+
+    def run(engine):
+        monkeypatch.setenv("DPD_ASLOSS_ENGINE", engine)
+        torch.manual_seed(0)
+        model = DPDistModel(device=dev)
+        model.load_tf_state_dict(synth.make_weights("wide"))
+        net = PoseNet().to(dev)
+        torch.manual_seed(1000)
+        rng = np.random.default_rng(0)
+        reg = IterativeRegistration(net, DPDistLoss(model), lr=1e-4, max_loops=8, distributed=False)
+        for _ in range(12):
+            src, tmpl, _ = synth.registration_pairs(16, 64, rng=rng)
+            loss, _ = reg.train_step(torch.tensor(src, device=dev), torch.tensor(tmpl, device=dev))
+        torch.cuda.synchronize()
+        w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        used = bool(getattr(model.params_, "_asloss_engines", None))
+        reg.close()
+        return hashlib.sha1(w.cpu().numpy().tobytes()).hexdigest(), loss.item(), used
+
+    a, b, c = run("1"), run("1"), run("0")
+    assert a[2] and not c[2]                     # the engine really ran in the first two and not in the third
+    assert a[:2] == b[:2] == c[:2], (a, b, c)
