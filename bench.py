@@ -337,7 +337,7 @@ def self_launch(n):
     environment contract as `python -m torch.distributed.run --nproc-per-node N`).  Rank 0 prints the JSON line; the exit code
     is the first non-zero rank exit code.  Children are stopped by PID, never by pattern."""
     import torch
-    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+    if not torch.cuda.is_available() or (torch.cuda.device_count() < n and os.environ.get("DPD_TEST_SHARE_GPU") != "1"):
         sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible\n" % (n, torch.cuda.device_count() if torch.cuda.is_available() else 0))
         return 2
     return spawn_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
@@ -429,6 +429,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DPDist path has no CPU fallback")
+    # DPD_TEST_SHARE_GPU=1 (tests only): every rank runs on GPU 0 and the process group is gloo -- the numbers mean nothing (the ranks
+    # time-share one device, collectives go through the host), but it is the only way to run this file's world > 1 control flow (two
+    # supervisors, the reducer's start-up cross-check, the collective schedule choice, the config-4 legs, the replica comparison) on a
+    # one-GPU box: tests/test_gpu_parity.py::test_bench_two_ranks_share_the_gpu
+    share_gpu = os.environ.get("DPD_TEST_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if use_dist:
@@ -439,7 +446,10 @@ def main():
         # (trainer.apply_gradients; this loop never reads params.flat between steps)
         os.environ.setdefault("DPD_DP_ADAM_SIDE", "1")
         hb.beat("init:process group")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()
 
     from dpdist_amd import lib, synth
@@ -841,7 +851,8 @@ def main():
         qps = 2.0 * B * N * world * a.steps / el
         out = {"metric": "query-points/sec (DPDist fwd+bwd)", "value": round(qps, 1), "unit": "query-points/sec",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+               "data": "synthetic" if not share_gpu else "synthetic; TEST MODE DPD_TEST_SHARE_GPU=1: all ranks on ONE GPU over gloo, timings meaningless",
                "config": {"workload": "DPDist training step (3DmFV 8^3 + 5^3-window decoder 2503-1024-1024-1024-3, "
                                       "fwd both directions + bwd AB half + Adam), S2 ModelNet-shaped clouds",
                           "pairs_per_gpu": B, "global_batch": B * world, "num_point": N, "query_points_per_step": 2 * B * N * world,

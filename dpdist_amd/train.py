@@ -175,12 +175,18 @@ def train(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    share_gpu = os.environ.get("DPD_TEST_SHARE_GPU") == "1"        # tests only: every rank on GPU 0 over gloo (as in bench.py)
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("DPD_DP_ADAM_SIDE", "1")      # optimizer on the collectives' stream (trainer.apply_gradients); the trainer joins it itself
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert F.batch_size % world == 0                               # :122-126
     dev_bs = F.batch_size // world
     N, K = F.num_point, int(F.K)

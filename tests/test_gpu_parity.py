@@ -2343,3 +2343,87 @@ def test_plane_weight_gradient_pair_on_a_narrow_decoder(dev, B, monkeypatch):
         a, b = grads["bf16"][n].double().flatten(), grads["f32"][n].double().flatten()
         cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
         assert cos >= 0.995 and abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0) <= 0.03, (n, cos)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu(dev):
+    """bench.py's world-size-2 control flow for real, on a one-GPU box: DPD_TEST_SHARE_GPU=1 puts both ranks on GPU 0 over gloo (timings
+    mean nothing).  Exactly the driver's command (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`): two
+    supervisors and their workers, the reducer's start-up cross-check with two ranks, the backward order chosen by BOTH ranks together
+    for the headline and for config 4, the pinned legs, the same-run one-rank leg, the exposed-communication probe, and the final
+    comparison of the replicas' parameters and Adam slots -- which must be bit-identical after all those steps."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    env = dict(os.environ, DPD_TEST_SHARE_GPU="1")
+    for k in ("DPD_BENCH_CHILD", "DPD_DP_BACKEND", "DPD_DP_MODE", "DPD_DP_SCHEDULE", "DPD_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK",
+              "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                                    # rank 0 prints ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["global_batch"] == 64 and "TEST MODE" in rec["data"]
+    dp = rec["dp"]
+    assert dp["crosscheck"]["ok"] and dp["replicas_bit_identical"] is True and rec["fallback"] is False
+    assert dp["schedule"]["schedule"] in ("early", "late") and set(dp["schedule"]["candidates_ms"]) == {"early", "late"}
+    c4 = rec["config4"]
+    assert c4["n_gpus"] == 2 and c4["global_batch"] == 128 and c4["dp"]["replicas_bit_identical"] is True
+    assert c4["dp"]["schedule"]["schedule"] in ("early", "grouped", "late") and len(c4["dp"]["schedule"]["candidates_ms"]) == 3
+    for leg in ("early_schedule", "grouped_schedule", "n1_same_run"):
+        assert c4[leg]["ms_per_step"] > 0, leg
+    assert "weak_scaling_efficiency_vs_n1_same_run" in c4
+
+
+def _torchrun_shared_gpu(args, timeout=1500):
+    import socket
+    import subprocess
+    import sys
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    env = dict(os.environ, DPD_TEST_SHARE_GPU="1")
+    for k in ("DPD_BENCH_CHILD", "DPD_DP_BACKEND", "DPD_DP_MODE", "DPD_DP_SCHEDULE", "DPD_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK",
+              "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port)] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_trainer_loop_two_ranks_share_the_gpu(dev, tmp_path):
+    """python -m dpdist_amd.train under torch.distributed.run with two ranks on one GPU (gloo): global batch 16 split 8 + 8, the backward
+    order chosen by both ranks on the first batch, two epochs, eval, rank 0's checkpoint."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _torchrun_shared_gpu(["-m", "dpdist_amd.train", "--max_epoch", "2", "--batch_size", "16", "--train_shapes", "48", "--test_shapes", "16",
+                              "--eval_every", "1", "--log_dir", str(tmp_path / "log")], timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "data-parallel schedule" in r.stdout and "candidates_ms" in r.stdout
+    assert any(f.startswith("model.ckpt") for f in os.listdir(str(tmp_path / "log"))), os.listdir(str(tmp_path / "log"))
+
+
+@pytest.mark.gpu
+def test_registration_demo_two_ranks_share_the_gpu(dev):
+    """BASELINE config 5's data-parallel leg end to end with two ranks on one GPU (gloo): DPDist trained identically on both ranks, frozen,
+    the pose network's gradient all-reduced (nothing of DPDist travels), held-out pairs split over the ranks, replicas bit-identical."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _torchrun_shared_gpu([os.path.join(root, "tools", "registration_demo.py"), "--gpus", "2", "--loss", "ours", "--dp_steps", "60", "--dp_pool", "8",
+                              "--reg_steps", "12", "--eval_pairs", "16", "--batch", "4"], timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["workload"]["global_batch"] == 8
+    d = rec["pcrnet_ours"]["dp"]
+    assert d["nranks"] == 2 and d["replicas_bit_identical"] is True and d["dpdist_collectives"] == 0 and d["crosscheck"]["ok"]
+    assert rec["pcrnet_ours"]["pairs"] == 16

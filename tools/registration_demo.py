@@ -44,7 +44,7 @@ def main():
             raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
         import bench                                  # plain `--gpus N`: start the N ranks ourselves (bench.spawn_ranks: by PID, timeout)
         import torch
-        if not torch.cuda.is_available() or torch.cuda.device_count() < a.gpus:
+        if not torch.cuda.is_available() or (torch.cuda.device_count() < a.gpus and os.environ.get("DPD_TEST_SHARE_GPU") != "1"):
             sys.stderr.write("registration_demo --gpus %d: only %d GPU(s) visible\n" % (a.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0))
             raise SystemExit(2)
         raise SystemExit(bench.spawn_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
@@ -63,13 +63,19 @@ def main():
     from dpdist_amd.model import DPDistLoss, DPDistModel
     from dpdist_amd.registration import IterativeRegistration, PoseNet, centroid_residual, find_errors, find_final_pose_inv
     from dpdist_amd.trainer import DPDistTrainer
+    share_gpu = os.environ.get("DPD_TEST_SHARE_GPU") == "1"      # tests only: every rank on GPU 0 over gloo (bench.py has the same switch)
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29521")
         hb.beat("init:process group")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     say = print if rank == 0 else (lambda *x, **k: None)
     cu = lambda x: torch.tensor(x, device=dev)   # noqa: E731
     out = {"n_gpus": world, "workload": {"batch_per_gpu": a.batch, "global_batch": a.batch * world, "num_point": 64, "loops": a.loops, "lim_rot": 45.0, "poses": "U(-45,45)^3 deg, U(-.01,.01)^3",
