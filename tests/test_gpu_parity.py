@@ -2427,3 +2427,28 @@ def test_registration_demo_two_ranks_share_the_gpu(dev):
     d = rec["pcrnet_ours"]["dp"]
     assert d["nranks"] == 2 and d["replicas_bit_identical"] is True and d["dpdist_collectives"] == 0 and d["crosscheck"]["ok"]
     assert rec["pcrnet_ours"]["pairs"] == 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(1, 64), (5, 32), (2, 200), (7, 8), (3, 100)])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f32x3"])
+def test_as_loss_engine_on_ragged_shapes(dev, dt, B, N, monkeypatch):
+    """The engine against the entry-by-entry node on the shapes the reference's consumers may bring (config 1's single pair, ragged point
+    counts, row counts that are not plane-shaped -- the engine then carves the exact type's buffers and the GEMMs convert per call):
+    loss and both input gradients bit for bit, gradients finite."""
+    from dpdist_amd import model as M
+    pcA, pcB, _ = synth.s2_modelnet_shaped(B, N, 11)
+    res = {}
+    for eng in ("0", "1"):
+        monkeypatch.setenv("DPD_ASLOSS_ENGINE", eng)
+        mod = _model(dev, "wide")
+        mod.params_.compute_dtype = dt
+        a, b = _cu(pcA, dev).requires_grad_(True), _cu(pcB, dev).requires_grad_(True)
+        loss = M.DPDistLoss(mod)(a, b)
+        ga, gb = torch.autograd.grad(loss * 3.0, [a, b])
+        res[eng] = (loss.detach().clone(), ga, gb)
+        if eng == "1":
+            assert getattr(mod.params_, "_asloss_engines", None), "the engine did not take this shape"
+    for x, y in zip(res["0"], res["1"]):
+        assert torch.equal(x, y), (x - y).abs().max().item()
+    assert torch.isfinite(res["1"][1]).all() and torch.isfinite(res["1"][2]).all()
