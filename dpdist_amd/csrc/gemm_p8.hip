@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_chain_kernel(ChainArgs c) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     int q = (int)(xcc & (kChainQueues - 1)), done_tiles = 0;
     auto stamp = [&](int i) {
-        if (c.stamps && tid == 0 && done_tiles < 4) c.stamps[((size_t)blockIdx.x * 4 + done_tiles) * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        if (c.stamps && tid == 0 && done_tiles < 4 && blockIdx.x < 256) c.stamps[((size_t)blockIdx.x * 4 + done_tiles) * 8 + i] = __builtin_amdgcn_s_memrealtime();
     };
     auto queue_tiles = [&](int x) { return ((tilesM - x + kChainQueues - 1) / kChainQueues) * tilesN * nst; };
     auto take = [&]() {
