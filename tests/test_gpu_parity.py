@@ -2300,7 +2300,8 @@ def test_data_parallel_schedule_is_selected_by_measurement(dev, dt, monkeypatch)
         torch.cuda.synchronize()
         cands = ["early", "grouped", "late"] if dt == "bf16" else ["early", "late"]
         assert sorted(info["candidates_ms"]) == sorted(cands) and all(v and v > 0 for v in info["candidates_ms"].values())
-        assert info["schedule"] == tr.dp_schedule and info["schedule"] == min(cands, key=lambda c: (info["candidates_ms"][c], cands.index(c)))
+        assert info["schedule"] == tr.dp_schedule and info["schedule"] in cands
+        assert info["candidates_ms"][info["schedule"]] <= min(info["candidates_ms"].values()) + 1e-4      # (the table is rounded to 1e-4 ms)
         assert torch.equal(P.flat.detach(), before[0]) and torch.equal(tr.m_state, before[1]) and torch.equal(tr.v_state, before[2])
         assert tr.t == before[3]
         l1 = tr.step(pcA, pcB, lab).clone()
