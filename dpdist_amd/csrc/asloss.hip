@@ -115,8 +115,11 @@ extern "C" int dpd_asloss_forward(const dpd_asloss* e, const float* pcA, const f
     // layers 1-3 (:513-544), then output layer + loss_pred (+ the output-layer backward) in one launch (:691-698, :976-979)
     if (int rc = dpd_decoder_fwd(pl ? nullptr : e->X, e->mask, Q, e->KP, e->H, &e->params, e->dtype, e->h1, e->h2, e->h3, nullptr, nullptr, e->ws,
                                  e->ws_bytes, pl, stream)) return rc;
-    return dpd_decoder_out_asloss(e->h3, e->mask, Q, e->H, e->B * e->N, &e->params, 1.0f, e->y, e->pred, loss, want_grad ? e->dy : nullptr,
-                                  want_grad ? e->g3 : nullptr, e->scratch, stream);
+    // plane compute types (H a multiple of 256): g3 leaves the fused output-layer kernel as the RC plane the first dH GEMM reads -- no fp32
+    // g3, no conversion launch (same bits: tests compare the gradients with the entry-by-entry node's)
+    const bool g3_plane = pl && want_grad && !(e->H & 255) && e->H <= 1024;
+    return dpd_decoder_out_asloss_planes(e->h3, e->mask, Q, e->H, e->B * e->N, &e->params, 1.0f, e->y, e->pred, loss, want_grad ? e->dy : nullptr,
+                                         (want_grad && !g3_plane) ? e->g3 : nullptr, g3_plane ? pl : nullptr, e->scratch, stream);
 }
 
 extern "C" int dpd_asloss_backward(const dpd_asloss* e, const float* upstream, float* gA, float* gB, void* stream) {
@@ -124,7 +127,9 @@ extern "C" int dpd_asloss_backward(const dpd_asloss* e, const float* upstream, f
     const int C = 2 * e->B, Q = C * e->N;
     const dpd_planes* pl = e->planes.np ? &e->planes : nullptr;
     // TF autodiff of the decoder down to its input rows, of the gather and of the encoder; gradients w.r.t. the two clouds only
-    if (int rc = dpd_decoder_bwd_data(nullptr, nullptr, nullptr, e->h1, e->h2, nullptr, Q, e->KP, e->H, &e->params, e->dtype, nullptr, e->g3, e->g2,
+    const bool g3_plane = pl && !(e->H & 255) && e->H <= 1024;       // as in dpd_asloss_forward: g3 is already the plane pl->g3_rc
+    if (int rc = dpd_decoder_bwd_data(nullptr, nullptr, nullptr, e->h1, e->h2, nullptr, Q, e->KP, e->H, &e->params, e->dtype, nullptr,
+                                      g3_plane ? nullptr : e->g3, e->g2,
                                       e->g1, e->dX, nullptr, e->ws, e->ws_bytes, pl, 6, stream)) return rc;
     if (int rc = dpd_patch_rows_bwd(e->dX, e->vox, C, e->N, e->m, e->k, e->KP, nullptr, e->dfv, stream)) return rc;
     if (int rc = dpd_mfv3d_bwd(e->pts, e->dfv, C, e->N, e->m, e->sigma, e->dpts, e->mfv_ws, e->mfv_ws_bytes, stream)) return rc;

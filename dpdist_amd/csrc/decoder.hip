@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256) void out_asloss_kernel(const float* __restrict
                                                           const float* __restrict__ b4, const float* __restrict__ mask,
                                                           float* __restrict__ y, float* __restrict__ pred, float* __restrict__ dy,
                                                           float* __restrict__ g3, int Q, int H, int BN, float gv,
-                                                          float* __restrict__ loss, unsigned long long* __restrict__ acc) {
+                                                          float* __restrict__ loss, unsigned long long* __restrict__ acc,
+                                                          uint16_t* __restrict__ g3_rc, long g3_plane, int g3_np) {
+    // g3_rc (round 5, the as-loss engine of the plane compute types): g3 leaves this kernel as the RC operand plane(s) of the first dH GEMM
+    // -- the same split as split_planes_kernel, which this saves (one launch and the fp32 round trip of g3; g3 itself may then be NULL)
     __shared__ float s_p[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float p0 = 0.f;
@@ -297,10 +300,10 @@ __global__ __launch_bounds__(256) void out_asloss_kernel(const float* __restrict
             pred[(size_t)row * 3 + lane] = lane == 0 ? pv[0] : (lane == 1 ? pv[1] : pv[2]);
         }
         p0 += pv[0];
-        if (g3) {
+        if (dy) {
             const float d0 = (yv[0] > 0.f && yv[0] < 6.f) ? gv * mk / 3.0f : 0.f;
             if (lane < 3) dy[(size_t)row * 3 + lane] = lane == 0 ? d0 : 0.f;
-            float* g = g3 + (size_t)row * H;
+            float* g = g3 ? g3 + (size_t)row * H : nullptr;
             if (out_row_fast(W4, H)) {
 #pragma unroll
                 for (int i = 0; i < kOutMaxI; ++i) {
@@ -312,10 +315,24 @@ __global__ __launch_bounds__(256) void out_asloss_kernel(const float* __restrict
                         o.y = x.y > 0.f ? d0 * rr.w0[i][1] : 0.f;
                         o.z = x.z > 0.f ? d0 * rr.w0[i][2] : 0.f;
                         o.w = x.w > 0.f ? d0 * rr.w0[i][3] : 0.f;
-                        *reinterpret_cast<float4*>(g + k) = o;
+                        if (g) *reinterpret_cast<float4*>(g + k) = o;
+                        if (g3_rc) {
+                            const float ov[4] = {o.x, o.y, o.z, o.w};
+                            unsigned pl4[4][3];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (g3_np == 1) { pl4[e][0] = bf16_bits(ov[e]); pl4[e][1] = 0; pl4[e][2] = 0; }
+                                else split3(ov[e], pl4[e]);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                if (q < g3_np)
+                                    *reinterpret_cast<uint2*>(g3_rc + q * g3_plane + (size_t)row * H + k) =
+                                        make_uint2(pl4[0][q] | (pl4[1][q] << 16), pl4[2][q] | (pl4[3][q] << 16));
+                        }
                     }
                 }
-            } else {
+            } else if (g) {
                 for (int k = lane; k < H; k += 64) g[k] = h[k] > 0.f ? d0 * W4[k * 3] : 0.f;
             }
         }
@@ -1204,16 +1221,27 @@ extern "C" int dpd_decoder_bwd_weights_pair_adam(const float* actA, const float*
 
 extern "C" int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
                                       float* y, float* pred, float* loss_pred, float* dy, float* g3, float* scratch, void* stream) {
+    return dpd_decoder_out_asloss_planes(h3, mask, Q, H, BN, p, gscale, y, pred, loss_pred, dy, g3, nullptr, scratch, stream);
+}
+
+extern "C" int dpd_decoder_out_asloss_planes(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
+                                             float* y, float* pred, float* loss_pred, float* dy, float* g3, const dpd_planes* pl, float* scratch,
+                                             void* stream) {
     using namespace dpd;
     if (!h3 || !mask || !p || !p->W4 || !p->b4 || !y || !pred || !loss_pred || !scratch) return DPD_E_NULL;
-    if (!dy != !g3) return DPD_E_NULL;
+    // pl with g3_rc (and dy given): g3 also (or, with g3 == NULL, only) as RC operand plane(s); needs the 16-byte fast path of the row kernel
+    uint16_t* g3_rc = (pl && dy) ? (uint16_t*)pl->g3_rc : nullptr;
+    if (g3_rc && (pl->Qb != Q || (pl->np != 1 && pl->np != 3) || (H & 255) || H > 256 * kOutMaxI || ((uintptr_t)p->W4 & 15) || ((uintptr_t)h3 & 15)))
+        return DPD_E_UNSUPPORTED;
+    if (dy && !g3 && !g3_rc) return DPD_E_NULL;
+    if (!dy && g3) return DPD_E_NULL;
     if (Q <= 0 || H <= 0 || BN <= 0 || Q != 2 * BN) return DPD_E_DIM;
     if ((H & 3) || ((uintptr_t)scratch & 7) || Q > 8 * 65535 || BN >= (1 << 14)) return DPD_E_UNSUPPORTED;   // 16-bit block count; 48-bit sum: Q rows x at most 2.0 x 2^32 must stay below 2^48
     const float gv = 0.5f * (1.0f / (float)BN) * gscale;      // = l1_loss_kernel mode 2
     // two rows per wave: 9.9 us against 11.2 (one) and 11.9 (four) at the PCRNet batch -- the kernel is a chain of round trips (rows and
     // W4 -> wave sums -> stores -> the atomic's return), not a throughput problem
     DPD_LAUNCH(out_asloss_kernel<2>, dim3((Q + 7) / 8), dim3(256), 0, (hipStream_t)stream, h3, p->W4, p->b4, mask, y, pred, dy, g3, Q, H, BN, gv,
-               loss_pred, (unsigned long long*)scratch);
+               loss_pred, (unsigned long long*)scratch, g3_rc, g3_rc ? (long)Q * H : 0L, g3_rc ? pl->np : 0);
     DPD_CHECK_LAUNCH();
     return 0;
 }
@@ -1321,7 +1349,8 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
     if ((phases & 24) && !(sg && sg->partials)) return DPD_E_NULL;
     // g3 = NULL: only when the fused output-layer kernel writes g3 as operand planes itself (plane compute types, below)
     bool g3_planes_done = false;
-    if (!g3 && !(pl && pl->g3_rc && pl->g3_r8 && fused && fused4 && !(Qb % kOBRows))) return DPD_E_NULL;
+    // (phases without 1 and no fp32 g3: dpd_decoder_out_asloss_planes has left g3 as the RC plane the first dH GEMM reads)
+    if (!g3 && !(pl && pl->g3_rc && ((pl->g3_r8 && fused && fused4 && !(Qb % kOBRows)) || !(phases & 1)))) return DPD_E_NULL;
     if ((phases & 8) && fused) {   // deferred second stage of the small gradients (a side stream / graph branch runs it)
         DPD_LAUNCH(small_grads_reduce, dim3(nred), dim3(256), 0, s, (const float*)part, nblk, H, db3, dW4, db4, rec, lossp, Qb);
         DPD_CHECK_LAUNCH();

@@ -68,6 +68,8 @@ SIGNATURES = {
                                           c_void_p, POINTER(Planes), c_void_p]),
     "dpd_decoder_out_asloss": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "dpd_decoder_out_asloss_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_float, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, POINTER(Planes), c_void_p, c_void_p]),
     "dpd_asloss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p]),

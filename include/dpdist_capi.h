@@ -296,6 +296,12 @@ int dpd_l1_loss(const float* pred, const float* labels, int BN, int mode, float 
  *   scratch: 8 bytes, 8-byte aligned, ZERO before the first call (the kernel leaves it zero; one per concurrently running stream). */
 int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
                            float* y, float* pred, float* loss_pred, float* dy, float* g3, float* scratch, void* stream);
+/* The same with g3 ALSO written as the RC operand plane(s) pl->g3_rc of the first data-gradient GEMM (plane compute types, pl->Qb == Q,
+ * H % 256 == 0, H <= 1024; the bits dpd_split_planes would produce from the fp32 g3): g3 may then be NULL, and dpd_decoder_bwd_data
+ * (phases = 6, g3 = NULL) goes on from the plane.  pl == NULL: exactly dpd_decoder_out_asloss.                                     */
+int dpd_decoder_out_asloss_planes(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
+                                  float* y, float* pred, float* loss_pred, float* dy, float* g3, const dpd_planes* pl, float* scratch,
+                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DPDist-as-a-loss ENGINE (round 5): the whole as-loss evaluation -- the reference's spliced graph
