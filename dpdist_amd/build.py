@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdpdist_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_x3.hip", "gemm_p8.hip", "mfv3d.hip", "patch_rows.hip", "decoder.hip", "loss_adam.hip", "chamfer.hip", "asloss.hip", "host_util.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_x3.hip", "gemm_p8.hip", "mfv3d.hip", "patch_rows.hip", "decoder.hip", "loss_adam.hip", "chamfer.hip", "asloss.hip", "pose.hip", "host_util.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -4,7 +4,8 @@
 //   w.r.t. the 'Network' scope only, i.e. THROUGH input1) and train_multi_gpu_pc_compare_dist.py:427-463 (the AUE splice).
 // No kernel of its own: it sequences the library's entry points exactly as dpdist_amd/model.py's autograd node did from Python, so the
 // results are bit for bit those of the one-by-one calls (tests/test_gpu_parity.py); what it removes is ~30 allocations and a dozen
-// ctypes calls per evaluation, which bounded the registration loop (8 evaluations per step at batch 16) on the HOST.
+// ctypes calls per evaluation (one forward + backward per registration step at batch 16: the seven refinements before it are pose-network only,
+// iterative_PCRNet_ours.py:414-441), and a fixed set of buffers is what lets the whole registration step be captured as a hipGraph.
 #include "common.h"
 
 namespace {

@@ -95,6 +95,8 @@ SIGNATURES = {
     "dpd_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "dpd_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "dpd_pose_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dpd_pose_apply_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "dpd_planes_bytes": (c_size_t, [c_int] * 6),
     "dpd_planes_carve": (c_int, [c_void_p, c_size_t] + [c_int] * 6 + [POINTER(Planes)]),
     "dpd_weights_to_planes": (c_int, [POINTER(DecoderParams), c_int, c_int, POINTER(Planes), c_void_p]),

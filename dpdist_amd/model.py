@@ -89,6 +89,7 @@ class DPDistParams(nn.Module):
         update `flat` through raw device pointers (the trainer's Adam kernels never bump `flat._version`) must call this."""
         self._tr_key = None
         self._wplanes = None
+        self.__dict__["_derived_gen"] = self.__dict__.get("_derived_gen", 0) + 1    # captured graphs that baked derived copies in re-capture
         for engines in self.__dict__.get("_asloss_engines", {}).values():      # the as-loss engines re-derive their weight copies
             for e in engines:
                 e._wkey = None
@@ -473,11 +474,19 @@ class DPDistLoss(nn.Module):
     """DPDist as a frozen loss (pcrnet-registration/iterative_PCRNet_ours.py:229-251):
     loss = (mean(output1[...,0]) + mean(output2[...,0])) / 2 for (source, template); gradients flow to the inputs only."""
 
+    capturable = True       # no host synchronisation, no host-side state per evaluation: the whole evaluation can sit inside a hipGraph
+
     def __init__(self, model):
         super().__init__()
         self.model = model
         for p in self.model.parameters():
             p.requires_grad_(False)
+
+    def graph_key(self):
+        """What a captured graph of this loss has baked in (registration.IterativeRegistration re-captures when it changes): the weight
+        buffer, its version, the compute type and the generation of the copies derived from the weights."""
+        P = self.model.params_
+        return (P.flat.data_ptr(), P.flat._version, P.compute_dtype, P.__dict__.get("_derived_gen", 0))
 
     def forward(self, source, template):
         mod = self.model

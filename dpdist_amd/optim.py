@@ -33,6 +33,7 @@ class TFAdam(torch.optim.Optimizer):
         self.m = torch.zeros(n4, device=dev)
         self.v = torch.zeros(n4, device=dev)
         self.t = 0
+        self.state_dev = torch.zeros(8, device=dev)   # [3] = lr_t for the captured (hipGraph) step: dpd_adam_tf_dev reads it from device memory
         self._params, off = params, 0
         with torch.no_grad():
             for p in params:
@@ -95,6 +96,17 @@ class TFAdam(torch.optim.Optimizer):
             self.v.copy_(extra["v"])
             self.t = int(extra["t"])
 
+    def _lr_t(self):
+        g = self.param_groups[0]
+        return g["lr"] * math.sqrt(1.0 - g["beta2"] ** self.t) / (1.0 - g["beta1"] ** self.t)
+
+    @torch.no_grad()
+    def prepare_replay(self):
+        """Before each replay of a hipGraph that captured `step()`: advance the step count on the host and put this step's lr_t (the
+        same double-precision expression, rounded to fp32 like the eager call's argument) where the captured launch reads it."""
+        self.t += 1
+        self.state_dev[3:4].fill_(self._lr_t())
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
@@ -102,6 +114,11 @@ class TFAdam(torch.optim.Optimizer):
         self._check_views()
         g = self.param_groups[0]
         b1, b2 = g["beta1"], g["beta2"]
+        if torch.cuda.is_current_stream_capturing():
+            # captured form: same kernel arithmetic, lr_t comes from state_dev[3] (written by prepare_replay before every replay)
+            L.check(L.load().dpd_adam_tf_dev(L.ptr(self.flat), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.flat.numel(),
+                                             L.ptr(self.state_dev), b1, b2, g["epsilon"], 1.0, L.cur_stream()), "dpd_adam_tf_dev")
+            return
         self.t += 1
         lr_t = g["lr"] * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         L.check(L.load().dpd_adam_tf(L.ptr(self.flat), L.ptr(self.grad), L.ptr(self.m), L.ptr(self.v), self.flat.numel(),

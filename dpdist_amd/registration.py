@@ -83,10 +83,14 @@ class PoseNet(nn.Module):
         B = source.shape[0]
         return f[:B], f[B:]
 
-    def forward(self, source, template):
+    def raw(self, source, template):
+        """get_pose's fc4 output (:273-284) BEFORE quat_normalize: [B,7] = (t, angle, axis)."""
         f = self.point(torch.cat([source, template], 0)).amax(1)            # max pool over the points
         B = source.shape[0]
-        pred = self.head(torch.cat([f[:B], f[B:]], 1))
+        return self.head(torch.cat([f[:B], f[B:]], 1))
+
+    def forward(self, source, template):
+        pred = self.raw(source, template)
         return quat_normalize(pred, self.lim_rot) if self.lim_rot else pred
 
 
@@ -198,6 +202,52 @@ def centroid_residual(T_pred, gt_pose, source):
     return out
 
 
+class _PoseApplyFn(torch.autograd.Function):
+    """quat_normalize -> quaternion normalisation -> Besl-McKay R -> moved cloud (-> T composition) as ONE launch of csrc/pose.hip per
+    direction instead of ~115 element-wise torch launches (`quat_normalize`, `predicted_pose_applied`, `transformation_quat_tensor`,
+    `compose` above are the same algebra in torch and stay the CPU / reference form; tests/test_registration.py compares the two).
+    Gradient: d moved -> d pred only (mode 1); the source cloud comes out of the forward-only refinements (:414-441)."""
+
+    @staticmethod
+    def forward(ctx, pred, source, T, lim_rot, mode):
+        from . import lib as L
+        B, N, _ = source.shape
+        L.req(pred, name="pred", shape=(B, 7)), L.req(source, name="source", shape=(B, N, 3))
+        pose, moved = torch.empty_like(pred), torch.empty_like(source)
+        T_out = None
+        if T is not None:
+            L.req(T, name="T", shape=(B, 4, 4))
+            T_out = torch.empty_like(T)
+        L.check(L.load().dpd_pose_apply_fwd(L.ptr(pred), L.ptr(source), L.ptr(T), B, N, float(lim_rot or 0.0), int(mode), L.ptr(pose),
+                                            L.ptr(moved), L.ptr(T_out), L.cur_stream()), "dpd_pose_apply_fwd")
+        ctx.save_for_backward(pred, source)
+        ctx.lim_rot, ctx.mode = float(lim_rot or 0.0), int(mode)
+        ctx.mark_non_differentiable(pose)
+        if T_out is None:
+            return pose, moved
+        ctx.mark_non_differentiable(T_out)
+        return pose, moved, T_out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from . import lib as L
+        if ctx.mode != 1:
+            raise RuntimeError("pose_apply: only the training evaluation (mode 1) is differentiable; the refinements are forward-only")
+        pred, source = ctx.saved_tensors
+        B, N, _ = source.shape
+        dmoved = grads[1].contiguous()
+        dpred = torch.empty_like(pred)
+        L.check(L.load().dpd_pose_apply_bwd(L.ptr(pred), L.ptr(source), L.ptr(dmoved), B, N, ctx.lim_rot, L.ptr(dpred), L.cur_stream()),
+                "dpd_pose_apply_bwd")
+        return dpred, None, None, None, None
+
+
+def pose_apply(pred, source, T=None, lim_rot=45.0, mode=0):
+    """(pose, moved[, T_out]) of the pose network's raw output on the GPU library (include/dpdist_capi.h: dpd_pose_apply_fwd):
+    mode 0 = one forward-only refinement (helper.py:309-329), mode 1 = the training evaluation (iterative_PCRNet_ours.py:211-224)."""
+    return _PoseApplyFn.apply(pred.contiguous(), source.contiguous(), None if T is None else T.contiguous(), lim_rot, mode)
+
+
 def flat_gradient_views(params):
     """One flat fp32 buffer with every parameter's `.grad` as a view into it (what `optim.TFAdam` does for its own parameters): the
     data-parallel step all-reduces that ONE buffer instead of a tensor per layer."""
@@ -211,20 +261,39 @@ def flat_gradient_views(params):
     return flat
 
 
+class _GraphRec:
+    """One captured registration step (or evaluation) for one batch shape: static inputs / outputs, the hipGraph(s) and the as-loss engines
+    whose buffers the graph's launches point into (they must live exactly as long as the graph)."""
+    __slots__ = ("src", "tmpl", "loss", "T", "g1", "g2", "pool", "loss_key")
+
+
 class IterativeRegistration:
-    """One training step = iterative_PCRNet_ours.py:410-470: 7 forward-only refinements (no gradient), then one step
-    in which the DPDist loss of (transformed source, template) is back-propagated THROUGH the frozen DPDist path into
-    the pose network; the optimizer is `tf.train.AdamOptimizer(learning_rate, name='Adam2')` (:239) = `optim.TFAdam`.
+    """One training step = iterative_PCRNet_ours.py:410-470: 7 forward-only refinements of the pose (`predicted_transformation` only is
+    fetched, :414-441: NO DPDist evaluation there), then one step in which the DPDist loss of (transformed source, template) is
+    back-propagated THROUGH the frozen DPDist path into the pose network -- one DPDist forward + backward per step; the optimizer is
+    `tf.train.AdamOptimizer(learning_rate, name='Adam2')` (:239) = `optim.TFAdam`.
     `loss_fn(moved_source, template) -> scalar` is DPDistLoss (the reference's 'ours') or any other differentiable
     cloud distance (the reference's Chamfer baseline, iterative_PCRNet.py).
+
+    Where the time goes (round 5: 9.2 ms per step at batch 16 for 0.4 ms of DPDist -- ~1300 tiny eager launches, host-bound) and what
+    this class does about it on the GPU:
+      * `fused_pose` (DPD_POSE_FUSED, default on): quat_normalize / normalisation / Besl-McKay R / moved cloud / T composition are ONE
+        launch of csrc/pose.hip per loop (dpd_pose_apply_fwd; backward dpd_pose_apply_bwd) instead of ~115 element-wise launches;
+      * `graph` (DPD_REG_GRAPH, default on; needs optim.TFAdam and a loss with `capturable = True`, e.g. DPDistLoss): after
+        `graph_warmup` eager steps for a batch shape the WHOLE step -- 7 refinements, the training forward, DPDist forward + backward on
+        a private as-loss engine, the pose network's backward, TF-form Adam with lr_t read from device memory -- is captured once as a
+        hipGraph and replayed.  Same kernels in the same order on the same inputs (dropout draws from the same Philox offsets torch's
+        eager launches would use): the training is bit for bit the eager one (tests/test_registration.py).
 
     Data parallel (BASELINE config 5, "8 x MI355X DP"; the reference itself is single-GPU here, iterative_PCRNet_ours.py:196): one
     process per GPU, every rank registers its own pairs; DPDist is FROZEN, so there is no DPDist collective at all --
     the one exchange step is the sum all-reduce of the pose network's flat gradient (0.9 M parameters = 3.7 MB) through the same
     reducer as the DPDist trainer (ddp.make_reducer: RCCL driven directly, start-up cross-check, torch.distributed fallback), then
-    every rank applies the same averaged gradient: replicas stay bit-identical.  `distributed=None` follows the process group."""
+    every rank applies the same averaged gradient: replicas stay bit-identical.  `distributed=None` follows the process group.  With a
+    reducer the step is two graphs (refine + forward + backward | Adam) around the eager collective."""
 
-    def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None, distributed=None, group=None):
+    def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None, distributed=None, group=None, graph=None,
+                 fused_pose=None, graph_warmup=2):
         import os
         import torch.distributed as dist
         from .optim import TFAdam
@@ -239,16 +308,31 @@ class IterativeRegistration:
                 self._flat_grad = flat_gradient_views(pose_net.parameters())
             self.reducer = make_reducer(self._flat_grad, [0, self._flat_grad.numel()], group,
                                         force=os.environ.get("DPD_FORCE_DIST") == "1", mode="allreduce")
+        self.fused_pose = (os.environ.get("DPD_POSE_FUSED", "1") == "1") if fused_pose is None else bool(fused_pose)
+        want_graph = (os.environ.get("DPD_REG_GRAPH", "1") == "1") if graph is None else bool(graph)
+        self.use_graph = want_graph and isinstance(self.opt, TFAdam) and bool(getattr(dpdist_loss, "capturable", False))
+        self.graph_warmup = int(graph_warmup)
+        self._graphs, self._graph_seen = {}, {}
+        self.graph_replays = 0
 
     def close(self):
         red, self.reducer = self.reducer, None
         if red is not None:
             red.close()
+        self._graphs.clear()
+
+    # ---- the step, piece by piece (eager; the graph captures exactly these calls)
+    def _fused(self, source):
+        return self.fused_pose and source.is_cuda and hasattr(self.net, "raw")
 
     def refine(self, source, template, loops):
         T = torch.eye(4, device=source.device).repeat(source.shape[0], 1, 1)
+        fused = self._fused(source)
         with torch.no_grad():
             for _ in range(loops):
+                if fused:                # one launch: quat_normalize, normalisation, R, moved cloud, T <- M T (csrc/pose.hip)
+                    _, source, T = pose_apply(self.net.raw(source, template), source, T, self.net.lim_rot, 0)
+                    continue
                 pose = self.net(source, template)
                 # helper.transformation_quat2mat (helper.py:309-329) normalises the quaternion (transforms3d.quat2mat)
                 pose = torch.cat([pose[:, :3], pose[:, 3:7] / pose[:, 3:7].norm(dim=1, keepdim=True).clamp_min(1e-12)], 1)
@@ -256,13 +340,7 @@ class IterativeRegistration:
                 T = compose(T, pose)
         return source, T
 
-    def loss_and_gradients(self, refined_source, template):
-        """The training `sess.run` of :468 without the update: loss, predicted pose; gradients are left in the parameters'
-        `.grad` (d loss / d moved source comes from the HIP backward-to-input path when loss_fn is DPDistLoss)."""
-        pose = self.net(refined_source, template)
-        moved = predicted_pose_applied(refined_source, pose)
-        loss = self.loss_fn(moved, template)                 # (mean(AB[...,0]) + mean(BA[...,0])) / 2, :248-251
-        self.opt.zero_grad()
+    def _rebind_flat_gradient(self):
         if self._flat_grad is not None and not hasattr(self.opt, "grad"):
             self._flat_grad.zero_()                          # (a foreign optimizer's zero_grad may have dropped the views: rebind)
             if any(p.grad is None for p in self.net.parameters() if p.requires_grad):
@@ -270,24 +348,123 @@ class IterativeRegistration:
                 for p in (q for q in self.net.parameters() if q.requires_grad):
                     p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
                     off += p.numel()
+
+    def _evaluate_grad(self, refined_source, template, T=None):
+        """forward + backward of the training evaluation (:468 without the collective and the update): (loss, pose, T' or None);
+        this rank's gradients are left in the parameters' `.grad`."""
+        Tn = None
+        if self._fused(refined_source):
+            pred = self.net.raw(refined_source, template)
+            out = pose_apply(pred, refined_source, T, self.net.lim_rot, 1)
+            pose, moved = out[0], out[1]
+            Tn = out[2] if T is not None else None
+        else:
+            pose = self.net(refined_source, template)
+            moved = predicted_pose_applied(refined_source, pose)
+            if T is not None:
+                with torch.no_grad():
+                    pn = torch.cat([pose[:, :3], pose[:, 3:7] / pose[:, 3:7].norm(dim=1, keepdim=True).clamp_min(1e-12)], 1)
+                    Tn = compose(T, pn)
+        loss = self.loss_fn(moved, template)                 # (mean(AB[...,0]) + mean(BA[...,0])) / 2, :248-251
+        self.opt.zero_grad()
+        self._rebind_flat_gradient()
         loss.backward()
+        return loss.detach(), pose.detach(), Tn
+
+    def _reduce(self):
         if self.reducer is not None and self.reducer.active:
             # the one collective of this path: mean over the ranks of the pose network's gradient (DPDist is frozen: nothing of it travels)
             self.reducer.reduce_async(0)
             self.reducer.wait()
             self._flat_grad.mul_(self.reducer.grad_scale)
-        return loss.detach(), pose.detach()
 
-    def train_step(self, source, template):
+    def loss_and_gradients(self, refined_source, template):
+        """The training `sess.run` of :468 without the update: loss, predicted pose; gradients are left in the parameters'
+        `.grad` (d loss / d moved source comes from the HIP backward-to-input path when loss_fn is DPDistLoss)."""
+        loss, pose, _ = self._evaluate_grad(refined_source, template)
+        self._reduce()
+        return loss, pose
+
+    def _train_step_eager(self, source, template):
         self.net.train()
         src, T = self.refine(source, template, self.max_loops - 1)
-        loss, pose = self.loss_and_gradients(src, template)
+        loss, _, Tn = self._evaluate_grad(src, template, T)
+        self._reduce()
         self.opt.step()
-        pose = torch.cat([pose[:, :3], pose[:, 3:7] / pose[:, 3:7].norm(dim=1, keepdim=True).clamp_min(1e-12)], 1)
-        return loss, compose(T, pose)
+        return loss, Tn
+
+    def train_step(self, source, template):
+        if self.use_graph and source.is_cuda:
+            return self._graph_step("train", source, template)
+        return self._train_step_eager(source, template)
 
     @torch.no_grad()
-    def evaluate(self, source, template):
+    def _evaluate_eager(self, source, template):
         self.net.eval()
         moved, T = self.refine(source, template, self.max_loops)
         return self.loss_fn(moved, template), T
+
+    def evaluate(self, source, template):
+        if self.use_graph and source.is_cuda:
+            return self._graph_step("eval", source, template)
+        return self._evaluate_eager(source, template)
+
+    # ---- hipGraph form
+    def _loss_key(self):
+        k = getattr(self.loss_fn, "graph_key", None)
+        return k() if callable(k) else None
+
+    def _graph_step(self, kind, source, template):
+        if source.shape != template.shape or source.dtype != torch.float32:
+            return self._train_step_eager(source, template) if kind == "train" else self._evaluate_eager(source, template)
+        key = (kind, tuple(source.shape), source.device.index)
+        rec = self._graphs.get(key)
+        if rec is not None and rec.loss_key != self._loss_key():     # the frozen loss changed under the graph (new DPDist weights): recapture
+            del self._graphs[key]
+            rec = None
+        if rec is None:
+            seen = self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if seen <= self.graph_warmup or len(self._graphs) >= 8:   # real (eager) steps first: library handles, autograd, engine shapes
+                return self._train_step_eager(source, template) if kind == "train" else self._evaluate_eager(source, template)
+            rec = self._graphs[key] = self._capture(kind, source, template)
+        rec.src.copy_(source)
+        rec.tmpl.copy_(template)
+        if kind == "eval":
+            rec.g1.replay()
+        elif rec.g2 is None:
+            self.opt.prepare_replay()
+            rec.g1.replay()
+        else:
+            rec.g1.replay()
+            self._reduce()
+            self.opt.prepare_replay()
+            rec.g2.replay()
+        self.graph_replays += 1
+        return rec.loss.clone(), rec.T.clone()
+
+    def _capture(self, kind, source, template):
+        from . import asloss
+        rec = _GraphRec()
+        rec.src, rec.tmpl, rec.pool, rec.g2 = source.clone(), template.clone(), {}, None
+        rec.loss_key = self._loss_key()
+        self.net.train(kind == "train")
+        with asloss.private_pool(rec.pool):
+            with torch.no_grad():
+                self.loss_fn(rec.src, rec.tmpl)              # creates the graph's own engine and derives the frozen weights OUTSIDE the capture
+            torch.cuda.synchronize()
+            rec.g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(rec.g1):
+                if kind == "eval":
+                    with torch.no_grad():
+                        moved, rec.T = self.refine(rec.src, rec.tmpl, self.max_loops)
+                        rec.loss = self.loss_fn(moved, rec.tmpl)
+                else:
+                    src, T = self.refine(rec.src, rec.tmpl, self.max_loops - 1)
+                    rec.loss, _, rec.T = self._evaluate_grad(src, rec.tmpl, T)
+                    if self.reducer is None or not self.reducer.active:
+                        self.opt.step()                      # captured: dpd_adam_tf_dev, lr_t from device memory (TFAdam.prepare_replay)
+            if kind == "train" and self.reducer is not None and self.reducer.active:
+                rec.g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(rec.g2, pool=rec.g1.pool()):
+                    self.opt.step()
+        return rec

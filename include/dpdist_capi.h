@@ -310,7 +310,7 @@ int dpd_decoder_out_asloss_planes(const float* h3, const float* mask, int Q, int
  * clouds -- behind ONE entry point per direction, on buffers sized once for a fixed (B, N).  Same kernels, same order and same bits as
  * calling dpd_mfv3d_fwd_stacked, dpd_patch_rows_fwd_scaled, dpd_decoder_fwd, dpd_decoder_out_asloss | dpd_decoder_bwd_data (phases 6),
  * dpd_patch_rows_bwd, dpd_mfv3d_bwd, dpd_asloss_combine one by one; what it removes is the host: ~30 buffer allocations and a dozen
- * foreign-function calls per evaluation bound the registration loop at its batch of 16 (8 evaluations per training step).
+ * foreign-function calls per evaluation bound the registration loop at its batch of 16 (one forward + backward per training step, one forward per evaluation batch).
  * All members point into ONE caller-owned allocation (dpd_asloss_bytes / dpd_asloss_carve: host-side pointer arithmetic only); the
  * DPDist weights are frozen in this mode: dpd_asloss_set_weights derives what the compute type needs from them (transposed fp32
  * copies or bf16 operand planes) ONCE and keeps the caller's parameter pointers -- call it again after the weights change.
@@ -360,6 +360,21 @@ int dpd_chamfer_fwd(const float* a, const float* b, int B, int N, int M, float* 
                     int32_t* arg_b, float* loss, void* stream);
 int dpd_chamfer_bwd(const float* a, const float* b, int B, int N, int M, const int32_t* arg_a, const int32_t* arg_b,
                     float gscale, float* da, float* db, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pose algebra of the iterative registration that consumes DPDist as its loss (row f2; csrc/pose.hip): ONE launch for the chain of
+ * ~115 element-wise ops the reference runs per refinement loop.  pred [B,7] = the pose network's raw output (t, angle, axis).
+ *   pose   [B,7]   (optional) quat_normalize(pred): (tanh(t) 0.1, cos(a/2), axis sin(a/2)), |a| <= lim_rot_deg
+ *                  (pcrnet-registration/models/ipcr_model.py:285-294); lim_rot_deg == 0: pose = pred
+ *   moved  [B,N,3] (optional) src R(u)^T + t (helper.py:539-570), u = q / max(|q|, 1e-12) in mode 0 (the forward-only refinements,
+ *                  helper.py:309-329) and q / (|q| + 1e-7) in mode 1 (the training evaluation, iterative_PCRNet_ours.py:211-224)
+ *   T_out  [B,4,4] (optional, needs T_in) [R(q / max(|q|, 1e-12)) t; 0 1] @ T_in (helper.py:309-329); must not alias T_in
+ * dpd_pose_apply_bwd: d moved [B,N,3] of a mode-1 forward -> dpred [B,7] (overwritten); src carries no gradient (the refinements
+ * are forward-only, iterative_PCRNet_ours.py:414-441).                                                                            */
+int dpd_pose_apply_fwd(const float* pred, const float* src, const float* T_in, int B, int N, float lim_rot_deg, int mode, float* pose,
+                       float* moved, float* T_out, void* stream);
+int dpd_pose_apply_bwd(const float* pred, const float* src, const float* dmoved, int B, int N, float lim_rot_deg, float* dpred,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * tf.train.AdamOptimizer step (epsilon-hat form), train_multi_gpu_pc_compare_dist.py:216,301:

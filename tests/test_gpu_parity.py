@@ -1314,6 +1314,7 @@ def test_as_loss_node_on_persistent_planes(dev, dt, golden_dir, monkeypatch):
     B = 16
     pcA, pcB, _ = synth.s2_modelnet_shaped(B, 64, 100)
     res = {}
+    monkeypatch.setenv("DPD_ASLOSS_ENGINE", "0")          # the plane NODE (model._AsLossFn on ops.AsLossPlanes); the engine has its own tests
     for planes in ("0", "1"):
         monkeypatch.setenv("DPD_ASLOSS_PLANES", planes)
         mod = _model(dev, "wide")
@@ -2241,6 +2242,26 @@ def test_as_loss_engine_is_bitwise_the_entry_by_entry_node(dev, dt, monkeypatch)
             fn(a2, b2).backward()
             with pytest.raises(RuntimeError, match="re-used"):
                 torch.autograd.grad(lv * 2.0, [a1, b1])
+            # ... also when that later evaluation kept no state of its own (no_grad): it still overwrote the engine's buffers
+            asloss.release_all(mod.params_)
+            assert asloss.pool_bytes(mod.params_) == 0
+            lv = fn(a1, b1)
+            torch.autograd.grad(lv * 2.0, [a1, b1], retain_graph=True)
+            with torch.no_grad():
+                fn(a2, b2)
+            with pytest.raises(RuntimeError, match="re-used"):
+                torch.autograd.grad(lv * 2.0, [a1, b1])
+            # the pool is bounded in bytes: idle engines of the least recently used shapes go first
+            old_cap, asloss.MAX_POOL_BYTES = asloss.MAX_POOL_BYTES, int(2.5 * next(iter(pool.values()))[0].nbytes)
+            try:
+                for Bx in (15, 14, 13):
+                    px, py, _ = synth.s2_modelnet_shaped(Bx, 64, 100)
+                    with torch.no_grad():
+                        fn(_cu(px, dev), _cu(py, dev))
+                assert asloss.pool_bytes(mod.params_) <= asloss.MAX_POOL_BYTES and len(pool) == 2
+                assert [k[0] for k in pool] == [14, 13]
+            finally:
+                asloss.MAX_POOL_BYTES = old_cap
     for x, y in zip(res["0"][:3], res["1"][:3]):
         assert torch.equal(x, y), (x.item(), y.item())
     for ga, gb in zip(res["0"][3] + res["0"][4], res["1"][3] + res["1"][4]):

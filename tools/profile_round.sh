@@ -74,7 +74,7 @@ python $R/tools/determinism_check.py f32 > $OUT/determinism.txt 2>&1
 # registration loop's step rate with and without it
 { python $R/tools/chain_bench.py 64 100; python $R/tools/chain_bench.py 32 100; } 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt
 { for b in 16 32; do for dt in f32 f32x3 bf16; do for e in 0 1; do DPD_ASLOSS_ENGINE=$e python $R/tools/asloss_bench.py --batch $b --dtype $dt | grep mode; done; done; done; } > $OUT/asloss_engine_ab.txt 2>/dev/null
-{ for e in 0 1; do echo "== DPD_ASLOSS_ENGINE=$e"; ( cd $R; DPD_ASLOSS_ENGINE=$e timeout 600 python tools/registration_demo.py --loss ours --dp_steps 1500 --reg_steps 1500 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read())['pcrnet_ours']; print(json.dumps({k: d[k] for k in ('train_s','host_gen_s','steps','pairs_per_s','eval_loss','rot_err_median_deg') if k in d}), 'gpu+host ms per registration step (8 DPDist evaluations):', round((d['train_s']-d['host_gen_s'])/d['steps']*1e3,3))" ); done; } > $OUT/registration_engine_ab.txt 2>&1
+{ for e in 0 1; do echo "== DPD_ASLOSS_ENGINE=$e"; ( cd $R; DPD_ASLOSS_ENGINE=$e timeout 600 python tools/registration_demo.py --loss ours --dp_steps 1500 --reg_steps 1500 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read())['pcrnet_ours']; print(json.dumps({k: d[k] for k in ('train_s','host_gen_s','steps','pairs_per_s','eval_loss','rot_err_median_deg') if k in d}), 'gpu+host ms per registration step (7 pose-only refinements + 1 DPDist forward/backward):', round((d['train_s']-d['host_gen_s'])/d['steps']*1e3,3))" ); done; } > $OUT/registration_engine_ab.txt 2>&1
 [ "${SWEEPS:-1}" = "0" ] || {
 # round 4: the bf16 backward -- weight gradients apart / grouped / split-K in the launch, dH || dW on two streams, tile plans
 ( cd $R; tools/bf16_trio_sweep.sh $OUT/bf16_trio_sweep.txt; PLANS="20:0:1,32:3:1 20:2:2,32:3:1 20:2:3,32:3:1 20:0:1,32:2:2 20:2:-3,32:3:1" SC1S="1 0" DPD_DW_TRIO=0 tools/bf16_bwd_sweep.sh $OUT/bf16_bwd_sweep.txt; tools/bf16_plan_sweep.sh $OUT/bf16_plan_sweep.txt; tools/trio_b32.sh $OUT/trio_other_configs.txt; tools/xcd_band_ab.sh $OUT/xcd_band_ab.txt ) > /dev/null 2>&1
