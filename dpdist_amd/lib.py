@@ -45,6 +45,10 @@ class Planes(Structure):     # include/dpdist_capi.h: dpd_planes
         "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc", "h3_rc", "sync")]
 
 
+class PoseNetW(Structure):   # include/dpdist_capi.h: dpd_pose_net
+    _fields_ = [("Wp", c_void_p * 5), ("bp", c_void_p * 5), ("Wh", c_void_p * 4), ("bh", c_void_p * 4), ("out_features", c_int)]
+
+
 class AsLoss(Structure):     # include/dpdist_capi.h: dpd_asloss (the as-loss engine; driven by dpdist_amd/asloss.py)
     _fields_ = ([(n, c_int) for n in ("B", "N", "m", "k", "KP", "H", "dtype")] + [("sigma", c_float)] +
                 [(n, c_void_p) for n in ("pts", "q", "fv", "ssq", "mask", "vox", "X", "h1", "h2", "h3", "y", "pred", "dy", "g3", "g2", "g1",
@@ -97,6 +101,9 @@ SIGNATURES = {
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "dpd_pose_apply_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpd_pose_apply_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "dpd_pose_refine_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpd_pose_refine": (c_int, [POINTER(PoseNetW), c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
     "dpd_planes_bytes": (c_size_t, [c_int] * 6),
     "dpd_planes_carve": (c_int, [c_void_p, c_size_t] + [c_int] * 6 + [POINTER(Planes)]),
     "dpd_weights_to_planes": (c_int, [POINTER(DecoderParams), c_int, c_int, POINTER(Planes), c_void_p]),

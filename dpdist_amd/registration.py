@@ -248,6 +248,49 @@ def pose_apply(pred, source, T=None, lim_rot=45.0, mode=0):
     return _PoseApplyFn.apply(pred.contiguous(), source.contiguous(), None if T is None else T.contiguous(), lim_rot, mode)
 
 
+def native_refine_supported(net):
+    """Whether `net` is the architecture csrc/pose.hip's forward implements (models/ipcr_model.py:198-233,273-284 as PoseNet builds it)."""
+    if not isinstance(net, PoseNet):
+        return False
+    lin_p = [m for m in net.point if isinstance(m, nn.Linear)]
+    lin_h = [m for m in net.head if isinstance(m, nn.Linear)]
+    if len(lin_p) != 5 or len(lin_h) != 4:
+        return False
+    out = lin_p[4].out_features
+    want_p = [(3, 64), (64, 64), (64, 64), (64, 128), (128, out)]
+    want_h = [(2 * out, 1024), (1024, 512), (512, 256), (256, 7)]
+    return (out == 1024 and [(m.in_features, m.out_features) for m in lin_p] == want_p
+            and [(m.in_features, m.out_features) for m in lin_h] == want_h and all(m.bias is not None for m in lin_p + lin_h))
+
+
+def pose_refine_native(net, source, template, loops, drop_mask=None, want_pred=False):
+    """`loops` forward-only refinements (iterative_PCRNet_ours.py:414-441) with the pose network, quat_normalize, the cloud move and the T
+    composition all on the library (include/dpdist_capi.h: dpd_pose_refine, five launches per loop): (moved source, T[, raw outputs
+    [loops,B,7]]).  drop_mask [loops,B,256] (0 or 1/keep) or None; the caller draws it (IterativeRegistration.refine does, in train mode)."""
+    from ctypes import byref
+    from . import lib as L
+    B, N, _ = source.shape
+    L.req(source, name="source", shape=(B, N, 3)), L.req(template, name="template", shape=(B, N, 3))
+    lin_p = [m for m in net.point if isinstance(m, nn.Linear)]
+    lin_h = [m for m in net.head if isinstance(m, nn.Linear)]
+    w = L.PoseNetW()
+    for i, m in enumerate(lin_p):
+        w.Wp[i], w.bp[i] = L.req(m.weight, name="weight").data_ptr(), L.req(m.bias, name="bias").data_ptr()
+    for i, m in enumerate(lin_h):
+        w.Wh[i], w.bh[i] = L.req(m.weight, name="weight").data_ptr(), L.req(m.bias, name="bias").data_ptr()
+    w.out_features = lin_p[4].out_features
+    lib = L.load()
+    nbytes = lib.dpd_pose_refine_workspace_bytes(B, N, w.out_features)
+    ws = torch.empty(nbytes // 4, device=source.device, dtype=torch.float32)
+    if drop_mask is not None:
+        L.req(drop_mask, name="drop_mask", shape=(loops, B, 256))
+    moved, T = torch.empty_like(source), torch.empty(B, 4, 4, device=source.device, dtype=torch.float32)
+    pred = torch.empty(loops, B, 7, device=source.device, dtype=torch.float32) if want_pred else None
+    L.check(lib.dpd_pose_refine(byref(w), L.ptr(source), L.ptr(template), B, N, int(loops), float(net.lim_rot or 0.0), L.ptr(drop_mask),
+                                L.ptr(ws), nbytes, L.ptr(moved), L.ptr(T), L.ptr(pred), L.cur_stream()), "dpd_pose_refine")
+    return (moved, T, pred) if want_pred else (moved, T)
+
+
 def flat_gradient_views(params):
     """One flat fp32 buffer with every parameter's `.grad` as a view into it (what `optim.TFAdam` does for its own parameters): the
     data-parallel step all-reduces that ONE buffer instead of a tensor per layer."""
@@ -279,6 +322,9 @@ class IterativeRegistration:
     this class does about it on the GPU:
       * `fused_pose` (DPD_POSE_FUSED, default on): quat_normalize / normalisation / Besl-McKay R / moved cloud / T composition are ONE
         launch of csrc/pose.hip per loop (dpd_pose_apply_fwd; backward dpd_pose_apply_bwd) instead of ~115 element-wise launches;
+      * `native_refine` (DPD_POSE_NATIVE, default on): the forward-only refinements run the pose NETWORK on the library too (shared MLP +
+        max pool in one launch per loop, the template's features once per call, three head launches, fc4 folded into the pose launch:
+        dpd_pose_refine, five launches per loop instead of ~25); the training evaluation keeps torch autograd;
       * `graph` (DPD_REG_GRAPH, default on; needs optim.TFAdam and a loss with `capturable = True`, e.g. DPDistLoss): after
         `graph_warmup` eager steps for a batch shape the WHOLE step -- 7 refinements, the training forward, DPDist forward + backward on
         a private as-loss engine, the pose network's backward, TF-form Adam with lr_t read from device memory -- is captured once as a
@@ -293,7 +339,7 @@ class IterativeRegistration:
     reducer the step is two graphs (refine + forward + backward | Adam) around the eager collective."""
 
     def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None, distributed=None, group=None, graph=None,
-                 fused_pose=None, graph_warmup=2):
+                 fused_pose=None, graph_warmup=2, native_refine=None):
         import os
         import torch.distributed as dist
         from .optim import TFAdam
@@ -309,6 +355,8 @@ class IterativeRegistration:
             self.reducer = make_reducer(self._flat_grad, [0, self._flat_grad.numel()], group,
                                         force=os.environ.get("DPD_FORCE_DIST") == "1", mode="allreduce")
         self.fused_pose = (os.environ.get("DPD_POSE_FUSED", "1") == "1") if fused_pose is None else bool(fused_pose)
+        want_native = (os.environ.get("DPD_POSE_NATIVE", "1") == "1") if native_refine is None else bool(native_refine)
+        self.native_refine = want_native and self.fused_pose and native_refine_supported(pose_net)
         want_graph = (os.environ.get("DPD_REG_GRAPH", "1") == "1") if graph is None else bool(graph)
         self.use_graph = want_graph and isinstance(self.opt, TFAdam) and bool(getattr(dpdist_loss, "capturable", False))
         self.graph_warmup = int(graph_warmup)
@@ -326,6 +374,14 @@ class IterativeRegistration:
         return self.fused_pose and source.is_cuda and hasattr(self.net, "raw")
 
     def refine(self, source, template, loops):
+        if self.native_refine and source.is_cuda and loops > 0 and source.dtype == torch.float32:
+            with torch.no_grad():
+                mask = None
+                drop = next((m for m in self.net.head if isinstance(m, nn.Dropout)), None)
+                if self.net.training and drop is not None and drop.p > 0:      # torch's dropout: keep with probability 1 - p, scale by 1 / (1 - p)
+                    keep = 1.0 - drop.p
+                    mask = torch.empty(loops, source.shape[0], 256, device=source.device).bernoulli_(keep).div_(keep)
+                return pose_refine_native(self.net, source.contiguous(), template.contiguous(), loops, mask)
         T = torch.eye(4, device=source.device).repeat(source.shape[0], 1, 1)
         fused = self._fused(source)
         with torch.no_grad():

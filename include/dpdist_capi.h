@@ -368,13 +368,32 @@ int dpd_chamfer_bwd(const float* a, const float* b, int B, int N, int M, const i
  *                  (pcrnet-registration/models/ipcr_model.py:285-294); lim_rot_deg == 0: pose = pred
  *   moved  [B,N,3] (optional) src R(u)^T + t (helper.py:539-570), u = q / max(|q|, 1e-12) in mode 0 (the forward-only refinements,
  *                  helper.py:309-329) and q / (|q| + 1e-7) in mode 1 (the training evaluation, iterative_PCRNet_ours.py:211-224)
- *   T_out  [B,4,4] (optional, needs T_in) [R(q / max(|q|, 1e-12)) t; 0 1] @ T_in (helper.py:309-329); must not alias T_in
+ *   T_out  [B,4,4] (optional) [R(q / max(|q|, 1e-12)) t; 0 1] @ T_in (helper.py:309-329); T_in NULL = the identity; must not alias T_in
  * dpd_pose_apply_bwd: d moved [B,N,3] of a mode-1 forward -> dpred [B,7] (overwritten); src carries no gradient (the refinements
  * are forward-only, iterative_PCRNet_ours.py:414-441).                                                                            */
 int dpd_pose_apply_fwd(const float* pred, const float* src, const float* T_in, int B, int N, float lim_rot_deg, int mode, float* pose,
                        float* moved, float* T_out, void* stream);
 int dpd_pose_apply_bwd(const float* pred, const float* src, const float* dmoved, int B, int N, float lim_rot_deg, float* dpred,
                        void* stream);
+
+/* The forward-only pose refinements of a registration step (iterative_PCRNet_ours.py:414-441: 7 per training step, 8 per evaluation batch;
+ * only `predicted_transformation` is fetched) with the pose NETWORK on the library as well: per loop, shared MLP 3-64-64-64-128-out_features +
+ * max pool over the points for source and template (models/ipcr_model.py:198-233; the template's features are computed once: it never
+ * moves), fc 2*out_features-1024-512-256, dropout, fc 7 (:273-284), quat_normalize (:285-294), then the source is moved and T composed
+ * (helper.py:309-329) -- five launches per loop.  Weights are torch.nn.Linear layout: W [out, in] row-major, fp32.
+ *   src, tmpl [B,N,3];  drop_mask [loops,B,256] or NULL: multiplied into the 256-wide layer (0 or 1/keep_prob: the caller draws it);
+ *   ws: dpd_pose_refine_workspace_bytes(B, N, out_features) bytes, 16-byte aligned;
+ *   moved [B,N,3], T_out [B,4,4]: the source and the accumulated transform after `loops` loops (T starts at the identity);
+ *   pred_out [loops,B,7] (optional): the network's raw output of every loop.
+ * out_features must be 1024, the reference's width (DPD_E_UNSUPPORTED otherwise).                                                        */
+typedef struct dpd_pose_net {
+    const float* Wp[5]; const float* bp[5];   /* shared MLP: 64x3, 64x64, 64x64, 128x64, out_features x 128 */
+    const float* Wh[4]; const float* bh[4];   /* head: 1024 x 2*out_features, 512x1024, 256x512, 7x256 */
+    int out_features;
+} dpd_pose_net;
+size_t dpd_pose_refine_workspace_bytes(int B, int N, int out_features);
+int dpd_pose_refine(const dpd_pose_net* net, const float* src, const float* tmpl, int B, int N, int loops, float lim_rot_deg,
+                    const float* drop_mask, void* ws, size_t ws_bytes, float* moved, float* T_out, float* pred_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * tf.train.AdamOptimizer step (epsilon-hat form), train_multi_gpu_pc_compare_dist.py:216,301:

@@ -456,10 +456,11 @@ def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(mo
     from dpdist_amd.registration import IterativeRegistration
     dev = torch.device("cuda:0")
 
-    def run(engine, graph, fused="1"):
+    def run(engine, graph, fused="1", native="1"):
         monkeypatch.setenv("DPD_ASLOSS_ENGINE", engine)
         monkeypatch.setenv("DPD_REG_GRAPH", graph)
         monkeypatch.setenv("DPD_POSE_FUSED", fused)
+        monkeypatch.setenv("DPD_POSE_NATIVE", native)
         torch.manual_seed(0)
         model = DPDistModel(device=dev)
         model.load_tf_state_dict(synth.make_weights("wide"))
@@ -493,8 +494,52 @@ def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(mo
     # (first loss: 6e-8 apart on the box of round 6) -- after that the two trainings drift like any two fp32 summation orders do through
     # ReLU gates and relu6 clips (3e-2 in the loss after 12 steps on the 'wide' weights), so only the first step is pinned here; the
     # kernels themselves are pinned to the torch algebra by test_fused_pose_kernels_match_the_torch_algebra
+    g, h = run("1", "1", native="0"), run("1", "0", native="0")      # torch pose network + csrc/pose.hip algebra: graph == eager again
+    assert g[:2] == h[:2], (g, h)
     f = run("1", "0", fused="0")
-    assert abs(f[1][0] - a[1][0]) <= 1e-5 and max(abs(x - y) for x, y in zip(f[1], a[1])) <= 0.1, (f[1], a[1])
+    assert abs(f[1][0] - g[1][0]) <= 1e-5 and max(abs(x - y) for x, y in zip(f[1], g[1])) <= 0.1, (f[1], g[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,loops", [(16, 64, 3), (5, 50, 2), (3, 150, 2), (33, 64, 1)])
+def test_native_pose_refinement_matches_the_torch_network(B, N, loops):
+    """dpd_pose_refine (pose network + quat_normalize + cloud move + T composition on the library, five launches per loop) against the torch
+    PoseNet driven through the torch algebra: raw network outputs of every loop, the moved source and the accumulated transform; ragged
+    batches (more than 16 rows: two row groups in the head) and point counts (more than one 64-point pass of the shared MLP); with an
+    explicit dropout mask against the same mask applied in torch."""
+    from dpdist_amd.registration import pose_refine_native
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    net = PoseNet().to(dev)
+    with torch.no_grad():                      # a head that actually moves the cloud, biases that are not all zero
+        for m in net.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.bias.normal_(0.0, 0.05)
+        net.head[-1].bias.copy_(torch.tensor([0.3, -0.2, 0.1, 0.25, 0.4, -0.3, 0.8], device=dev))
+    src, tmpl, _ = synth.registration_pairs(B, N, seed=5)
+    src, tmpl = torch.tensor(src, device=dev), torch.tensor(tmpl, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for mask in (None, (torch.rand(loops, B, 256, generator=g) < 0.7).float().div(0.7).to(dev)):
+        moved, T, pred = pose_refine_native(net, src, tmpl, loops, mask, want_pred=True)
+        # torch, loop by loop, in float64 (the reference arithmetic both fp32 forms approximate)
+        net64 = PoseNet().double().to(dev)
+        net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        s, t = src.double(), tmpl.double()
+        Tr = torch.eye(4, device=dev, dtype=torch.float64).repeat(B, 1, 1)
+        with torch.no_grad():
+            for it in range(loops):
+                f = net64.point(torch.cat([s, t], 0)).amax(1)
+                h = net64.head[:6](torch.cat([f[:B], f[B:]], 1))
+                if mask is not None:
+                    h = h * mask[it].double()
+                raw = net64.head[7](h)
+                assert (pred[it].double() - raw).abs().max().item() <= 2e-5 * max(1.0, raw.abs().max().item()), (it, "raw output")
+                pose = quat_normalize(raw, net.lim_rot)
+                pose = torch.cat([pose[:, :3], pose[:, 3:7] / pose[:, 3:7].norm(dim=1, keepdim=True).clamp_min(1e-12)], 1)
+                s = transformation_quat_tensor(s, pose[:, 3:7], pose[:, :3])
+                Tr = compose(Tr, pose)
+        assert (s - src.double()).abs().max().item() > 1e-2          # the loops did move the cloud
+        assert (moved.double() - s).abs().max().item() <= 5e-5 and (T.double() - Tr).abs().max().item() <= 5e-5
 
 
 @pytest.mark.gpu

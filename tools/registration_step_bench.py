@@ -2,9 +2,11 @@
 """BASELINE config 5 on one GPU: ms per registration TRAINING step (batch 16, 64 points, 8 loops: 7 pose-only refinements + 1 DPDist
 forward/backward + TF-form Adam, pcrnet-registration/iterative_PCRNet_ours.py:410-470) for the three forms of the step:
 
-    eager, torch pose algebra   (round 5: ~1300 launches, host-bound)
-    eager, csrc/pose.hip        (one launch per loop for the quaternion chain)
-    hipGraph                    (the whole step captured once and replayed; bitwise the eager training: tests/test_registration.py)
+    eager_torch     torch pose network + torch pose algebra (round 5: ~1300 launches, host-bound)
+    eager_fused     torch pose network, one launch per loop for the quaternion chain (csrc/pose.hip: dpd_pose_apply_*)
+    eager_native    + the forward-only refinements' pose network on the library (dpd_pose_refine: 5 launches per loop)
+    graph_fused     eager_fused captured once as a hipGraph and replayed
+    graph           eager_native captured (the default form; bitwise its eager training: tests/test_registration.py)
 
 Inputs are resident on the GPU before the clock starts (pair generation is the data loader's business, not this path's).  Also prints
 what one DPDist forward+backward costs on its own (the as-loss engine, same shape), i.e. the share of the step that IS the hot path.
@@ -28,7 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--loops", type=int, default=8)
     ap.add_argument("--dtype", default="f32")
-    ap.add_argument("--forms", default="eager_torch,eager_fused,graph")
+    ap.add_argument("--forms", default="eager_torch,eager_fused,eager_native,graph_fused,graph")
     a = ap.parse_args()
     from dpdist_amd import synth
     from dpdist_amd.model import DPDistLoss, DPDistModel
@@ -38,14 +40,15 @@ def main():
     pool = [tuple(torch.tensor(x, device=dev) for x in synth.registration_pairs(a.batch, 64, rng=rng)[:2]) for _ in range(32)]
     out = {"workload": {"batch": a.batch, "num_point": 64, "loops": a.loops, "dpdist_dtype": a.dtype}}
 
-    def harness(graph, fused):
+    def harness(graph, fused, native=True):
         torch.manual_seed(0)
         model = DPDistModel(device=dev)
         model.load_tf_state_dict(synth.make_weights("wide"))
         model.params_.compute_dtype = a.dtype
         net = PoseNet().to(dev)
         torch.manual_seed(1000)
-        return model, IterativeRegistration(net, DPDistLoss(model), lr=1e-4, max_loops=a.loops, distributed=False, graph=graph, fused_pose=fused)
+        return model, IterativeRegistration(net, DPDistLoss(model), lr=1e-4, max_loops=a.loops, distributed=False, graph=graph, fused_pose=fused,
+                                            native_refine=native)
 
     def timed(fn, n):
         torch.cuda.synchronize()
@@ -56,8 +59,8 @@ def main():
         return (time.perf_counter() - t0) / n * 1e3
 
     for form in a.forms.split(","):
-        graph, fused = form == "graph", form != "eager_torch"
-        model, reg = harness(graph, fused)
+        graph, fused, native = form.startswith("graph"), form != "eager_torch", form in ("eager_native", "graph")
+        model, reg = harness(graph, fused, native)
         for i in range(8):
             reg.train_step(*pool[i % len(pool)])
         ms = min(timed(lambda i: reg.train_step(*pool[i % len(pool)]), a.steps) for _ in range(3))
@@ -67,7 +70,7 @@ def main():
         loss, _ = reg.train_step(*pool[0])
         out[form] = {"train_ms_per_step": round(ms, 4), "eval_ms_per_batch": round(ms_eval, 4), "pairs_per_s": round(a.batch / ms * 1e3, 1),
                      "graph_replays": reg.graph_replays, "last_loss": loss.item()}
-        if form == "graph":
+        if graph:
             # GPU time of one replay alone (events around back-to-back replays of the captured step, no input copies)
             rec = reg._graphs[("train", (a.batch, 64, 3), 0)]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
