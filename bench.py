@@ -392,6 +392,25 @@ def spawn_ranks(n, cmd, timeout_s=None):
     return rc
 
 
+DP_MODES = ("allreduce", "rs_ag", "zero1")      # communication forms the start-up measurement chooses among (bit-identical results)
+# how much compute is still to run when a gradient bucket's collective is issued in the "early" order, as a fraction of the one-rank step
+# (profiles/r05_step_timeline.txt: layers 2-4 are issued before the last data-gradient GEMM + dW1; layer 1 last, with only the next step's
+# encoder + gather -- Adam runs on the collectives' stream -- to hide under), and the one-rank cost of the plumbing (profiles/r05_dp_single_rank.txt)
+DP_WINDOWS = {"f32": ((35.7 + 91.2) / 561.0, 30.0, 15.0), "f32x3": ((42.0 + 71.6) / 520.0, 33.0, 15.0), "bf16": (45.0 / 278.0, 35.0, 7.0)}
+
+
+def dp_model(step_ms_n1, dtype, bucket_bounds, wire="f32"):
+    """`dp.model`: what the data-parallel step should cost at N = 2 / 4 / 8 given THIS run's one-rank step time (dpdist_amd/ddp.py:
+    predict_scaling; assumptions inside the record).  No multi-GPU box has been available: this is the expectation a hardware curve is
+    read against."""
+    from dpdist_amd import ddp
+    frac, late_us, plumb = DP_WINDOWS[dtype]
+    bb = list(bucket_bounds)
+    early = 4 * (bb[-1] - bb[1])                 # layers 2-4 (issued first), then layer 1
+    late = 4 * (bb[1] - bb[0])
+    return ddp.predict_scaling(step_ms_n1, [early, late], [frac * step_ms_n1 * 1e3, late_us], plumbing_us=plumb, wire=wire)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -480,7 +499,9 @@ def main():
     if use_dist:
         dist.barrier()
         hb.beat("aux:schedule of the headline step")
-        headline_sched = tr.select_dp_schedule(pcA, pcB, lab)      # collective; parameters and Adam state are restored afterwards
+        # collective; parameters and Adam state are restored afterwards.  Order x communication form (all bitwise-equivalent except
+        # "grouped"); DPD_DP_SCHEDULE / DPD_DP_MODE pin either axis
+        headline_sched = tr.select_dp_schedule(pcA, pcB, lab, modes=DP_MODES)
 
     keep = []
     try:                  # a descheduled launcher thread idles the GPU within a millisecond (shared host): ask for priority
@@ -567,7 +588,7 @@ def main():
         sched = None
         if distributed:      # the order of the data-parallel backward: measured here, decided by all ranks together (unless DPD_DP_SCHEDULE pins it)
             hb.beat("aux:schedule " + label[:30])
-            sched = tr2.select_dp_schedule(a2, b2, l2)
+            sched = tr2.select_dp_schedule(a2, b2, l2, modes=None if mode is not None else DP_MODES)
         for _ in range(a.warmup):
             tr2.step(a2, b2, l2)
         # Device spin-up, as for the headline: the chip needs ~25 ms of sustained work of THIS kind before its clock
@@ -610,6 +631,12 @@ def main():
         if distributed:
             out2["dp"] = dp_report(tr2, lambda: tr2.step(a2, b2, l2))
             out2["dp"]["schedule"] = sched
+        else:
+            try:
+                out2["dp_model"] = dp_model(e2 / a.steps * 1e3, "bf16", P2.bucket_bounds)
+                out2["dp_model_bf16_wire"] = dp_model(e2 / a.steps * 1e3, "bf16", P2.bucket_bounds, wire="bf16")["per_world"]
+            except Exception as e:
+                out2["dp_model"] = {"error": repr(e)}
         if not distributed and not a.no_roofline and rank == 0:
             # the plane-GEMM family of THIS configuration against the dense bf16 matrix-core peak (same method as `roofline` below)
             try:
@@ -649,16 +676,22 @@ def main():
                                     "backward order chosen by measurement at start-up")
                 try:
                     c4["early_schedule"] = bf16_b64(True, "config 4 with DPD_DP_SCHEDULE=early (separate dW launches, buckets reduced under the backward)",
-                                                    env={"DPD_DP_SCHEDULE": "early"})
+                                                    mode="allreduce", env={"DPD_DP_SCHEDULE": "early"})
                 except Exception as e:
                     c4["early_schedule"] = {"error": repr(e)}
                 try:     # the sharded optimizer (ZeRO-1: reduce-scatter -> Adam on 1/P -> all-gather of the parameters), same step
                     c4["zero1"] = bf16_b64(True, "config 4 with DPD_DP_MODE=zero1 (sharded Adam)", mode="zero1")
                 except Exception as e:
                     c4["zero1"] = {"error": repr(e)}
+                try:     # bf16 on the links: half the bytes, but the cross-rank sum is taken in bf16 -- it changes numerics, so it is never a
+                    # candidate of the measured choice: an explicit pinned leg
+                    c4["bf16_wire"] = bf16_b64(True, "config 4 with DPD_DP_WIRE=bf16 (gradients rounded to bf16 on the links; pinned leg, changes numerics)",
+                                               mode="allreduce", env={"DPD_DP_WIRE": "bf16"})
+                except Exception as e:
+                    c4["bf16_wire"] = {"error": repr(e)}
                 try:     # the single-GPU launch order with ONE grouped weight-gradient launch and ONE all-reduce behind it (DPD_DP_SCHEDULE=grouped)
                     c4["grouped_schedule"] = bf16_b64(True, "config 4 with DPD_DP_SCHEDULE=grouped (one dW launch, one all-reduce)",
-                                                      env={"DPD_DP_SCHEDULE": "grouped"})
+                                                      mode="allreduce", env={"DPD_DP_SCHEDULE": "grouped"})
                 except Exception as e:
                     c4["grouped_schedule"] = {"error": repr(e)}
                 c4["n1_same_run"] = bf16_b64(False, "the same step on one rank without collectives (all ranks run it concurrently)")
@@ -667,9 +700,14 @@ def main():
                 c4["weak_scaling_efficiency_vs_n1_same_run"] = round(c4["value"] / (c4["n_gpus"] * n1v), 4)
                 if c4["n_gpus"] == 1:
                     c4["scaling_note"] = "ONE rank: the efficiency above is the cost of the data-parallel plumbing only; nothing crossed a link"
-                for leg in ("zero1", "grouped_schedule", "early_schedule"):
+                for leg in ("zero1", "grouped_schedule", "early_schedule", "bf16_wire"):
                     if "value" in c4[leg]:
                         c4[leg]["weak_scaling_efficiency_vs_n1_same_run"] = round(c4[leg]["value"] / (c4["n_gpus"] * n1v), 4)
+                try:     # the expectation for real multi-GPU nodes, from this run's one-rank step
+                    c4["dp"]["model"] = dp_model(c4["n1_same_run"]["ms_per_step"], "bf16", P.bucket_bounds)
+                    c4["dp"]["model_bf16_wire"] = dp_model(c4["n1_same_run"]["ms_per_step"], "bf16", P.bucket_bounds, wire="bf16")["per_world"]
+                except Exception as e:
+                    c4["dp"]["model"] = {"error": repr(e)}
                 cfg34 = ("config4", c4)
             elif not use_dist:
                 cfg34 = ("config3", bf16_b64(False, "BASELINE config 3: bf16 training step, 64 pairs"))
@@ -864,6 +902,11 @@ def main():
         if dp is not None:
             out["dp"] = dp
             out["dp_backend"], out["fallback"] = dp["backend"], dp["fallback"]
+        try:        # one rank: from this run's step; N ranks: from the one-rank step the plumbing cost is known for (the model's own input)
+            step_n1 = el / a.steps * 1e3 - (DP_WINDOWS[a.dtype][2] * 1e-3 if dp is not None else 0.0)
+            (out["dp"] if dp is not None else out)["model" if dp is not None else "dp_model"] = dp_model(step_n1, a.dtype, P.bucket_bounds)
+        except Exception as e:
+            out["dp_model"] = {"error": repr(e)}
         if others is not None:
             out["other_compute_types"] = others
         if cfg34:

@@ -553,35 +553,86 @@ def crosscheck(red, group=None):
             "elements": hi - lo, "backend": red.backend, "mode": red.mode, "wire": red.wire}
 
 
-def select_schedule(candidates, time_fn, device, group=None):
-    """Pick the data-parallel schedule by MEASUREMENT, on all ranks together (the agree-then-act pattern of make_reducer): every rank
-    times every candidate in the same order with `time_fn(name) -> milliseconds per step` (which runs real steps, collectives included,
-    so the ranks stay in lock step), the per-candidate times are all-reduced with MAX (a step is as slow as its slowest rank), and every
-    rank takes the candidate with the smallest maximum -- the same one everywhere, whatever each rank measured locally; ties go to the
-    earlier candidate.  Returns (choice, {name: max-over-ranks ms}).  A candidate whose time_fn raises on ANY rank is dropped on every
-    rank (its time becomes +inf through the MAX)."""
+# ---- what a hardware scaling curve should look like (no multi-GPU box has been available to any round: this is the expectation the first
+# real curve is read against, computed from numbers measured on ONE rank)
+XGMI_LINK_GBPS_UNIDIR = 76.8      # one xGMI link, one direction (153.6 GB/s per link both ways; 7 links per MI355X, point to point)
+XGMI_RING_EFFICIENCY = 0.7        # measured all-reduce bus bandwidth / link peak on MI300X-class 8-GPU nodes for 10-100 MB messages
+RCCL_LATENCY_US = (12.0, 3.0)     # launch + protocol latency of one collective: a + b * (N - 1) microseconds
+
+
+def allreduce_us(nbytes, world, link_gbps=XGMI_LINK_GBPS_UNIDIR, eta=XGMI_RING_EFFICIENCY, latency=RCCL_LATENCY_US):
+    """Ring all-reduce of `nbytes` over `world` fully connected GPUs: every GPU sends 2 (N-1)/N of the bytes; RCCL can run up to N-1 rings
+    over distinct links (N = 2: ONE link, which is why two GPUs are the worst case per byte), each at the link's one-direction rate."""
+    if world <= 1:
+        return 0.0
+    bus = eta * (world - 1) * link_gbps * 1e9
+    return latency[0] + latency[1] * (world - 1) + 2.0 * (world - 1) / world * nbytes / bus * 1e6
+
+
+def predict_scaling(step_ms_n1, bucket_bytes, windows_us, plumbing_us=0.0, wire="f32", worlds=(2, 4, 8)):
+    """Expected data-parallel step for N ranks from one-rank measurements.
+      step_ms_n1    the step without any collective (measured)
+      bucket_bytes  fp32 bytes of each gradient bucket in the order they are issued (early schedule: [layers 2-4, layer 1])
+      windows_us    how much compute is still to run after each bucket is issued, i.e. what its collective can hide under
+                    (layers 2-4: the last data-gradient GEMM + dW1; layer 1: the next step's encoder + gather when Adam runs on the
+                    collectives' stream) -- from the one-rank kernel timeline
+      plumbing_us   cost of the data-parallel plumbing on one rank (measured: forced-distributed step minus plain step)
+    Per N: wire bytes per GPU, collective time per bucket, predicted exposed time and weak-scaling efficiency.  A MODEL, with its
+    assumptions in the record; it exists so that a measured curve can be compared with something stated beforehand."""
+    scale = 0.5 if wire == "bf16" else 1.0
+    out = {"assumptions": {"link_GBps_one_direction": XGMI_LINK_GBPS_UNIDIR, "links_used": "N-1 (one ring per direct link)",
+                           "ring_efficiency": XGMI_RING_EFFICIENCY, "collective_latency_us": "%g + %g (N-1)" % RCCL_LATENCY_US,
+                           "wire": wire, "hide_windows_us": [round(w, 1) for w in windows_us], "plumbing_us_one_rank": round(plumbing_us, 1),
+                           "step_ms_one_rank": round(step_ms_n1, 4)},
+           "per_world": {}}
+    for n in worlds:
+        coll = [allreduce_us(b * scale, n) for b in bucket_bytes]
+        exposed = sum(max(0.0, c - w) for c, w in zip(coll, windows_us))
+        step = step_ms_n1 * 1e3 + plumbing_us + exposed
+        out["per_world"][str(n)] = {"bytes": int(sum(bucket_bytes) * scale), "wire_bytes_per_gpu": int(2.0 * (n - 1) / n * sum(bucket_bytes) * scale),
+                                    "links": n - 1, "collective_us": [round(c, 1) for c in coll], "predicted_exposed_us": round(exposed, 1),
+                                    "predicted_ms_per_step": round(step / 1e3, 4),
+                                    "predicted_efficiency": round(step_ms_n1 * 1e3 / step, 4), "predicted_speedup": round(n * step_ms_n1 * 1e3 / step, 2)}
+    return out
+
+
+def select_schedule(candidates, time_fn, device, group=None, supported=None):
+    """Pick the data-parallel schedule by MEASUREMENT, on all ranks together (the agree-then-act pattern of make_reducer):
+      1. `supported(name) -> bool` (local, NO collectives) says what this rank can run; the flags are MIN-reduced, so a candidate any rank
+         cannot run is dropped on EVERY rank before anything is timed;
+      2. every rank times every remaining candidate in the same order with `time_fn(name) -> milliseconds per step` (which runs real steps,
+         collectives included, so the ranks stay in lock step); the times are MAX-reduced (a step is as slow as its slowest rank) and every
+         rank takes the candidate with the smallest maximum -- the same one everywhere, whatever each rank measured locally; ties go to the
+         earlier candidate.
+    An exception inside time_fn is NOT swallowed: a rank that fails in the middle of a candidate has left its peers inside a
+    collective, nothing here can repair that, and the launch watchdog must see -- and report -- the real error.
+    Returns (choice, {name: max-over-ranks ms, or None for a candidate dropped in step 1})."""
     cands = list(candidates)
     if not cands:
         raise ValueError("no schedule candidates")
-    ms = []
-    for c in cands:
-        try:
-            ms.append(float(time_fn(c)))
-        except Exception:
-            ms.append(float("inf"))
-    t = torch.tensor(ms, device=device, dtype=torch.float64)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def reduce_(t, op):
+        if not multi:
+            return t
         if t.is_cuda and dist.get_backend(group) == "gloo":
             tc = t.cpu()
-            dist.all_reduce(tc, op=dist.ReduceOp.MAX, group=group)
-            t = tc
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    vals = [float(x) for x in t.tolist()]
-    best = min(range(len(cands)), key=lambda i: (vals[i], i))
-    if vals[best] == float("inf"):
-        raise RuntimeError("every data-parallel schedule candidate failed on some rank: %r" % (cands,))
-    return cands[best], {c: (round(v, 4) if v != float("inf") else None) for c, v in zip(cands, vals)}
+            dist.all_reduce(tc, op=op, group=group)
+            return tc
+        dist.all_reduce(t, op=op, group=group)
+        return t
+
+    ok = [1 if (supported is None or supported(c)) else 0 for c in cands]
+    ok = [int(x) for x in reduce_(torch.tensor(ok, device=device, dtype=torch.int32), dist.ReduceOp.MIN).tolist()]
+    live = [c for c, o in zip(cands, ok) if o]
+    if not live:
+        raise RuntimeError("no data-parallel schedule candidate is supported on every rank: %r" % (cands,))
+    ms = [float(time_fn(c)) for c in live]
+    vals = [float(x) for x in reduce_(torch.tensor(ms, device=device, dtype=torch.float64), dist.ReduceOp.MAX).tolist()]
+    best = min(range(len(live)), key=lambda i: (vals[i], i))
+    table = {c: None for c in cands}
+    table.update({c: round(v, 4) for c, v in zip(live, vals)})
+    return live[best], table
 
 
 def _agree(flag, device, group):

@@ -49,6 +49,10 @@ def build_parser():
     p.add_argument("--eval_every", type=int, default=10)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--restore", default="", help="TF V2 checkpoint prefix (model.ckpt) or .npz to start from")
+    p.add_argument("--dp_schedule", default=os.environ.get("DPD_DP_SCHEDULE", "early"), choices=["early", "grouped", "late", "auto"],
+                   help="order of the data-parallel backward.  Default 'early': deterministic, a multi-GPU run is bitwise reproducible and "
+                        "resumable.  'auto' MEASURES order x communication form on the first batch (all ranks together), stores the choice in "
+                        "<log_dir>/dp_schedule.json and re-uses the stored choice of the run it resumes (--restore) instead of measuring again")
     return p
 
 
@@ -224,7 +228,26 @@ def train(argv=None):
                 noise = cu((np.random.randn(F.batch_size, N, 3) * F.add_noise).astype(np.float32)[lo:hi])
             yield cu(pcA[lo:hi].copy()), cu(pcB[lo:hi].copy()), cu(lab[lo:hi].copy()), noise
 
-    sched_done = [world == 1]
+    # data-parallel form of the step: pinned (default "early") unless --dp_schedule auto; a measured choice is stored next to the
+    # checkpoints and re-used on resume, so that a resumed run continues in the form it was started in (two measurements can
+    # pick different winners when candidates are close, and "grouped" sums dW in another fp32 order)
+    sched_done = [world == 1 or F.dp_schedule != "auto"]
+    if world > 1 and F.dp_schedule != "auto":
+        tr.dp_schedule = F.dp_schedule
+        tr.dp_schedule_info = {"schedule": F.dp_schedule, "mode": tr.reducer.mode if tr.reducer is not None else None, "source": "--dp_schedule (pinned)"}
+        log_string("data-parallel schedule: %s" % (tr.dp_schedule_info,))
+    elif world > 1:
+        side = os.path.join(os.path.dirname(os.path.abspath(F.restore)), "dp_schedule.json") if F.restore else ""
+        stored = None
+        if side and os.path.exists(side):            # every rank reads the same file
+            with open(side) as f:
+                stored = json.load(f)
+        if stored and stored.get("schedule") in ("early", "grouped", "late") and stored.get("mode") in ("allreduce", "rs_ag", "zero1"):
+            tr.set_dp_mode(stored["mode"])           # collective
+            tr.dp_schedule = stored["schedule"]
+            tr.dp_schedule_info = dict(stored, source="re-used from %s" % side)
+            log_string("data-parallel schedule: %s" % (tr.dp_schedule_info,))
+            sched_done[0] = True
 
     def run_epoch(ds, training):
         sums, n = torch.zeros(2, device=dev), 0
@@ -233,8 +256,12 @@ def train(argv=None):
         if training and not sched_done[0] and cur is not None:
             # data-parallel runs: the order of the backward (early / grouped / late) is measured on the first batch by all ranks together;
             # weights, Adam slots and the global step are restored afterwards (DPDistTrainer.select_dp_schedule)
-            info = tr.select_dp_schedule(cur[0], cur[1], cur[2])
+            os.environ["DPD_DP_SCHEDULE"] = "auto"
+            info = tr.select_dp_schedule(cur[0], cur[1], cur[2], modes=None if "DPD_DP_MODE" in os.environ else ("allreduce", "rs_ag", "zero1"))
             log_string("data-parallel schedule: %s" % (info,))
+            if rank == 0:
+                with open(os.path.join(F.log_dir, "dp_schedule.json"), "w") as f:
+                    json.dump(info, f)
             sched_done[0] = True
         while cur is not None:
             nxt = next(it, None)                                   # composed one batch ahead (host work overlaps the GPU step)

@@ -213,8 +213,12 @@ class DPDistTrainer:
         # less GEMM time at bf16 B = 64) and ONE all-reduce behind it; "late" = plain order, collectives after dW1 (A/B reference).
         # DPD_DP_SCHEDULE pins it; otherwise `select_dp_schedule` MEASURES the candidates at start-up (all ranks together) and the
         # initial value is only what runs until then
-        self.dp_schedule = os.environ.get("DPD_DP_SCHEDULE", "early")
-        self.dp_schedule_info = {"schedule": self.dp_schedule, "source": "DPD_DP_SCHEDULE" if "DPD_DP_SCHEDULE" in os.environ else "default"}
+        # the DETERMINISTIC default is "early"; measurement is opt-in per caller (bench.py; dpdist_amd.train --dp_schedule auto) or
+        # DPD_DP_SCHEDULE=auto
+        env_sched = os.environ.get("DPD_DP_SCHEDULE", "early")
+        self.dp_schedule = "early" if env_sched == "auto" else env_sched
+        self.dp_schedule_info = {"schedule": self.dp_schedule,
+                                 "source": "DPD_DP_SCHEDULE" if env_sched not in ("auto",) and "DPD_DP_SCHEDULE" in os.environ else "default"}
         self._wdirty = True        # transposed copies / bf16 planes of the weights need a refresh before their next use
         self._after_dw1 = None
         self._side = None          # side stream of the prefetch pipeline (created on first use)
@@ -662,32 +666,74 @@ class DPDistTrainer:
             self._ev_w1done.wait(torch.cuda.current_stream())      # W1p is complete before anything that follows this step
         return self.loss
 
-    def dp_schedule_candidates(self):
-        c = ["early"]
-        # (the sharded optimizer is only exercised with the orders its tests run: early / late)
-        if self._trio and not (self.reducer is not None and getattr(self.reducer, "mode", "") == "zero1"):
-            c.append("grouped")
-        c.append("late")
-        return c
+    def dp_schedule_candidates(self, modes=None):
+        """Orders of the data-parallel backward, optionally crossed with communication forms ("mode/order"): all of them give the same
+        averaged gradient bit for bit except "grouped" (one grouped dW launch: same sums in another fp32 order)."""
+        orders = ["early", "grouped", "late"]
+        if not modes:
+            return orders
+        return ["%s/%s" % (m, o) for m in modes for o in orders]
 
-    def select_dp_schedule(self, pcA, pcB, labels, candidates=None, steps=20, warmup=5, spinup=40):
-        """Decide the data-parallel backward order by measurement: every candidate runs `warmup` + `steps` real training
-        steps on this batch -- collectives, optimizer and all -- timed between synchronisations; the times are MAX-reduced over the ranks
-        and every rank takes the same winner (ddp.select_schedule).  The parameters, the Adam slots and the step counter are restored
-        after every candidate, so the training run that follows starts from where it was.  COLLECTIVE: every rank must call it, with its
-        own shard.  A schedule pinned through DPD_DP_SCHEDULE is kept (and reported).  Returns the dict that bench.py / train.py put
-        into their `dp` record."""
+    def _dp_supported(self, name):
+        mode, _, order = name.rpartition("/")
+        mode = mode or (self.reducer.mode if self.reducer is not None else "allreduce")
+        if mode not in ("allreduce", "rs_ag", "zero1") or order not in ("early", "grouped", "late"):
+            return False
+        if mode == "zero1" and getattr(self.reducer, "wire", "f32") != "f32":
+            return False                    # the sharded optimizer keeps fp32 master shards: fp32 wire only
+        # (the grouped launch exists for the one-plane type; the sharded optimizer is only exercised with the orders its tests run)
+        return order != "grouped" or (self._trio and mode != "zero1")
+
+    def set_dp_mode(self, mode):
+        """Switch the communication form of the data-parallel step (allreduce | rs_ag | zero1) by re-creating the reducer.  COLLECTIVE:
+        every rank must call it with the same mode (communicators are created, the start-up cross-check runs again)."""
+        red = self.reducer
+        if red is None or red.mode == mode:
+            return
+        self._join_optimizer()
+        torch.cuda.synchronize()
+        group, force = getattr(red, "group", None), os.environ.get("DPD_FORCE_DIST") == "1"
+        if red.active and red.mode == "zero1" and red._calls:          # the slots live sharded: make them whole before the partition goes
+            red.gather_params(self.m_state)
+            red.gather_params(self.v_state)
+            torch.cuda.synchronize()
+        if hasattr(red, "close"):
+            red.close()
+        self.reducer = make_reducer(self.grad, self.P.bucket_bounds, group, force=force, mode=mode)
+
+    def select_dp_schedule(self, pcA, pcB, labels, candidates=None, steps=20, warmup=5, spinup=40, modes=None):
+        """Decide the data-parallel step's form by measurement: every candidate -- an order of the backward (early / grouped / late),
+        crossed with the communication forms in `modes` (allreduce / rs_ag / zero1) when given -- runs `warmup` + `steps` real training
+        steps on this batch, collectives, optimizer and all, timed between synchronisations; the times are MAX-reduced over the ranks and
+        every rank takes the same winner (ddp.select_schedule; candidates some rank cannot run are dropped collectively beforehand).
+        The parameters, the Adam slots and the step counter are restored after every candidate, so the run that follows starts from where
+        it was.  COLLECTIVE: every rank must call it, with its own shard.
+
+        Reproducibility: "grouped" sums the weight gradients in another fp32 order than the separate launches, and two runs can measure
+        different winners when candidates are close -- a run that must be bitwise reproducible PINS the schedule (DPD_DP_SCHEDULE=<order>,
+        DPD_DP_MODE=<mode>; dpdist_amd.train does by default and stores a measured choice next to its checkpoints).  Callers opt in:
+        bench.py measures; dpdist_amd.train only with --dp_schedule auto.  Returns the dict for the `dp` record."""
         import time
         from . import ddp
         if self.reducer is None or not getattr(self.reducer, "active", False):
             self.dp_schedule_info = {"schedule": self.dp_schedule, "source": "no collectives: nothing to choose"}
             return self.dp_schedule_info
-        if "DPD_DP_SCHEDULE" in os.environ:
+        if os.environ.get("DPD_DP_SELECT"):          # "steps,warmup,spinup" (tests that time-share one GPU between many ranks shorten it)
+            steps, warmup, spinup = (int(x) for x in os.environ["DPD_DP_SELECT"].split(","))
+        pinned_order = os.environ.get("DPD_DP_SCHEDULE", "auto") != "auto"
+        pinned_mode = "DPD_DP_MODE" in os.environ or not modes
+        if pinned_order and pinned_mode:
+            self.dp_schedule_info = {"schedule": self.dp_schedule, "mode": self.reducer.mode, "source": "pinned: DPD_DP_SCHEDULE / DPD_DP_MODE"}
             return self.dp_schedule_info
-        cands = list(candidates) if candidates is not None else self.dp_schedule_candidates()
+        if candidates is not None:
+            cands = list(candidates)
+        else:
+            orders = [self.dp_schedule] if pinned_order else ["early", "grouped", "late"]
+            cands = orders if pinned_mode else ["%s/%s" % (m, o) for m in modes for o in orders]
         self._join_optimizer()
         torch.cuda.synchronize()
         keep = (self.P.flat.detach().clone(), self.m_state.clone(), self.v_state.clone(), self.t)
+        mode0 = self.reducer.mode
 
         def restore():
             self._join_optimizer()
@@ -700,7 +746,10 @@ class DPDistTrainer:
             self.P.invalidate_derived()
 
         def time_fn(name):
-            self.dp_schedule = name
+            mode, _, order = name.rpartition("/")
+            if mode:
+                self.set_dp_mode(mode)          # collective; every rank walks the same candidate list in the same order
+            self.dp_schedule = order
             try:
                 for _ in range(warmup):
                     self.step(pcA, pcB, labels)
@@ -721,10 +770,14 @@ class DPDistTrainer:
                 self.step(pcA, pcB, labels)
         finally:
             restore()
-        choice, table = ddp.select_schedule(cands, time_fn, self.P.flat.device, group)
-        self.dp_schedule = choice
-        self.dp_schedule_info = {"schedule": choice, "source": "measured at start-up: %d steps per candidate after a %d-step spin-up, MAX over ranks" % (steps, spinup),
-                                 "candidates_ms": table}
+        choice, table = ddp.select_schedule(cands, time_fn, self.P.flat.device, group, supported=self._dp_supported)
+        mode, _, order = choice.rpartition("/")
+        self.set_dp_mode(mode or mode0)
+        self.dp_schedule = order
+        self.dp_schedule_info = {"schedule": order, "mode": self.reducer.mode,
+                                 "source": "measured at start-up: %d steps per candidate after a %d-step spin-up, MAX over ranks" % (steps, spinup),
+                                 "candidates_ms": table,
+                                 "note": "bitwise-equivalent candidates except 'grouped' (another fp32 summation order of dW); pin with DPD_DP_SCHEDULE / DPD_DP_MODE"}
         return self.dp_schedule_info
 
     # -- optimizer state <-> TF global variables ------------------------------------------------------------------

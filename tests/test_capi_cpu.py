@@ -196,17 +196,44 @@ def test_asloss_engine_carve_is_a_partition_of_the_callers_buffer(lib, B, N, H, 
 
 
 def test_schedule_selection_single_process():
-    """ddp.select_schedule without a process group: the smallest time wins, ties go to the earlier candidate, a failing candidate is
-    dropped, and all failing is an error."""
+    """ddp.select_schedule without a process group: the smallest time wins, ties go to the earlier candidate, an unsupported candidate is
+    dropped before anything is timed, none supported is an error, and an exception inside a timed candidate is NOT swallowed."""
     from dpdist_amd.ddp import select_schedule
     t = {"early": 0.33, "grouped": 0.29, "late": 0.31}
     assert select_schedule(["early", "grouped", "late"], t.__getitem__, torch.device("cpu")) == ("grouped", t)
     assert select_schedule(["a", "b"], lambda n: 1.0, torch.device("cpu"))[0] == "a"
+    timed = []
+
+    def time_fn(n):
+        timed.append(n)
+        return t[n]
+    assert select_schedule(["early", "grouped"], time_fn, torch.device("cpu"), supported=lambda n: n != "grouped") == ("early", {"early": 0.33, "grouped": None})
+    assert timed == ["early"]
+    with pytest.raises(RuntimeError, match="supported"):
+        select_schedule(["grouped"], time_fn, torch.device("cpu"), supported=lambda n: False)
 
     def flaky(n):
-        if n == "grouped":
-            raise RuntimeError("no")
-        return t[n]
-    assert select_schedule(["early", "grouped"], flaky, torch.device("cpu")) == ("early", {"early": 0.33, "grouped": None})
-    with pytest.raises(RuntimeError):
+        raise RuntimeError("boom")
+    with pytest.raises(RuntimeError, match="boom"):
         select_schedule(["grouped"], flaky, torch.device("cpu"))
+
+
+def test_scaling_model_of_the_data_parallel_step():
+    """ddp.predict_scaling (the `dp.model` record of bench.py): a ring all-reduce over N-1 direct xGMI links -- two GPUs share ONE link and
+    are the worst case per byte, collectives that fit under their hide window cost nothing, the bf16 wire halves the bytes."""
+    from dpdist_amd import ddp
+    assert ddp.allreduce_us(1e7, 1) == 0.0
+    assert ddp.allreduce_us(1e7, 2) > ddp.allreduce_us(1e7, 4) > ddp.allreduce_us(1e7, 8)
+    m = ddp.predict_scaling(0.56, [8.4e6, 10.3e6], [127.0, 30.0], plumbing_us=15.0)
+    pw = m["per_world"]
+    assert set(pw) == {"2", "4", "8"} and pw["8"]["links"] == 7 and pw["2"]["wire_bytes_per_gpu"] == int(18.7e6)
+    assert pw["8"]["wire_bytes_per_gpu"] == int(2 * 7 / 8 * 18.7e6)
+    assert pw["2"]["predicted_efficiency"] < pw["4"]["predicted_efficiency"] < pw["8"]["predicted_efficiency"] < 1.0
+    for n in ("2", "4", "8"):
+        exp = sum(max(0.0, c - w) for c, w in zip(pw[n]["collective_us"], (127.0, 30.0)))
+        assert abs(pw[n]["predicted_exposed_us"] - exp) <= 0.11
+        assert abs(pw[n]["predicted_ms_per_step"] - (0.56 + (15.0 + pw[n]["predicted_exposed_us"]) / 1e3)) <= 2e-4
+    half = ddp.predict_scaling(0.56, [8.4e6, 10.3e6], [127.0, 30.0], plumbing_us=15.0, wire="bf16")["per_world"]
+    assert half["8"]["bytes"] * 2 == pw["8"]["bytes"] and half["8"]["predicted_exposed_us"] < pw["8"]["predicted_exposed_us"]
+    huge = ddp.predict_scaling(0.56, [8.4e6, 10.3e6], [1e6, 1e6])["per_world"]
+    assert all(v["predicted_exposed_us"] == 0 and v["predicted_efficiency"] == 1.0 for v in huge.values())

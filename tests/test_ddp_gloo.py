@@ -310,13 +310,23 @@ def _sched_worker(rank, world, port, out):
         return local[name]
 
     choice, table = select_schedule(["early", "grouped", "late"], time_fn, torch.device("cpu"))
-    # a candidate that fails on ONE rank is dropped on every rank
-    def flaky(name):
+    # a candidate ONE rank cannot run is dropped on every rank BEFORE anything is timed (a rank that raised in the middle of a candidate
+    # would leave its peers inside a collective)
+    calls2 = []
+
+    def timed2(name):
+        calls2.append(name)
         dist.barrier()
-        if name == "grouped" and rank == 1:
-            raise RuntimeError("unsupported here")
         return local[name]
-    choice2, table2 = select_schedule(["early", "grouped"], flaky, torch.device("cpu"))
+    choice2, table2 = select_schedule(["early", "grouped"], timed2, torch.device("cpu"), supported=lambda n: not (n == "grouped" and rank == 1))
+    assert calls2 == ["early"]
+    # an exception inside time_fn is not swallowed (here: raised on every rank at the same point, so nobody is left behind)
+    try:
+        select_schedule(["early"], lambda n: (_ for _ in ()).throw(RuntimeError("boom")), torch.device("cpu"))
+        raised = False
+    except RuntimeError as e:
+        raised = "boom" in str(e)
+    assert raised
     # a tie goes to the earlier candidate on every rank
     choice3, _ = select_schedule(["a", "b"], lambda n: (dist.barrier(), 1.0)[1], torch.device("cpu"))
     out.put((rank, choice, table, calls, choice2, table2, choice3))

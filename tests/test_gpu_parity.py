@@ -2320,20 +2320,47 @@ def test_data_parallel_schedule_is_selected_by_measurement(dev, dt, monkeypatch)
         tr.join_optimizer()
         torch.cuda.synchronize()
         cands = ["early", "grouped", "late"] if dt == "bf16" else ["early", "late"]
-        assert sorted(info["candidates_ms"]) == sorted(cands) and all(v and v > 0 for v in info["candidates_ms"].values())
-        assert info["schedule"] == tr.dp_schedule and info["schedule"] in cands
-        assert info["candidates_ms"][info["schedule"]] <= min(info["candidates_ms"].values()) + 1e-4      # (the table is rounded to 1e-4 ms)
+        table = info["candidates_ms"]
+        assert sorted(table) == ["early", "grouped", "late"] and (table["grouped"] is None) == (dt != "bf16")      # dropped collectively, never timed
+        assert all(table[c] and table[c] > 0 for c in cands)
+        assert info["schedule"] == tr.dp_schedule and info["schedule"] in cands and info["mode"] == tr.reducer.mode == "allreduce"
+        assert table[info["schedule"]] <= min(table[c] for c in cands) + 1e-4      # (the table is rounded to 1e-4 ms)
         assert torch.equal(P.flat.detach(), before[0]) and torch.equal(tr.m_state, before[1]) and torch.equal(tr.v_state, before[2])
         assert tr.t == before[3]
         l1 = tr.step(pcA, pcB, lab).clone()
         assert torch.isfinite(l1).all()
+        # the wider choice: order x communication form; the reducer is re-created per form (communicators, cross-check),
+        # the sharded optimizer's slots are made whole again, and the state is still bit for bit what it was
+        tr.join_optimizer()
+        torch.cuda.synchronize()
+        before = (P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), tr.t)
+        info3 = tr.select_dp_schedule(pcA, pcB, lab, steps=3, warmup=1, spinup=5, modes=("allreduce", "rs_ag", "zero1"))
+        tr.join_optimizer()
+        torch.cuda.synchronize()
+        t3 = info3["candidates_ms"]
+        assert sorted(t3) == sorted("%s/%s" % (m, o) for m in ("allreduce", "rs_ag", "zero1") for o in ("early", "grouped", "late"))
+        assert t3["zero1/grouped"] is None and (t3["allreduce/grouped"] is None) == (dt != "bf16")
+        assert all(t3["%s/%s" % (m, o)] > 0 for m in ("allreduce", "rs_ag", "zero1") for o in ("early", "late"))
+        assert info3["mode"] == tr.reducer.mode and info3["schedule"] == tr.dp_schedule and tr.reducer.crosscheck["ok"]
+        assert t3["%s/%s" % (info3["mode"], info3["schedule"])] <= min(v for v in t3.values() if v) + 1e-4
+        assert torch.equal(P.flat.detach(), before[0]) and torch.equal(tr.m_state, before[1]) and torch.equal(tr.v_state, before[2])
+        assert tr.t == before[3]
+        assert torch.isfinite(tr.step(pcA, pcB, lab)).all()
         tr.close()
         # pinned by the environment: nothing is measured
         monkeypatch.setenv("DPD_DP_SCHEDULE", "late")
         tr2 = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
         info2 = tr2.select_dp_schedule(pcA, pcB, lab)
         assert info2["schedule"] == "late" and "candidates_ms" not in info2 and tr2.dp_schedule == "late"
+        # ... and with the order pinned the communication form can still be measured (one order x three forms)
+        info4 = tr2.select_dp_schedule(pcA, pcB, lab, steps=2, warmup=1, spinup=2, modes=("allreduce", "zero1"))
+        assert sorted(info4["candidates_ms"]) == ["allreduce/late", "zero1/late"] and info4["schedule"] == "late"
         tr2.close()
+        # DPD_DP_SCHEDULE=auto: the trainer starts on the deterministic default and a caller's select_dp_schedule measures
+        monkeypatch.setenv("DPD_DP_SCHEDULE", "auto")
+        tr3 = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
+        assert tr3.dp_schedule == "early"
+        tr3.close()
     finally:
         if own:
             dist.destroy_process_group()
@@ -2368,12 +2395,15 @@ def test_plane_weight_gradient_pair_on_a_narrow_decoder(dev, B, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_share_the_gpu(dev):
-    """bench.py's world-size-2 control flow for real, on a one-GPU box: DPD_TEST_SHARE_GPU=1 puts both ranks on GPU 0 over gloo (timings
-    mean nothing).  Exactly the driver's command (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`): two
-    supervisors and their workers, the reducer's start-up cross-check with two ranks, the backward order chosen by BOTH ranks together
-    for the headline and for config 4, the pinned legs, the same-run one-rank leg, the exposed-communication probe, and the final
-    comparison of the replicas' parameters and Adam slots -- which must be bit-identical after all those steps."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_ranks_share_the_gpu(dev, world):
+    """bench.py's world-size-N control flow for real, on a one-GPU box: DPD_TEST_SHARE_GPU=1 puts all ranks on GPU 0 over gloo (timings
+    mean nothing).  Exactly the driver's command (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) for N = 2, 4
+    and 8: N supervisors and their workers, the rendezvous, the reducer's start-up cross-check with N ranks (its amplitude adapts to N),
+    order x communication form of the backward chosen by ALL ranks together for the headline and for config 4 (the reducer is re-created
+    per form: all-reduce, reduce-scatter + all-gather, the sharded optimizer on its real partition), the pinned legs incl. zero1 and the
+    bf16 wire, the same-run one-rank leg, the exposed-communication probe, and the final comparison of all N replicas' parameters and
+    Adam slots -- which must be bit-identical after all those steps.  The line also carries dp.model (the expectation for real nodes)."""
     import json
     import socket
     import subprocess
@@ -2383,30 +2413,37 @@ def test_bench_two_ranks_share_the_gpu(dev):
     so.bind(("127.0.0.1", 0))
     port = so.getsockname()[1]
     so.close()
-    env = dict(os.environ, DPD_TEST_SHARE_GPU="1")
+    env = dict(os.environ, DPD_TEST_SHARE_GPU="1", DPD_DP_SELECT="2,1,2")      # (N ranks time-share one GPU and reduce through the host)
     for k in ("DPD_BENCH_CHILD", "DPD_DP_BACKEND", "DPD_DP_MODE", "DPD_DP_SCHEDULE", "DPD_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK",
               "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines                                    # rank 0 prints ONE line
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["global_batch"] == 64 and "TEST MODE" in rec["data"]
+    assert rec["n_gpus"] == world and rec["value"] > 0 and rec["config"]["global_batch"] == 32 * world and "TEST MODE" in rec["data"]
     dp = rec["dp"]
-    assert dp["crosscheck"]["ok"] and dp["replicas_bit_identical"] is True and rec["fallback"] is False
-    assert dp["schedule"]["schedule"] in ("early", "late") and set(dp["schedule"]["candidates_ms"]) == {"early", "late"}
+    assert dp["crosscheck"]["ok"] and dp["replicas_bit_identical"] is True and rec["fallback"] is False and dp["nranks"] == world
+    forms = {"%s/%s" % (m, o) for m in ("allreduce", "rs_ag", "zero1") for o in ("early", "grouped", "late")}
+    sch = dp["schedule"]
+    assert set(sch["candidates_ms"]) == forms and sch["schedule"] in ("early", "late") and sch["mode"] == dp["mode"]
+    assert all((sch["candidates_ms"][f] is None) == f.endswith("grouped") for f in forms)         # f32: no grouped launch, dropped by all ranks
+    assert set(dp["model"]["per_world"]) == {"2", "4", "8"} and 0 < dp["model"]["per_world"]["8"]["predicted_efficiency"] <= 1
     c4 = rec["config4"]
-    assert c4["n_gpus"] == 2 and c4["global_batch"] == 128 and c4["dp"]["replicas_bit_identical"] is True
-    assert c4["dp"]["schedule"]["schedule"] in ("early", "grouped", "late") and len(c4["dp"]["schedule"]["candidates_ms"]) == 3
-    for leg in ("early_schedule", "grouped_schedule", "n1_same_run"):
-        assert c4[leg]["ms_per_step"] > 0, leg
-    assert "weak_scaling_efficiency_vs_n1_same_run" in c4
+    assert c4["n_gpus"] == world and c4["global_batch"] == 64 * world and c4["dp"]["replicas_bit_identical"] is True
+    s4 = c4["dp"]["schedule"]
+    assert set(s4["candidates_ms"]) == forms and s4["candidates_ms"]["zero1/grouped"] is None and s4["candidates_ms"]["allreduce/grouped"] > 0
+    for leg in ("early_schedule", "grouped_schedule", "zero1", "bf16_wire", "n1_same_run"):
+        assert c4[leg]["ms_per_step"] > 0, (leg, c4[leg])
+    assert c4["zero1"]["dp"]["mode"] == "zero1" and c4["zero1"]["dp"]["replicas_bit_identical"] is True
+    assert c4["bf16_wire"]["dp"]["wire"] == "bf16" and c4["bf16_wire"]["dp"]["crosscheck"]["ok"]
+    assert "weak_scaling_efficiency_vs_n1_same_run" in c4 and set(c4["dp"]["model"]["per_world"]) == {"2", "4", "8"}
 
 
-def _torchrun_shared_gpu(args, timeout=1500):
+def _torchrun_shared_gpu(args, timeout=1500, env=None):
     import socket
     import subprocess
     import sys
@@ -2414,7 +2451,7 @@ def _torchrun_shared_gpu(args, timeout=1500):
     so.bind(("127.0.0.1", 0))
     port = so.getsockname()[1]
     so.close()
-    env = dict(os.environ, DPD_TEST_SHARE_GPU="1")
+    env = dict(os.environ, DPD_TEST_SHARE_GPU="1", **(env or {}))
     for k in ("DPD_BENCH_CHILD", "DPD_DP_BACKEND", "DPD_DP_MODE", "DPD_DP_SCHEDULE", "DPD_FORCE_DIST", "RANK", "WORLD_SIZE", "LOCAL_RANK",
               "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
@@ -2425,14 +2462,28 @@ def _torchrun_shared_gpu(args, timeout=1500):
 
 @pytest.mark.gpu
 def test_trainer_loop_two_ranks_share_the_gpu(dev, tmp_path):
-    """python -m dpdist_amd.train under torch.distributed.run with two ranks on one GPU (gloo): global batch 16 split 8 + 8, the backward
-    order chosen by both ranks on the first batch, two epochs, eval, rank 0's checkpoint."""
+    """python -m dpdist_amd.train under torch.distributed.run with two ranks on one GPU (gloo): global batch 16 split 8 + 8, two epochs,
+    eval, rank 0's checkpoint.  --dp_schedule auto: order x communication form chosen by both ranks on the first batch and stored in
+    dp_schedule.json; the resumed run (--restore) re-uses the stored choice instead of measuring again; without the flag the run is pinned
+    to the deterministic default ("early") and nothing is measured."""
+    import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = _torchrun_shared_gpu(["-m", "dpdist_amd.train", "--max_epoch", "2", "--batch_size", "16", "--train_shapes", "48", "--test_shapes", "16",
-                              "--eval_every", "1", "--log_dir", str(tmp_path / "log")], timeout=900)
+    log = str(tmp_path / "log")
+    base = ["-m", "dpdist_amd.train", "--batch_size", "16", "--train_shapes", "48", "--test_shapes", "16", "--eval_every", "1"]
+    r = _torchrun_shared_gpu(base + ["--max_epoch", "2", "--log_dir", log, "--dp_schedule", "auto"], timeout=900, env={"DPD_DP_SELECT": "2,1,2"})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "data-parallel schedule" in r.stdout and "candidates_ms" in r.stdout
-    assert any(f.startswith("model.ckpt") for f in os.listdir(str(tmp_path / "log"))), os.listdir(str(tmp_path / "log"))
+    assert any(f.startswith("model.ckpt") for f in os.listdir(log)), os.listdir(log)
+    stored = json.load(open(os.path.join(log, "dp_schedule.json")))
+    assert stored["schedule"] in ("early", "late") and stored["mode"] in ("allreduce", "rs_ag", "zero1") and len(stored["candidates_ms"]) == 9
+    r2 = _torchrun_shared_gpu(base + ["--max_epoch", "1", "--log_dir", str(tmp_path / "log2"), "--dp_schedule", "auto", "--restore",
+                                      os.path.join(log, "model.ckpt.npz")], timeout=900)
+    assert r2.returncode == 0, (r2.stdout[-1500:], r2.stderr[-3000:])
+    assert "re-used from" in r2.stdout and "candidates_ms" in r2.stdout and "measured at start-up" in r2.stdout      # (the stored record, not a new table)
+    assert not os.path.exists(str(tmp_path / "log2" / "dp_schedule.json"))
+    r3 = _torchrun_shared_gpu(base + ["--max_epoch", "1", "--log_dir", str(tmp_path / "log3")], timeout=900)
+    assert r3.returncode == 0, (r3.stdout[-1500:], r3.stderr[-3000:])
+    assert "--dp_schedule (pinned)" in r3.stdout and "candidates_ms" not in r3.stdout
 
 
 @pytest.mark.gpu
