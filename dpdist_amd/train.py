@@ -245,7 +245,7 @@ def train(argv=None):
         if stored and stored.get("schedule") in ("early", "grouped", "late") and stored.get("mode") in ("allreduce", "rs_ag", "zero1"):
             tr.set_dp_mode(stored["mode"])           # collective
             tr.dp_schedule = stored["schedule"]
-            tr.dp_schedule_info = dict(stored, source="re-used from %s" % side)
+            tr.dp_schedule_info = dict(stored, source="re-used from %s (%s)" % (side, stored.get("source")))
             log_string("data-parallel schedule: %s" % (tr.dp_schedule_info,))
             sched_done[0] = True
 
