@@ -411,6 +411,100 @@ def dp_model(step_ms_n1, dtype, bucket_bounds, wire="f32"):
     return ddp.predict_scaling(step_ms_n1, [early, late], [frac * step_ms_n1 * 1e3, late_us], plumbing_us=plumb, wire=wire)
 
 
+def section8d_legs(L, tr, pcA, pcB, lab, dev, steps, warmup):
+    """SURVEY 8(d)'s other two figures, in the driver-timed line (N = 1 only; run BEFORE the headline region like config 3):
+      fwd_only   eval_one_epoch_3d (train_multi_gpu_pc_compare_dist.py:809-873): encoder + window gather + decoder + loss, both directions,
+                 no backward -- the headline's trainer, batch and compute type;
+      as_loss    DPDist as a frozen loss (pcrnet-registration/iterative_PCRNet_ours.py:248-257): loss_pred of (source, template) and its
+                 gradient w.r.t. both clouds through the as-loss engine, forward + backward and forward only, B = 16 (the registration
+                 batch) and 32, f32 and bf16.
+    Each leg: ms per evaluation (wall clock over `n` back-to-back evaluations between synchronisations, after a spin-up of its own),
+    query-points/s, and from a separate profiled pass (hipEvent pairs around every GEMM launch) the GEMM time per evaluation, its share of
+    the evaluation and the GEMM family's fraction of the matrix-core peak of its type."""
+    import torch
+    from dpdist_amd import synth
+    from dpdist_amd.model import DPDistLoss, DPDistModel
+    N = 64
+    FWD_FLOP = 2.0 * (2503 * 1024 + 2 * 1024 * 1024)            # layers 1-3 per query point (the 1024 x 3 output layer is not a GEMM launch)
+    out = {}
+
+    def timed(fn, n, spin_ms=25.0):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < spin_ms:       # this leg's own clock spin-up (DESIGN.md section 5)
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+        best = float("inf")
+        for _rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n * 1e3)
+        return best
+
+    def gemm_pass(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        L.dpd_prof_enable(1)
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ms_, fl_ = ctypes.c_double(0), ctypes.c_double(0)
+        cnt = L.dpd_prof_collect(ctypes.byref(ms_), ctypes.byref(fl_))
+        L.dpd_prof_enable(0)
+        return (cnt / float(n), ms_.value / n) if cnt > 0 else (0, 0.0)
+
+    def record(ms, Q, flop_per_q, peak, fn, n):
+        launches, gms = gemm_pass(fn, n)
+        r = {"ms_per_eval": round(ms, 4), "value": round(Q / (ms * 1e-3), 1), "unit": "query-points/sec"}
+        if gms > 0:
+            tf = Q * flop_per_q / (gms * 1e-3) / 1e12
+            r.update({"gemm_launches": round(launches, 1), "gemm_ms": round(gms, 4), "gemm_share_of_eval": round(gms / ms, 3),
+                      "gemm_frac_of_peak": round(tf / peak, 4), "gemm_tflops": round(tf, 1)})
+        return r
+
+    n = max(steps, 20)
+    # forward only on the headline trainer
+    B = tr.B
+    ms = timed(lambda: tr.evaluate(pcA, pcB, lab), n)
+    peak = PEAK_FP32_MFMA_TFLOPS if tr.P.compute_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    out["fwd_only"] = dict(record(ms, 2 * B * N, FWD_FLOP * (6 if tr.P.compute_dtype == "f32x3" else 1), peak, lambda: tr.evaluate(pcA, pcB, lab), n),
+                           what="forward only (eval_one_epoch_3d): encoder + gather + decoder + loss, both directions", batch=B,
+                           dtype=tr.P.compute_dtype)
+    # as-loss engine
+    model = DPDistModel(device=dev)
+    model.params_.reset_parameters_tf(generator=torch.Generator().manual_seed(1234))
+    loss_fn = DPDistLoss(model)
+    asl = {"what": "DPDist as a frozen loss through the as-loss engine (dpd_asloss_forward / _backward): loss_pred and d loss / d both clouds",
+           "flop_note": "GEMM flops per query point: forward 9.32 M (layers 1-3), backward-to-input the same again (dX of layers 3-1)"}
+    for Bx in (16, 32):
+        a_, b_, _ = synth.s2_modelnet_shaped(Bx, N, 100)
+        src = torch.tensor(a_, device=dev, requires_grad=True)
+        tmpl = torch.tensor(b_, device=dev)
+        for dt in ("f32", "bf16"):
+            model.params_.compute_dtype = dt
+            pk = PEAK_FP32_MFMA_TFLOPS if dt == "f32" else PEAK_BF16_MFMA_TFLOPS
+
+            def fb():
+                src.grad = None
+                loss_fn(src, tmpl).backward()
+
+            def fo():
+                with torch.no_grad():
+                    loss_fn(src, tmpl)
+            Q = 2 * Bx * N
+            asl["b%d_%s" % (Bx, dt)] = {"fwd_bwd": record(timed(fb, n), Q, 2 * FWD_FLOP, pk, fb, n),
+                                        "fwd_only": record(timed(fo, n), Q, FWD_FLOP, pk, fo, n)}
+    out["as_loss"] = asl
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -714,6 +808,13 @@ def main():
         except Exception as e:   # never take the headline number down
             cfg34 = ("config4" if world > 1 else "config3", {"error": repr(e)})
 
+    legs8d = None
+    if rank == 0 and world == 1 and not use_dist and not a.no_other_dtypes and B == 32:
+        hb.beat("aux:forward-only and as-loss legs")
+        try:
+            legs8d = section8d_legs(L, tr, pcA, pcB, lab, dev, a.steps, a.warmup)
+        except Exception as e:   # never take the headline number down
+            legs8d = {"error": repr(e)}
     hb.beat("aux:other compute types")
     others = None
     if rank == 0 and world == 1 and not use_dist and not a.no_other_dtypes:
@@ -909,6 +1010,8 @@ def main():
             out["dp_model"] = {"error": repr(e)}
         if others is not None:
             out["other_compute_types"] = others
+        if legs8d is not None:
+            out.update(legs8d) if "error" not in legs8d else out.__setitem__("fwd_only", legs8d)
         if cfg34:
             out[cfg34[0]] = cfg34[1]
         if world == 1 and not a.no_cpu_baseline:

@@ -2443,6 +2443,39 @@ def test_bench_ranks_share_the_gpu(dev, world):
     assert "weak_scaling_efficiency_vs_n1_same_run" in c4 and set(c4["dp"]["model"]["per_world"]) == {"2", "4", "8"}
 
 
+@pytest.mark.gpu
+def test_bench_line_on_one_gpu(dev):
+    """`python bench.py` as the driver runs it at N = 1 (short): ONE JSON line with the contract's keys, the roofline object measured by
+    hipEvents in this run, and -- SURVEY 8(d), VERDICT r5 #3 -- the forward-only and as-loss legs, config 3 and the data-parallel
+    expectation (dp_model) in the same line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DPD_FORCE_DIST", "DPD_TEST_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["metric"].startswith("query-points/sec") and rec["n_gpus"] == 1 and rec["steps"] == 10 and rec["warmup"] == 3
+    assert rec["dtype"] == "f32" and rec["vs_baseline"] is None and rec["scaling"] == "weak" and rec["higher_is_better"] is True
+    assert abs(rec["value"] - 2 * 32 * 64 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
+    roof = rec["roofline"]
+    assert roof["bound"] == "mfma" and 0.5 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    fo = rec["fwd_only"]
+    assert fo["batch"] == 32 and fo["dtype"] == "f32" and 0 < fo["ms_per_eval"] < rec["ms_per_step"] and 0.3 < fo["gemm_frac_of_peak"] <= 1.0
+    assert abs(fo["value"] - 2 * 32 * 64 / (fo["ms_per_eval"] * 1e-3)) <= 1e-3 * fo["value"]
+    asl = rec["as_loss"]
+    for key in ("b16_f32", "b16_bf16", "b32_f32", "b32_bf16"):
+        leg = asl[key]
+        assert 0 < leg["fwd_only"]["ms_per_eval"] < leg["fwd_bwd"]["ms_per_eval"], key
+        assert 0 < leg["fwd_bwd"]["gemm_share_of_eval"] <= 1.0 and leg["fwd_bwd"]["gemm_launches"] == 6, (key, leg)
+    assert set(rec["dp_model"]["per_world"]) == {"2", "4", "8"}
+    assert rec["config3"]["dtype"] == "bf16" and rec["config3"]["pairs_per_gpu"] == 64 and "dp_model" in rec["config3"]
+
+
 def _torchrun_shared_gpu(args, timeout=1500, env=None):
     import socket
     import subprocess
