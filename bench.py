@@ -346,12 +346,12 @@ def self_launch(n):
 def spawn_ranks(n, cmd, timeout_s=None):
     """Run `cmd` n times with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set (rendezvous on 127.0.0.1, free port).  Every rank of
     bench.py supervises itself (per-phase watchdog + one retry on torch.distributed collectives: dpdist_amd/launch.py); the
-    overall limit here (DPD_SPAWN_TIMEOUT, default 1500 s) is the backstop behind that: on expiry the ranks are stopped by PID and
+    overall limit here (default 1500 s) is the backstop behind that: on expiry the ranks are stopped by PID and
     the code is 124."""
     import socket
     import subprocess
     if timeout_s is None:
-        timeout_s = float(os.environ.get("DPD_SPAWN_TIMEOUT", "1500"))
+        timeout_s = 1500.0
     t_start = time.time()
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -518,7 +518,10 @@ def main():
     ap.add_argument("--no-other-dtypes", action="store_true",
                     help="skip the extra single-GPU timing of the same step in the other compute types")
     ap.add_argument("--prefetch", action="store_true", help="side-stream input pipeline (DPDistTrainer.step(prefetch=...))")
-    ap.add_argument("--plan", default="", help="GEMM plan overrides for tuning, e.g. '0:10,1:9:1' = op:tile[:split_k]")
+    ap.add_argument("--plan", default="", help="GEMM plan overrides for tuning, e.g. '0:30,4:33:2' = op:tile[:split_k]")
+    ap.add_argument("--spinup-ms", type=float, default=40.0, help="device spin-up before the timed region (0 = off: profiler passes)")
+    ap.add_argument("--trace", action="store_true", help="diagnostic: per-10-step times of the timed region (adds syncs)")
+    ap.add_argument("--cfg4", action="store_true", help="with DPD_FORCE_DIST=1: also run the config-4 legs on one GPU")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -557,7 +560,6 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # data-parallel steps: the optimizer runs on the collectives' stream and is joined where the next step first reads the weights
         # (trainer.apply_gradients; this loop never reads params.flat between steps)
-        os.environ.setdefault("DPD_DP_ADAM_SIDE", "1")
         hb.beat("init:process group")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -578,7 +580,7 @@ def main():
     g = torch.Generator().manual_seed(1234)            # same random-init weights on every rank (replicated variables)
     P.reset_parameters_tf(generator=g)
     hb.beat("reducer:communicators + start-up cross-check")   # make_reducer: librccl bind, ncclCommInitRank, known-pattern reduce
-    tr = DPDistTrainer(P, B, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4)
+    tr = DPDistTrainer(P, B, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4, adam_on_side=use_dist)
     hb.beat("crosscheck:passed")
     pcA, pcB, lab = synth.s2_modelnet_shaped(B, N, 100 + rank)
     pcA, pcB, lab = (torch.tensor(x, device=dev) for x in (pcA, pcB, lab))
@@ -614,7 +616,7 @@ def main():
         if red is None or not red.active:
             return None
         rep = {"backend": red.backend, "fallback": hb.fallback, "attempt": hb.attempt, "mode": red.mode, "wire": red.wire,
-               "two_communicators": bool(getattr(red, "two_comms", False)), "optimizer_on_collective_stream": bool(trn.adam_on_side),
+               "optimizer_on_collective_stream": bool(trn.adam_on_side),
                "nranks": int(red.nranks),
                "nranks_source": "ncclCommCount" if red.backend == "rccl" else "torch.distributed.get_world_size",
                "wire_bytes_per_gpu_per_step": red.wire_bytes_per_step, "payload_bytes_per_step": 4 * P.numel,
@@ -674,7 +676,8 @@ def main():
         if mode is not None:
             os.environ["DPD_DP_MODE"] = mode
         try:
-            tr2 = DPDistTrainer(P2, B2, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4, distributed=distributed)
+            tr2 = DPDistTrainer(P2, B2, num_point=N, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4, distributed=distributed,
+                                adam_on_side=bool(distributed))
         finally:
             if mode is not None:
                 os.environ.pop("DPD_DP_MODE") if old_mode is None else os.environ.__setitem__("DPD_DP_MODE", old_mode)
@@ -688,7 +691,7 @@ def main():
         # Device spin-up, as for the headline: the chip needs ~25 ms of sustained work of THIS kind before its clock
         # settles, and W + K = 25 steps of 0.28 ms are 7 ms.  The auxiliary leg spins up on its own step (more untimed warm-up steps: 40 ms
         # worth on one rank, a fixed 150 when ranks must stay in step); the W + K steps timed BEFORE it are reported as ms_per_step_cold.
-        spin2 = float(os.environ.get("DPD_BENCH_SPINUP_MS", "40"))
+        spin2 = a.spinup_ms
         cold2, spin_steps = None, 0
         if spin2 > 0:
             (sync if distributed else torch.cuda.synchronize)()
@@ -762,7 +765,7 @@ def main():
     cfg34 = None
     if not a.no_other_dtypes and a.dtype == "f32" and B == 32:
         try:
-            if world > 1 or (use_dist and os.environ.get("DPD_BENCH_CFG4") == "1"):   # (the env: exercise this leg on one GPU)
+            if world > 1 or (use_dist and a.cfg4):   # (--cfg4: exercise this leg on one GPU)
                 # every rank takes part in both legs (the first has collectives)
                 # the headline leg runs the schedule that WON the start-up measurement (dp.schedule: candidates_ms, MAX over ranks); the
                 # pinned legs below are the record of what each candidate does over the full K steps
@@ -822,7 +825,7 @@ def main():
         # enum dpd_dtype).  Reported next to `value`, never as `value`: f32x3 is fp32-equivalent (tests prove it at
         # least as accurate as the exact-fp32 MFMA path), bf16 is the mixed-precision type of BASELINE configs 3-4.
         others = {}
-        for dt in os.environ.get("DPD_BENCH_OTHERS", "f32,f32x3,bf16").split(","):
+        for dt in ("f32", "f32x3", "bf16"):
             if dt == a.dtype:
                 continue
             try:
@@ -855,12 +858,12 @@ def main():
     nxt = (pcA, pcB, None) if a.prefetch else None
     # Device spin-up (NOT training steps, nothing of the model is touched): an MI355X that was idle -- or busy with a different
     # kind of load -- needs ~25 ms of sustained fp32-MFMA work before its power management settles on the steady clock
-    # (tools/ramp_probe.py, DPD_BENCH_TRACE=1: 0.645 -> 0.58 ms per step over the first 40 steps, every time).  The driver's
+    # (tools/ramp_probe.py, --trace: 0.645 -> 0.58 ms per step over the first 40 steps, every time).  The driver's
     # `--steps 20 --warmup 5` is a 15 ms measurement; without this it times the ramp, not the step.  Reported as `spinup_ms`.
-    spin_ms = float(os.environ.get("DPD_BENCH_SPINUP_MS", "40"))
+    spin_ms = a.spinup_ms
     hb.beat("warmup:cold pass + spin-up")
     el_cold = None
-    if spin_ms > 0 and os.environ.get("DPD_BENCH_COLD", "1") == "1":
+    if spin_ms > 0:
         # the number WITHOUT the spin-up, reported next to the headline as ms_per_step_cold: the same W untimed + K timed steps, run
         # first (the chip comes out of the auxiliary legs above or out of idle: this times the clock ramp, see below)
         for _ in range(a.warmup):
@@ -888,7 +891,7 @@ def main():
         tr.step(pcA, pcB, lab, prefetch=nxt)
     hb.beat("timed:%d steps" % a.steps)
     sync()
-    trace = os.environ.get("DPD_BENCH_TRACE") == "1"      # diagnostic: per-10-step times of the timed region (adds syncs)
+    trace = a.trace
     marks = []
     t0 = time.perf_counter()
     for i in range(a.steps):

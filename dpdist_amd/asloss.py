@@ -25,7 +25,6 @@ the stream, so the engine whose buffers the captured launches point into is crea
 and is never handed to anybody else.
 """
 import contextlib
-import os
 import weakref
 from ctypes import c_void_p
 
@@ -34,7 +33,11 @@ import torch
 from . import lib as L
 
 MAX_ENGINES = 4
-MAX_POOL_BYTES = int(os.environ.get("DPD_ASLOSS_POOL_BYTES", str(4 << 30)))      # idle + busy engines of one parameter set
+MAX_POOL_BYTES = 4 << 30      # idle + busy engines of one parameter set
+# module switches (tests and tools/asloss_bench.py flip them; no environment variables): the engine itself, and -- for the plane compute
+# types without it -- the node on persistent planes (round 4) against the round-3 form that converted both operands of every GEMM
+ENGINE = True
+PLANES = True
 
 _private = None
 
@@ -128,7 +131,7 @@ class Engine:
 
 
 def enabled():
-    return os.environ.get("DPD_ASLOSS_ENGINE", "1") == "1"
+    return ENGINE
 
 
 def acquire(P, flat, B, N, m, k, sigma, device):
@@ -136,7 +139,7 @@ def acquire(P, flat, B, N, m, k, sigma, device):
     does not take, or MAX_ENGINES evaluations already waiting for their backward): the caller then takes the allocating path."""
     if not enabled() or B * N >= 16384:
         return None
-    if L.DTYPES[P.compute_dtype] != 0 and os.environ.get("DPD_ASLOSS_PLANES", "1") != "1":
+    if L.DTYPES[P.compute_dtype] != 0 and not PLANES:
         return None                 # A/B reference of round 4: the plane types without persistent planes
     private = _private is not None
     pool = _private if private else P.__dict__.setdefault("_asloss_engines", {})

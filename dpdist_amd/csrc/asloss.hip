@@ -2,8 +2,8 @@
 // carved once from one caller-owned allocation (include/dpdist_capi.h: dpd_asloss).  Replaces the reference's spliced graph
 //   pcrnet-registration/iterative_PCRNet_ours.py:229-257 (import_meta_graph + input_map, loss = mean of the two output means, gradients
 //   w.r.t. the 'Network' scope only, i.e. THROUGH input1) and train_multi_gpu_pc_compare_dist.py:427-463 (the AUE splice).
-// No kernel of its own: it sequences the library's entry points exactly as dpdist_amd/model.py's autograd node did from Python, so the
-// results are bit for bit those of the one-by-one calls (tests/test_gpu_parity.py); what it removes is ~30 allocations and a dozen
+// It sequences the library's entry points as dpdist_amd/model.py's autograd node does from Python (the backward's non-GEMM tail through
+// dpd_asloss_tail: the same device routines in three launches instead of six), so the results are bit for bit those of the one-by-one calls (tests/test_gpu_parity.py); what it removes is ~30 allocations and a dozen
 // ctypes calls per evaluation (one forward + backward per registration step at batch 16: the seven refinements before it are pose-network only,
 // iterative_PCRNet_ours.py:414-441), and a fixed set of buffers is what lets the whole registration step be captured as a hipGraph.
 #include "common.h"
@@ -19,7 +19,7 @@ constexpr size_t al(size_t b) { return (b + 255) / 256 * 256; }
 
 struct Sizes {
     int Q, KP, G;
-    size_t pts, fv, ssq, row, vox, X, h, q3, dX, scratch, mfv_ws, ws, wT2, wT1, pX, ph, pW1, pW23, sync;
+    size_t pts, fv, ssq, row, vox, X, h, q3, dX, scratch, mfv_ws, ws, wT2, wT1, pX, ph, pW1, pW23;
 };
 
 Sizes sizes_of(int B, int N, int m, int k, int H, int dtype) {
@@ -32,7 +32,7 @@ Sizes sizes_of(int B, int N, int m, int k, int H, int dtype) {
     z.scratch = 256; z.mfv_ws = al(dpd_mfv3d_bwd_workspace_bytes(2 * B, m)); z.ws = al(dpd_workspace_bytes(z.Q, z.KP, H, dtype));
     z.wT2 = al((size_t)H * H * f); z.wT1 = al((size_t)H * KP * f);
     const size_t np = dtype == DPD_F32_X3 ? 3 : 1;
-    z.pX = al(np * 2 * Q * KP); z.ph = al(np * 2 * Q * H); z.pW1 = al(np * 2 * KP * H); z.pW23 = al(np * 2 * (size_t)H * H); z.sync = DPD_SYNC_BYTES;
+    z.pX = al(np * 2 * Q * KP); z.ph = al(np * 2 * Q * H); z.pW1 = al(np * 2 * KP * H); z.pW23 = al(np * 2 * (size_t)H * H);
     return z;
 }
 
@@ -51,7 +51,7 @@ extern "C" size_t dpd_asloss_bytes(int B, int N, int m, int k, int H, int dtype)
     const Sizes z = sizes_of(B, N, m, k, H, dtype);
     size_t n = 2 * z.pts + z.fv + z.ssq + z.row + z.vox + z.h /*h3*/ + 3 * z.q3 + z.h /*g3*/ + z.dX + z.fv /*dfv*/ + z.pts /*dpts*/ + z.scratch +
                z.mfv_ws + z.ws;
-    if (planes_shape(z, H, dtype)) n += z.pX + 5 * z.ph + 2 * z.pW1 + 4 * z.pW23 + z.sync;
+    if (planes_shape(z, H, dtype)) n += z.pX + 5 * z.ph + 2 * z.pW1 + 4 * z.pW23;
     else n += z.X + 4 * z.h + 2 * z.wT2 + z.wT1;
     return n;
 }
@@ -78,7 +78,6 @@ extern "C" int dpd_asloss_carve(void* mem, size_t bytes, int B, int N, int m, in
         pl.X_rc = take(z.pX); pl.h1_rc = take(z.ph); pl.h2_rc = take(z.ph); pl.g3_rc = take(z.ph); pl.g2_rc = take(z.ph); pl.g1_rc = take(z.ph);
         pl.W1_r8 = take(z.pW1); pl.W1_rc = take(z.pW1);
         pl.W2_r8 = take(z.pW23); pl.W3_r8 = take(z.pW23); pl.W2_rc = take(z.pW23); pl.W3_rc = take(z.pW23);
-        pl.sync = take(z.sync);
     } else {
         e.X = (float*)take(z.X); e.h1 = (float*)take(z.h); e.h2 = (float*)take(z.h); e.g2 = (float*)take(z.h); e.g1 = (float*)take(z.h);
         e.W2T = (float*)take(z.wT2); e.W3T = (float*)take(z.wT2); e.W1pT = (float*)take(z.wT1);
@@ -90,7 +89,6 @@ extern "C" int dpd_asloss_carve(void* mem, size_t bytes, int B, int N, int m, in
 extern "C" int dpd_asloss_init(const dpd_asloss* e, void* stream) {
     if (!e || !e->scratch) return DPD_E_NULL;
     DPD_HIP(hipMemsetAsync(e->scratch, 0, 256, (hipStream_t)stream));
-    if (e->planes.sync) DPD_HIP(hipMemsetAsync(e->planes.sync, 0, DPD_SYNC_BYTES, (hipStream_t)stream));
     return 0;
 }
 
@@ -132,6 +130,11 @@ extern "C" int dpd_asloss_backward(const dpd_asloss* e, const float* upstream, f
     if (int rc = dpd_decoder_bwd_data(nullptr, nullptr, nullptr, e->h1, e->h2, nullptr, Q, e->KP, e->H, &e->params, e->dtype, nullptr,
                                       g3_plane ? nullptr : e->g3, e->g2,
                                       e->g1, e->dX, nullptr, e->ws, e->ws_bytes, pl, 6, stream)) return rc;
+    // the non-GEMM tail: three launches (gather backward || encoder statistics, combine, apply + input gradients); the separate entries for
+    // shapes the fused form does not take
+    const int rc_tail = dpd_asloss_tail(e->dX, e->vox, e->pts, upstream, e->B, e->N, e->m, e->k, e->KP, e->sigma, e->dfv, e->mfv_ws, e->mfv_ws_bytes,
+                                        gA, gB, stream);
+    if (rc_tail != DPD_E_UNSUPPORTED) return rc_tail;
     if (int rc = dpd_patch_rows_bwd(e->dX, e->vox, C, e->N, e->m, e->k, e->KP, nullptr, e->dfv, stream)) return rc;
     if (int rc = dpd_mfv3d_bwd(e->pts, e->dfv, C, e->N, e->m, e->sigma, e->dpts, e->mfv_ws, e->mfv_ws_bytes, stream)) return rc;
     return dpd_asloss_combine(e->dpts, e->dX, upstream, e->B, e->N, e->k, e->KP, gA, gB, stream);

@@ -20,48 +20,29 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
             int ldb, long b_plane, float* C, int ldc, const float* bias, const float* gate, int epilogue, int tile,
             hipStream_t s, float* colsum, const X3Out* out = nullptr, const X3Extra* ex = nullptr, int split_k = 1, void* ws = nullptr,
             size_t ws_bytes = 0, const uint16_t* gate16 = nullptr, int gate16_r8 = 0, void* red_cnt = nullptr, int red_cnt_words = 0);
-int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
-                   const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
-                   hipStream_t s, int split_k = 1, void* ws = nullptr, size_t ws_bytes = 0);
 int split_planes(const float* src, int R, int C, int ld, int np, uint16_t* rc, int ld_rc, long rc_plane, uint16_t* r8,
                  long r8_plane, hipStream_t s);
 int split_planes_multi(SplitJobs jobs, hipStream_t s);
-extern int g_rs_xcd_band;
 
 // process-wide GEMM plan (tile, split_k) per call site; 0 = automatic.  The only global state of the library:
 // a tuning knob (dpd_set_gemm_plan), never needed for correctness.
 enum { OP_FWD_L1 = 0, OP_FWD_L23 = 1, OP_BWD_DH = 2, OP_BWD_DX = 3, OP_BWD_DW1 = 4, OP_BWD_DW23 = 5, OP_BWD_DH_T = 6, OP_BWD_DX_T = 7,
-       OP_BWD_DW1_G = 8, OP_COUNT = 9 };   // _T: the same product with a transposed weight copy (NN form); _G: fused gather
+       OP_COUNT = 8 };   // _T: the same product with a transposed weight copy (NN form)
 // Defaults measured on MI355X at B=32 (tools/gemm_bench.py, profiles/): LDS-DMA ring kernels everywhere;
 //   fwd L1 (4096x1024x2528)  128x128 16-wave 3-stage ring  ~127 TFLOP/s    fwd L2/3 (K=1024) 128x128 3-stage  ~120
 //   bwd dH (2048x1024x1024)   64x64  3-stage               ~ 93..106       bwd dX            64x64 3-stage    ~103
 //   bwd dW1 (2528x1024x2048)  64x64  3-stage, split-K 2    ~102            bwd dW2/3         64x64 3-stage    ~ 97
 // (run-to-run spread between boxes is ~10 %; the ranking inside one run is stable.  DMA kernels need K % 32 == 0;
 //  gemm_f32 falls back to the register-staged 64x64 kernel otherwise.)
-static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32, 30};
-static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 3};   // (0 = tail split, gemm_rs.h: measured no gain on dW1, 0.525 vs 0.5215 ms of GEMM per step)
-static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
+static int g_plan_tile[OP_COUNT] = {32, 32, 8, 8, 33, 33, 32, 32};
+static int g_plan_split[OP_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1};   // (0 = tail split, gemm_rs.h: measured no gain on dW1, 0.525 vs 0.5215 ms of GEMM per step)
+static int g_x3_tile[OP_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};   // one-plane (bf16) tile override per call site, 0 = automatic
 // split-K of the plane weight-gradient GEMMs (K = query rows is long, M x N gives 64-160 tiles of 128x128 for 256 CUs):
 //   n > 1: n slices per output tile, reduced INSIDE the launch by the last-arriving slice in slice order (gemm_x3.hip: inlaunch_reduce;
 //          deterministic); n < -1: the round-2 form, |n| fp32 slabs + a reduce launch (A/B reference); 1: off; 0: automatic
-static int g_x3_split[OP_COUNT] = {1, 1, 1, 1, 0, 0, 1, 1, 1};
+static int g_x3_split[OP_COUNT] = {1, 1, 1, 1, 0, 0, 1, 1};
 static int g_x3_pair_tile = 0, g_x3_pair_split = 0;   // plane dW2+dW3 pair: tile (0 = automatic), split-K (as above)
 static int g_x3_trio_tile = 0, g_x3_trio_split = 1;   // plane dW1+dW2+dW3 in one launch (dpd_decoder_bwd_weights_trio): tile, split-K
-// chained persistent launches of the one-plane compute type (gemm_x3.hip: gemm_chain): 0 = off, 1 = automatic, 21 / 23 = force that tile
-// default OFF: measured slower than the separate launches (round 5, DESIGN.md 3.6: +11 us per chain at B = 64 -- a hand-off costs what a kernel
-// boundary costs on this chip, and the tiles themselves take as long inside the persistent launch as apart)
-static int g_chain_fwd = 0, g_chain_bwd = 0;
-static unsigned long long* g_chain_stamps = nullptr;  // dpd_set_chain_stamps (debug)
-// tile of a chained launch over `rows` x H outputs, or 0: the 256x128 tile when it gives every CU a workgroup (B = 64: 8192 rows), else
-// the 128x128 tile when THAT does (the data-gradient chain at B = 64, the forward at B = 32)
-static int chain_tile(int mode, int rows, int H, int r8_rows) {
-    if (mode == 0) return 0;
-    auto ok = [&](int bm) { return !(rows % bm) && !(H % 128) && !(r8_rows % bm); };
-    if (mode == 21 || mode == 23) return ok(mode == 21 ? 256 : 128) ? mode : 0;
-    if (ok(256) && (long)(rows / 256) * (H / 128) >= 224) return 21;
-    if (ok(128) && (long)(rows / 128) * (H / 128) >= 200) return 23;
-    return 0;
-}
 constexpr size_t kRedCntBytes = 8192;                 // arrival words of the in-launch reduction: the last 8 KiB of the base workspace
 
 // Compute type of the three wide layers (the `dtype` argument of the decoder entry points):
@@ -118,7 +99,7 @@ static int gemm_dt(int dtype, int op, int transA, int transB, int M, int N, int 
         // the 128x128 one-workgroup-per-CU kernels need >= ~200 tiles to fill the chip (B = 32 forward); smaller batches
         // (as-loss mode at the PCRNet batch of 16: M = 2048 -> 128 tiles) run the 64x64 kernel, 3 workgroups per CU
         const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-        if ((tile == 9 || tile == 5 || tile == 10) && tiles128 < 200) tile = 8;
+        if (tile == 9 && tiles128 < 200) tile = 8;
         // register-streamed NN products: once there are two 128x128 tiles per CU, 64x64 wave tiles (half the operand loads per
         // flop) keep two waves per SIMD as well -- measured at B = 64: family 0.75 -> 0.85 of peak, step 1.206 -> 1.081 ms
         if (tile == 32 && tiles128 >= 512 && !transA && !transB) tile = 30;
@@ -976,10 +957,8 @@ extern "C" int dpd_set_gemm_plan(int op, int tile, int split_k) {
         return 0;
     }
     if (op == 32 && tile >= 0 && tile <= 16 && split_k >= -4 && split_k <= 4) { dpd::g_x3_pair_tile = tile; dpd::g_x3_pair_split = split_k; return 0; }
-    if (op == 40 && tile >= 0 && tile <= 2) { dpd::g_rs_xcd_band = tile; return 0; }      // XCD-blocked tile map of the fp32 register-streamed GEMMs
-    if ((op == 48 || op == 49) && (tile == 0 || tile == 1 || tile == 21 || tile == 23)) { (op == 48 ? dpd::g_chain_fwd : dpd::g_chain_bwd) = tile; return 0; }
     if (op == 33 && tile >= 0 && tile <= 16 && split_k >= 1 && split_k <= 4) { dpd::g_x3_trio_tile = tile; dpd::g_x3_trio_split = split_k; return 0; }
-    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 39 || split_k < 0 || split_k > 8) return DPD_E_DIM;
+    if (op < 0 || op >= dpd::OP_COUNT || tile < 0 || tile > 33 || split_k < 0 || split_k > 8) return DPD_E_DIM;
     dpd::g_plan_tile[op] = tile;
     dpd::g_plan_split[op] = split_k;
     return 0;
@@ -1019,8 +998,7 @@ PlaneSizes plane_sizes(int Q, int Qb, int KP, int H, int np) {
 extern "C" size_t dpd_planes_bytes(int Q, int Qb, int KP, int H, int dtype, int with_dx) {
     if (dtype != 1 && dtype != 2) return 0;
     const PlaneSizes z = plane_sizes(Q, Qb, KP, H, dtype == 1 ? 3 : 1);
-    return z.X_rc + z.X_r8 + 2 * (z.h_rc + z.h_r8) + (with_dx ? 6 : 5) * z.g + (with_dx ? 2 : 1) * z.W1 + 4 * z.W23 + (dtype == 2 ? z.h_rc : 0) +
-           DPD_SYNC_BYTES;
+    return z.X_rc + z.X_r8 + 2 * (z.h_rc + z.h_r8) + (with_dx ? 6 : 5) * z.g + (with_dx ? 2 : 1) * z.W1 + 4 * z.W23 + (dtype == 2 ? z.h_rc : 0);
 }
 
 extern "C" int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, int H, int dtype, int with_dx, dpd_planes* out) {
@@ -1042,28 +1020,6 @@ extern "C" int dpd_planes_carve(void* mem, size_t bytes, int Q, int Qb, int KP, 
     out->W2_rc = take(z.W23); out->W3_rc = take(z.W23);
     out->W1_rc = with_dx ? take(z.W1) : nullptr;
     out->h3_rc = (dtype == 2) ? take(z.h_rc) : nullptr;
-    out->sync = take(DPD_SYNC_BYTES);      // zeroed by dpd_planes_sync_reset / every dpd_patch_rows_fwd* given these planes
-    return 0;
-}
-
-extern "C" int dpd_planes_sync_reset(const dpd_planes* pl, void* stream) {
-    if (!pl) return DPD_E_NULL;
-    if (!pl->sync) return 0;
-    DPD_HIP(hipMemsetAsync(pl->sync, 0, DPD_SYNC_BYTES, (hipStream_t)stream));
-    return 0;
-}
-
-extern "C" int dpd_planes_sync_status(const dpd_planes* pl, void* stream) {
-    if (!pl) return DPD_E_NULL;
-    if (!pl->sync) return 0;
-    unsigned err = 0;
-    DPD_HIP(hipMemcpyAsync(&err, (const unsigned*)pl->sync + 9, sizeof(err), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    DPD_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return (int)(err & 0x7fffffffu);
-}
-
-extern "C" int dpd_set_chain_stamps(void* device_buf) {
-    dpd::g_chain_stamps = (unsigned long long*)device_buf;
     return 0;
 }
 
@@ -1130,29 +1086,6 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
     if (pl) {   // operands from / results to the persistent planes (no conversion passes)
         X3Out o1 = make_out(pl, pl->h1_rc, Q, pl->h1_r8, pl->Qb, H), o2 = make_out(pl, pl->h2_rc, Q, pl->h2_r8, pl->Qb, H);
         const bool w1 = o1.rc || o1.r8, w2 = o2.rc || o2.r8;
-        // one plane, no fp32 copies of h1 / h2 wanted, whole tiles: layers 1 -> 2 -> 3 as ONE persistent launch (gemm_x3.hip: gemm_chain_kernel),
-        // bitwise the three launches below
-        const int ctile = (pl->np == 1 && pl->sync && !h1 && !h2 && pl->X_rc && pl->h1_rc && pl->h2_rc && pl->W1_r8 && pl->W2_r8 && pl->W3_r8 &&
-                           !(KP % 32) && (h3 || h3_plane))
-                              ? chain_tile(g_chain_fwd, Q, H, (pl->h1_r8 || pl->h2_r8) ? pl->Qb : 0) : 0;
-        if (ctile) {
-            ChainStage cs[3];
-            const uint16_t* a_in[3] = {(const uint16_t*)pl->X_rc, (const uint16_t*)pl->h1_rc, (const uint16_t*)pl->h2_rc};
-            const uint16_t* w_in[3] = {(const uint16_t*)pl->W1_r8, (const uint16_t*)pl->W2_r8, (const uint16_t*)pl->W3_r8};
-            const float* b_in[3] = {p->b1, p->b2, p->b3};
-            for (int i = 0; i < 3; ++i) {
-                cs[i].A = a_in[i]; cs[i].lda = i ? H : KP; cs[i].B = w_in[i]; cs[i].ldb = H; cs[i].b_fmt = 1; cs[i].K = i ? H : KP;
-                cs[i].bias = b_in[i]; cs[i].epilogue = EPI_BIAS_RELU;
-            }
-            cs[0].out = o1; cs[1].out = o2;
-            if (h3_plane) cs[2].out = make_out(pl, pl->h3_rc, Q, nullptr, 0, H);
-            else { cs[2].C = h3; cs[2].ldc = H; }
-            const int rc = gemm_chain(3, cs, Q, H, ctile, (unsigned*)pl->sync, g_chain_stamps, s);
-            if (rc != DPD_E_UNSUPPORTED) {
-                if (rc) return rc;
-                goto out_layer;
-            }
-        }
         if (int rc = gemm_dt(dtype, OP_FWD_L1, 0, 0, Q, H, KP, X, KP, p->W1p, H, h1, H, p->b1, nullptr, 2, nullptr, 0, scr, s, nullptr,
                              pl->X_rc, pl->W1_r8, w1 ? &o1 : nullptr)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s, nullptr,
@@ -1166,57 +1099,10 @@ extern "C" int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP,
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
         if (int rc = gemm_dt(dtype, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
     }
-out_layer:
     if (!y) return 0;
     DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
     DPD_CHECK_LAUNCH();
     return 0;
-}
-
-// The same weight-gradient GEMMs with Adam applied in their epilogue (gemm_shared.h: AdamEpi): single-GPU steps only -- with a gradient
-// all-reduce between compute_gradients and apply_gradients the separate optimizer kernel stays.
-extern "C" int dpd_has_adam_epilogue(void) {
-#ifdef DPD_ADAM_EPI
-    return 1;
-#else
-    return 0;
-#endif
-}
-
-static int adam_epi_from(const dpd_adam_epi* ad, int pair, dpd::AdamEpi* out) {
-    if (!ad || !ad->p || !ad->m || !ad->v) return DPD_E_NULL;
-    if (pair && (!ad->p2 || !ad->m2 || !ad->v2)) return DPD_E_NULL;
-    if (((uintptr_t)ad->p | (uintptr_t)ad->m | (uintptr_t)ad->v | (uintptr_t)ad->wt | (uintptr_t)ad->p2 | (uintptr_t)ad->m2 | (uintptr_t)ad->v2 |
-         (uintptr_t)ad->wt2) & 15) return DPD_E_UNSUPPORTED;
-    *out = dpd::AdamEpi{ad->p, ad->m, ad->v, ad->wt, pair ? ad->p2 : nullptr, pair ? ad->m2 : nullptr, pair ? ad->v2 : nullptr,
-                        pair ? ad->wt2 : nullptr, ad->lr_t, ad->b1, ad->b2, ad->eps, ad->gscale};
-    return 0;
-}
-
-extern "C" int dpd_decoder_bwd_weights_adam(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout, int dtype,
-                                            float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
-                                            const float* db_partials, const dpd_adam_epi* ad, void* stream) {
-    dpd::AdamEpi e;
-    if (int rc = adam_epi_from(ad, 0, &e)) return rc;
-    if (layer < 1 || layer > 3) return DPD_E_DIM;
-    if (dtype != 0) return DPD_E_UNSUPPORTED;          // (exact fp32 for now: the plane kernels would have to write the weights' planes per group)
-    dpd::g_adam_epi = &e;
-    const int rc = dpd_decoder_bwd_weights(layer, act, lda, g, Qb, Kin, Nout, dtype, dW, db, ws, ws_bytes, pl, db_partials, stream);
-    dpd::g_adam_epi = nullptr;
-    return rc;
-}
-
-extern "C" int dpd_decoder_bwd_weights_pair_adam(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB,
-                                                 float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws, size_t ws_bytes,
-                                                 const dpd_planes* pl, float* dbA, const float* db_partials, const dpd_adam_epi* ad,
-                                                 void* stream) {
-    dpd::AdamEpi e;
-    if (int rc = adam_epi_from(ad, 1, &e)) return rc;
-    if (dtype != 0) return DPD_E_UNSUPPORTED;
-    dpd::g_adam_epi = &e;
-    const int rc = dpd_decoder_bwd_weights_pair(actA, gA, dWA, actB, gB, dWB, lda, Qb, Kin, Nout, dtype, ws, ws_bytes, pl, dbA, db_partials, stream);
-    dpd::g_adam_epi = nullptr;
-    return rc;
 }
 
 extern "C" int dpd_decoder_out_asloss(const float* h3, const float* mask, int Q, int H, int BN, const dpd_decoder_params* p, float gscale,
@@ -1244,55 +1130,6 @@ extern "C" int dpd_decoder_out_asloss_planes(const float* h3, const float* mask,
                loss_pred, (unsigned long long*)scratch, g3_rc, g3_rc ? (long)Q * H : 0L, g3_rc ? pl->np : 0);
     DPD_CHECK_LAUNCH();
     return 0;
-}
-
-// ---- fused window gather (DPD_F32): layer 1 reads its input rows straight from the Fisher vectors --------------------
-static int check_gather(const dpd_gather* g, int rows, size_t* a_bytes, size_t* xyz_off) {
-    if (!g || !g->fv || !g->xyz || !g->rowinfo || !g->table) return DPD_E_NULL;
-    if (g->C <= 0 || g->G <= 0 || rows <= 0) return DPD_E_DIM;
-    // ONE buffer descriptor serves both: xyz must live behind fv in the same allocation, 32-bit offsets
-    if ((const char*)g->xyz < (const char*)g->fv) return DPD_E_UNSUPPORTED;
-    *xyz_off = (size_t)((const char*)g->xyz - (const char*)g->fv);
-    if (*xyz_off < (size_t)g->C * g->G * DPD_FV_CHANNELS * sizeof(float)) return DPD_E_DIM;
-    *a_bytes = *xyz_off + (size_t)rows * 16;
-    return 0;
-}
-
-extern "C" int dpd_decoder_fwd_gather(const dpd_gather* src, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
-                                      float* h1, float* h2, float* h3, float* y, float* pred, void* stream) {
-    using namespace dpd;
-    if (!mask || !p || !h1 || !h2 || !h3 || !y || !pred) return DPD_E_NULL;
-    if (!p->W1p || !p->b1 || !p->W2 || !p->b2 || !p->W3 || !p->b3 || !p->W4 || !p->b4) return DPD_E_NULL;
-    if (Q <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
-    if ((H & 63) || (KP & 31)) return DPD_E_UNSUPPORTED;
-    size_t a_bytes = 0, xyz_off = 0;
-    if (int rc = check_gather(src, Q, &a_bytes, &xyz_off)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    int t1 = g_plan_tile[OP_FWD_L1];
-    if (t1 < 30 || t1 > 33) t1 = 32;
-    if (int rc = gemm_rs_gather(1, Q, H, KP, src->fv, a_bytes, xyz_off, (const uint2*)src->table, (const uint2*)src->rowinfo, p->W1p, H, h1,
-                                H, p->b1, EPI_BIAS_RELU, t1, s)) return rc;
-    const Scratch scr{nullptr, 0};
-    if (int rc = gemm_dt(0, OP_FWD_L23, 0, 0, Q, H, H, h1, H, p->W2, H, h2, H, p->b2, nullptr, 2, nullptr, 0, scr, s)) return rc;
-    if (int rc = gemm_dt(0, OP_FWD_L23, 0, 0, Q, H, H, h2, H, p->W3, H, h3, H, p->b3, nullptr, 2, nullptr, 0, scr, s)) return rc;
-    DPD_LAUNCH(out_fwd_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, h3, p->W4, p->b4, mask, y, pred, Q, H);
-    DPD_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int dpd_decoder_bwd_weights_gather(const dpd_gather* src, const float* g1, int Qb, int KP, int H, float* dW1, void* ws,
-                                              size_t ws_bytes, void* stream) {   // (db1: from dpd_decoder_bwd_data's sg->db1)
-    using namespace dpd;
-    if (!g1 || !dW1) return DPD_E_NULL;
-    if (Qb <= 0 || KP <= 0 || H <= 0) return DPD_E_DIM;
-    if ((H & 63) || (KP & 31) || (Qb & 31)) return DPD_E_UNSUPPORTED;
-    size_t a_bytes = 0, xyz_off = 0;
-    if (int rc = check_gather(src, Qb, &a_bytes, &xyz_off)) return rc;
-    int t = g_plan_tile[OP_BWD_DW1_G], split = g_plan_split[OP_BWD_DW1_G];
-    if (t < 30 || t > 33) t = 33;
-    if (split > 1 && (!ws || (size_t)split * KP * H * sizeof(float) > ws_bytes)) split = 1;
-    return gemm_rs_gather(2, KP, H, Qb, src->fv, a_bytes, xyz_off, (const uint2*)src->table, (const uint2*)src->rowinfo, g1, H, dW1, H,
-                          nullptr, EPI_NONE, t, (hipStream_t)stream, split, ws, ws_bytes);
 }
 
 extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const float* y, const float* h1,
@@ -1412,27 +1249,6 @@ extern "C" int dpd_decoder_bwd_data(const float* dpred, const float* mask, const
         }
         X3Out o2 = make_out(pl, pl->g2_rc, Qb, pl->g2_r8, Qb, H), o1 = make_out(pl, dX ? pl->g1_rc : nullptr, Qb, pl->g1_r8, Qb, H);
         const bool w2 = o2.rc || o2.r8, w1 = o1.rc || o1.r8;
-        // one plane, both dH GEMMs wanted, no fp32 copies of g2 / g1: g3 -> g2 -> g1 as ONE persistent launch, bitwise the two launches below
-        const int ctile = ((phases & 6) == 6 && pl->np == 1 && pl->sync && !g2 && !g1 && !h2 && !h1 && pl->g3_rc && pl->g2_rc && w1 && pl->W3_rc &&
-                           pl->W2_rc && (pl->h2_r8 || pl->h2_rc) && (pl->h1_r8 || pl->h1_rc))
-                              ? chain_tile(g_chain_bwd, Qb, H, Qb) : 0;
-        if (ctile) {
-            ChainStage cs[2];
-            cs[0].A = (const uint16_t*)pl->g3_rc; cs[0].B = (const uint16_t*)pl->W3_rc; cs[0].out = o2; cs[0].colsum = db2;
-            cs[0].gate16 = (const uint16_t*)(pl->h2_r8 ? pl->h2_r8 : pl->h2_rc); cs[0].gate16_r8 = pl->h2_r8 != nullptr;
-            cs[1].A = (const uint16_t*)pl->g2_rc; cs[1].B = (const uint16_t*)pl->W2_rc; cs[1].out = o1; cs[1].colsum = db1;
-            cs[1].gate16 = (const uint16_t*)(pl->h1_r8 ? pl->h1_r8 : pl->h1_rc); cs[1].gate16_r8 = pl->h1_r8 != nullptr;
-            for (int i = 0; i < 2; ++i) { cs[i].lda = H; cs[i].ldb = H; cs[i].b_fmt = 0; cs[i].K = H; cs[i].epilogue = EPI_GATE; }
-            const int rc = gemm_chain(2, cs, Qb, H, ctile, (unsigned*)pl->sync, g_chain_stamps, s);
-            if (rc != DPD_E_UNSUPPORTED) {
-                if (rc) return rc;
-                phases &= ~6;
-                if (dX)
-                    if (int rc2 = gemm_dt(dtype, OP_BWD_DX, 0, 1, Qb, KP, H, g1, H, p->W1p, H, dX, KP, nullptr, nullptr, 0, nullptr, 0, scr, s, nullptr,
-                                          pl->g1_rc, pl->W1_rc, nullptr)) return rc2;
-                return 0;
-            }
-        }
         if (phases & 2)
             if (int rc = gemm_dt(dtype, OP_BWD_DH, 0, 1, Qb, H, H, g3, H, p->W3, H, g2, H, nullptr, h2, 3, nullptr, 0, scr, s, db2, pl->g3_rc,
                                  pl->W3_rc, w2 ? &o2 : nullptr, nullptr, h2 ? nullptr : (pl->h2_r8 ? pl->h2_r8 : pl->h2_rc), pl->h2_r8 != nullptr)) return rc;
@@ -1472,7 +1288,7 @@ extern "C" int dpd_decoder_bwd_weights(int layer, const float* act, int lda, con
                                        int dtype, float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl,
                                        const float* db_partials, void* stream) {
     using namespace dpd;
-    if ((!dW && !(g_adam_epi && layer != 4)) || ((!act || !g) && !(pl && dtype != 0))) return DPD_E_NULL;   // (act / g may be NULL when their R8 planes exist: checked below)
+    if (!dW || ((!act || !g) && !(pl && dtype != 0))) return DPD_E_NULL;   // (act / g may be NULL when their R8 planes exist: checked below)
     if (layer == 4 && (!db || !act || !g)) return DPD_E_NULL;
     if (layer < 1 || layer > 4 || Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2) return DPD_E_UNSUPPORTED;
@@ -1536,7 +1352,7 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                                             float* dWB, int lda, int Qb, int Kin, int Nout, int dtype, void* ws,
                                             size_t ws_bytes, const dpd_planes* pl, float* dbA, const float* db_partials, void* stream) {
     using namespace dpd;
-    if ((!dWA || !dWB) && !g_adam_epi) return DPD_E_NULL;
+    if (!dWA || !dWB) return DPD_E_NULL;
     if ((!actA || !actB || !gA || !gB) && !(dtype != 0 && pl && pl->h1_r8 && pl->h2_r8 && pl->g2_r8 && pl->g3_r8)) return DPD_E_NULL;
     if (Qb <= 0 || Kin <= 0 || Nout <= 0 || lda < Kin) return DPD_E_DIM;
     if (dtype < 0 || dtype > 2 || (Nout & 3) || (Kin & 3) || (lda & 3) || (Qb & 31)) return DPD_E_UNSUPPORTED;
@@ -1595,8 +1411,8 @@ extern "C" int dpd_decoder_bwd_weights_pair(const float* actA, const float* gA, 
                        (hipStream_t)stream, nullptr, have ? pl->h2_r8 : nullptr, have ? pl->g3_r8 : nullptr, nullptr);
     }
     int tile = g_plan_tile[OP_BWD_DW23];
-    if (!((tile >= 4 && tile <= 14) || (tile >= 30 && tile <= 39))) tile = 8;
-    if (dbA && !(db_partials && tile >= 30 && tile <= 39)) return DPD_E_UNSUPPORTED;   // layer 2's bias gradient from the stored partials
+    if (!((tile == 8 || tile == 9) || (tile >= 30 && tile <= 33))) tile = 8;
+    if (dbA && !(db_partials && tile >= 30 && tile <= 33)) return DPD_E_UNSUPPORTED;   // layer 2's bias gradient from the stored partials
     ColsumTwoStep cs{};
     cs.part_in = db_partials; cs.out = dbA; cs.nparts = (Qb + 31) / 32;     // (layer 2 = problem A: the first half of the scratch)
     return gemm_f32(1, 0, Kin, Nout, Qb, actA, lda, gA, Nout, dWA, Nout, nullptr, nullptr, 0, 1, tile, nullptr, 0,

@@ -380,9 +380,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_dma_kernel(GemmArgs g) {
     }
     GemmArgs gs = g;
     if (grp) gs.C = g.C2;
-#ifdef DPD_ADAM_EPI
-    if (grp) { gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
-#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -414,7 +411,6 @@ struct GemmProf {
     signed char form[kMax];   // GEMM launches: 0 = NN / NT, 1 = TN (dpd_prof_collect_form)
     int created = 0;   // events [0, created) exist
 };
-int g_rs_xcd_band = 0;     // dpd_set_gemm_plan(40, mode, 1): 0 off, 1 the weight-gradient (TN) products, 2 every register-streamed GEMM
 static GemmProf g_prof;
 static std::mutex g_prof_mu;   // the profiler is process-wide (one GEMM stream at a time is the supported use); the lock keeps it memory-safe
 
@@ -473,55 +469,28 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 
 template <bool AK, bool BKC>
 static int launch_tile(int tile, const GemmArgs& g, hipStream_t s) {
-    if (tile >= 30 && tile <= 39) return launch_rs_tile<AK, BKC>(tile, g, s);   // register-streamed kernels (gemm_rs.h)
+    if (tile >= 30 && tile <= 33) return launch_rs_tile<AK, BKC>(tile, g, s);   // register-streamed kernels (gemm_rs.h)
     switch (tile) {
-        // LDS-DMA ring kernels (round 1).  Product call sites: tile 8 (the NT forms g W^T when the caller passes no transposed weight
-        // copies) and tile 9 (128x128 reference of tools/x3_bench.py); the other ring configurations are A/B references of the tuning
-        // tools and of tests/test_gpu_parity.py::test_gemm_f32 and are compiled only with -DDPD_ABLATIONS (DPD_ABLATIONS=1 build).
+        // LDS-DMA ring kernels (round 1): tile 8 serves the NT forms g W^T when the caller passes no transposed weight copies, tile 9 is the
+        // 128x128 reference of tools/x3_bench.py.  (The other ring / register-staged configurations were A/B references of rounds 1-3; removed
+        // in round 6 -- profiles/r03_gemm_bench.txt has their numbers.)
         case 8: return launch_dma<2, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 48 KiB  (3 blocks/CU)
         case 9: return launch_dma<4, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 96 KiB (1 block/CU)
-        case 4: return launch_dma<2, 2, 4, AK, BKC>(g, s);   // LDS-DMA ring,  64x64,  256 thr, 64 KiB  (2 blocks/CU)
-#ifdef DPD_ABLATIONS
-        case 5: return launch_dma<4, 4, 4, AK, BKC>(g, s);   // LDS-DMA ring, 128x128, 1024 thr, 128 KiB (1 block/CU)
-        case 6: return launch_dma<4, 2, 3, AK, BKC>(g, s);   // LDS-DMA ring, 128x64,  512 thr, 72 KiB  (2 blocks/CU)
-        case 7: return launch_dma<2, 4, 3, AK, BKC>(g, s);   // LDS-DMA ring,  64x128, 512 thr, 72 KiB  (2 blocks/CU)
-        case 10: return launch_dma<4, 4, 5, AK, BKC>(g, s);  // LDS-DMA ring, 128x128, 1024 thr, 160 KiB (all of a CU's LDS)
-        case 11: return launch_dma<2, 4, 3, AK, BKC, 2, 1>(g, s);   // 128x128, 8 waves of 64x32 (2 accumulators), 96 KiB
-        case 12: return launch_dma<2, 2, 3, AK, BKC, 2, 2>(g, s);   // 128x128, 4 waves of 64x64 (4 accumulators), 96 KiB
-        case 13: return launch_dma<2, 2, 3, AK, BKC, 2, 1>(g, s);   // 128x64,  4 waves of 64x32, 72 KiB (2 blocks/CU)
-        case 14: return launch_dma<4, 2, 3, AK, BKC, 1, 2>(g, s);   // 128x128, 8 waves of 32x64
-#else
-        case 5: case 6: case 7: case 10: case 11: case 12: case 13: case 14: return DPD_E_UNSUPPORTED;
-#endif
-        case 1: return launch_cfg<128, 128, 32, AK, BKC>(g, s);
-        case 2: return launch_cfg<128, 64, 32, AK, BKC>(g, s);
-        case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);
+        case 3: return launch_cfg<64, 64, 32, AK, BKC>(g, s);   // register-staged 64x64: any K % 4 == 0 (the fallback for ragged K)
         default: return DPD_E_UNSUPPORTED;
     }
 }
 
-// efficiency of covering an M x N output with BMxBN tiles on 256 CUs (whole "rounds" of blocks)
-static double tile_eff(int M, int N, int BM, int BN, int split) {
-    const long nblk = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * split;
-    const long rounds = (nblk + 255) / 256;
-    return (double)M * N * split / ((double)rounds * 256.0 * BM * BN);
-}
-
-thread_local const AdamEpi* g_adam_epi = nullptr;
-
 int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile, void* ws,
              size_t ws_bytes, hipStream_t s, float* colsum, const float* A2, const float* B2, float* C2, const ColsumTwoStep* cs2) {
-    const AdamEpi* adam = g_adam_epi;
-    if (!A || !B || (!C && !adam)) return DPD_E_NULL;
-    if (adam && (split_k != 1 || epilogue != EPI_NONE || colsum || !adam->p || !adam->m || !adam->v || (A2 && (!adam->p2 || !adam->m2 || !adam->v2))))
-        return DPD_E_UNSUPPORTED;
+    if (!A || !B || !C) return DPD_E_NULL;
     // split_k == 0: "tail split" (gemm_rs.h): whole-K tiles, only the partial last round of tiles is cut along K (needs ws for
     // (pieces - 1) slabs of M*N floats; pieces <= 4).  Silently a plain launch when it does not apply.
     bool tail_auto = false;
     if (split_k == 0) {
         split_k = 1;
-        tail_auto = tile >= 30 && tile <= 39 && ws && ws_bytes >= (size_t)3 * M * N * sizeof(float) && epilogue == EPI_NONE;
+        tail_auto = tile >= 30 && tile <= 33 && ws && ws_bytes >= (size_t)3 * M * N * sizeof(float) && epilogue == EPI_NONE;
     }
     if (M <= 0 || N <= 0 || K <= 0 || split_k < 1) return DPD_E_DIM;
     if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3)) return DPD_E_UNSUPPORTED;
@@ -531,38 +500,22 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
     if (epilogue == EPI_GATE && !gate) return DPD_E_NULL;
     if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;
 
-    if (tile == 0) {
-        // Measured on MI355X (tools/gemm_bench.py, profiles/): the 64x64 tile (4 resident blocks = 16 waves per CU)
-        // beats 128x64 and 128x128 at every decoder shape (112 vs 100 vs 90 TFLOP/s on layer 1) because the other
-        // blocks' MFMAs cover each block's barrier / global-load latency; MFMA is so slow in fp32 that the extra L2
-        // traffic of the small tile (16 flop/B) is irrelevant.  Larger tiles only when the grid would not fill.
-        (void)tile_eff;
-        tile = 3;
-    }
-    const bool whole_tiles = (tile >= 4 && tile <= 14) || (tile >= 30 && tile <= 39);   // kernels that need whole 32-deep K-tiles
+    if (tile == 0) tile = 3;     // the register-staged 64x64 kernel: takes every shape
+    const bool whole_tiles = (tile == 8 || tile == 9) || (tile >= 30 && tile <= 33);   // kernels that need whole 32-deep K-tiles
     if (whole_tiles && (K % 32 != 0 || M < 4 || N < 4 || (split_k > 1 && ((K + split_k - 1) / split_k + 31) / 32 * 32 * (split_k - 1) >= K)))
         tile = 3;   // these kernels need whole K-tiles (and a non-empty last split): fall back to the register-staged kernel
     GemmArgs g{};
     g.A = A; g.B = B; g.bias = bias; g.gate = gate;
     g.colsum = (split_k > 1) ? nullptr : colsum;
     g.A2 = A2; g.B2 = B2; g.C2 = C2;
-    if (adam) {
-#ifdef DPD_ADAM_EPI
-        if (!(tile >= 30 && tile <= 33)) return DPD_E_UNSUPPORTED;      // instantiated for the register-streamed dW kernels only
-        g.ad = *adam;
-#else
-        return DPD_E_UNSUPPORTED;       // ablation build only (gemm_shared.h)
-#endif
-    }
-    if (tail_auto && !colsum && !A2 && !adam) { g.tail_split = -1; g.tail_slab = (float*)ws; }
-    g.xcd_band = (g_rs_xcd_band == 2 || (g_rs_xcd_band == 1 && transA && !transB)) ? 1 : 0;
+    if (tail_auto && !colsum && !A2) { g.tail_split = -1; g.tail_slab = (float*)ws; }
     if (cs2) {   // deterministic bias gradients in two steps (register-streamed kernels only; rows of a partial block = 32)
-        if (!(tile >= 30 && tile <= 39) || (cs2->part_out && (split_k > 1 || colsum))) return DPD_E_UNSUPPORTED;
+        if (!(tile >= 30 && tile <= 33) || (cs2->part_out && (split_k > 1 || colsum))) return DPD_E_UNSUPPORTED;
         g.colsum_part = cs2->part_out;
         g.colsum_part_in = cs2->part_in; g.colsum_part_in2 = cs2->part_in2;
         g.colsum_b = cs2->out; g.colsum_b2 = cs2->out2; g.colsum_nparts = cs2->nparts;
     }
-    if (A2 && (!B2 || (!C2 && !adam) || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
+    if (A2 && (!B2 || !C2 || split_k > 1 || epilogue != EPI_NONE || colsum)) return DPD_E_UNSUPPORTED;
     if (A2 && !whole_tiles) return DPD_E_UNSUPPORTED;   // grouped launches exist for the DMA / register-streamed kernels only
     if (colsum && split_k > 1) return DPD_E_UNSUPPORTED;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
@@ -589,43 +542,6 @@ int gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int ld
         const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
         DPD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, split_k, (long)M * N, M,
                            N, C, ldc, bias, gate, epilogue);
-        return (int)hipGetLastError();
-    }
-    return 0;
-}
-
-// Layer-1 GEMMs with the window gather fused into the A operand (gemm_rs.h, ASRC 1 / 2):
-//   which = 1: C [M = query rows, N] = epi( X W ),  X gathered;  K = KP (whole 32-deep K-tiles)
-//   which = 2: C [M = KP window columns, N] = X^T G,  X^T gathered, G [K = rows, N] row-major
-int gemm_rs_gather(int which, int M, int N, int K, const float* fv, size_t a_bytes, size_t xyz_off, const uint2* ktab,
-                   const uint2* rowinfo, const float* B, int ldb, float* C, int ldc, const float* bias, int epilogue, int tile,
-                   hipStream_t s, int split_k, void* ws, size_t ws_bytes) {
-    if (!fv || !ktab || !rowinfo || !B || !C) return DPD_E_NULL;
-    if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
-    if ((K % 32) || (N & 3) || (ldb & 3) || (ldc & 3) || (which == 2 && (M & 3))) return DPD_E_UNSUPPORTED;
-    if (a_bytes > 0xfffffff0ull || xyz_off > 0xfffffff0ull) return DPD_E_UNSUPPORTED;   // 32-bit buffer offsets
-    if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) && !bias) return DPD_E_NULL;
-    GemmArgs g{};
-    g.A = fv; g.B = B; g.C = C; g.bias = bias;
-    g.ktab = ktab; g.rowinfo = rowinfo; g.xyz_off = (unsigned)xyz_off; g.a_bytes = (unsigned)a_bytes;
-    g.M = M; g.N = N; g.K = K; g.lda = 0; g.ldb = ldb; g.ldc = ldc;
-    g.epi = epilogue; g.split_k = 1; g.k_chunk = K; g.slab_stride = 0;
-    if (split_k > 1) {       // deterministic slabs + the fused reduce kernel, as in gemm_f32()
-        const int chunk = (((K + split_k - 1) / split_k) + 31) / 32 * 32;
-        if (chunk * (split_k - 1) >= K) return DPD_E_UNSUPPORTED;
-        if (!ws || (size_t)split_k * M * N * sizeof(float) > ws_bytes) return DPD_E_WORKSPACE;
-        g.split_k = split_k; g.k_chunk = chunk; g.C = (float*)ws; g.ldc = N; g.slab_stride = (long)M * N; g.epi = EPI_NONE;
-    }
-    struct ProfScope {
-        bool on; hipStream_t s; double fl; int form;
-        ~ProfScope() { prof_end(on, s, fl, form); }
-    } prof_scope{prof_begin(s), s, 2.0 * M * N * K, which == 2 ? 1 : 0};
-    if (int rc = which == 1 ? launch_rs_gather_fwd(tile, g, s) : launch_rs_gather_dw(tile, g, s)) return rc;
-    if (split_k > 1) {
-        const long total4 = (long)M * N / 4;
-        const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-        DPD_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, split_k, (long)M * N, M, N, C, ldc, bias,
-                   (const float*)nullptr, epilogue);
         return (int)hipGetLastError();
     }
     return 0;

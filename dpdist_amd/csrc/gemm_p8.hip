@@ -1,4 +1,4 @@
-// Phase-staggered plane GEMM (gemm_p8_kernel) and the chained persistent launch built on its tile routine (gemm_chain_kernel).
+// Phase-staggered plane GEMM (gemm_p8_kernel).
 // Split from gemm_x3.hip in round 5 (its own translation unit: the two halves compile in parallel).
 #include "gemm_x3.h"
 
@@ -275,201 +275,10 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_p8_kernel(X3Args g) {
                                                                       (t0 % tilesN) * BN, threadIdx.x, NoDep{});
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// gemm_chain_kernel (round 5): up to three DEPENDENT one-plane GEMMs with the same output shape [M, N] in ONE persistent launch --
-// the decoder's forward layers 1 -> 2 -> 3 (NN: rows x weights, bias + ReLU, plane outputs) and its data-gradient chain g3 -> g2 -> g1
-// (NT, ReLU gate, plane outputs).  Launched apart, each of these GEMMs pays 10-13 us of fill / plane epilogue / drain around a K loop of
-// 8-36 us (DESIGN.md 3.4 b, 3.5 d), and every launch ends with 256 CUs draining and the next starts with 256 CUs filling.  Here a tile of
-// stage s + 1 and row band r starts as soon as the tilesN tiles of band r of stage s have been published -- no grid-wide boundary.
-//
-// Work distribution = TICKETS, which is what makes the launch deadlock-free under ANY residency or placement (HIP promises neither
-// dispatch order nor co-residency: MI355X_MICROARCH.md "Workgroup dispatch"): there is one queue per XCD, queue x lists the tiles of the row
-// bands x, x + 8, ... stage by stage (all of stage 0, then all of stage 1, ...), band by band, and a workgroup takes its next tile with one
-// atomic increment of its queue's counter.  A tile depends only on tiles with LOWER tickets of the SAME queue, and a ticket is only ever
-// held by a running workgroup, so by induction every wait ends.  A workgroup that finds its home queue (its own XCD: the consumer then
-// finds the producers' rows in its L2's neighbourhood -- speed only) exhausted goes on to the other queues, so every queue drains wherever
-// the workgroups landed.
-//
-// Hand-off (cdna_hip_programming.md Guideline 16, recipe R1): plane outputs by 16-byte write-through (sc1) stores, every storing wave drains
-// them (s_waitcnt vmcnt(0)), barrier, ONE lane adds 1 to the band's arrival word; the consumer's lane 0 polls that ONE word relaxed (with
-// s_sleep), then ONE agent-scope acquire (drops this CU's stale L1 lines), barrier, then plain LDS-DMA loads.  The weights' pieces of the
-// first two K-tiles are issued BEFORE the poll (p8_tile<SPLIT>): they depend on nobody.
-//
-// State: `sync` = kChainWords 32-bit words that must be ZERO at launch and are left zero: the last workgroup to leave (an exit counter,
-// behind a drained vmcnt) clears every word it or anybody else touched.  The error word is sticky: a poll that gives up (spin_limit) sets
-// bit 0 and the tile goes ahead (the result is then wrong, the launch still ends) -- dpd_planes_sync_status() reads it.
-// Results are bitwise those of the same GEMMs launched apart: same tile routine, same K order, same epilogue.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kChainQueues = 8, kChainMaxBands = 320, kChainArr = 256, kChainTickStride = 32;
-// ticket counter of queue x at [32 x] (a 128-byte line each: 32 workgroups hammer one), exit counter [8], error [9], arrivals [256 + s * 320 + band]
-constexpr int kChainWords = kChainArr + 2 * kChainMaxBands;
-static_assert(kChainWords * 4 <= DPD_SYNC_BYTES, "dpd_planes.sync");
-
-struct ChainArgs {
-    X3Args st[3];
-    unsigned* sync;
-    unsigned long long* stamps;      // optional [gridDim][4 tiles][8] s_memtime stamps of lane 0 (tools/chain_stamps.py), NULL = off
-    int nst, tilesM, tilesN;
-    unsigned spin_limit;
-};
-
-__device__ __forceinline__ unsigned chain_add(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// one poll of an arrival word on the VECTOR path, past this CU's L1 (sc1): a uniform address would otherwise be polled through the scalar cache
-__device__ __forceinline__ unsigned chain_poll(const unsigned* p) {
-    unsigned r;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
-    return r;
-}
-
-template <bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT>
-__global__ __launch_bounds__(64 * WR * WC) void gemm_chain_kernel(ChainArgs c) {
-    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
-    constexpr unsigned RING = 3u * (BM + BN) * 64 * 2;
-    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
-    // behind the ring: [0] the next ticket, [1 .. 8] a snapshot of the eight queue counters (which queue to go on with when this one is exhausted)
-    volatile unsigned* box = reinterpret_cast<volatile unsigned*>(smem_x3 + RING);
-    const int tid = threadIdx.x;
-    unsigned* tick = c.sync;
-    unsigned* arr = c.sync + kChainArr;
-    const int nst = c.nst, tilesM = c.tilesM, tilesN = c.tilesN;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-    int q = (int)(xcc & (kChainQueues - 1)), done_tiles = 0;
-    auto stamp = [&](int i) {
-        if (c.stamps && tid == 0 && done_tiles < 4 && blockIdx.x < 256) c.stamps[((size_t)blockIdx.x * 4 + done_tiles) * 8 + i] = __builtin_amdgcn_s_memrealtime();
-    };
-    auto queue_tiles = [&](int x) { return ((tilesM - x + kChainQueues - 1) / kChainQueues) * tilesN * nst; };
-    auto take = [&]() {
-        if (tid == 0) box[0] = chain_add(tick + q * kChainTickStride);
-    };
-    take();
-    __syncthreads();
-    unsigned ticket = __builtin_amdgcn_readfirstlane(box[0]);
-    for (;;) {
-        while (ticket >= (unsigned)queue_tiles(q)) {       // queue exhausted: lanes 0..7 read the eight counters (ONE round trip); a queue that is not, or leave
-            __syncthreads();
-            if (tid < kChainQueues) box[1 + tid] = __hip_atomic_load(tick + tid * kChainTickStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            int nq = -1;
-            for (int i = 1; i < kChainQueues; ++i) {
-                const int x = (q + i) & (kChainQueues - 1);
-                if (nq < 0 && box[1 + x] < (unsigned)queue_tiles(x)) nq = x;
-            }
-            if (nq < 0) goto leave;
-            q = nq;
-            __syncthreads();
-            take();
-            __syncthreads();
-            ticket = __builtin_amdgcn_readfirstlane(box[0]);
-        }
-        const int per = queue_tiles(q) / nst;
-        const int stg = (int)ticket / per, rem = (int)ticket % per;
-        const int band = q + kChainQueues * (rem / tilesN), col = rem % tilesN;
-        stamp(0);
-        const X3Args& g = c.st[stg];
-        auto dep = [&]() {
-            if (stg > 0) {
-                if (tid == 0) {
-                    unsigned* w = arr + (stg - 1) * kChainMaxBands + band;
-                    unsigned spins = 0;
-                    while (chain_poll(w) < (unsigned)tilesN) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > c.spin_limit) {
-                            __hip_atomic_fetch_or(c.sync + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                __syncthreads();
-            }
-            stamp(1);
-        };
-        p8_tile<1, true, BKC, WR, WC, TM, TN, LATE_WAIT, 0, true, true>(g, smem_x3, 0, g.A, g.B, band * BM, col * BN, tid, dep);
-        stamp(2);
-        // the next ticket: requested behind this wave's stores, so that its round trip hides under their drain (hipcc waits for a returning
-        // atomic at the end of the lane-0 branch: anywhere earlier that wait would stall wave 0, and with it the workgroup, ~1 us per tile)
-        take();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // EVERY storing wave: its write-through stores are acknowledged
-        __syncthreads();
-        if (tid == 0 && stg + 1 < nst) chain_add(arr + stg * kChainMaxBands + band);
-        stamp(3);
-        ++done_tiles;
-        ticket = __builtin_amdgcn_readfirstlane(box[0]);
-    }
-leave:
-    if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // all of this workgroup's accesses to the words have been performed
-        if (chain_add(c.sync + 8) == gridDim.x - 1) {                              // the last one out leaves the words as it found them: zero
-            for (int i = 0; i < kChainQueues; ++i) __hip_atomic_store(tick + i * kChainTickStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int st = 0; st + 1 < nst; ++st)
-                for (int b = 0; b < tilesM; ++b) __hip_atomic_store(arr + st * kChainMaxBands + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(c.sync + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-template <bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT>
-static int launch_chain(const ChainArgs& c, hipStream_t s) {
-    constexpr int BM = 32 * WR * TM, BN = 32 * WC * TN;
-    constexpr size_t lds = (size_t)3 * (BM + BN) * 64 * 2 + 48;
-    static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = gemm_chain_kernel<BKC, WR, WC, TM, TN, LATE_WAIT>;
-    static LdsOptIn lds_opt;
-    if (int rc = ensure_dyn_lds(lds_opt, (const void*)kern, lds)) return rc;
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!cus[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    const int tiles = c.tilesM * c.tilesN;
-    DPD_LAUNCH(kern, dim3(tiles < cus[dev] ? tiles : cus[dev]), dim3(64 * WR * WC), lds, s, c);
-    return (int)hipGetLastError();
-}
-
-// tile: 21 = 256x128 (8 waves of 64x64), 23 = 128x128 (8 waves of 32x64).  Returns DPD_E_UNSUPPORTED for anything the chained form does not
-// take (the caller then launches the GEMMs apart): ragged tiles, fp32 outputs of an intermediate stage, more than one plane.
-int gemm_chain(int nst, const ChainStage* st, int M, int N, int tile, unsigned* sync, unsigned long long* stamps, hipStream_t s) {
-    if (nst < 2 || nst > 3 || !st || !sync) return DPD_E_UNSUPPORTED;
-    const int bm = tile == 21 ? 256 : (tile == 23 ? 128 : 0), bn = 128;
-    if (!bm || M <= 0 || N <= 0 || (M % bm) || (N % bn)) return DPD_E_UNSUPPORTED;
-    if (M / bm > kChainMaxBands) return DPD_E_UNSUPPORTED;
-    ChainArgs c{};
-    double flops = 0.0;
-    for (int i = 0; i < nst; ++i) {
-        const ChainStage& t = st[i];
-        const bool last = i + 1 == nst;
-        if (!t.A || !t.B || t.K <= 0 || (t.K % 32) || (t.lda & 7) || (t.ldb & 7) || t.b_fmt != st[0].b_fmt) return DPD_E_UNSUPPORTED;
-        if (!last && (t.C || !t.out.rc || st[i + 1].A != t.out.rc || st[i + 1].lda != t.out.ld_rc || st[i + 1].K != N)) return DPD_E_UNSUPPORTED;
-        if (!t.C && !t.out.rc && !t.out.r8) return DPD_E_NULL;
-        if ((t.out.rc || t.out.r8) && (t.out.np != 1 || (t.out.ld_rc & 7) || (t.out.r8 && (t.out.r8_rows % bm)))) return DPD_E_UNSUPPORTED;
-        if (t.C && ((t.ldc & 3) || (N & 3))) return DPD_E_UNSUPPORTED;
-        if ((t.epilogue == EPI_BIAS || t.epilogue == EPI_BIAS_RELU) && !t.bias) return DPD_E_NULL;
-        if (t.epilogue == EPI_GATE && !t.gate16) return DPD_E_NULL;
-        if (t.epilogue < 0 || t.epilogue > 3) return DPD_E_UNSUPPORTED;
-        X3Args& g = c.st[i];
-        g.e.C = t.C; g.e.bias = t.bias; g.e.gate16 = t.gate16; g.e.gate16_r8 = t.gate16_r8; g.e.colsum = t.colsum;
-        g.e.M = M; g.e.N = N; g.e.K = t.K; g.e.ldc = t.C ? t.ldc : N; g.e.epi = t.epilogue;
-        g.e.split_k = 1; g.e.k_chunk = t.K; g.e.slab_stride = 0;
-        g.A = t.A; g.B = t.B; g.a_plane = (long)M * t.K; g.b_plane = (long)t.K * N; g.lda = t.lda; g.ldb = t.ldb;
-        g.out_rc = t.out.rc; g.out_r8 = t.out.r8; g.rc_plane = t.out.rc_plane; g.r8_plane = t.out.r8_plane;
-        g.ld_rc = t.out.ld_rc; g.r8_rows = t.out.r8_rows; g.np_out = 1;
-        flops += 2.0 * M * N * t.K;
-    }
-    c.sync = sync; c.stamps = stamps; c.nst = nst; c.tilesM = M / bm; c.tilesN = N / bn;
-    static const unsigned spin = [] { const char* e = getenv("DPD_CHAIN_SPIN_LIMIT"); return e ? (unsigned)strtoul(e, nullptr, 10) : 4000000u; }();
-    c.spin_limit = spin;
-    struct ProfScope {
-        bool on; hipStream_t s; double fl;
-        ~ProfScope() { prof_end(on, s, fl); }
-    } prof_scope{prof_begin(s), s, flops};
-    const bool nt = st[0].b_fmt == 0;      // B as RC planes (k contiguous): the data-gradient chain
-    if (tile == 21) return nt ? launch_chain<true, 4, 2, 2, 2, true>(c, s) : launch_chain<false, 4, 2, 2, 2, true>(c, s);
-    return nt ? launch_chain<true, 4, 2, 1, 2, false>(c, s) : launch_chain<false, 4, 2, 1, 2, false>(c, s);
-}
+// (Round 5 built a persistent CHAINED launch on p8_tile -- layers 1 -> 2 -> 3 / g3 -> g2 -> g1 as one launch with per-XCD ticket queues and
+// per-band arrival words; SC1 / SPLIT / Dep are its hooks.  Bitwise the separate launches, 11 us SLOWER per chain at B = 64
+// (profiles/r05_chain_bench.txt: a hand-off costs what a kernel boundary costs, and a tile takes as long inside the persistent launch as
+// apart); removed in round 6, DESIGN.md section 3.6 keeps the finding.)
 
 template <int NP, bool AK, bool BKC, int WR, int WC, int TM, int TN, bool LATE_WAIT, int ABL = 0>
 static int launch_p8(const X3Args& g, hipStream_t s) {
@@ -489,13 +298,9 @@ static int launch_p8(const X3Args& g, hipStream_t s) {
 template <bool AK, bool BKC>
 static int launch_p8_tile(int np, int tile, const X3Args& g, hipStream_t s) {
     switch (tile) {
-        case 20: if (np == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64
-        case 21: if (np == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // ... group 0 waits after its MFMAs
-        case 22: if (np == 1) return launch_p8<1, AK, BKC, 2, 4, 2, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x256, 8 waves of 64x64
+        case 21: if (np == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // 256x128, 8 waves of 64x64 (group 0 waits after its MFMAs)
         case 23: if (np == 1) return launch_p8<1, AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 32x64
         case 24: if (np == 3) return launch_p8<3, AK, BKC, 4, 2, 1, 2, true>(g, s); return DPD_E_UNSUPPORTED;    // 128x128, 8 waves of 32x64, 3 planes
-        case 25: if (np == 3) return launch_p8<3, AK, BKC, 2, 4, 2, 1, true>(g, s); return DPD_E_UNSUPPORTED;    // 128x128, 8 waves of 64x32, 3 planes
-        case 26: if (np == 3) return launch_p8<3, AK, BKC, 4, 2, 1, 2, false>(g, s); return DPD_E_UNSUPPORTED;   // 24 with both groups waiting before B1
 #ifdef DPD_ABLATIONS
 #define DPD_P8_ABL(code) case 200 + code: if (np == 1) return launch_p8<1, AK, BKC, 4, 2, 2, 2, true, code>(g, s); return DPD_E_UNSUPPORTED;
         DPD_P8_ABL(32) DPD_P8_ABL(1) DPD_P8_ABL(2) DPD_P8_ABL(3) DPD_P8_ABL(4) DPD_P8_ABL(5) DPD_P8_ABL(7) DPD_P8_ABL(8) DPD_P8_ABL(16) DPD_P8_ABL(24)

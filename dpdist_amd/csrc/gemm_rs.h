@@ -18,17 +18,9 @@
 //   * the workgroup (WR x WC waves, one per SIMD for 2x2) only exists to place waves that share operand rows/columns on
 //     one CU (L1 reuse) and to make the block -> tile map XCD-aware; waves never wait for each other, so ragged tiles
 //     simply retire early.
-// Fused window gather (ASRC != 0): the decoder's layer-1 input X [Q, KP] = [5^3 x 20 window | q - centre | 0] is
-// never materialised.  Per-lane source addresses are arbitrary anyway, so the A operand is gathered straight from the Fisher
-// vectors fv [C, m^3, 20] (L2 resident, 40 KB per cloud):
-//   ASRC = 1 (forward, rows = query points): lane (row, half) reads the float4 of window column k4 = 8 t + 4 half + b at
-//            fv + rowbase(row) + ktab[k4].delta when the neighbour is inside the grid ((rowmask & ktab[k4].req) == req); an
-//            out-of-grid neighbour gets voffset 0xffffffff -> the buffer range check returns the zero padding of
-//            tf.extract_volume_patches for free; ktab is read with scalar loads (k4 is uniform per half-wave);
-//   ASRC = 2 (dW1 = X^T g1, rows of dW = window columns): the lane's window column is fixed (delta, req in registers), the
-//            query row changes with the contraction step; its {fv row, validity bits} is a broadcast dwordx2 load issued two
-//            K-tiles ahead of the gather it feeds.
-// The q - centre columns come from xyz [Q,4] placed behind fv in the same buffer; pad columns are out of range by construction.
+// (A fused-window-gather form of this kernel -- X never materialised, the A operand gathered from the Fisher vectors per lane -- was
+// built in round 2, was bitwise, and measured slower (layer 1: 180 us against 147 + 13.5 us: the per-lane address arithmetic sits in the
+// in-order issue stream of an MFMA-bound wave; profiles/r02_variants.txt); removed in round 6.)
 // Results are bitwise identical to the LDS kernels (a k-ordered fmaf chain per output element; the permutation inside a
 // K-tile changes the ORDER of the chain, so "identical" holds between rs configurations, not against the ring kernels).
 #pragma once
@@ -62,20 +54,10 @@ __device__ __forceinline__ void rs_load_step(__amdgpu_buffer_rsrc_t r, unsigned 
     }
 }
 
-constexpr unsigned kReqXyz = 0x40000000u, kReqZero = 0x80000000u;   // ktab[].y markers (never subsets of a row's validity bits)
-
-__device__ __forceinline__ unsigned gather_voff(unsigned rbase, unsigned rmask, unsigned rxyz, unsigned delta, unsigned req) {
-    unsigned v = ((rmask & req) == req) ? rbase + delta : 0xffffffffu;
-    return (req == kReqXyz) ? rxyz + delta : v;
-}
-
 // D = pipeline depth in K-tiles (operand register sets): the loads of K-tile t+D-1 are issued, step by step, between the
 // MFMAs of K-tile t, so every operand has D-1 whole tile times ((TM*TN*16) MFMAs x 64 cycles each) to arrive.
-template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D, int ASRC = 0, bool ADAM = false>
+template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
-    static_assert(ASRC == 0 || D == 2, "the gather pipelines are written for two operand sets");
-    static_assert(ASRC != 1 || AK, "ASRC 1 gathers a K-contiguous A (rows = queries)");
-    static_assert(ASRC != 2 || !AK, "ASRC 2 gathers an M-contiguous A (rows of the result = window columns)");
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,16 +77,6 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
             t = g.tail_first + u / g.tail_split; z = u % g.tail_split;
             kbeg = z * g.tail_chunk; kend = min(g.K, (int)kbeg + g.tail_chunk);
         }
-    } else if (g.xcd_band && g.split_k == 1 && !(tilesM & 1) && !(tilesN & 3)) {
-        // XCD-blocked map (round 4, opt-in: dpd_set_gemm_plan(40, 1, 1)): the 8 XCDs tile the output as 2 (rows) x 4 (columns), so that an XCD's
-        // private L2 sees half of A and a QUARTER of B (2 MB of g at the dW shapes: resident) instead of whole row bands that stream
-        // all of B from the Infinity Cache once per band; inside the XCD consecutive workgroups walk a row band (they share the A rows)
-        const int x = blockIdx.x % kNumXCD, l = blockIdx.x / kNumXCD;
-        const int tmh = tilesM >> 1, tnq = tilesN >> 2, per_x = tmh * tnq;
-        grp = l / per_x;
-        const int l2 = l % per_x;
-        t = ((x >> 2) * tmh + l2 / tnq) * tilesN + (x & 3) * tnq + l2 % tnq;
-        z = 0; kbeg = 0; kend = g.K;
     } else {
         const int sid = xcd_remap(blockIdx.x, per_z * g.split_k * ngrp);
         grp = sid / (per_z * g.split_k);
@@ -119,8 +91,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
     const float* gB = grp ? g.B2 : g.B;
     const unsigned lda = g.lda, ldb = g.ldb;
 
-    const __amdgpu_buffer_rsrc_t ra = ASRC ? rs_rsrc(gA, g.a_bytes)
-                                           : rs_rsrc(gA, AK ? ((size_t)(g.M - 1) * lda + g.K) * 4 : ((size_t)(g.K - 1) * lda + g.M) * 4);
+    const __amdgpu_buffer_rsrc_t ra = rs_rsrc(gA, AK ? ((size_t)(g.M - 1) * lda + g.K) * 4 : ((size_t)(g.K - 1) * lda + g.M) * 4);
     const __amdgpu_buffer_rsrc_t rb = rs_rsrc(gB, BKC ? ((size_t)(g.N - 1) * ldb + g.K) * 4 : ((size_t)(g.K - 1) * ldb + g.N) * 4);
     unsigned va[TM], vb[TN];
 #pragma unroll
@@ -162,68 +133,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
                     egate[i][j][r] = g.gate[(size_t)row * g.ldc + min(n0 + 32 * j + l31, g.N - 1)];
                 }
     }
-    // ---- gather state (ASRC != 0) ----
-    const uint2* __restrict__ ktab = g.ktab;
-    unsigned gbase[TM], gmask[TM], gxyz[TM];      // ASRC 1: per row {fv byte offset, validity bits, xyz byte offset}
-    unsigned cdelta[TM], creq[TM];                // ASRC 2: per window column {byte offset, required bits}
-    uint2 info[2][4][4];                          // ASRC 2: {fv row, validity bits} of the query rows of a K-tile, per (b, s)
-    __amdgpu_buffer_rsrc_t rinfo;
-    if (ASRC == 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned r = min(m0 + 32 * i + l31, g.M - 1);
-            const uint2 ri = g.rowinfo[r];
-            gbase[i] = ri.x; gmask[i] = ri.y; gxyz[i] = g.xyz_off + r * 16u;
-        }
-    }
-    if (ASRC == 2) {
-        rinfo = rs_rsrc(g.rowinfo, (size_t)g.K * 8);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned c = min(m0 + 32 * i + l31, g.M - 1);
-            const uint2 e = ktab[c >> 2];
-            cdelta[i] = e.x + (c & 3u) * 4u; creq[i] = e.y;
-        }
-    }
-    uint2 tabs[2][8];                             // ASRC 1: the 8 ktab entries of a K-tile (scalar loads), set = tile parity
-    auto tab_step = [&](int kt, int p) {          // 64 contiguous bytes -> one s_load_dwordx16, issued a whole tile before use
-        const unsigned k4 = (kbeg + 32u * min(kt, nt - 1)) >> 2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tabs[p][e] = ktab[k4 + e];
-    };
-    auto info_step = [&](int kt, int p, int b, int s) {     // broadcast load: every lane of a half reads the same 8 bytes
-        const unsigned r0 = kbeg + 32u * min(kt, nt - 1) + 4u * b + s;
-        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rinfo, 128u * half, r0 * 8u, 0);   // rows r0 (half 0) and r0 + 16 (half 1)
-        info[p][b][s] = make_uint2(v[0], v[1]);
-    };
-
     RsFrag fa[D][TM], fb[D][TN];
     // all loads of K-tile kt (clamped to the last tile: a redundant reload instead of a branch) into register set d
     auto load_step = [&](int kt, int d, int b, int s) {
         const int ktc = min(kt, nt - 1);
         const unsigned k0 = kbeg + 32u * ktc;
-        if (ASRC == 1) {
-            if (s == 0) {
-                const uint2 e0 = tabs[d][b], e1 = tabs[d][4 + b];   // scalar registers, loaded one tile earlier (tab_step)
-                const unsigned delta = half ? e1.x : e0.x, req = half ? e1.y : e0.y;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const rs_u4 x = __builtin_amdgcn_raw_buffer_load_b128(ra, gather_voff(gbase[i], gmask[i], gxyz[i], delta, req), 0, 0);
-                    fa[d][i].v[b][0] = __uint_as_float(x.x); fa[d][i].v[b][1] = __uint_as_float(x.y);
-                    fa[d][i].v[b][2] = __uint_as_float(x.z); fa[d][i].v[b][3] = __uint_as_float(x.w);
-                }
-            }
-        } else if (ASRC == 2) {
-            const uint2 ri = info[d][b][s];                          // the info set of this tile's parity (see the pipeline below)
-            const unsigned rrow = k0 + 16u * half + 4u * b + s;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[d][i].v[b][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    ra, gather_voff(ri.x, ri.y, g.xyz_off + rrow * 16u, cdelta[i], creq[i]), 0, 0));
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) rs_load_step<AK>(ra, va[i], k0, lda, b, s, fa[d][i]);
-        }
+        for (int i = 0; i < TM; ++i) rs_load_step<AK>(ra, va[i], k0, lda, b, s, fa[d][i]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) rs_load_step<BKC>(rb, vb[j], k0, ldb, b, s, fb[d][j]);
     };
@@ -235,11 +151,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                if (do_load) {
-                    load_step(kt_next, nxt, b, s);
-                    if (ASRC == 2) info_step(kt_next + 2, nxt, b, s);   // this (b, s) slot of the info set was consumed just above
-                    if (ASRC == 1 && b == 3 && s == 1) tab_step(kt_next + 2, nxt);   // set `nxt` was last read at (b = 3, s = 0)
-                }
+                if (do_load) load_step(kt_next, nxt, b, s);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -250,34 +162,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
             }
     };
 
-    // prologue: K-tiles 0 .. D-2 in flight.  ASRC 2: info set p holds the query rows of the tiles of parity p; a tile's info is
-    // loaded two tiles before its gather: info(0) -> gather(0) -> info(2) into set 0, info(1) into set 1.
-    if (ASRC == 2) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) info_step(0, 0, b, s);
-    }
-    if (ASRC == 1) {
-        tab_step(0, 0);
-        tab_step(1, 1);
-    }
+    // prologue: K-tiles 0 .. D-2 in flight
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int s = 0; s < 4; ++s) load_step(d, d, b, s);
-    if (ASRC == 2) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                info_step(2, 0, b, s);
-                info_step(1, 1, b, s);
-            }
-    }
-    if (ASRC == 1) tab_step(2, 0);     // set 0 (tile 0) was consumed by the prologue loads above
     // The loop body is branch-free on purpose: with a conditional load hipcc's waitcnt pass must assume the not-taken path
     // and waits for the loads it has just issued; a straight-line body gets the exact counted vmcnt.
     int kt = 0;
@@ -290,12 +181,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
     for (int j = 0; j < D - 1; ++j)
         if (kt + j < nt) tile(j, 0, 0, false);
 
-    if (ADAM) asm volatile("" ::: "memory");      // the tile's parameters and moments are requested AFTER the K loop (registers)
     GemmArgs gs = g;
     if (grp) gs.C = g.C2;
-#ifdef DPD_ADAM_EPI
-    if (grp) { gs.ad.p = g.ad.p2; gs.ad.m = g.ad.m2; gs.ad.v = g.ad.v2; gs.ad.wt = g.ad.wt2; }
-#endif
     if (g.tail_split > 1 && z > 0) {      // K piece of a tail tile: its own slab, dense [M, N]
         gs.C = g.tail_slab + (size_t)(z - 1) * g.M * g.N;
         gs.ldc = g.N;
@@ -336,9 +223,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_rs_kernel(GemmArgs g) {
                     if (epi == EPI_GATE) x = (egate[i][j][r] > 0.f) ? x : 0.f;
                     v[r] = x;
                 }
-                put_tile<ADAM>(gs, v, zs, m0 + 32 * i, n0 + 32 * j + l31, half);
+                put_tile(gs, v, zs, m0 + 32 * i, n0 + 32 * j + l31, half);
             } else {
-                store_tile<ADAM>(gs, acc[i][j], zs, m0 + 32 * i, n0 + 32 * j + l31, half);
+                store_tile(gs, acc[i][j], zs, m0 + 32 * i, n0 + 32 * j + l31, half);
             }
         }
 }
@@ -359,7 +246,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(float* __restrict__ C,
     }
 }
 
-template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D, int ASRC = 0>
+template <bool AK, bool BKC, int TM, int TN, int WR, int WC, int D>
 static int launch_rs(const GemmArgs& g_in, hipStream_t s) {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     GemmArgs g = g_in;
@@ -384,18 +271,7 @@ static int launch_rs(const GemmArgs& g_in, hipStream_t s) {
             }
         }
     }
-#ifdef DPD_ADAM_EPI
-    if (g.ad.p) {       // Adam epilogue: the plain TN forms of the weight gradients only (everything else has no use for it)
-        if constexpr (!AK && !BKC && ASRC == 0 && D == 2 && WC == 2) {
-            if (g.tail_split > 1 || g.split_k != 1) return DPD_E_UNSUPPORTED;
-            DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D, ASRC, true>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);
-            return (int)hipGetLastError();
-        } else {
-            return DPD_E_UNSUPPORTED;
-        }
-    }
-#endif
-    DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D, ASRC>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);
+    DPD_LAUNCH((gemm_rs_kernel<AK, BKC, TM, TN, WR, WC, D>), dim3(nblk), dim3(64 * WR * WC), 0, s, g);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     if (g.tail_split > 1) {
         const long total4 = (long)(g.M - row0) * g.N / 4;
@@ -407,25 +283,7 @@ static int launch_rs(const GemmArgs& g_in, hipStream_t s) {
     return 0;
 }
 
-// fused-gather forms (g.ktab / g.rowinfo set): layer-1 forward (NN, A = gathered rows) and dW1 (TN, A = gathered columns)
-static int launch_rs_gather_fwd(int tile, const GemmArgs& g, hipStream_t s) {
-    switch (tile) {
-        case 30: return launch_rs<true, false, 2, 2, 2, 2, 2, 1>(g, s);
-        case 31: return launch_rs<true, false, 2, 1, 2, 2, 2, 1>(g, s);
-        case 33: return launch_rs<true, false, 1, 1, 2, 2, 2, 1>(g, s);
-        default: return launch_rs<true, false, 1, 2, 2, 2, 2, 1>(g, s);   // 32: 64x128 workgroup, 32x64 wave tile
-    }
-}
-static int launch_rs_gather_dw(int tile, const GemmArgs& g, hipStream_t s) {
-    switch (tile) {
-        case 30: return launch_rs<false, false, 2, 2, 2, 2, 2, 2>(g, s);
-        case 31: return launch_rs<false, false, 2, 1, 2, 2, 2, 2>(g, s);
-        case 32: return launch_rs<false, false, 1, 2, 2, 2, 2, 2>(g, s);
-        default: return launch_rs<false, false, 1, 1, 2, 2, 2, 2>(g, s);   // 33: 64x64 workgroup, 32x32 wave tile
-    }
-}
-
-// tile codes 30..39: register-streamed kernels (wave tile, waves per workgroup, pipeline depth)
+// tile codes 30..33: register-streamed kernels (wave tile, waves per workgroup, pipeline depth)
 template <bool AK, bool BKC>
 static int launch_rs_tile(int tile, const GemmArgs& g, hipStream_t s) {
     switch (tile) {
@@ -433,14 +291,6 @@ static int launch_rs_tile(int tile, const GemmArgs& g, hipStream_t s) {
         case 31: return launch_rs<AK, BKC, 2, 1, 2, 2, 2>(g, s);   // 128x64,  4 waves of 64x32
         case 32: return launch_rs<AK, BKC, 1, 2, 2, 2, 2>(g, s);   //  64x128, 4 waves of 32x64
         case 33: return launch_rs<AK, BKC, 1, 1, 2, 2, 2>(g, s);   //  64x64,  4 waves of 32x32
-        case 34: return launch_rs<AK, BKC, 2, 1, 2, 2, 3>(g, s);   // 128x64,  3 operand sets (two K-tiles ahead)
-        case 35: return launch_rs<AK, BKC, 1, 2, 2, 2, 3>(g, s);   //  64x128, 3 operand sets
-        case 36: return launch_rs<AK, BKC, 1, 1, 2, 2, 3>(g, s);   //  64x64,  3 operand sets
-        case 37: return launch_rs<AK, BKC, 2, 2, 2, 4, 2>(g, s);   // 128x256, 8 waves (2 per SIMD)
-        // round 4: two-wave workgroups of 32x32 wave tiles -- finer tiles for grids that leave a partial wave of 64x64 workgroups
-        // (dW1: 640 tiles = 2.5 per CU; as 32x64 tiles 1264 = 4.94 per CU of six resident)
-        case 38: return launch_rs<AK, BKC, 1, 1, 1, 2, 2>(g, s);   //  32x64,  2 waves of 32x32
-        case 39: return launch_rs<AK, BKC, 1, 1, 2, 1, 2>(g, s);   //  64x32,  2 waves of 32x32
         default: return DPD_E_UNSUPPORTED;
     }
 }

@@ -2,36 +2,18 @@
 #pragma once
 #include "common.h"
 
-// The Adam epilogue of the weight-gradient GEMMs (AdamEpi below) is a measured-and-rejected experiment (DESIGN.md section 3.4 h): it is
-// compiled only into the ablation build (DPD_ABLATIONS=1 python -m dpdist_amd.build --force) -- carrying its 88 bytes of kernel arguments
-// and its epilogue branch in every GEMM costs the default step ~1 us (0.5595 vs 0.5608 ms, A/B of the two trees on one box).
-#ifdef DPD_ABLATIONS
-#define DPD_ADAM_EPI 1
-#endif
-
 namespace dpd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_GATE = 3 };
 
-// TF-form Adam on one element (tf.train.AdamOptimizer, epsilon-hat form): ONE definition for the optimizer kernels (loss_adam.hip) and
-// for the weight-gradient GEMMs that apply it in their epilogue (below)
+// TF-form Adam on one element (tf.train.AdamOptimizer, epsilon-hat form): ONE definition for the optimizer kernels (loss_adam.hip)
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
     m = b1 * m + (1.0f - b1) * g;
     v = b2 * v + (1.0f - b2) * g * g;
     p = p - lr_t * m / (sqrtf(v) + eps);
 }
-
-// Optional Adam update in the epilogue of a weight-gradient GEMM (single-GPU steps: nothing stands between dW and apply_gradients):
-// the C tile IS the gradient tile, so the tile's parameters and moments are read, updated and written back here -- while the other
-// workgroups of the CU keep the matrix cores busy -- and the optimizer kernel loses its 19 MB of matrices (read g, p, m, v; write p, m,
-// v and the derived copies: 25-35 us of HBM time per step).  Same adam_one on the same gradient value: the same bits as the kernel.
-struct AdamEpi {
-    float* p;  float* m;  float* v;  float* wt;      // parameter and moments, laid out like C ([M][ldc]); wt: transposed copy [N][M] or NULL
-    float* p2; float* m2; float* v2; float* wt2;     // second problem of a grouped launch
-    float lr_t, b1, b2, eps, gscale;
-};
 
 struct GemmArgs {
     const float* A;
@@ -54,12 +36,6 @@ struct GemmArgs {
     const float* A2;  // optional second problem of identical shape (grouped launch): blocks [per_z, 2*per_z)
     const float* B2;
     float* C2;
-    // optional fused window gather (gemm_rs.h, ASRC != 0): the A operand is not read from memory at A/lda but gathered from
-    // the Fisher vectors through the per-row / per-column tables of patch_rows.hip (A = fv base, ONE buffer with xyz behind it)
-    const uint2* ktab;      // [K/4 or M/4] per float4 window column: {byte offset of the neighbour's channels, required-validity bits}
-    const uint2* rowinfo;   // [rows] per query row: {byte offset (c*G + v)*80 of its voxel in fv, validity bits of its 3 x k neighbour offsets}
-    unsigned xyz_off;       // byte offset of xyz [rows,4] from the fv base (same allocation)
-    unsigned a_bytes;       // bytes covered by the A buffer descriptor (fv + xyz)
     int M, N, K;
     int lda, ldb, ldc;
     int epi;
@@ -69,18 +45,9 @@ struct GemmArgs {
     // at the same time; piece 0 stores to C, piece z > 0 to tail_slab + (z-1)*M*N, a small kernel adds the slabs (fixed order)
     int tail_first, tail_split, tail_chunk;
     float* tail_slab;
-    int xcd_band;     // register-streamed kernels: XCD-blocked block -> tile map (gemm_rs.h), 0 = contiguous chunk of tiles per XCD
     int k_chunk;      // K range per split (multiple of BK)
     long slab_stride; // floats between split-K slabs (0 when split_k == 1)
-#ifdef DPD_ADAM_EPI
-    AdamEpi ad;       // ad.p != NULL: apply Adam to the tile instead of (or besides, C != NULL) storing the gradient
-#endif
 };
-
-// host side: the Adam epilogue of the NEXT plain GEMM launched from this thread (set and cleared by dpd_decoder_bwd_weights*_adam around
-// the weight-gradient call; gemm_f32() / gemm_x3() copy it into their GemmArgs and refuse every form that has no single whole-K tile
-// per output element: split-K, tail split, epilogues, column sums)
-extern thread_local const AdamEpi* g_adam_epi;
 
 // host-side bundle of the two-step bias-gradient pointers (see GemmArgs::colsum_part)
 struct ColsumTwoStep {
@@ -163,9 +130,6 @@ __device__ __forceinline__ void quad_transpose4(float (&a)[4], int lane) {
 // transposed inside each quad of lanes (lane 4q+j then holds the four consecutive columns 4q..4q+3 of row 8g + 4 half + j) and
 // leaves as four 16-byte stores per lane: the same 128-byte row segments, a quarter of the instructions.  Needs a 16-byte
 // aligned C, ldc % 4 == 0, N % 4 == 0 and a tile that starts on a multiple of four columns; anything else keeps the dword form.
-// ADAM: compile-time switch of the Adam epilogue (its loads and their 64-bit addresses would otherwise be hoisted above the K loop of EVERY
-// kernel that inlines this function: the 64x64 dW kernel went from 152 to 268 VGPRs, i.e. from three waves per SIMD to one)
-template <bool ADAM = false>
 __device__ __forceinline__ void put_tile(const GemmArgs& g, float (&v)[16], int z, int row0, int col_in, int half) {
     const bool col_ok = col_in < g.N;
     const int col = col_ok ? col_in : g.N - 1;
@@ -176,16 +140,10 @@ __device__ __forceinline__ void put_tile(const GemmArgs& g, float (&v)[16], int 
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < g.M && col_ok) cs += v[r];
     }
-#ifdef DPD_ADAM_EPI
-    AdamEpi ad = g.ad;
-    if (!ADAM) ad.p = nullptr;
-#else
-    AdamEpi ad{};
-#endif
-    if (Cz || ad.p) {
+    if (Cz) {
         const int l31 = threadIdx.x & 31;
         const int col0 = __builtin_amdgcn_readfirstlane(col_in - l31);   // first column of the tile (wave-uniform)
-        const bool wide = !((g.ldc | g.N | col0) & 3) && !(((uintptr_t)Cz | (uintptr_t)ad.p | (uintptr_t)ad.m | (uintptr_t)ad.v) & 15);
+        const bool wide = !((g.ldc | g.N | col0) & 3) && !((uintptr_t)Cz & 15);
         if (wide) {
             const int cq = col0 + (l31 & ~3), j = l31 & 3;
 #pragma unroll
@@ -193,53 +151,13 @@ __device__ __forceinline__ void put_tile(const GemmArgs& g, float (&v)[16], int 
                 float a[4] = {v[4 * gi], v[4 * gi + 1], v[4 * gi + 2], v[4 * gi + 3]};
                 quad_transpose4(a, l31);
                 const int row = row0 + 8 * gi + 4 * half + j;
-                const bool in = row < g.M && cq < g.N;
-                const size_t off = (size_t)row * g.ldc + cq;
-                if (in && Cz) *reinterpret_cast<float4*>(Cz + off) = make_float4(a[0], a[1], a[2], a[3]);
-                if (ad.p) {
-                    if (in) {
-                        float4 P = *reinterpret_cast<float4*>(ad.p + off);
-                        float4 Mo = *reinterpret_cast<float4*>(ad.m + off);
-                        float4 Vo = *reinterpret_cast<float4*>(ad.v + off);
-                        adam_one(P.x, a[0] * ad.gscale, Mo.x, Vo.x, ad.lr_t, ad.b1, ad.b2, ad.eps);
-                        adam_one(P.y, a[1] * ad.gscale, Mo.y, Vo.y, ad.lr_t, ad.b1, ad.b2, ad.eps);
-                        adam_one(P.z, a[2] * ad.gscale, Mo.z, Vo.z, ad.lr_t, ad.b1, ad.b2, ad.eps);
-                        adam_one(P.w, a[3] * ad.gscale, Mo.w, Vo.w, ad.lr_t, ad.b1, ad.b2, ad.eps);
-                        *reinterpret_cast<float4*>(ad.p + off) = P;
-                        *reinterpret_cast<float4*>(ad.m + off) = Mo;
-                        *reinterpret_cast<float4*>(ad.v + off) = Vo;
-                        a[0] = P.x; a[1] = P.y; a[2] = P.z; a[3] = P.w;
-                    }
-                    quad_transpose4(a, l31);        // back to the accumulator layout: v[] = the NEW parameters (transposed copy, operand planes)
-                    v[4 * gi] = a[0]; v[4 * gi + 1] = a[1]; v[4 * gi + 2] = a[2]; v[4 * gi + 3] = a[3];
-                }
+                if (row < g.M && cq < g.N) *reinterpret_cast<float4*>(Cz + (size_t)row * g.ldc + cq) = make_float4(a[0], a[1], a[2], a[3]);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < g.M && col_ok) {
-                    const size_t off = (size_t)row * g.ldc + col;
-                    if (Cz) Cz[off] = v[r];
-                    if (ad.p) {
-                        float P = ad.p[off], Mo = ad.m[off], Vo = ad.v[off];
-                        adam_one(P, v[r] * ad.gscale, Mo, Vo, ad.lr_t, ad.b1, ad.b2, ad.eps);
-                        ad.p[off] = P; ad.m[off] = Mo; ad.v[off] = Vo;
-                        v[r] = P;
-                    }
-                }
-            }
-        }
-        if (ad.p && ad.wt && col_ok) {
-            // transposed copy [N][M]: a lane holds ONE column and four consecutive rows per row group -> 16 contiguous bytes of row `col`
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                const int row = row0 + 8 * gi + 4 * half;
-                if (row + 3 < g.M && !(g.M & 3))
-                    *reinterpret_cast<float4*>(ad.wt + (size_t)col * g.M + row) = make_float4(v[4 * gi], v[4 * gi + 1], v[4 * gi + 2], v[4 * gi + 3]);
-                else
-                    for (int e = 0; e < 4; ++e)
-                        if (row + e < g.M) ad.wt[(size_t)col * g.M + row + e] = v[4 * gi + e];
+                if (row < g.M && col_ok) Cz[(size_t)row * g.ldc + col] = v[r];
             }
         }
     }
@@ -252,11 +170,10 @@ __device__ __forceinline__ void put_tile(const GemmArgs& g, float (&v)[16], int 
     }
 }
 
-template <bool ADAM = false>
 __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16& acc, int z, int row0, int col_in, int half) {
     float v[16];
     tile_values(g, acc, row0, col_in, half, v);
-    put_tile<ADAM>(g, v, z, row0, col_in, half);
+    put_tile(g, v, z, row0, col_in, half);
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -350,24 +267,6 @@ struct X3Extra {
     float* C3 = nullptr;
     int M3 = 0;
 };
-
-// one GEMM of a chained persistent launch (gemm_x3.hip: gemm_chain): C / planes [M, N] = epi(A B) with A an RC plane [M][lda] (k contiguous;
-// for every stage but the first it IS the previous stage's out.rc) and B as R8 planes (b_fmt 1: [K/8][N][8], forward) or RC planes
-// (b_fmt 0: [N][K], the data gradients); one bf16 plane
-struct ChainStage {
-    const uint16_t* A = nullptr;
-    int lda = 0;
-    const uint16_t* B = nullptr;
-    int ldb = 0, b_fmt = 1, K = 0;
-    const float* bias = nullptr;
-    const uint16_t* gate16 = nullptr;
-    int gate16_r8 = 0, epilogue = 0;
-    float* colsum = nullptr;
-    X3Out out;
-    float* C = nullptr;      // fp32 result: last stage only
-    int ldc = 0;
-};
-int gemm_chain(int nst, const ChainStage* st, int M, int N, int tile, unsigned* sync, unsigned long long* stamps, hipStream_t s);
 
 struct SplitJob {
     const float* src;

@@ -331,7 +331,8 @@ static int launch_x3(const X3Args& g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 128x128 (8 waves of 64x32), 3 = 64x128, 4 = 128x64, 5 = 64x64
+// tile codes: 1 = 128x128 (4 waves of 64x64), 2 = 128x128 (8 waves of 64x32), 3 = 64x128, 4 = 128x64, 5 = 64x64, 13 = 192x128 (BK 64, one plane);
+// 21 / 23 / 24 = the phase-staggered kernels of gemm_p8.hip
 // TN products with both operands read from their RC planes (RCT images + LDS transpose reads)
 template <int NP>
 static int launch_x3_tile_tr(int tile, const X3Args& g, hipStream_t s) {
@@ -352,25 +353,13 @@ static int launch_x3_tile(int tile, const X3Args& g, hipStream_t s) {
         case 3: return launch_x3<NP, AK, BKC, 2, 2, 1, 2, 4, 32>(g, s);
         case 4: return launch_x3<NP, AK, BKC, 2, 2, 2, 1, 4, 32>(g, s);
         case 5: return launch_x3<NP, AK, BKC, 2, 2, 1, 1, 4, 32>(g, s);
-        case 6: return launch_x3<NP, AK, BKC, 2, 2, 2, 2, 6, 16>(g, s);   // BK = 16: finer, deeper ring
-        case 7: return launch_x3<NP, AK, BKC, 2, 4, 2, 1, 6, 16>(g, s);
-        // BK = 64 (one plane only: a 3-plane stage would not fit the LDS): 4x fewer barriers per MFMA
-        case 8: if (NP == 1) return launch_x3<1, AK, BKC, 4, 2, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;   // 256x128, 8 waves of 64x64, 144 KiB
-        case 9: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 1, 4, 64>(g, s); return DPD_E_UNSUPPORTED;   // 128x128, 8 waves of 64x32, 128 KiB
-        case 10: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x128, 4 waves of 64x64
-        case 11: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 2, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x256, 8 waves of 64x64
-        case 12: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 1, 2, 4, 64>(g, s); return DPD_E_UNSUPPORTED;  // 64x128, 4 waves of 32x64
-        // 192x128 (round 4): the tile with the smallest BM + BN (= LDS fill bytes per flop) that covers dW1 + dW2 + dW3 in at most one
-        // workgroup per CU (112 + 48 + 48 = 208 tiles): 8 waves of 96x32, BK = 64, 3 stages x 40 KiB
+        // 192x128 at BK = 64 (round 4, one plane only: a 3-plane stage would not fit the LDS): the tile with the smallest BM + BN (= LDS fill bytes
+        // per flop) that covers dW1 + dW2 + dW3 in at most one workgroup per CU (112 + 48 + 48 = 208 tiles): 8 waves of 96x32, 3 stages x 40 KiB.
+        // (BK = 16 rings, the other BK = 64 shapes and the four-wave 96x64 / 64x96 forms were A/B references of rounds 2-4; removed in round 6 --
+        // profiles/r03_x3_bench*.txt, r04_bf16_trio_sweep.txt hold their numbers.)
         case 13: if (NP == 1) return launch_x3<1, AK, BKC, 2, 4, 3, 1, 3, 64>(g, s); return DPD_E_UNSUPPORTED;
-        case 14: if (NP == 1) return launch_x3<1, AK, BKC, 4, 2, 1, 3, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x192, 8 waves of 32x96
-        // the same tiles on FOUR waves of 96x64 / 64x96 (one per SIMD): 5 fragment reads per 6 MFMAs instead of 4 per 3 -- 37 % less LDS read traffic.
-        // Measured SLOWER in the grouped weight-gradient launch (0.2877 vs 0.2792 ms per bf16 step at B = 64): the second wave per SIMD is worth more
-        // than the fragment traffic; kept selectable (dpd_set_gemm_plan(33, 15 | 16, 1)) and tested
-        case 15: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 3, 2, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 192x128, 4 waves of 96x64
-        case 16: if (NP == 1) return launch_x3<1, AK, BKC, 2, 2, 2, 3, 3, 64>(g, s); return DPD_E_UNSUPPORTED;  // 128x192, 4 waves of 64x96
         // phase-staggered kernels (gemm_p8.hip; K % 32 == 0, no split-K): one plane at BK = 64 (20..23), three planes at BK = 32 (24..26)
-        case 20: case 21: case 22: case 23: case 24: case 25: case 26:
+        case 21: case 23: case 24:
             return g.e.split_k == 1 ? launch_p8_code(NP, AK, BKC, tile, g, s) : DPD_E_UNSUPPORTED;
 #ifdef DPD_ABLATIONS
         case 232: case 201: case 202: case 203: case 204: case 205: case 207: case 208: case 216: case 224:
@@ -397,7 +386,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     const bool uneven = A2 && (M2 != M || three);      // problems of different rows / a third problem: ring kernels, TN only
     if (A2 && (!B2 || !C2 || out || colsum || epilogue != EPI_NONE)) return DPD_E_UNSUPPORTED;
     if (three && (!A2 || !ex->B3 || !ex->C3 || ex->M3 <= 0)) return DPD_E_UNSUPPORTED;
-    if (uneven && (a_fmt != 1 || b_fmt != 1 || tile < 1 || (tile > 5 && (tile < 13 || tile > 16)) || (M2 & 7) || (three && (ex->M3 & 7))))
+    if (uneven && (a_fmt != 1 || b_fmt != 1 || tile < 1 || (tile > 5 && tile != 13) || (M2 & 7) || (three && (ex->M3 & 7))))
         return DPD_E_UNSUPPORTED;
     const int nprob = A2 ? (three ? 3 : 2) : 1;
     // split-K (deterministic slabs in `ws` + the reduce kernel of gemm_f32.hip): plain products only (the dW shapes: K = query rows
@@ -419,7 +408,7 @@ int gemm_x3(int np, int a_fmt, int b_fmt, int M, int N, int K, const uint16_t* A
     if (M <= 0 || N <= 0 || K <= 0) return DPD_E_DIM;
     if (np != 1 && np != 3) return DPD_E_UNSUPPORTED;
     if ((K % 32) || (N & 3) || (ldc & 3) || (lda & 7) || (ldb & 7)) return DPD_E_UNSUPPORTED;
-    if (tile >= 8 && tile <= 16 && (K % 64)) return DPD_E_UNSUPPORTED;   // BK = 64 kernels take whole 64-deep K-tiles
+    if (tile == 13 && (K % 64)) return DPD_E_UNSUPPORTED;   // BK = 64 kernels take whole 64-deep K-tiles
     if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_RELU) && !bias) return DPD_E_NULL;
     if (epilogue == EPI_GATE && !gate && !gate16) return DPD_E_NULL;
     if (epilogue < 0 || epilogue > 3) return DPD_E_UNSUPPORTED;

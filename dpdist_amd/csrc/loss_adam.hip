@@ -325,28 +325,8 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
     }
 }
 
-// Optimizer schedule on the device, so that a captured (hipGraph) training step needs no per-step host parameters.
-// state (8 floats, caller-owned, zero-filled = "before the first step" once state[1] = state[2] = 1):
-//   [0] global step (int32 bits)   [1] beta1_power   [2] beta2_power   [3] lr_t of the step being taken   [4] its learning rate
-// One thread: lr = max(base * rate^floor(step / decay_step), floor) on the step counter BEFORE the increment
-// (train_multi_gpu_pc_compare_dist.py:976-990, exponential_decay(staircase=True) + tf.maximum), the beta powers as the running
-// fp32 products TensorFlow keeps in its beta1_power / beta2_power variables, lr_t = lr sqrt(1 - b2^t) / (1 - b1^t).
-__global__ void adam_sched_kernel(float* __restrict__ st, float base_lr, int decay_step, float decay_rate, float floor_lr,
-                                  float b1, float b2) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int step = __float_as_int(st[0]);
-    const int n = decay_step > 0 ? step / decay_step : 0;
-    float lr = base_lr;
-    for (int i = 0; i < n && lr > 0.f; ++i) lr *= decay_rate;
-    lr = fmaxf(lr, floor_lr);
-    const float b1p = st[1] * b1, b2p = st[2] * b2;
-    st[0] = __int_as_float(step + 1);
-    st[1] = b1p;
-    st[2] = b2p;
-    st[3] = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-    st[4] = lr;
-}
-
+// Adam with lr_t read from DEVICE memory (state[3]), so that a captured (hipGraph) step carries no per-step host parameter: the consumer's
+// optimizer (optim.TFAdam.prepare_replay writes state[3] before every replay of the registration step).
 __global__ __launch_bounds__(256) void adam_tf_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, size_t n, const float* __restrict__ st, float b1,
                                                            float b2, float eps, float gscale) {
@@ -379,14 +359,6 @@ __global__ __launch_bounds__(256) void adam_tf_dev_kernel(float* __restrict__ p,
 }
 
 }  // namespace dpd
-
-extern "C" int dpd_adam_sched(float* state, float base_lr, int decay_step, float decay_rate, float floor_lr, float b1, float b2,
-                              void* stream) {
-    if (!state) return DPD_E_NULL;
-    DPD_LAUNCH(dpd::adam_sched_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, base_lr, decay_step, decay_rate, floor_lr, b1, b2);
-    DPD_CHECK_LAUNCH();
-    return 0;
-}
 
 extern "C" int dpd_adam_tf_dev(float* p, const float* g, float* m, float* v, size_t n, const float* state, float b1, float b2,
                                float eps, float gscale, void* stream) {
@@ -447,13 +419,7 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
         f.WT[w] = fu->WT[w]; f.w_off[w] = fu->w_off[w]; f.w_rows[w] = fu->w_rows[w]; f.w_cols[w] = fu->w_cols[w];
         f.rc[w] = planes ? (uint16_t*)fu->W_rc[w] : nullptr;
         f.r8[w] = planes ? (uint16_t*)fu->W_r8[w] : nullptr;
-        if (fu->skip_w[w]) {          // updated in the epilogue of its weight-gradient GEMM: covered, nothing to do here
-            const long cnt = (long)fu->w_rows[w] * fu->w_cols[w];
-            if (fu->w_rows[w] <= 0 || fu->w_cols[w] <= 0 || fu->w_off[w] < 0 || (size_t)(fu->w_off[w] + cnt) > n) return DPD_E_DIM;
-            if (nc && fu->w_off[w] < hi[nc - 1]) return DPD_E_DIM;
-            lo[nc] = fu->w_off[w]; hi[nc] = fu->w_off[w] + cnt; ++nc;
-            f.WT[w] = nullptr; f.rc[w] = nullptr; f.r8[w] = nullptr;
-        } else if (fu->WT[w] || f.rc[w] || f.r8[w]) {
+        if (fu->WT[w] || f.rc[w] || f.r8[w]) {
             const long cnt = (long)fu->w_rows[w] * fu->w_cols[w];
             if (fu->w_rows[w] <= 0 || fu->w_cols[w] <= 0 || (fu->w_cols[w] & 63) || (fu->w_rows[w] & 3) || (fu->w_off[w] & 3) ||
                 fu->w_off[w] < 0 || (size_t)(fu->w_off[w] + cnt) > n || ((uintptr_t)fu->WT[w] & 15))
@@ -461,7 +427,7 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
             if ((f.rc[w] || f.r8[w]) && ((fu->w_rows[w] & 7) || (((uintptr_t)f.rc[w] | (uintptr_t)f.r8[w]) & 15))) return DPD_E_UNSUPPORTED;
             if (nc && fu->w_off[w] < hi[nc - 1]) return DPD_E_DIM;
             lo[nc] = fu->w_off[w]; hi[nc] = fu->w_off[w] + cnt; ++nc;
-            f.direct[w] = !fu->WT[w] && (f.rc[w] || f.r8[w]) && !(fu->w_cols[w] & 127) && getenv("DPD_ADAM_LDS_TILES") == nullptr;
+            f.direct[w] = !fu->WT[w] && (f.rc[w] || f.r8[w]) && !(fu->w_cols[w] & 127);
             if (f.direct[w]) tiles += ((fu->w_rows[w] / 8) * (fu->w_cols[w] / 128) + 3) / 4;
             else tiles += ((fu->w_rows[w] + 63) / 64) * (fu->w_cols[w] / 64);
         }
@@ -499,13 +465,11 @@ extern "C" int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t 
     if (vblocks == 0 && vec_elems) vblocks = 1;
     const unsigned grid = (unsigned)(tiles + f.ntail + vblocks);
     if (grid == 0) return DPD_E_DIM;
-    // algorithmic bytes: 28 B per parameter (read p, g, m, v; write p, m, v; the matrices a weight-gradient GEMM already updated do not
-    // count), + the copies written in the same pass (transposed fp32: 4 B, bf16 operand planes: np x 2 B per layout) + the block partials
+    // algorithmic bytes: 28 B per parameter (read p, g, m, v; write p, m, v) + the copies written in the same pass (transposed fp32: 4 B, bf16 operand planes: np x 2 B per layout) + the block partials
     double by = 0.0;
     for (int w = 0; w < 3; ++w) {
         const double cnt = (double)fu->w_rows[w] * fu->w_cols[w];
-        if (fu->skip_w[w]) by -= 28.0 * cnt;
-        else by += cnt * ((f.WT[w] ? 4.0 : 0.0) + f.np * 2.0 * ((f.rc[w] ? 1.0 : 0.0) + (f.r8[w] ? 1.0 : 0.0)));
+        by += cnt * ((f.WT[w] ? 4.0 : 0.0) + f.np * 2.0 * ((f.rc[w] ? 1.0 : 0.0) + (f.r8[w] ? 1.0 : 0.0)));
     }
     by += 28.0 * (double)n + (fu->partials ? (double)fu->nparts * fu->rec * 4.0 : 0.0);
     StageProf prof(stream, DPD_STAGE_OPTIMIZER, by);

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "patch_rows_bwd.h"
 
 namespace dpd {
 
@@ -827,11 +828,9 @@ __device__ __forceinline__ void build_tables(const float* p, int n0, int np_, co
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const float* __restrict__ pts, float* __restrict__ part,
-                                                                       MfvConst k, int nslice) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void mfv3d_bwd_stats_block(const float* __restrict__ pts, float* __restrict__ part, const MfvConst& k, int nslice,
+                                                      int c, int sl, float* sm) {
     const int N = k.N, G = k.G, m = k.m;
-    const int c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
     const int n0 = min(N, sl * nslice), np_ = min(N, n0 + nslice) - n0;
     float2* s_zq = reinterpret_cast<float2*>(sm);   // [3][np_][m]
     float* s_S = sm + 6 * nslice * m;
@@ -895,6 +894,29 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const floa
         float* out = part + ((size_t)(c * kSlices + sl) * kRec) * G + g;
 #pragma unroll
         for (int i = 0; i < kRec; ++i) out[(size_t)i * G] = rec[i];
+    }
+}
+
+__global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_stats_kernel(const float* __restrict__ pts, float* __restrict__ part,
+                                                                       MfvConst k, int nslice) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    mfv3d_bwd_stats_block(pts, part, k, nslice, blockIdx.x / kSlices, blockIdx.x % kSlices, sm);
+}
+
+// As-loss backward (asloss.hip): the window-gather backward (dX -> dfv; patch_rows_bwd.h) and the statistics pass above read nothing of each
+// other, so they share ONE launch -- workgroups [0, ngather) gather, the rest take the statistics of their point slice (the two used to be
+// 17 + 12 us of latency-bound launches back to back at the PCRNet batch).  Same routines, same bits.
+__global__ __launch_bounds__(kFwdThreads) void asloss_tail_a_kernel(const float* __restrict__ dX, const int32_t* __restrict__ vox,
+                                                                     float* __restrict__ dfv, const float* __restrict__ pts,
+                                                                     float* __restrict__ part, MfvConst k, int nslice, int kwin, int KP,
+                                                                     int gslices, int ngather) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if ((int)blockIdx.x < ngather) {
+        patch_rows_bwd_block<kFwdThreads>(dX, vox, dfv, k.N, k.m, kwin, KP, blockIdx.x / gslices, blockIdx.x % gslices, gslices,
+                                          reinterpret_cast<int*>(sm));
+    } else {
+        const int b = blockIdx.x - ngather;
+        mfv3d_bwd_stats_block(pts, part, k, nslice, b / kSlices, b % kSlices, sm);
     }
 }
 
@@ -1012,8 +1034,19 @@ __global__ __launch_bounds__(512) void mfv3d_bwd_combine_kernel(const float* __r
     }
 }
 
+// FINAL (as-loss backward): instead of dpts, the evaluation's two input gradients leave this kernel (= dpd_asloss_combine on its output):
+//   clouds c < B are pcA, queried by the BA half of the rows; c >= B are pcB, queried by the AB half (models/dpdist_and_aue.py:56-69):
+//   g[r, d] = (dpts[c, n, d] + dX[qrow, E + d]) * upstream
+struct AslossFinal {
+    const float* dX;
+    const float* scale;
+    float* gA;
+    float* gB;
+    int B, KP, E;
+};
+template <bool FINAL>
 __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const float* __restrict__ pts, const float* __restrict__ comb,
-                                                                       float* __restrict__ dpts, MfvConst k, int nslice) {
+                                                                       float* __restrict__ dpts, MfvConst k, int nslice, AslossFinal fin) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int N = k.N, G = k.G, m = k.m;
     const int c = blockIdx.x / kSlices, sl = blockIdx.x % kSlices;
@@ -1084,12 +1117,21 @@ __global__ __launch_bounds__(kFwdThreads) void mfv3d_bwd_apply_kernel(const floa
         }
     }
     __syncthreads();
-    float* out = dpts + ((size_t)c * N + n0) * 3;
+    float* out = FINAL ? nullptr : dpts + ((size_t)c * N + n0) * 3;
     for (int i = tid; i < np_ * 3; i += kFwdThreads) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += s_part[w * nslice * 3 + i];
-        out[i] = t / k.sigma;
+        const float v = t / k.sigma;
+        if (FINAL) {
+            const int which = c >= fin.B ? 1 : 0, BN = fin.B * N;
+            const int r = (c - which * fin.B) * N + n0 + i / 3, d = i % 3;
+            const int qrow = which ? r : BN + r;
+            const float sc = fin.scale ? *fin.scale : 1.0f;
+            (which ? fin.gB : fin.gA)[(size_t)r * 3 + d] = (v + fin.dX[(size_t)qrow * fin.KP + fin.E + d]) * sc;
+        } else {
+            out[i] = v;
+        }
     }
 }
 
@@ -1181,19 +1223,52 @@ extern "C" int dpd_mfv3d_bwd(const float* pts, const float* dfv, int C, int N, i
         const int nslice = (N + kSlices - 1) / kSlices;
         const size_t l1 = (size_t)(6 * nslice * m + 3 * nslice + 4) * sizeof(float), l2 = bwd_sliced_lds_bytes(nslice, m);
         if (int rc = set_lds(mfv3d_bwd_stats_kernel, l1)) return rc;
-        if (int rc = set_lds(mfv3d_bwd_apply_kernel, l2)) return rc;
+        if (int rc = set_lds(mfv3d_bwd_apply_kernel<false>, l2)) return rc;
         DPD_LAUNCH(mfv3d_bwd_stats_kernel, dim3(C * kSlices), dim3(kFwdThreads), l1, (hipStream_t)stream, pts, (float*)ws, k, nslice);
         DPD_CHECK_LAUNCH();
         DPD_LAUNCH(mfv3d_bwd_combine_kernel, dim3(C * 4), dim3(512), 0, (hipStream_t)stream, dfv, (float*)ws, k);
         DPD_CHECK_LAUNCH();
-        DPD_LAUNCH(mfv3d_bwd_apply_kernel, dim3(C * kSlices), dim3(kFwdThreads), l2, (hipStream_t)stream, pts, (const float*)ws, dpts, k,
-                   nslice);
+        DPD_LAUNCH(mfv3d_bwd_apply_kernel<false>, dim3(C * kSlices), dim3(kFwdThreads), l2, (hipStream_t)stream, pts, (const float*)ws, dpts, k,
+                   nslice, AslossFinal{});
         DPD_CHECK_LAUNCH();
         return 0;
     }
     const size_t lds = bwd_lds_bytes(N, m);
     if (int rc = set_lds(mfv3d_bwd_kernel, lds)) return rc;
     DPD_LAUNCH(mfv3d_bwd_kernel, dim3(C), dim3(kFwdThreads), lds, (hipStream_t)stream, pts, dfv, dpts, k);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+// The non-GEMM tail of an as-loss backward in THREE launches instead of six (dpd_patch_rows_bwd + dpd_mfv3d_bwd's three + dpd_asloss_combine):
+//   [window-gather backward || encoder statistics]  ->  combine  ->  apply + the two input gradients.
+// Bitwise the separate calls (same device routines; tests/test_gpu_parity.py).  DPD_E_UNSUPPORTED for shapes the sliced encoder backward
+// does not take (the caller then makes the separate calls).
+extern "C" int dpd_asloss_tail(const float* dX, const int32_t* vox, const float* pts, const float* upstream, int B, int N, int m, int k, int KP,
+                               float sigma, float* dfv, void* mfv_ws, size_t mfv_ws_bytes, float* gA, float* gB, void* stream) {
+    using namespace dpd;
+    if (!dX || !vox || !pts || !dfv || !mfv_ws || !gA || !gB) return DPD_E_NULL;
+    if (B <= 0 || N <= 0) return DPD_E_DIM;
+    if (k < 1 || k > 7 || !(k & 1) || N > 8192) return DPD_E_UNSUPPORTED;
+    if (KP < k * k * k * kF + 3 || (KP & 3)) return DPD_E_DIM;
+    const int C = 2 * B;
+    MfvConst kc{};
+    if (int rc = make_const(N, m, sigma, kc)) return rc;
+    if (kc.G > 512 || N < 2 * kSlices || mfv_ws_bytes < dpd_mfv3d_bwd_workspace_bytes(C, m)) return DPD_E_UNSUPPORTED;
+    const int nslice = (N + kSlices - 1) / kSlices;
+    const int gslices = (kc.G * 5 + kFwdThreads - 1) / kFwdThreads;      // one (voxel, channel group) item per thread
+    const size_t l1 = (size_t)(6 * nslice * m + 3 * nslice + 4) * sizeof(float), lg = (size_t)N * sizeof(int), l2 = bwd_sliced_lds_bytes(nslice, m);
+    if (int rc = set_lds(asloss_tail_a_kernel, l1 > lg ? l1 : lg)) return rc;
+    static LdsOptIn opt_final;      // (set_lds keys its flag on the kernel's TYPE, which the two instantiations of the apply kernel share)
+    if (int rc = ensure_dyn_lds(opt_final, (const void*)mfv3d_bwd_apply_kernel<true>, l2)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    DPD_LAUNCH(asloss_tail_a_kernel, dim3(C * gslices + C * kSlices), dim3(kFwdThreads), l1 > lg ? l1 : lg, s, dX, vox, dfv, pts, (float*)mfv_ws, kc,
+               nslice, k, KP, gslices, C * gslices);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(mfv3d_bwd_combine_kernel, dim3(C * 4), dim3(512), 0, s, (const float*)dfv, (float*)mfv_ws, kc);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(mfv3d_bwd_apply_kernel<true>, dim3(C * kSlices), dim3(kFwdThreads), l2, s, pts, (const float*)mfv_ws, (float*)nullptr, kc, nslice,
+               AslossFinal{dX, upstream, gA, gB, B, KP, k * k * k * kF});
     DPD_CHECK_LAUNCH();
     return 0;
 }

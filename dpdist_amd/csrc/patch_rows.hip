@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "gemm_shared.h"
+#include "patch_rows_bwd.h"
 
 namespace dpd {
 
@@ -80,102 +81,16 @@ __global__ __launch_bounds__(256) void patch_rows_fwd_kernel(const float* __rest
     }
 }
 
-// Forward with operand-plane outputs for the bf16-matrix-core decoder (gemm_x3.hip): block = 8 consecutive rows x one
-// half of the float4 column units.  A thread gathers the same float4 unit of the 8 rows, splits the 32 values once and
-// writes them in both chunk orientations: RC (8 bytes = half a chunk per row and plane) and, for the rows that carry
-// gradient (< r8_rows), R8 (4 chunks of 8 rows, 64 contiguous bytes per plane); fp32 X only if requested.
+// Forward with operand-plane outputs for the bf16-matrix-core decoder (gemm_x3.hip): RC planes (k contiguous) for all rows and, for the
+// rows that carry gradient (< r8_rows), R8 planes (chunks of 8 rows); fp32 X only if requested.
 struct RowInfo {
     int ix, iy, iz, cloud;
     float dx, dy, dz;
 };
 
-__global__ __launch_bounds__(256) void patch_rows_planes_kernel(const float* __restrict__ q, const float* __restrict__ fv,
-                                                                float* __restrict__ X, float* __restrict__ mask,
-                                                                int32_t* __restrict__ vox, int Q, int N, int m, int k, int KP,
-                                                                GridAxis ax, int np, uint16_t* __restrict__ rc, long rc_plane,
-                                                                uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
-                                                                const float* __restrict__ ssq, int nsl) {
-    __shared__ RowInfo s_row[8];
-    __shared__ __attribute__((aligned(16))) float s_sc[8][kF];
-    if (ssq && threadIdx.x < 8 * kF) {
-        const int rr = threadIdx.x / kF, ch = threadIdx.x % kF;
-        s_sc[rr][ch] = fv_scale(ssq, nsl, (8 * (int)(blockIdx.x >> 1) + rr) / N, ch);
-    }
-    const int rg = blockIdx.x >> 1, part2 = blockIdx.x & 1, tid = threadIdx.x;
-    const int G = m * m * m, h = (k - 1) / 2;
-    if (tid < 8) {
-        const int r = 8 * rg + tid;
-        const float qx = q[(size_t)r * 3], qy = q[(size_t)r * 3 + 1], qz = q[(size_t)r * 3 + 2];
-        int ix = cell_of(ax, m, qx), iy = cell_of(ax, m, qy), iz = cell_of(ax, m, qz);
-        const bool valid = (ix >= 0) && (iy >= 0) && (iz >= 0);
-        if (!valid) { ix = 0; iy = 0; iz = 0; }
-        s_row[tid] = RowInfo{ix, iy, iz, r / N, qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz]};
-        if (part2 == 0) {
-            mask[r] = valid ? 1.f : 0.f;
-            vox[r] = (iy * m + ix) * m + iz;
-        }
-    }
-    __syncthreads();
-    const int E4 = k * k * k * (kF / 4), E = E4 * 4, U = KP / 4;
-    const int ubeg = part2 ? (U / 2) : 0, uend = part2 ? U : (U / 2);
-    const bool want_r8 = r8 && (8 * rg < r8_rows);
-    for (int j = ubeg + tid; j < uend; j += 256) {
-        float4 v[8];
-        if (j < E4) {
-            const int nb = j / 5, part = j % 5;
-            const int d0 = nb / (k * k) - h, d1 = (nb / k) % k - h, d2 = nb % k - h;
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const RowInfo ri = s_row[rr];
-                const int g0 = ri.iy + d0, g1 = ri.ix + d1, g2 = ri.iz + d2;   // grid axes are (y, x, z), slowest first
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((unsigned)g0 < (unsigned)m && (unsigned)g1 < (unsigned)m && (unsigned)g2 < (unsigned)m)
-                    x = *reinterpret_cast<const float4*>(fv + ((size_t)ri.cloud * G + (size_t)((g0 * m + g1) * m + g2)) * kF + part * 4);
-                if (ssq) {
-                    const float4 sc = *reinterpret_cast<const float4*>(&s_sc[rr][part * 4]);
-                    x.x *= sc.x; x.y *= sc.y; x.z *= sc.z; x.w *= sc.w;
-                }
-                v[rr] = x;
-            }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const RowInfo ri = s_row[rr];
-                v[rr] = (j == E4) ? make_float4(ri.dx, ri.dy, ri.dz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        (void)E;
-        unsigned pl[8][4][3];   // [row][element][plane]
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const float e[4] = {v[rr].x, v[rr].y, v[rr].z, v[rr].w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) split3(e[t], pl[rr][t]);
-            if (X) *reinterpret_cast<float4*>(X + (size_t)(8 * rg + rr) * KP + 4 * j) = v[rr];
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {   // compile-time plane index: pl[] stays in registers
-            if (p >= np) break;
-            if (rc) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr)
-                    *reinterpret_cast<uint2*>(rc + p * rc_plane + (size_t)(8 * rg + rr) * KP + 4 * j) =
-                        make_uint2(pl[rr][0][p] | (pl[rr][1][p] << 16), pl[rr][2][p] | (pl[rr][3][p] << 16));
-            }
-            if (want_r8) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    *reinterpret_cast<uint4*>(r8 + p * r8_plane + ((size_t)rg * KP + 4 * j + t) * 8) =
-                        make_uint4(pl[0][t][p] | (pl[1][t][p] << 16), pl[2][t][p] | (pl[3][t][p] << 16),
-                                   pl[4][t][p] | (pl[5][t][p] << 16), pl[6][t][p] | (pl[7][t][p] << 16));
-            }
-        }
-    }
-}
-
-// Round 3: the same outputs.  Measured on the kernel above (tools/gather_bench.py, B = 64: 31 us for 62 MB, no faster with one plane
-// than with three): five divisions by the RUN-TIME window side per gathered float4 (no integer divider on gfx950: ~35 VALU
-// instructions each), and R8 planes written as 16-byte pieces 64 bytes apart.  Here a workgroup owns the 8 rows of one row group:
+// The round-1 form (a thread gathers one float4 unit of 8 rows and writes both orientations: B = 64: 31 us for 62 MB, no faster with one
+// plane than with three) paid five divisions by the RUN-TIME window side per gathered float4 (no integer divider on gfx950: ~35 VALU
+// instructions each) and wrote R8 planes as 16-byte pieces 64 bytes apart; removed in round 6.  Here a workgroup owns the 8 rows of one row group:
 //   * the window geometry of a float4 unit (offset from the row's own voxel, the three neighbour displacements) is an LDS table
 //     built once per workgroup instead of once per gather;
 //   * pass A: wave w owns row w, its lanes walk the row's 8-column groups (no index division): two float4 gathers, convert, one
@@ -192,21 +107,13 @@ __device__ unsigned long long g_pr_stamps[1024 * 8];       // s_memtime mileston
 #else
 #define PR_STAMP(i) do { } while (0)
 #endif
-// The producer of X_rc also zeroes the ticket / arrival words of the chained decoder launches that consume it (dpd_planes.sync, DPD_SYNC_BYTES):
-// block 0, a few stores; the kernel boundary publishes them
-__device__ __forceinline__ void zero_sync_words(unsigned* __restrict__ w) {
-    if (w && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < DPD_SYNC_BYTES / 4; i += blockDim.x) w[i] = 0u;
-}
-
 template <int NP>
 __global__ __launch_bounds__(512) void patch_rows_planes3_kernel(const float* __restrict__ q, const float* __restrict__ fv,
                                                                  float* __restrict__ X, float* __restrict__ mask,
                                                                  int32_t* __restrict__ vox, int Q, int N, int m, int k, int KP,
                                                                  GridAxis ax, uint16_t* __restrict__ rc, long rc_plane,
                                                                  uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
-                                                                 const float* __restrict__ ssq, int nsl, unsigned* __restrict__ sync_zero) {
-    zero_sync_words(sync_zero);
+                                                                 const float* __restrict__ ssq, int nsl) {
     extern __shared__ __attribute__((aligned(16))) int2 s_tab[];               // [KP/4] per float4 unit: {offset in floats from the row's voxel, d0 | d1<<8 | d2<<16 | kind<<24}
     uint16_t* s_img = reinterpret_cast<uint16_t*>(s_tab + KP / 4);             // [NP][8][KP] (only when R8 planes are written)
     __shared__ RowInfo s_row[8];
@@ -332,9 +239,7 @@ void patch_rows_planes_lds_kernel(const float* __restrict__ q, const float* __re
                                                                     float* __restrict__ mask, int32_t* __restrict__ vox, int Q, int N,
                                                                     int m, int k, int KP, GridAxis ax, uint16_t* __restrict__ rc,
                                                                     long rc_plane, uint16_t* __restrict__ r8, long r8_plane, int r8_rows,
-                                                                    const float* __restrict__ ssq, int nsl, unsigned mg_k, unsigned mg_kk,
-                                                                    unsigned* __restrict__ sync_zero) {
-    zero_sync_words(sync_zero);
+                                                                    const float* __restrict__ ssq, int nsl, unsigned mg_k, unsigned mg_kk) {
     extern __shared__ __attribute__((aligned(16))) int2 s_tab2[];             // [KP/4] unit table (as above), then the planes
     const int U = KP / 4, U2 = KP / 8;
     const int G = m * m * m, h = (k - 1) / 2, GF = G * kF;
@@ -583,64 +488,13 @@ __global__ __launch_bounds__(512) void patch_rows_fwd_lds_kernel(const float* __
     }
 }
 
-// Backward as a gather (deterministic, no atomics): block (c, slice) owns a slice of the voxels of cloud c and,
-// for every (voxel, float4 channel group), sums the window column of every query of the cloud that covers it.
+// Backward as a gather (patch_rows_bwd.h): block (c, slice) owns a slice of the voxels of cloud c
 __global__ __launch_bounds__(256) void patch_rows_bwd_kernel(const float* __restrict__ dX, const int32_t* __restrict__ vox,
                                                               float* __restrict__ dfv, int N, int m, int k, int KP,
                                                               int slices) {
     extern __shared__ int s_vox[];   // [N] voxel coordinates of the cloud's queries, packed (a0 | a1<<8 | a2<<16)
-    const int c = blockIdx.x / slices, sl = blockIdx.x % slices;      // (pinning a cloud's slices to one XCD was measured: no change, 16.8 us)
-    const int tid = threadIdx.x;
-    const int G = m * m * m, h = (k - 1) / 2;
-    for (int n = tid; n < N; n += 256) {
-        const int v = vox[(size_t)c * N + n];
-        s_vox[n] = (v / (m * m)) | (((v / m) % m) << 8) | ((v % m) << 16);
-    }
-    __syncthreads();
-    const int gper = (G + slices - 1) / slices;
-    const int gbeg = sl * gper, gend = min(G, gbeg + gper);
-    const float* dXc = dX + (size_t)c * N * KP;
-    for (int item = tid; item < (gend - gbeg) * 5; item += 256) {
-        const int g = gbeg + item / 5, part = item % 5;
-        const int g0 = g / (m * m) + h, g1 = (g / m) % m + h, g2 = g % m + h;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // Two passes per 64 queries: (1) which of them cover this voxel -- LDS reads (the same address in every lane) and compares only,
-        // a 64-bit hit mask; (2) the hits, sixteen at a time, all sixteen loads issued before the first add (a load inside an `if` made every
-        // hit a serial L2 round trip).  A query covers 5^3 of 8^3 voxels, so a thread loads ~16 window columns instead of probing 64
-        // (round 2 issued a load for every query and dropped three quarters of them by a select).  The kernel stays latency bound at the
-        // PCRNet batch (~12 us back to back, C = 32 clouds of 64 queries; a streaming plane-owner form with the voxels in LDS was 14.7).
-        // Same values added in the same order (n ascending) as before.
-        for (int n0 = 0; n0 < N; n0 += 64) {
-            unsigned long long hm = 0;
-            const int lim = min(64, N - n0);
-            for (int j = 0; j < lim; ++j) {
-                const int pv = s_vox[n0 + j];
-                const int d0 = g0 - (pv & 255), d1 = g1 - ((pv >> 8) & 255), d2 = g2 - (pv >> 16);
-                if ((unsigned)d0 < (unsigned)k && (unsigned)d1 < (unsigned)k && (unsigned)d2 < (unsigned)k) hm |= 1ull << j;
-            }
-            while (__any(hm != 0)) {
-                float4 x[16];
-                bool hit[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    hit[j] = hm != 0;
-                    const int bit = hit[j] ? __ffsll((long long)hm) - 1 : 0;
-                    hm = hit[j] ? (hm & (hm - 1)) : 0;
-                    const int n = n0 + bit;
-                    const int pv = s_vox[n];
-                    const int d0 = g0 - (pv & 255), d1 = g1 - ((pv >> 8) & 255), d2 = g2 - (pv >> 16);
-                    const size_t off = hit[j] ? (size_t)n * KP + ((d0 * k + d1) * k + d2) * kF + part * 4 : 0;
-                    x[j] = *reinterpret_cast<const float4*>(dXc + off);
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    acc.x = hit[j] ? acc.x + x[j].x : acc.x; acc.y = hit[j] ? acc.y + x[j].y : acc.y;
-                    acc.z = hit[j] ? acc.z + x[j].z : acc.z; acc.w = hit[j] ? acc.w + x[j].w : acc.w;
-                }
-            }
-        }
-        *reinterpret_cast<float4*>(dfv + ((size_t)c * G + g) * kF + part * 4) = acc;
-    }
+    // (pinning a cloud's slices to one XCD was measured: no change, 16.8 us)
+    patch_rows_bwd_block<256>(dX, vox, dfv, N, m, k, KP, blockIdx.x / slices, blockIdx.x % slices, slices, s_vox);
 }
 
 __global__ __launch_bounds__(256) void patch_rows_dq_kernel(const float* __restrict__ dX, float* __restrict__ dq, int Q,
@@ -678,89 +532,7 @@ __global__ __launch_bounds__(256) void stack_clouds_kernel(const float* __restri
     q[n + i] = a;
 }
 
-// Front end of the fused-gather path: input stacking (models/dpdist_and_aue.py:45,56-61,69) + the query lookup of
-// get_pc_grid_binary_mask_from_centers (:459-492) in ONE launch, one thread per query row r = c*N + n:
-//   pts  [2B,N,3] = [pcA + noise ; pcB]        encoder input
-//   mask [Q], vox [Q]                           as dpd_patch_rows_fwd
-//   xyz  [Q,4]  = (q - centre, 0)               the three centre-relative columns of the decoder input row (:455)
-//   rowinfo [Q] = { (c*G + vox)*80 bytes , validity bits } bit 8*a + d set <=> neighbour offset d of grid axis a (y, x, z) is inside the grid
-__global__ __launch_bounds__(256) void front_kernel(const float* __restrict__ pcA, const float* __restrict__ pcB,
-                                                     const float* __restrict__ noise, int B, int N, int m, int k, GridAxis ax,
-                                                     float* __restrict__ pts, float* __restrict__ q_out, float* __restrict__ mask,
-                                                     int32_t* __restrict__ vox, float4* __restrict__ xyz, uint2* __restrict__ rowinfo) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= 2 * B * N) return;
-    const int c = r / N, n = r % N, h = (k - 1) / 2;
-    const bool first = c < B;
-    const size_t ia = ((size_t)(first ? c : c - B) * N + n) * 3;
-    float a[3], b[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { a[d] = pcA[ia + d]; b[d] = pcB[ia + d]; }
-    // rows of the first half: encoder point = pcA + noise, query = pcB; second half: encoder point = pcB, query = pcA (un-noised)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float e = first ? (noise ? a[d] + noise[ia + d] : a[d]) : b[d];
-        pts[(size_t)r * 3 + d] = e;
-        if (q_out) q_out[(size_t)r * 3 + d] = first ? b[d] : a[d];
-    }
-    const float qx = first ? b[0] : a[0], qy = first ? b[1] : a[1], qz = first ? b[2] : a[2];
-    int ix = cell_of(ax, m, qx), iy = cell_of(ax, m, qy), iz = cell_of(ax, m, qz);
-    const bool valid = (ix >= 0) && (iy >= 0) && (iz >= 0);
-    if (!valid) { ix = 0; iy = 0; iz = 0; }
-    const int v = (iy * m + ix) * m + iz;
-    mask[r] = valid ? 1.f : 0.f;
-    vox[r] = v;
-    xyz[r] = make_float4(qx - ax.c[ix], qy - ax.c[iy], qz - ax.c[iz], 0.f);
-    unsigned bits = 0;
-    const int i3[3] = {iy, ix, iz};      // grid axes are (y, x, z), slowest first
-#pragma unroll
-    for (int a3 = 0; a3 < 3; ++a3)
-        for (int d = 0; d < k; ++d)
-            if ((unsigned)(i3[a3] + d - h) < (unsigned)m) bits |= 1u << (8 * a3 + d);
-    rowinfo[r] = make_uint2((unsigned)(c * m * m * m + v) * (unsigned)(kF * sizeof(float)), bits);
-}
-
-// ktab[k4] for the float4 column k4 of a decoder input row: window columns -> {byte offset of that neighbour's 4 channels
-// relative to the row's own voxel, the validity bits it needs}; the q - centre float4 and the zero padding are marked.
-__global__ __launch_bounds__(256) void gather_table_kernel(uint2* __restrict__ tab, int n4, int m, int k) {
-    const int k4 = blockIdx.x * 256 + threadIdx.x;
-    if (k4 >= n4) return;
-    const int E4 = k * k * k * (kF / 4), h = (k - 1) / 2;
-    if (k4 < E4) {
-        const int nb = k4 / 5, part = k4 % 5;
-        const int d0 = nb / (k * k), d1 = (nb / k) % k, d2 = nb % k;
-        const int delta = ((((d0 - h) * m + (d1 - h)) * m + (d2 - h)) * kF + part * 4) * 4;
-        tab[k4] = make_uint2((unsigned)delta, (1u << d0) | (1u << (8 + d1)) | (1u << (16 + d2)));
-    } else {
-        tab[k4] = make_uint2(0u, k4 == E4 ? 0x40000000u : 0x80000000u);
-    }
-}
-
 }  // namespace dpd
-
-extern "C" int dpd_front(const float* pcA, const float* pcB, const float* noise, int B, int N, int m, int k, float* pts, float* q,
-                         float* mask, int32_t* vox, float* xyz, void* rowinfo, void* stream) {
-    using namespace dpd;
-    if (!pcA || !pcB || !pts || !mask || !vox || !xyz || !rowinfo) return DPD_E_NULL;
-    if (B <= 0 || N <= 0) return DPD_E_DIM;
-    if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
-    if (((uintptr_t)xyz & 15) || ((uintptr_t)rowinfo & 7)) return DPD_E_UNSUPPORTED;
-    const int Q = 2 * B * N;
-    DPD_LAUNCH(front_kernel, dim3((Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, pcA, pcB, noise, B, N, m, k, make_axis(m), pts, q,
-               mask, vox, (float4*)xyz, (uint2*)rowinfo);
-    DPD_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int dpd_gather_table(int m, int k, int KP, void* table, void* stream) {
-    using namespace dpd;
-    if (!table) return DPD_E_NULL;
-    if (m < 1 || m > 10 || k < 1 || k > 7 || !(k & 1)) return DPD_E_UNSUPPORTED;
-    if (KP < k * k * k * kF + 3 || (KP & 31) || ((uintptr_t)table & 7)) return DPD_E_DIM;
-    DPD_LAUNCH(gather_table_kernel, dim3((KP / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint2*)table, KP / 4, m, k);
-    DPD_CHECK_LAUNCH();
-    return 0;
-}
 
 extern "C" int dpd_stack_clouds(const float* pcA, const float* pcB, const float* noise, int B, int N, float* pts, float* q,
                                 void* stream) {
@@ -795,12 +567,7 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
                        (planes ? pl->np * 2.0 * KP * ((pl->X_rc ? (double)Q : 0.0) + (pl->X_r8 ? (double)pl->Qb : 0.0)) : 0.0));
     if (planes) {
         if ((pl->np != 1 && pl->np != 3) || pl->Q != Q || pl->Qb > Q || pl->Qb < 0) return DPD_E_DIM;
-        static const bool old_form = getenv("DPD_GATHER_PLANES_V1") != nullptr;      // A/B reference: the round-1 kernel
-        if (old_form) {
-            if (pl->sync) DPD_HIP(hipMemsetAsync(pl->sync, 0, DPD_SYNC_BYTES, (hipStream_t)stream));
-            DPD_LAUNCH(patch_rows_planes_kernel, dim3((Q / 8) * 2), dim3(256), 0, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
-                       KP, make_axis(m), pl->np, (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
-        } else if (!X && !(N & 7) && !getenv("DPD_GATHER_PLANES_V2") &&
+        if (!X && !(N & 7) &&
                    (size_t)pl->np * m * m * m * kF * sizeof(uint16_t) + (size_t)(KP / 4) * sizeof(int2) <= 100 * 1024) {
             // no fp32 rows wanted and a row group never straddles two clouds: the cloud's planes are made once per workgroup, in LDS
             const size_t lds = (size_t)pl->np * m * m * m * kF * sizeof(uint16_t) + (size_t)(KP / 4) * sizeof(int2);
@@ -811,14 +578,12 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
                 static LdsOptIn ll1;
                 if (int rc2 = ensure_dyn_lds(ll1, (const void*)patch_rows_planes_lds_kernel<1>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes_lds_kernel<1>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
-                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk,
-                           (unsigned*)pl->sync);
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk);
             } else {
                 static LdsOptIn ll3;
                 if (int rc2 = ensure_dyn_lds(ll3, (const void*)patch_rows_planes_lds_kernel<3>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes_lds_kernel<3>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, mask, vox, Q, N, m, k, KP,
-                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk,
-                           (unsigned*)pl->sync);
+                           make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices, mg_k, mg_kk);
             }
         } else {
             const size_t lds = (pl->X_r8 ? (size_t)pl->np * 8 * KP * sizeof(uint16_t) : 0) + (size_t)(KP / 4) * sizeof(int2);
@@ -827,14 +592,12 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
                 static LdsOptIn lo1;
                 if (int rc2 = ensure_dyn_lds(lo1, (const void*)patch_rows_planes3_kernel<1>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes3_kernel<1>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
-                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices,
-                           (unsigned*)pl->sync);
+                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
             } else {
                 static LdsOptIn lo3;
                 if (int rc2 = ensure_dyn_lds(lo3, (const void*)patch_rows_planes3_kernel<3>, lds)) return rc2;
                 DPD_LAUNCH(patch_rows_planes3_kernel<3>, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k,
-                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices,
-                           (unsigned*)pl->sync);
+                           KP, make_axis(m), (uint16_t*)pl->X_rc, (long)Q * KP, (uint16_t*)pl->X_r8, (long)pl->Qb * KP, pl->Qb, ssq, kMfvSlices);
             }
         }
         DPD_CHECK_LAUNCH();
@@ -846,7 +609,7 @@ extern "C" int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const 
         bool exact = true;
         for (int x = 0; x < k * k * k; ++x)
             if ((int)((x * mg_kk) >> 16) != x / (k * k) || (int)(((x % (k * k)) * mg_k) >> 16) != (x % (k * k)) / k) exact = false;
-        if (exact && !(N & 7) && !(Q & 7) && lds <= 100 * 1024 && !getenv("DPD_GATHER_ROWS_V1")) {
+        if (exact && !(N & 7) && !(Q & 7) && lds <= 100 * 1024) {
             static LdsOptIn lr;
             if (int rc2 = ensure_dyn_lds(lr, (const void*)patch_rows_fwd_lds_kernel, lds)) return rc2;
             DPD_LAUNCH(patch_rows_fwd_lds_kernel, dim3(Q / 8), dim3(512), lds, (hipStream_t)stream, q, fv, X, mask, vox, Q, N, m, k, KP,

@@ -338,12 +338,8 @@ class DirectRcclReducer:
     `hipEventDisableSystemFence` event: recording it costs the compute stream ~0.3 us, the hop is paid by the side stream, and
     `wait()` joins the side stream with one more light event.
 
-    DPD_DP_TWO_COMMS=1 (opt-in, the round-3 form): the LAST bucket's all-reduce is enqueued on the COMPUTE stream itself through a
-    second communicator -- no event, no hop: it starts the moment dW1 ends and Adam follows it in stream order (-14 us on one rank).
-    Two RCCL kernels of different communicators can then be in flight on one device; they must become co-resident on every GPU or
-    the ranks deadlock.  With <= 64 RCCL workgroups on 256 CUs they should, but no run with more than one GPU has ever shown it, so
-    the serialised form is the default until one has; `bench.py`'s watchdog falls back to torch.distributed if
-    either form hangs.
+    (A second communicator for the last bucket on the compute stream itself -- the round-3 form, -14 us on one rank, two RCCL kernels of
+    different communicators in flight on one device -- never ran on more than one GPU and was removed in round 6.)
 
     wire = "f32" | "bf16" as in BucketReducer (staging copies on the stream of the collective); mode = "allreduce" | "zero1"
     (ncclReduceScatter in place; `gather_params` = ncclAllGather in place on the side stream).  One rank (force) works: RCCL's
@@ -368,11 +364,9 @@ class DirectRcclReducer:
             raise ValueError("DirectRcclReducer: mode must be allreduce|zero1 (rs_ag lives in BucketReducer)")
         if self.mode == "zero1" and self.wire != "f32":
             raise ValueError("zero1 shards fp32 master weights: fp32 wire only")
-        self.two_comms = os.environ.get("DPD_DP_TWO_COMMS", "0") == "1" and self.mode == "allreduce"
         dev = flat_grad.device
         self._side = torch.cuda.Stream(device=dev)
         self._comm_side = _Rccl.new_comm(group, dev)
-        self._comm_main = _Rccl.new_comm(group, dev) if self.two_comms else None
         self.nranks = _Rccl.count(self._comm_side)      # as the communicator reports it, not as the environment claims
         if self.nranks != self.world:
             raise RuntimeError("ncclCommCount says %d ranks, the process group %d" % (self.nranks, self.world))
@@ -414,7 +408,6 @@ class DirectRcclReducer:
         self._calls.append((lo, hi))
         g = self.flat[lo:hi]
         self._covered += hi - lo
-        last = self._covered >= self.bounds[-1] - self.bounds[0]
         main = torch.cuda.current_stream()
         if self.mode == "zero1":
             self._fork(main)
@@ -427,17 +420,6 @@ class DirectRcclReducer:
                             "ncclReduceScatter")
             if main_n < hi - lo:
                 self._allreduce(self.flat[lo + main_n:hi], self._comm_side, self._side)
-            return
-        if last and self.two_comms:
-            e0 = self.exposure.begin()
-            if self.wire == "bf16":
-                full = self._staging((lo, hi), hi - lo)
-                full.copy_(g)
-                self._allreduce(full, self._comm_main, main)
-                g.copy_(full)
-            else:
-                self._allreduce(g, self._comm_main, main)
-            self.exposure.end(e0)
             return
         self._fork(main)
         if self.wire == "bf16":
@@ -465,8 +447,8 @@ class DirectRcclReducer:
     def wait_side(self):
         """The stream on which the reduced gradient is complete WITHOUT joining it into the compute stream: every collective of the
         step was enqueued on the side stream, so whatever is enqueued there next (the optimizer) follows them in stream order -- no
-        event, no hop.  None in the two-communicator form (its last bucket ran on the compute stream): the caller then uses wait()."""
-        if self.two_comms or self.mode != "allreduce":
+        event, no hop.  None for the sharded forms: the caller then uses wait()."""
+        if self.mode != "allreduce":
             self.wait()
             return None
         self._side_used = False
@@ -493,12 +475,10 @@ class DirectRcclReducer:
         return 1.0 / self.world
 
     def close(self):
-        for c in ("_comm_side", "_comm_main"):
-            comm = getattr(self, c, None)
-            if comm:
-                torch.cuda.synchronize()
-                _Rccl.lib().ncclCommDestroy(comm)
-                setattr(self, c, None)
+        comm, self._comm_side = getattr(self, "_comm_side", None), None
+        if comm:
+            torch.cuda.synchronize()
+            _Rccl.lib().ncclCommDestroy(comm)
 
 
 def crosscheck(red, group=None):
@@ -658,7 +638,6 @@ def make_reducer(flat_grad, bounds, group=None, force=False, mode=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     want = os.environ.get("DPD_DP_BACKEND", "rccl")
     mode = mode or os.environ.get("DPD_DP_MODE", "allreduce")      # `mode`: a caller that cannot shard its optimizer pins "allreduce"
-    check = os.environ.get("DPD_DP_CROSSCHECK", "1") == "1"
     if (dist.is_initialized() and (world > 1 or force) and flat_grad.is_cuda and want == "rccl" and dist.get_backend(group) == "nccl"
             and mode in ("allreduce", "zero1")):
         err = None
@@ -673,15 +652,14 @@ def make_reducer(flat_grad, bounds, group=None, force=False, mode=None):
             except Exception as e:      # plumbing only: the torch.distributed path computes the same sums
                 err = e
             if _agree(red is not None, flat_grad.device, group):
-                if check:
-                    try:
-                        red.crosscheck = crosscheck(red, group)
-                    except Exception as e:
-                        err, red.crosscheck = e, {"ok": False, "error": repr(e)}
-                    if not _agree(red.crosscheck["ok"], flat_grad.device, group):
-                        err = err or RuntimeError("start-up cross-check failed: %r" % (red.crosscheck,))
-                        red.close()
-                        red = None
+                try:
+                    red.crosscheck = crosscheck(red, group)
+                except Exception as e:
+                    err, red.crosscheck = e, {"ok": False, "error": repr(e)}
+                if not _agree(red.crosscheck["ok"], flat_grad.device, group):
+                    err = err or RuntimeError("start-up cross-check failed: %r" % (red.crosscheck,))
+                    red.close()
+                    red = None
                 if red is not None:
                     return red
             elif red is not None:
@@ -689,7 +667,7 @@ def make_reducer(flat_grad, bounds, group=None, force=False, mode=None):
                 red = None
         sys.stderr.write("dpdist_amd.ddp: direct RCCL unavailable on some rank (%r here), using torch.distributed collectives\n" % (err,))
     red = BucketReducer(flat_grad, bounds, group, force=force, mode=mode)
-    if red.active and check:
+    if red.active:
         red.crosscheck = crosscheck(red, group)
         if not red.crosscheck["ok"]:
             raise RuntimeError("torch.distributed gradient reducer failed its start-up cross-check: %r" % (red.crosscheck,))

@@ -27,22 +27,13 @@ class SmallGrads(Structure):
 class AdamFuse(Structure):   # include/dpdist_capi.h: dpd_adam_fuse
     _fields_ = [("WT", c_void_p * 3), ("w_off", c_long * 3), ("w_rows", c_int * 3), ("w_cols", c_int * 3),
                 ("W_rc", c_void_p * 3), ("W_r8", c_void_p * 3), ("np", c_int), ("partials", c_void_p),
-                ("nparts", c_int), ("rec", c_int), ("H", c_int), ("Qb", c_int), ("tail_off", c_long), ("loss", c_void_p),
-                ("skip_w", c_int * 3)]
-
-
-class AdamEpi(Structure):    # include/dpdist_capi.h: dpd_adam_epi
-    _fields_ = [(n, c_void_p) for n in ("p", "m", "v", "wt", "p2", "m2", "v2", "wt2")] + [(n, c_float) for n in ("lr_t", "b1", "b2", "eps", "gscale")]
-
-
-class Gather(Structure):     # include/dpdist_capi.h: dpd_gather
-    _fields_ = [("fv", c_void_p), ("xyz", c_void_p), ("rowinfo", c_void_p), ("table", c_void_p), ("C", c_int), ("G", c_int)]
+                ("nparts", c_int), ("rec", c_int), ("H", c_int), ("Qb", c_int), ("tail_off", c_long), ("loss", c_void_p)]
 
 
 class Planes(Structure):     # include/dpdist_capi.h: dpd_planes
     _fields_ = [("np", c_int), ("Q", c_int), ("Qb", c_int)] + [(n, c_void_p) for n in (
         "X_rc", "X_r8", "h1_rc", "h1_r8", "h2_rc", "h2_r8", "g3_rc", "g3_r8", "g2_rc", "g2_r8", "g1_rc", "g1_r8",
-        "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc", "h3_rc", "sync")]
+        "W1_r8", "W2_r8", "W3_r8", "W1_rc", "W2_rc", "W3_rc", "h3_rc")]
 
 
 class PoseNetW(Structure):   # include/dpdist_capi.h: dpd_pose_net
@@ -74,6 +65,8 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_out_asloss_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams), c_float, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, POINTER(Planes), c_void_p, c_void_p]),
+    "dpd_asloss_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t,
+                                c_void_p, c_void_p, c_void_p]),
     "dpd_asloss_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpd_patch_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p]),
@@ -83,19 +76,10 @@ SIGNATURES = {
                                      POINTER(DecoderParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      POINTER(SmallGrads), c_void_p, c_size_t, POINTER(Planes), c_int, c_void_p]),
     "dpd_stack_clouds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "dpd_front": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 7),
-    "dpd_gather_table": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
-    "dpd_decoder_fwd_gather": (c_int, [POINTER(Gather), c_void_p, c_int, c_int, c_int, POINTER(DecoderParams)] + [c_void_p] * 6),
-    "dpd_decoder_bwd_weights_gather": (c_int, [POINTER(Gather), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dpd_decoder_bwd_weights": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights_pair": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p, c_void_p]),
     "dpd_decoder_bwd_weights_trio": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p]),
-    "dpd_has_adam_epilogue": (c_int, []),
-    "dpd_decoder_bwd_weights_adam": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_size_t, POINTER(Planes), c_void_p, POINTER(AdamEpi), c_void_p]),
-    "dpd_decoder_bwd_weights_pair_adam": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_size_t, POINTER(Planes), c_void_p, c_void_p,
-                                                                                POINTER(AdamEpi), c_void_p]),
     "dpd_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "dpd_chamfer_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "dpd_chamfer_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
@@ -114,9 +98,6 @@ SIGNATURES = {
     "dpd_asloss_forward": (c_int, [POINTER(AsLoss), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "dpd_asloss_backward": (c_int, [POINTER(AsLoss), c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpd_asloss_forward_backward": (c_int, [POINTER(AsLoss), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dpd_planes_sync_reset": (c_int, [POINTER(Planes), c_void_p]),
-    "dpd_planes_sync_status": (c_int, [POINTER(Planes), c_void_p]),
-    "dpd_set_chain_stamps": (c_int, [c_void_p]),
     "dpd_weights_transpose": (c_int, [POINTER(DecoderParams), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dpd_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_long, c_void_p]),
@@ -127,7 +108,6 @@ SIGNATURES = {
                             c_float, c_void_p]),
     "dpd_adam_tf_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float,
                                   POINTER(AdamFuse), c_void_p]),
-    "dpd_adam_sched": (c_int, [c_void_p, c_float, c_int, c_float, c_float, c_float, c_float, c_void_p]),
     "dpd_adam_tf_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_float, c_float, c_float, c_void_p]),
     "dpd_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                              c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -15,7 +15,6 @@ dpdist_and_aue.py:36, dpdist_util.py:514-543, tf_util.py:207,217) and are create
 All arithmetic runs in the HIP kernels of dpdist_amd/csrc via ops.py; autograd is wired by `_DPDistFn`.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -249,11 +248,11 @@ class _AsLossFn(torch.autograd.Function):
         B, N, _ = pcA.shape
         need_grad = pcA.requires_grad or pcB.requires_grad
         ctx.P, ctx.cfg = P, (B, N, m, k, sigma)
-        ctx.fused_out = B * N < 16384 and os.environ.get("DPD_ASLOSS_CHAIN") != "1"
+        ctx.fused_out = B * N < 16384
         ctx.planes = None
         ctx.engine = None
         # round 5: the whole evaluation behind ONE foreign call per direction on an engine's persistent buffers (dpdist_amd/asloss.py:
-        # same kernels, same bits; DPD_ASLOSS_ENGINE=0 = the entry-by-entry path below)
+        # same kernels, same bits; asloss.ENGINE = False = the entry-by-entry path below)
         eng = asloss.acquire(P, flat, B, N, m, k, sigma, pcA.device) if ctx.fused_out else None
         if eng is not None:
             L.req(pcA, name="pcA", shape=(B, N, 3)), L.req(pcB, name="pcB", shape=(B, N, 3))
@@ -262,9 +261,9 @@ class _AsLossFn(torch.autograd.Function):
                 ctx.engine, ctx.engine_version = eng, eng.version
                 eng.hold(ctx)
             return loss[0]
-        if ctx.fused_out and ops.AsLossPlanes.usable(P, 2 * B * N, P.compute_dtype) and os.environ.get("DPD_ASLOSS_PLANES", "1") == "1":
+        if ctx.fused_out and ops.AsLossPlanes.usable(P, 2 * B * N, P.compute_dtype) and asloss.PLANES:
             # plane compute types: the rows, h1, h2 (and g3 / g2 / g1 in the backward) live as bf16 RC planes written by their producers,
-            # the frozen weights' planes are cached: no conversion launch per GEMM, no fp32 X / h1 / h2 (round 4; DPD_ASLOSS_PLANES=0 = before)
+            # the frozen weights' planes are cached: no conversion launch per GEMM, no fp32 X / h1 / h2 (round 4; asloss.PLANES = False = before)
             cp = P.cparams(flat)
             pl = ops.AsLossPlanes(P, flat, 2 * B * N, P.compute_dtype, pcA.device)
             pts, mask, vox = ops.front_end_planes(pcA, pcB, m, sigma, k, pl)
@@ -285,7 +284,7 @@ class _AsLossFn(torch.autograd.Function):
             if need_grad:
                 ctx.save_for_backward(pts, flat, vox, h1, h2, g3)
             return loss[0]
-        # three-launch form (very large batches; DPD_ASLOSS_CHAIN=1 for A/B timing): out_fwd, l1_loss(mode 2), out_bwd
+        # three-launch form (very large batches: B * N >= 16384): out_fwd, l1_loss(mode 2), out_bwd
         h1, h2, h3, y, pred = ops.decoder_fwd(X, mask, params, P.H, dtype=P.compute_dtype)
         loss, dpred = ops.l1_loss(pred, mask[:B * N], mode=2 if need_grad else 0)
         ctx.save_for_backward(pts, flat, vox, h1, h2, mask, h3, y, dpred if need_grad else pred)
@@ -301,7 +300,7 @@ class _AsLossFn(torch.autograd.Function):
             eng = ctx.engine
             if eng.version != ctx.engine_version:
                 raise RuntimeError("DPDist as-loss node: its engine's buffers have been re-used by a later evaluation (a second backward after "
-                                   "the first one released them); set DPD_ASLOSS_ENGINE=0 for graphs that are differentiated repeatedly")
+                                   "the first one released them); set dpdist_amd.asloss.ENGINE = False for graphs that are differentiated repeatedly")
             gA, gB = eng.backward(g)
             eng.release()
             return gA, gB, None, None, None, None, None

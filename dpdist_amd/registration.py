@@ -320,12 +320,12 @@ class IterativeRegistration:
 
     Where the time goes (round 5: 9.2 ms per step at batch 16 for 0.4 ms of DPDist -- ~1300 tiny eager launches, host-bound) and what
     this class does about it on the GPU:
-      * `fused_pose` (DPD_POSE_FUSED, default on): quat_normalize / normalisation / Besl-McKay R / moved cloud / T composition are ONE
+      * `fused_pose` (default on): quat_normalize / normalisation / Besl-McKay R / moved cloud / T composition are ONE
         launch of csrc/pose.hip per loop (dpd_pose_apply_fwd; backward dpd_pose_apply_bwd) instead of ~115 element-wise launches;
-      * `native_refine` (DPD_POSE_NATIVE, default on): the forward-only refinements run the pose NETWORK on the library too (shared MLP +
+      * `native_refine` (default on): the forward-only refinements run the pose NETWORK on the library too (shared MLP +
         max pool in one launch per loop, the template's features once per call, three head launches, fc4 folded into the pose launch:
         dpd_pose_refine, five launches per loop instead of ~25); the training evaluation keeps torch autograd;
-      * `graph` (DPD_REG_GRAPH, default on; needs optim.TFAdam and a loss with `capturable = True`, e.g. DPDistLoss): after
+      * `graph` (default on; needs optim.TFAdam and a loss with `capturable = True`, e.g. DPDistLoss): after
         `graph_warmup` eager steps for a batch shape the WHOLE step -- 7 refinements, the training forward, DPDist forward + backward on
         a private as-loss engine, the pose network's backward, TF-form Adam with lr_t read from device memory -- is captured once as a
         hipGraph and replayed.  Same kernels in the same order on the same inputs (dropout draws from the same Philox offsets torch's
@@ -338,8 +338,8 @@ class IterativeRegistration:
     every rank applies the same averaged gradient: replicas stay bit-identical.  `distributed=None` follows the process group.  With a
     reducer the step is two graphs (refine + forward + backward | Adam) around the eager collective."""
 
-    def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None, distributed=None, group=None, graph=None,
-                 fused_pose=None, graph_warmup=2, native_refine=None):
+    def __init__(self, pose_net, dpdist_loss, lr=1e-4, max_loops=8, optimizer=None, distributed=None, group=None, graph=True,
+                 fused_pose=True, graph_warmup=2, native_refine=True):
         import os
         import torch.distributed as dist
         from .optim import TFAdam
@@ -354,11 +354,9 @@ class IterativeRegistration:
                 self._flat_grad = flat_gradient_views(pose_net.parameters())
             self.reducer = make_reducer(self._flat_grad, [0, self._flat_grad.numel()], group,
                                         force=os.environ.get("DPD_FORCE_DIST") == "1", mode="allreduce")
-        self.fused_pose = (os.environ.get("DPD_POSE_FUSED", "1") == "1") if fused_pose is None else bool(fused_pose)
-        want_native = (os.environ.get("DPD_POSE_NATIVE", "1") == "1") if native_refine is None else bool(native_refine)
-        self.native_refine = want_native and self.fused_pose and native_refine_supported(pose_net)
-        want_graph = (os.environ.get("DPD_REG_GRAPH", "1") == "1") if graph is None else bool(graph)
-        self.use_graph = want_graph and isinstance(self.opt, TFAdam) and bool(getattr(dpdist_loss, "capturable", False))
+        self.fused_pose = bool(fused_pose)
+        self.native_refine = bool(native_refine) and self.fused_pose and native_refine_supported(pose_net)
+        self.use_graph = bool(graph) and isinstance(self.opt, TFAdam) and bool(getattr(dpdist_loss, "capturable", False))
         self.graph_warmup = int(graph_warmup)
         self._graphs, self._graph_seen = {}, {}
         self.graph_replays = 0

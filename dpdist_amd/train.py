@@ -49,6 +49,7 @@ def build_parser():
     p.add_argument("--eval_every", type=int, default=10)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--restore", default="", help="TF V2 checkpoint prefix (model.ckpt) or .npz to start from")
+    p.add_argument("--prefetch", type=int, default=0, help="1 = next batch's encoder + gather on a side stream (measured slower on MI355X)")
     p.add_argument("--dp_schedule", default=os.environ.get("DPD_DP_SCHEDULE", "early"), choices=["early", "grouped", "late", "auto"],
                    help="order of the data-parallel backward.  Default 'early': deterministic, a multi-GPU run is bitwise reproducible and "
                         "resumable.  'auto' MEASURES order x communication form on the first batch (all ranks together), stores the choice in "
@@ -186,7 +187,6 @@ def train(argv=None):
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("DPD_DP_ADAM_SIDE", "1")      # optimizer on the collectives' stream (trainer.apply_gradients); the trainer joins it itself
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -213,7 +213,8 @@ def train(argv=None):
     params = DPDistParams(k=K, mlp=(1024, 1024, 1024), device=dev)
     params.reset_parameters_tf(generator=torch.Generator().manual_seed(F.seed))               # replicated variables
     tr = DPDistTrainer(params, dev_bs, num_point=N, Embedding_Size=F.embedding_size, sigma3dmfv=sigma,
-                       base_lr=F.learning_rate_dpdist, decay_step=F.decay_step, decay_rate=F.decay_rate)
+                       base_lr=F.learning_rate_dpdist, decay_step=F.decay_step, decay_rate=F.decay_rate,
+                       adam_on_side=world > 1)         # optimizer on the collectives' stream (trainer.apply_gradients); the trainer joins it itself
     if F.restore:                                                                            # saver.restore (:443-453)
         # weights AND, when the checkpoint has them (ours do, like the reference's Saver()), global step + Adam state
         got = tr.load_tf_global_variables(dict(np.load(F.restore)) if F.restore.endswith(".npz") else read_checkpoint(F.restore))
@@ -268,8 +269,8 @@ def train(argv=None):
             a, b, l, noise = cur
             if training:
                 # trainer-side prefetch (encoder + gather of the next batch on a side stream) measured slower than plain
-                # stream order on MI355X, see bench.py --prefetch; opt in with DPD_PREFETCH=1
-                pf = (nxt[0], nxt[1], nxt[3]) if (nxt is not None and os.environ.get("DPD_PREFETCH") == "1") else None
+                # stream order on MI355X, see bench.py --prefetch; opt in with --prefetch 1
+                pf = (nxt[0], nxt[1], nxt[3]) if (nxt is not None and F.prefetch) else None
                 loss = tr.step(a, b, l, noise, prefetch=pf)
             else:
                 loss = tr.evaluate(a, b, l, noise)[0]

@@ -33,10 +33,29 @@ def learning_rate(step, base=1e-4, decay_step=300 * 512, decay_rate=0.5, floor=1
 
 
 class DPDistTrainer:
+    # stage forms (all on = the measured best; each off = the form it replaced, same results up to the stated tolerance of its test)
+    OPTIONS = {
+        "fuse_loss": True,     # training loss inside the output-layer backward (off: a separate dpd_l1_loss launch)
+        "fuse_out": True,      # ... which also runs the output layer's forward (off: out_fwd launch in the decoder forward)
+        "fused_adam": True,    # one optimizer launch incl. the weights' derived copies and the small-gradient reduction (off: three)
+        "front2": True,        # front end in two launches (stack + encoder, norm + gather) instead of four
+        "det_db": True,        # exact fp32: db1 / db2 as deterministic by-products of the dW GEMMs (off: atomics in the dH epilogues)
+        "h3_plane": True,      # bf16: layer 3's activation as ONE bf16 plane (off: fp32 h3)
+        "keep_f32_h": False,   # plane types: also write the fp32 h1 / h2 / g1 / g2 (on: for inspection)
+        "dw_trio": None,       # plane types: dW1 + dW2 + dW3 as one grouped launch (None: on for one plane, off for three)
+        "dp_buckets": 2,       # data-parallel "early" order: 2 = layers 2-4 as one collective, 3 = one per layer
+    }
+
     def __init__(self, params: DPDistParams, batch_size, num_point=64, Embedding_Size=512, sigma3dmfv=0.125, base_lr=1e-4,
                  decay_step=300 * 512, decay_rate=0.5, beta1=0.9, beta2=0.999, eps=1e-8, group=None, distributed=None,
-                 compute_dtype=None):
+                 compute_dtype=None, adam_on_side=False, options=None):
+        """options: overrides of OPTIONS (below) -- the unfused / older forms of single stages, kept because they are the fallbacks for
+        shapes the fused forms do not take; tests run them against the defaults.  adam_on_side: see `apply_gradients`."""
         self.P = params
+        unknown = set(options or {}) - set(self.OPTIONS)
+        if unknown:
+            raise ValueError("unknown trainer options: %s" % sorted(unknown))
+        opt = dict(self.OPTIONS, **(options or {}))
         self.dt = L.DTYPES[params.compute_dtype if compute_dtype is None else compute_dtype]
         dev = params.flat.device
         self.B, self.N = int(batch_size), int(num_point)
@@ -48,26 +67,14 @@ class DPDistTrainer:
         C, Q, BN = 2 * B, 2 * B * N, B * N
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)   # noqa: E731
         self.pts, self.q = f(C, N, 3), f(C, N, 3)
-        # Exact-fp32 compute type, opt-in (DPD_FUSED_GATHER=1): the window gather fused into the layer-1 GEMMs (csrc/gemm_rs.h,
-        # SURVEY K2) -- X [Q,KP] (41 MB at B = 32, 82 MB at B = 64) is never materialised; bitwise the same results.  Measured
-        # SLOWER on MI355X at B = 32 (layer 1: 180 us against 147 + 13.5 us for gather kernel + plain GEMM; dW1: 152 against
-        # 91 us: the per-lane address arithmetic sits in the in-order issue stream of an MFMA-bound wave), so the default
-        # keeps X.  fv and the q - centre columns share ONE allocation either way (one buffer descriptor).
         G = self.m ** 3
-        self.fused = self.dt == 0 and KP % 32 == 0 and BN % 32 == 0 and os.environ.get("DPD_FUSED_GATHER", "0") == "1"
+        # fv and the q - centre columns share ONE allocation (one buffer descriptor)
         self._fvx = f(C * G * 20 + Q * 4)
         self.fv = self._fvx[:C * G * 20].view(C, G, 20)
         self.xyz = self._fvx[C * G * 20:].view(Q, 4)
         self.mask = f(Q)
         self.vox = torch.empty(Q, device=dev, dtype=torch.int32)
-        if self.fused:
-            self.X = None
-            self.rowinfo = torch.empty(Q, 2, device=dev, dtype=torch.int32)
-            self.ktab = torch.empty(KP // 4, 2, device=dev, dtype=torch.int32)
-            L.check(L.load().dpd_gather_table(self.m, params.k, KP, L.ptr(self.ktab), L.cur_stream()), "dpd_gather_table")
-            self._gsrc = L.Gather(self.fv.data_ptr(), self.xyz.data_ptr(), self.rowinfo.data_ptr(), self.ktab.data_ptr(), C, G)
-        else:
-            self.X = f(Q, KP)
+        self.X = f(Q, KP)
         self.h1, self.h2, self.h3 = None, None, f(Q, H)      # h1 / h2: allocated below unless the planes stand in for them
         self.y, self.pred = f(Q, 3), f(Q, 3)
         self.dpred, self.dy = f(BN, 3), f(BN, 3)
@@ -87,12 +94,9 @@ class DPDistTrainer:
             self._plane_mem = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             self._planes = L.Planes()
             L.check(lib.dpd_planes_carve(L.ptr(self._plane_mem), nbytes, Q, BN, KP, H, self.dt, 0, self._planes), "dpd_planes_carve")
-            # ticket / arrival words of the chained decoder launches (dpd_planes.sync): zero once here; the window gather re-zeroes them
-            # every step and every chained launch leaves them zero
-            L.check(lib.dpd_planes_sync_reset(self._planes, L.cur_stream()), "dpd_planes_sync_reset")
         # Plane compute types: layer 2/3, the weight gradients and the ReLU gate of the backward all read h1 / h2 from their bf16
-        # planes, so the fp32 copies are not written at all (2 x 33.5 MB per forward at B = 64); DPD_KEEP_F32_H=1 keeps them
-        if self._planes is None or os.environ.get("DPD_KEEP_F32_H", "0") == "1":
+        # planes, so the fp32 copies are not written at all (2 x 33.5 MB per forward at B = 64); options["keep_f32_h"] keeps them
+        if self._planes is None or opt["keep_f32_h"]:
             self.h1, self.h2 = f(Q, H), f(Q, H)
             self.g1, self.g2 = f(BN, H), f(BN, H)
         # g3: the fused output-layer backward writes it as planes when it can (H % 256 == 0, H <= 1024, block partials fit)
@@ -113,21 +117,19 @@ class DPDistTrainer:
         self._partials = f(((BN + 7) // 8) * (4 * H + 8))      # block partials of db3 / dW4 / db4 (deferred reduction)
         self._csmall = L.make_small_grads(gv[1], gv[3], gv[5], gv[6], gv[7], self._partials)
         # training loss fused into the output-layer backward (no separate loss launch); labels pointer is filled in per step
-        self.fuse_loss = H % 256 == 0 and H <= 1024 and os.environ.get("DPD_FUSE_LOSS", "1") == "1"
+        self.fuse_loss = H % 256 == 0 and H <= 1024 and bool(opt["fuse_loss"])
         self._db_partials = f(2 * ((BN + 31) // 32) * H)       # 32-row partial column sums of g2 / g1 (deterministic db2 / db1)
-        # optimizer schedule on the device (include/dpdist_capi.h: dpd_adam_sched): [step, beta1_power, beta2_power, lr_t, lr]
-        self.opt_state = torch.zeros(8, device=dev, dtype=torch.float32)
-        self.opt_state[1:3] = 1.0
-        self._dev_t, self._last_lr = 0, base_lr
+        self._last_lr = base_lr
         # one-launch optimizer (dpd_adam_tf_fused): Adam + the transposed copies + (single-GPU steps) the reduction of the
-        # output layer's block partials; DPD_FUSED_ADAM=0 keeps the three separate launches
-        self.fused_adam = os.environ.get("DPD_FUSED_ADAM", "1") == "1"
-        # training step: the output layer's forward runs inside its fused backward (no out_fwd launch); DPD_FUSE_OUT=0 = separate
-        self.fuse_out = self.fuse_loss and os.environ.get("DPD_FUSE_OUT", "1") == "1"
+        # output layer's block partials
+        self.fused_adam = bool(opt["fused_adam"])
+        # training step: the output layer's forward runs inside its fused backward (no out_fwd launch)
+        self.fuse_out = self.fuse_loss and bool(opt["fuse_out"])
         self._out_pending = False
         self._h3_in_plane = False      # set by _decode(skip_out=True) of a DPD_BF16 step, read by the backward that must follow it
-        # front end in two launches (dpd_mfv3d_fwd_stacked + dpd_patch_rows_fwd_scaled) instead of four; DPD_FRONT2=0 = four
-        self.front2 = not self.fused and os.environ.get("DPD_FRONT2", "1") == "1"
+        # front end in two launches (dpd_mfv3d_fwd_stacked + dpd_patch_rows_fwd_scaled) instead of four
+        self.front2 = bool(opt["front2"])
+        self._det_db_opt, self._h3_plane_opt, self._dp_buckets = bool(opt["det_db"]), bool(opt["h3_plane"]), int(opt["dp_buckets"])
         self._ssq = f(C * 4 * 20)
         self._fv_scaled = True
         seg = params._segments
@@ -145,69 +147,15 @@ class DPDistTrainer:
             if i == 1:
                 af.partials, af.nparts, af.rec, af.H, af.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
                 af.tail_off, af.loss = seg["b3"][0], self.loss.data_ptr()
-        # Adam inside the weight-gradient GEMMs (include/dpdist_capi.h: dpd_decoder_bwd_weights*_adam): single-GPU exact-fp32 steps; the
-        # optimizer launch then only takes the biases and the output layer (descriptor [2] = [1] with the three matrices skipped).
-        # OPT-IN (DPD_ADAM_IN_DW=1): bit-identical, but measured SLOWER (0.573 vs 0.561 ms per step): the workgroups of a dW GEMM finish
-        # their K loops together, so the 112 MB of p / m / v traffic arrive as one burst at the end of each launch (+19 us on the two
-        # GEMMs) instead of hiding under the matrix cores, and the optimizer kernel only gets 18 us shorter (DESIGN.md section 3.4 h)
-        self.adam_in_dw = (self.dt == 0 and self.reducer is None and not self.fused and BN % 32 == 0
-                           and os.environ.get("DPD_ADAM_IN_DW", "0") == "1" and L.load().dpd_has_adam_epilogue() == 1)
-        self._adam_now = None      # (lr_t) while a step that applies Adam in the dW epilogues is in flight
-        self._keep_grad = os.environ.get("DPD_KEEP_GRAD", "0") == "1"      # also store dW (the optimizer no longer reads it)
-        if self.adam_in_dw:
-            base = lambda t, n: t.data_ptr() + 4 * seg[n][0]      # noqa: E731
-            pf, mf, vf = params.flat, self.m_state, self.v_state
-            _, _, _, b1_, b2_, eps_ = self.hp
-            self._aepi1, self._aepi23 = L.AdamEpi(), L.AdamEpi()
-            e1, e2 = self._aepi1, self._aepi23
-            e1.p, e1.m, e1.v, e1.wt = base(pf, "W1p"), base(mf, "W1p"), base(vf, "W1p"), None
-            e2.p, e2.m, e2.v, e2.wt = base(pf, "W2"), base(mf, "W2"), base(vf, "W2"), self.W2T.data_ptr()
-            e2.p2, e2.m2, e2.v2, e2.wt2 = base(pf, "W3"), base(mf, "W3"), base(vf, "W3"), self.W3T.data_ptr()
-            for e in (e1, e2):
-                e.b1, e.b2, e.eps, e.gscale = b1_, b2_, eps_, 1.0
-            sk = L.AdamFuse()
-            for j, (n, rows) in enumerate((("W1p", KP), ("W2", H), ("W3", H))):
-                sk.w_off[j], sk.w_rows[j], sk.w_cols[j], sk.skip_w[j] = seg[n][0], rows, H, 1
-            sk.partials, sk.nparts, sk.rec, sk.H, sk.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
-            sk.tail_off, sk.loss = seg["b3"][0], self.loss.data_ptr()
-            self._afuse.append(sk)
-        # Adam for W1p (55 % of the parameters) as soon as dW1 exists, on a side stream, under the dW2 + dW3 GEMM: that launch keeps the
-        # matrix cores busy and leaves most of the HBM bandwidth idle, the optimizer is the opposite (exact fp32, single GPU; the main
-        # optimizer launch then skips W1p).  OPT-IN (DPD_ADAM_W1_EARLY=1): bit-identical, measured SLOWER (0.567 vs 0.562 ms per step) --
-        # like every two-stream form tried on this runtime (DESIGN.md section 3.4 c, h): the cross-queue hand-over and the interference
-        # with the GEMM cost more than the 13 us of optimizer time that move under it.
-        self.adam_w1_early = (self.dt == 0 and self.reducer is None and not self.fused and self.W2T is not None
-                              and os.environ.get("DPD_ADAM_W1_EARLY", "0") == "1")
-        if self.adam_w1_early:
-            ew = L.AdamFuse()
-            for j, (n, rows, T) in enumerate((("W1p", KP, None), ("W2", H, self.W2T), ("W3", H, self.W3T))):
-                ew.w_off[j], ew.w_rows[j], ew.w_cols[j] = seg[n][0], rows, H
-                if T is None:
-                    ew.skip_w[j] = 1
-                else:
-                    ew.WT[j] = T.data_ptr()
-            ew.partials, ew.nparts, ew.rec, ew.H, ew.Qb = self._partials.data_ptr(), (BN + 7) // 8, 4 * H + 8, H, BN
-            ew.tail_off, ew.loss = seg["b3"][0], self.loss.data_ptr()
-            self._afuse_w1 = ew
-            self._w1_range = (seg["W1p"][0], seg["W1p"][1])
-            self._ev_dw1 = self._ev_w1done = None
-            self._side_opt = None
         # [b3 | W4 | b4] end the flat buffer (up to 3 elements of alignment padding behind them)
         self._tail_ok = 0 <= params.numel - (seg["b3"][0] + 4 * H + 3) <= 3 and H % 256 == 0 and H <= 1024
-        # hipGraph mode (single GPU): the whole step is captured once per input-buffer set and replayed; weight-derived
-        # buffers and the small-gradient reduction run on parallel branches of the graph, off the critical path
-        self.use_graph = os.environ.get("DPD_GRAPH", "0") == "1"   # opt-in: measured 4 % SLOWER than eager launches on MI355X / ROCm 7
-        self._graphs, self._seen_keys, self._gstreams = {}, set(), None
-        self.graph_replays = 0
         # one plane (bf16): dW1 + dW2 + dW3 as one grouped launch; three planes (f32x3): measured SLOWER grouped (0.557 vs 0.523 ms at B = 32:
-        # its dW1 alone runs the phase-staggered 128x128 kernel, the grouped launch needs the ring kernel), so opt-in there (DPD_DW_TRIO=1)
+        # its dW1 alone runs the phase-staggered 128x128 kernel, the grouped launch needs the ring kernel), so opt-in there (options["dw_trio"])
+        self._trio = self._planes is not None and bool(self._planes.np == 1 if opt["dw_trio"] is None else opt["dw_trio"])
         # data-parallel steps: Adam on the collectives' stream, joined only where the weights are read next (opt-in: a caller that reads
         # params.flat right after step() must call join_optimizer(); bench.py and dpdist_amd.train switch it on)
-        self.adam_on_side = os.environ.get("DPD_DP_ADAM_SIDE", "0") == "1"
+        self.adam_on_side = bool(adam_on_side)
         self._ev_opt, self._opt_pending = None, False
-        if not hasattr(self, "_side_opt"):
-            self._side_opt = None
-        self._trio = self._planes is not None and os.environ.get("DPD_DW_TRIO", "1" if self._planes.np == 1 else "0") == "1"
         # order of a DATA-PARALLEL backward (see `backward`): "early" = every weight gradient as soon as its inputs exist, buckets
         # all-reduced under the rest of the backward; "grouped" = the single-GPU launch order (ONE grouped dW1 + dW2 + dW3 launch: 20 us
         # less GEMM time at bf16 B = 64) and ONE all-reduce behind it; "late" = plain order, collectives after dW1 (A/B reference).
@@ -264,11 +212,6 @@ class DPDistTrainer:
                                                    L.ptr(self._ssq), L.cur_stream()), "dpd_mfv3d_fwd_stacked")
             self._fv_scaled = False
         else:
-            if self.fused and gate is not None:
-                # fused-gather mode has no X: mask (output-layer backward) and fv / xyz / rowinfo (the gathering dW1 GEMM) are read
-                # by the CURRENT step's backward until dW1 is done -- the whole front end must wait, not only the gather
-                gate.wait()
-                gate = None
             self._load_batch(pcA, pcB, noise)
             self._encode()
         if gate is not None:
@@ -277,12 +220,6 @@ class DPDistTrainer:
 
     def _load_batch(self, pcA, pcB, noise):
         shp = (self.B, self.N, 3)
-        if self.fused:      # stacking + query lookup in one launch (the gather itself happens inside the layer-1 GEMMs)
-            L.check(L.load().dpd_front(L.ptr(L.req(pcA, name="pcA", shape=shp)), L.ptr(L.req(pcB, name="pcB", shape=shp)),
-                                       None if noise is None else L.ptr(L.req(noise, name="add_noise", shape=shp)), self.B, self.N,
-                                       self.m, self.k, L.ptr(self.pts), None, L.ptr(self.mask), L.ptr(self.vox), L.ptr(self.xyz),
-                                       L.ptr(self.rowinfo), L.cur_stream()), "dpd_front")
-            return
         L.check(L.load().dpd_stack_clouds(L.ptr(L.req(pcA, name="pcA", shape=shp)), L.ptr(L.req(pcB, name="pcB", shape=shp)),
                                           None if noise is None else L.ptr(L.req(noise, name="add_noise", shape=shp)), self.B, self.N,
                                           L.ptr(self.pts), L.ptr(self.q), L.cur_stream()), "dpd_stack_clouds")
@@ -293,8 +230,6 @@ class DPDistTrainer:
                 "dpd_mfv3d_fwd")
 
     def _gather(self):
-        if self.fused:
-            return
         lib, s, P = L.load(), L.cur_stream(), self.P
         C, N = 2 * self.B, self.N
         # fv of the two-launch front end still lacks its L2 norm: the gather applies it from the per-slice sums of squares
@@ -314,38 +249,32 @@ class DPDistTrainer:
         lib, s, P = L.load(), L.cur_stream(), self.P
         Q = 2 * self.B * self.N
         self._join_optimizer()          # the weights (and what is derived from them) of a side-stream optimizer step
-        skip_out = bool(skip_out and self.fuse_out and not self.fused)
+        skip_out = bool(skip_out and self.fuse_out)
         self._out_pending = skip_out
         # DPD_BF16 training step: layer 3's activation leaves its GEMM as ONE bf16 plane and the fused output-layer kernel reads that
-        # (17 MB less to write and 33 MB less to read per step at B = 64); DPD_H3_PLANE=0 keeps the fp32 h3
+        # (17 MB less to write and 33 MB less to read per step at B = 64); options["h3_plane"] = False keeps the fp32 h3
         self._h3_in_plane = bool(skip_out and self.fuse_loss and self._planes is not None and self._planes.np == 1
-                                 and self._planes.h3_rc and self._tail_ok and os.environ.get("DPD_H3_PLANE", "1") == "1")
+                                 and self._planes.h3_rc and self._tail_ok and self._h3_plane_opt)
         h3 = None if self._h3_in_plane else self.h3
         if self._wdirty:
             self.refresh_weight_planes()
-        if self.fused:
-            L.check(lib.dpd_decoder_fwd_gather(self._gsrc, L.ptr(self.mask), Q, P.KP, P.H, self._cparams, L.ptr(self.h1),
-                                               L.ptr(self.h2), L.ptr(self.h3), L.ptr(self.y), L.ptr(self.pred), s),
-                    "dpd_decoder_fwd_gather")
-            return
         L.check(lib.dpd_decoder_fwd(L.ptr(self.X), L.ptr(self.mask), Q, P.KP, P.H, self._cparams, self.dt, L.ptr(self.h1),
                                     L.ptr(self.h2), L.ptr(h3), None if skip_out else L.ptr(self.y),
                                     None if skip_out else L.ptr(self.pred), L.ptr(self.ws), self.ws.numel() * 4, self._planes, s),
                 "dpd_decoder_fwd")
 
-    def backward(self, labels, fork_small=None, join_weights=None, defer_small=False):
-        """fork_small / join_weights (graph capture only): callables that move the small-gradient reduction to a parallel
-        branch right after the output layer, and join the branch that derives the transposed weights before the dH GEMMs."""
+    def backward(self, labels, defer_small=False):
+        """defer_small: db3 / dW4 / db4 and the loss stay block partials (the fused optimizer launch sums them)."""
         lib, s, P = L.load(), L.cur_stream(), self.P
         BN = self.B * self.N
         L.req(labels, name="labels", numel=BN)
-        if self._wdirty and join_weights is None:
+        if self._wdirty:
             self.refresh_weight_planes()
         d, wsb = self._gviews, self.ws.numel() * 4
         gv = self._gviews
         # exact-fp32 compute type: db1 / db2 are by-products of the dW GEMMs (column sums of the operand they stream: deterministic),
         # so the data chain's atomic column sums are switched off; the plane compute types keep the fused-epilogue form
-        det_db = self.dt == 0 and BN % 32 == 0 and not self.fused and os.environ.get("DPD_DET_DB", "1") == "1"
+        det_db = self.dt == 0 and BN % 32 == 0 and self._det_db_opt
         sdb1, sdb2 = (None, None) if det_db else (gv[1], gv[3])
         dbp = self._db_partials if det_db else None
         if self.fuse_loss:      # d loss_samples / d pred and the two loss values come out of the output-layer backward
@@ -363,32 +292,14 @@ class DPDistTrainer:
                                              phases, L.cur_stream()), "dpd_decoder_bwd_data")   # stream at CALL time (graph branches)
 
         def dw(layer, act, g, dW):
-            if layer == 1 and self.fused:
-                L.check(lib.dpd_decoder_bwd_weights_gather(self._gsrc, L.ptr(self.g1), BN, P.KP, P.H, L.ptr(dW), L.ptr(self.ws), wsb, L.cur_stream()),
-                        "dpd_decoder_bwd_weights_gather")
-                return
             db = gv[2 * layer - 1] if (det_db and layer in (1, 2)) else None
-            if self._adam_now is not None and layer == 1:      # Adam on W1p in the epilogue; the gradient itself is not stored
-                self._aepi1.lr_t = self._adam_now
-                L.check(lib.dpd_decoder_bwd_weights_adam(layer, L.ptr(act), act.stride(0), L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
-                                                         L.ptr(dW) if self._keep_grad else None, L.ptr(db), L.ptr(self.ws), wsb, self._planes,
-                                                         L.ptr(dbp) if db is not None else None, self._aepi1, L.cur_stream()),
-                        "dpd_decoder_bwd_weights_adam(1)")
-                return
             L.check(lib.dpd_decoder_bwd_weights(layer, L.ptr(act), act.stride(0) if act is not None else dW.shape[0], L.ptr(g), BN, dW.shape[0], dW.shape[1], self.dt,
                                                 L.ptr(dW), L.ptr(db), L.ptr(self.ws), wsb, self._planes, L.ptr(dbp) if db is not None else None,
                                                 L.cur_stream()),
                     "dpd_decoder_bwd_weights(%d)" % layer)
 
         def dw23():
-            if BN % 32 == 0 and self._adam_now is not None:
-                self._aepi23.lr_t = self._adam_now
-                kg = self._keep_grad
-                L.check(lib.dpd_decoder_bwd_weights_pair_adam(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]) if kg else None, L.ptr(self.h2),
-                                                              L.ptr(self.g3), L.ptr(d[4]) if kg else None, P.H, BN, P.H, P.H, self.dt,
-                                                              L.ptr(self.ws), wsb, self._planes, L.ptr(gv[3]) if det_db else None, L.ptr(dbp),
-                                                              self._aepi23, L.cur_stream()), "dpd_decoder_bwd_weights_pair_adam")
-            elif BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
+            if BN % 32 == 0:      # layers 2 and 3 have identical shapes: one grouped launch
                 L.check(lib.dpd_decoder_bwd_weights_pair(L.ptr(self.h1), L.ptr(self.g2), L.ptr(d[2]), L.ptr(self.h2), L.ptr(self.g3),
                                                          L.ptr(d[4]), P.H, BN, P.H, P.H, self.dt, L.ptr(self.ws), wsb, self._planes,
                                                          L.ptr(gv[3]) if det_db else None, L.ptr(dbp), L.cur_stream()),
@@ -397,7 +308,7 @@ class DPDistTrainer:
                 dw(2, self.h1, self.g2, d[2])
                 dw(3, self.h2, self.g3, d[4])
 
-        if self.reducer and self._trio and self._adam_now is None and self.dp_schedule == "grouped":
+        if self.reducer and self._trio and self.dp_schedule == "grouped":
             # DPD_DP_SCHEDULE=grouped (plane compute types, opt-in until an 8-GPU run has compared them): the single-GPU order -- data chain,
             # then dW1 + dW2 + dW3 as ONE grouped launch (20 us less GEMM time at B = 64 than the three early launches) -- and the whole
             # gradient as ONE all-reduce behind it; with the optimizer on the collectives' stream its tail overlaps the next front end
@@ -418,10 +329,10 @@ class DPDistTrainer:
             # Data-parallel schedule: every weight gradient is produced as early as its inputs exist, smallest bucket first,
             # so that the all-reduces (serial on the RCCL stream) start ~250 us before the backward ends instead of after dW1:
             #   output layer -> dW3 -> [bucket 2: W3,b3,W4,b4] -> g2 -> dW2 -> [bucket 1: W2,b2] -> g1 -> dW1 -> [bucket 0]
-            # DPD_DP_BUCKETS=2 (default): layers 2-4 travel as ONE collective after dW2 (8.4 MB, ~140 us of GEMMs still to come)
+            # options["dp_buckets"] = 2 (default): layers 2-4 travel as ONE collective after dW2 (8.4 MB, ~140 us of GEMMs still to come)
             # -- every collective costs the compute stream a cross-stream event hop (~20 us on this runtime)
             # and the exposed part is the layer-1 bucket either way; =3: one collective per bucket, the first after dW3.
-            three = os.environ.get("DPD_DP_BUCKETS", "2") == "3"
+            three = self._dp_buckets == 3
             data(1)
             if three:
                 dw(3, self.h2, self.g3, d[4])
@@ -439,14 +350,8 @@ class DPDistTrainer:
                 self._after_dw1()
             self.reducer.reduce_async(0)
             return
-        if fork_small is not None:
-            data(1 | 16)
-            fork_small(lambda: data(8))
-            join_weights()
-            data(2 | 4)
-        else:
-            data(7 | 16 if defer_small else 7)     # 16: db3 / dW4 / db4 and the loss stay block partials (the optimizer sums them)
-        if self._trio and self._adam_now is None and not self.reducer:
+        data(7 | 16 if defer_small else 7)     # 16: db3 / dW4 / db4 and the loss stay block partials (the optimizer sums them)
+        if self._trio and not self.reducer:
             # plane compute types: dW1 + dW2 + dW3 as ONE grouped launch (288 tiles of 128x128 for 256 CUs; apart they leave 96-192
             # CUs idle for the ~27 us a K = 4096 loop takes: DESIGN.md section 3.5)
             rc = lib.dpd_decoder_bwd_weights_trio(BN, P.KP, P.H, self.dt, L.ptr(d[0]), L.ptr(d[2]), L.ptr(d[4]), L.ptr(self.ws), wsb, self._planes,
@@ -468,31 +373,16 @@ class DPDistTrainer:
             self.reducer.reduce_async(1)
             self.reducer.reduce_async(2)
 
-    def _sched(self):
-        """(graph mode) advance the device-side optimizer schedule by one step (global step, beta powers, lr_t)."""
-        base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
-        L.check(L.load().dpd_adam_sched(L.ptr(self.opt_state), base_lr, int(decay_step), decay_rate, 1e-7, b1, b2, L.cur_stream()),
-                "dpd_adam_sched")
-
-    def _adam(self):
-        """(graph mode) Adam with lr_t read from the device-side schedule."""
-        base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
-        L.check(L.load().dpd_adam_tf_dev(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
-                                         self.P.numel, L.ptr(self.opt_state), b1, b2, eps, 1.0, L.cur_stream()), "dpd_adam_tf_dev")
-        self._wdirty = True
-        self.P.invalidate_derived()
-
-    def apply_gradients(self, tail_from_partials=False, matrices_done=False, w1_done=False, side_stream=None):
-        """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990).  Eager
-        steps compute lr_t on the host (a device-side schedule kernel of one thread costs 4.7 us per step on MI355X: launch
-        latency); only the captured hipGraph step keeps the schedule on the device."""
+    def apply_gradients(self, tail_from_partials=False):
+        """tf.train.AdamOptimizer.apply_gradients with the staircase learning rate (train_multi_gpu...:216,301,976-990); lr_t is
+        computed on the host (a device-side schedule kernel of one thread costs 4.7 us per step on MI355X: launch latency)."""
         base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
         lr = learning_rate(self.t, base_lr, decay_step, decay_rate)     # global_step before the increment (TF semantics)
         self.t += 1
         self._last_lr = lr
         lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         gscale = 1.0
-        side = side_stream          # (single-GPU experiment DPD_ADAM_SIDE=1: the caller has ordered this stream behind the backward)
+        side = None
         if self.reducer:
             self._join_optimizer()
             if self.adam_on_side and self.reducer.active and self.reducer.mode == "allreduce" and self.reducer.backend == "rccl":
@@ -521,8 +411,7 @@ class DPDistTrainer:
         import contextlib
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if self.fused_adam and (self.W2T is not None or self._afuse[0].np or tail_from_partials):
-                # matrices_done: W1p / W2 / W3 (and W2T / W3T) were updated in the epilogues of their weight-gradient GEMMs with this lr_t
-                af = self._afuse[2] if matrices_done else (self._afuse_w1 if w1_done else self._afuse[1 if tail_from_partials else 0])
+                af = self._afuse[1 if tail_from_partials else 0]
                 L.check(L.load().dpd_adam_tf_fused(L.ptr(self.P.flat), L.ptr(self.grad), L.ptr(self.m_state), L.ptr(self.v_state),
                                                    self.P.numel, lr_t, b1, b2, eps, gscale, af, L.cur_stream()), "dpd_adam_tf_fused")
                 # the transposed copies / operand planes written in the same pass are already those of the new weights
@@ -541,7 +430,7 @@ class DPDistTrainer:
 
     def _join_optimizer(self):
         """Make the current stream wait for an optimizer step that runs on the reducer's side stream (data-parallel steps with
-        DPD_DP_ADAM_SIDE=1).  Every method of the trainer that reads the weights or the optimizer state calls this first; code that
+        adam_on_side).  Every method of the trainer that reads the weights or the optimizer state calls this first; code that
         reads `params.flat` directly after `step()` must call `join_optimizer()` itself."""
         if self._opt_pending:
             red = self.reducer
@@ -552,18 +441,6 @@ class DPDistTrainer:
             self._opt_pending = False
 
     join_optimizer = _join_optimizer
-
-    def _sync_dev_schedule(self):
-        """Put the host's step count into the device-side schedule (before graph replays that follow eager steps / a restore)."""
-        if self._dev_t != self.t:
-            _, _, _, b1, b2, _ = self.hp
-            st = torch.zeros(8)
-            st[1], st[2] = b1 ** self.t, b2 ** self.t
-            self.opt_state.copy_(st)
-            # slot 0 holds the int32 global step: written through an int32 view (a float32 round trip of a small integer's bit
-            # pattern is a denormal, which a flush-to-zero host silently turns into step 0)
-            self.opt_state.view(torch.int32)[0:1].copy_(torch.tensor([self.t], dtype=torch.int32))
-            self._dev_t = self.t
 
     @property
     def lr(self):
@@ -587,10 +464,6 @@ class DPDistTrainer:
         """One training step.  Returns the device tensor [loss_samples, loss_pred] of THIS rank's shard (no host sync).
         prefetch = (pcA', pcB', noise' or None): the NEXT step's inputs (already complete on the current stream); their
         front end runs on a side stream under this step's backward and optimizer."""
-        if self.use_graph and prefetch is None and self.reducer is None and self._pref_key is None:
-            out = self._graph_step(pcA, pcB, labels, noise)
-            if out is not None:
-                return out
         self._take_front(pcA, pcB, noise)
         self._decode(skip_out=True)
         if prefetch is not None:
@@ -599,8 +472,7 @@ class DPDistTrainer:
                 self._side = torch.cuda.Stream(device=self.P.flat.device)
                 # device-local ordering only: events without the system-scope fence (a torch.cuda.Event record in mid-stream costs
                 # the compute stream ~6 us, these 0.3 us: tools/event_cost.py)
-                light = os.environ.get("DPD_LIGHT_EVENTS", "1") == "1"
-                self._ev_front, self._ev_xfree, self._ev_fwd = (LightEvent(system_fence=not light) for _ in range(3))
+                self._ev_front, self._ev_xfree, self._ev_fwd = (LightEvent(system_fence=False) for _ in range(3))
             main = torch.cuda.current_stream()
             self._ev_fwd.record(main)                  # inputs complete + this step's gather/decoder ordered before the side work
 
@@ -612,58 +484,13 @@ class DPDistTrainer:
                     self._ev_front.record(self._side)
                 self._pref_key = self._key(*prefetch)
             self._after_dw1 = launch_front
-        # DPD_ADAM_SIDE=1 (single GPU, opt-in experiment): the optimizer on a side stream under the NEXT step's encoder + window gather, joined at the
-        # decoder (what DPD_DP_ADAM_SIDE does behind the collectives).  The loss must then come from the small-gradient reduction on the compute
-        # stream (no deferral into the optimizer launch): callers read it right after step()
-        side_single = self.reducer is None and not self.use_graph and os.environ.get("DPD_ADAM_SIDE", "0") == "1"
-        defer = self.fused_adam and self.fuse_loss and self._tail_ok and self.reducer is None and not side_single
-        in_dw = self.adam_in_dw and defer
-        w1_early = self.adam_w1_early and defer and not in_dw
-        if w1_early:
-            if self._side_opt is None:
-                from .hipevents import LightEvent
-                self._side_opt = torch.cuda.Stream(device=self.P.flat.device)
-                self._ev_dw1, self._ev_w1done = LightEvent(system_fence=False), LightEvent(system_fence=False)
-            base_lr, decay_step, decay_rate, b1, b2, eps = self.hp
-            lr_now = learning_rate(self.t, base_lr, decay_step, decay_rate)
-            lr_t_now = lr_now * math.sqrt(1.0 - b2 ** (self.t + 1)) / (1.0 - b1 ** (self.t + 1))
-            chained = self._after_dw1
-            main_s = torch.cuda.current_stream()
-
-            def early_w1():
-                if chained is not None:
-                    chained()
-                self._ev_dw1.record(main_s)
-                off, cnt = self._w1_range
-                with torch.cuda.stream(self._side_opt):
-                    self._ev_dw1.wait(self._side_opt)
-                    sl = slice(off, off + cnt)
-                    L.check(L.load().dpd_adam_tf(L.ptr(self.P.flat.detach()[sl]), L.ptr(self.grad[sl]), L.ptr(self.m_state[sl]),
-                                                 L.ptr(self.v_state[sl]), cnt, lr_t_now, b1, b2, eps, 1.0, L.cur_stream()), "dpd_adam_tf(W1p)")
-                    self._ev_w1done.record(self._side_opt)
-            self._after_dw1 = early_w1
-        if in_dw:       # lr_t of THIS step (apply_gradients recomputes the same value when it advances the step counter)
-            base_lr, decay_step, decay_rate, b1, b2, _ = self.hp
-            lr = learning_rate(self.t, base_lr, decay_step, decay_rate)
-            self._adam_now = lr * math.sqrt(1.0 - b2 ** (self.t + 1)) / (1.0 - b1 ** (self.t + 1))
+        # single-GPU steps: the reduction of the output layer's block partials (and the loss) is deferred into the optimizer launch
+        defer = self.fused_adam and self.fuse_loss and self._tail_ok and self.reducer is None
         try:
             self.backward(labels.reshape(-1), defer_small=defer)
         finally:
             self._after_dw1 = None
-            self._adam_now = None
-        sstream = None
-        if side_single:
-            if self._side_opt is None:
-                from .hipevents import LightEvent
-                self._side_opt = torch.cuda.Stream(device=self.P.flat.device)
-                self._ev_dw1, self._ev_w1done = LightEvent(system_fence=False), LightEvent(system_fence=False)
-            self._join_optimizer()
-            self._ev_dw1.record(torch.cuda.current_stream())
-            self._ev_dw1.wait(self._side_opt)
-            sstream = self._side_opt
-        self.apply_gradients(tail_from_partials=defer, matrices_done=in_dw, w1_done=w1_early, side_stream=sstream)
-        if w1_early:
-            self._ev_w1done.wait(torch.cuda.current_stream())      # W1p is complete before anything that follows this step
+        self.apply_gradients(tail_from_partials=defer)
         return self.loss
 
     def dp_schedule_candidates(self, modes=None):
@@ -822,72 +649,8 @@ class DPDistTrainer:
             got.append("adam_slots")
         if "batch" in sd:      # beta1_power / beta2_power are functions of the step count (beta^(t+1)): nothing else to restore
             self.t = int(round(float(np.asarray(sd["batch"]))))
-            self._dev_t = -1
             got.append("schedule")
         return got
-
-    # -- hipGraph mode --------------------------------------------------------------------------------------------
-    def _graph_step(self, pcA, pcB, labels, noise):
-        """Replay (or first capture) the whole step for this set of input buffers.  Returns None when the step should run
-        eagerly instead: the first time a buffer set is seen (that eager step also initialises every lazily-configured
-        kernel before a capture), or when too many different buffer sets have been captured."""
-        shp = (self.B, self.N, 3)
-        L.req(pcA, name="pcA", shape=shp), L.req(pcB, name="pcB", shape=shp), L.req(labels, name="labels", numel=self.B * self.N)
-        if noise is not None:
-            L.req(noise, name="add_noise", shape=shp)
-        key = (pcA.data_ptr(), pcB.data_ptr(), labels.data_ptr(), None if noise is None else noise.data_ptr())
-        g = self._graphs.get(key)
-        if g is None:
-            if key not in self._seen_keys or len(self._graphs) >= 8:
-                if len(self._seen_keys) >= 64:     # callers that pass fresh tensors every step: do not grow without bound
-                    self._seen_keys.clear()
-                self._seen_keys.add(key)
-                return None
-            g = self._capture(pcA, pcB, labels, noise)
-            self._graphs[key] = g
-        self._sync_dev_schedule()
-        g[0].replay()
-        self._last_lr = learning_rate(self.t, *self.hp[:3])
-        self.t += 1
-        self._dev_t = self.t
-        self.graph_replays += 1
-        self.front_launches += 1
-        self._wdirty = True            # the replay ends with Adam: derived buffers are one step behind the weights
-        self.P.invalidate_derived()
-        return self.loss
-
-    def _capture(self, pcA, pcB, labels, noise):
-        dev = self.P.flat.device
-        if self._gstreams is None:
-            self._gstreams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-        s1, s2 = self._gstreams
-        lab = labels.reshape(-1)
-        g = torch.cuda.CUDAGraph()
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g):
-            main = torch.cuda.current_stream()
-            # branch 1: everything derived from the weights of the PREVIOUS step + the optimizer schedule of this one
-            s1.wait_stream(main)
-            with torch.cuda.stream(s1):
-                self.refresh_weight_planes()
-                self._sched()
-            need_w_fwd = self._planes is not None          # bf16 compute types read weight planes in the forward already
-            if need_w_fwd:
-                main.wait_stream(s1)
-            self.front_launches -= 1
-            self._front(pcA, pcB, noise)
-            self._decode()
-
-            def fork_small(fn):                            # branch 2: reduction of the db3 / dW4 / db4 block partials
-                s2.wait_stream(main)
-                with torch.cuda.stream(s2):
-                    fn()
-
-            self.backward(lab, fork_small=fork_small, join_weights=lambda: main.wait_stream(s1))
-            main.wait_stream(s2)
-            main.wait_stream(s1)
-            self._adam()
-        return (g, (pcA, pcB, labels, noise))               # keep the captured input tensors alive
 
     @torch.no_grad()
     def evaluate(self, pcA, pcB, labels, noise=None):

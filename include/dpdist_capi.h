@@ -95,27 +95,6 @@ int dpd_mfv3d_fwd_stacked(const float* pcA, const float* pcB, const float* noise
 int dpd_patch_rows_fwd_scaled(const float* q, const float* fv, const float* ssq, int C, int N, int m, int k, int KP,
                               float* X, float* mask, int32_t* vox, const struct dpd_planes* pl, void* stream);
 
-/* ---------------------------------------------------------------------------------------------
- * Fused-gather path (DPD_F32): the decoder input rows X [Q,KP] are never materialised -- layer 1 and its weight gradient read
- * them straight out of the Fisher vectors inside the GEMM (csrc/gemm_rs.h).
- * dpd_front = dpd_stack_clouds + the lookup half of dpd_patch_rows_fwd in one launch:
- *   pcA, pcB, noise [B,N,3] (noise may be NULL) -> pts [2B,N,3], q [2B,N,3] (may be NULL), mask [Q], vox [Q],
- *   xyz [Q,4] = (q - centre, 0) (16-byte aligned), rowinfo [Q] x 8 bytes = {byte offset of fv row c*G + vox, neighbour-validity bits}.
- * dpd_gather_table fills `table` [KP/4] x 8 bytes (per float4 column of a row: neighbour offset + the validity bits it needs;
- *   depends on (m, k, KP) only: build once).
- * dpd_gather names the sources; `xyz` MUST lie behind `fv` in the same allocation (one 32-bit-offset buffer descriptor
- *   covers both): allocate [C*G*20 floats | Q*4 floats] and pass the two views.                                       */
-int dpd_front(const float* pcA, const float* pcB, const float* noise, int B, int N, int m, int k, float* pts, float* q,
-              float* mask, int32_t* vox, float* xyz, void* rowinfo, void* stream);
-int dpd_gather_table(int m, int k, int KP, void* table, void* stream);
-typedef struct dpd_gather {
-    const float* fv;        /* [C, G, 20] Fisher vectors (dpd_mfv3d_fwd)                       */
-    const float* xyz;       /* [Q, 4] from dpd_front, behind fv in the same allocation           */
-    const void* rowinfo;    /* [Q] x 8 bytes from dpd_front                                      */
-    const void* table;      /* [KP/4] x 8 bytes from dpd_gather_table                            */
-    int C, G;               /* clouds, Gaussians per cloud (m^3)                                 */
-} dpd_gather;
-
 /* Backward of the gather: dX [Q,KP] -> dq [C,N,3] (overwritten; = dX[:,E:E+3]) and
  * dfv [C,m^3,20] (overwritten; scatter-add of the window columns).  Either output may be NULL.  */
 int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, int N, int m, int k, int KP, float* dq,
@@ -128,6 +107,16 @@ int dpd_patch_rows_bwd(const float* dX, const int32_t* vox, int C, int N, int m,
  *   gB [B,N,3] = scale * (dpts[B:2B] + dq[0:B])                                                                         */
 int dpd_asloss_combine(const float* dpts, const float* dX, const float* scale, int B, int N, int k, int KP, float* gA, float* gB,
                        void* stream);
+
+/* The WHOLE non-GEMM tail of an as-loss backward -- dpd_patch_rows_bwd (dX -> dfv), dpd_mfv3d_bwd (dfv -> dpts) and dpd_asloss_combine -- in
+ * THREE launches instead of six: [window-gather backward || the encoder backward's statistics pass] -> combine -> apply + both input
+ * gradients.  Bit for bit the separate calls.  pts [2B,N,3] = the encoder input of the forward, vox [2BN] from the window gather, dX
+ * [2BN,KP]; scratch: dfv [2B,m^3,20] floats and mfv_ws (dpd_mfv3d_bwd_workspace_bytes(2B, m)).  DPD_E_UNSUPPORTED for shapes the sliced
+ * encoder backward does not take (N < 8, m > 8): make the separate calls then.
+ * Replaces TF autodiff of local_z_3d / get_3dmfv_tf (utils/dpdist_util.py:22-141,911-930) inside tf.gradients(loss, inputs)
+ * (pcrnet-registration/iterative_PCRNet_ours.py:255-257).                                                                        */
+int dpd_asloss_tail(const float* dX, const int32_t* vox, const float* pts, const float* upstream, int B, int N, int m, int k, int KP,
+                    float sigma, float* dfv, void* mfv_ws, size_t mfv_ws_bytes, float* gA, float* gB, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit decoder (shared MLP).  Replaces tf_util.conv2d x4 (utils/dpdist_util.py:513-544,
@@ -156,14 +145,6 @@ int dpd_weights_transpose(const dpd_decoder_params* p, int KP, int H, float* W2T
 int dpd_decoder_fwd(const float* X, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
                     int dtype, float* h1, float* h2, float* h3, float* y, float* pred, void* ws, size_t ws_bytes,
                     const dpd_planes* pl, void* stream);
-
-/* dpd_decoder_fwd with layer 1 gathering its rows from `src` (DPD_F32; KP % 32 == 0), and the layer-1 weight gradient
- * dW1 [KP,H] = X^T g1 over the first Qb rows gathered the same way (Qb % 32 == 0).  Bitwise identical to running the
- * register-streamed kernels on a materialised X.                                                                  */
-int dpd_decoder_fwd_gather(const dpd_gather* src, const float* mask, int Q, int KP, int H, const dpd_decoder_params* p,
-                           float* h1, float* h2, float* h3, float* y, float* pred, void* stream);
-int dpd_decoder_bwd_weights_gather(const dpd_gather* src, const float* g1, int Qb, int KP, int H, float* dW1, void* ws,
-                                   size_t ws_bytes, void* stream);   /* ws: dpd_workspace_bytes() (split-K slabs), may be NULL */
 
 /* `dtype` of the decoder entry points = compute type of the three wide layers (inputs/outputs are always fp32):
  *   DPD_F32     exact fp32 on the fp32 matrix-core instruction (bitwise an fmaf chain), no workspace needed in
@@ -196,21 +177,7 @@ struct dpd_planes {
     void* h3_rc;  /* DPD_BF16 only (NULL otherwise): layer 3's activation as ONE bf16 plane [Q,H] instead of fp32 -- dpd_decoder_fwd writes it when
                    * h3 == NULL and y == NULL, the fused output-layer kernel of dpd_decoder_bwd_data (which then runs the output layer's forward
                    * as well: dpd_small_grads.fwd_y) reads it; 2 instead of 4 bytes per element written once and read once per step */
-    void* sync;   /* optional (NULL = never chain), DPD_SYNC_BYTES: ticket / arrival words of the CHAINED launches -- with it (and np == 1, whole
-                   * 128- or 256-row tiles, no fp32 copies of the intermediate results requested, and dpd_set_gemm_plan(48 / 49, 1, 0): opt-in)
-                   * dpd_decoder_fwd runs layers 1 -> 2 -> 3 and dpd_decoder_bwd_data (phases 2 | 4 together) the chain g3 -> g2 -> g1 as ONE
-                   * persistent launch each, bitwise the separate launches.  The words must be ZERO when such a launch starts and every launch leaves them zero; they are zeroed by
-                   * dpd_planes_sync_reset and by every dpd_patch_rows_fwd* that is given these planes (the producer of X_rc), so a caller that
-                   * follows the producer table above never sees a dirty word.  dpd_planes_sync_status reports a poll that gave up.            */
 };
-#define DPD_SYNC_BYTES 4096
-/* zero pl->sync on `stream` (no-op without sync words); call once after dpd_planes_carve when X_rc is not produced by dpd_patch_rows_fwd* */
-int dpd_planes_sync_reset(const dpd_planes* pl, void* stream);
-/* synchronises `stream` and returns the sticky error word of the chained launches (0 = every hand-off completed; bit 0 = a poll gave up
- * after DPD_CHAIN_SPIN_LIMIT rounds and its tile was computed from incomplete rows), or a negative DPD_E_* / positive hipError_t        */
-int dpd_planes_sync_status(const dpd_planes* pl, void* stream);
-/* debug / measurement: s_memtime stamps of the chained launches' workgroups into `device_buf` ([256][4][8] uint64, NULL = off; process-wide) */
-int dpd_set_chain_stamps(void* device_buf);
 
 /* Bytes for ALL members (with_dx: also g1_rc and W1_rc, needed only when dX is requested), and the carve-up of one
  * caller buffer of that size into the members (host-side pointer arithmetic only).                          */
@@ -328,12 +295,12 @@ typedef struct dpd_asloss {
     float* scratch;                    /* 8 bytes for dpd_decoder_out_asloss: zeroed by dpd_asloss_init */
     void* mfv_ws; size_t mfv_ws_bytes; /* dpd_mfv3d_bwd_workspace_bytes(2B, m) */
     void* ws; size_t ws_bytes;         /* dpd_workspace_bytes(Q, KP, H, dtype) */
-    dpd_planes planes;                 /* plane compute types: X, h1, h2, g3, g2, g1 as RC planes, the weights' R8 + RC planes, sync words */
+    dpd_planes planes;                 /* plane compute types: X, h1, h2, g3, g2, g1 as RC planes, the weights' R8 + RC planes */
     dpd_decoder_params params;         /* filled by dpd_asloss_set_weights */
 } dpd_asloss;
 size_t dpd_asloss_bytes(int B, int N, int m, int k, int H, int dtype);
 int dpd_asloss_carve(void* mem, size_t bytes, int B, int N, int m, int k, int H, int dtype, float sigma, dpd_asloss* out);
-/* zero what must be zero before the first evaluation (the loss accumulator, the planes' sync words): once, on `stream` */
+/* zero what must be zero before the first evaluation (the loss accumulator): once, on `stream` */
 int dpd_asloss_init(const dpd_asloss* e, void* stream);
 /* `e` is updated (its params member); p's W*T members are ignored (the engine owns its own transposed copies) */
 int dpd_asloss_set_weights(dpd_asloss* e, const dpd_decoder_params* p, void* stream);
@@ -426,40 +393,12 @@ typedef struct dpd_adam_fuse {
     int nparts, rec, H, Qb;
     long tail_off;
     float* loss;
-    int skip_w[3];   /* != 0: matrix w was already updated by dpd_decoder_bwd_weights*_adam: its interval is left alone */
 } dpd_adam_fuse;
 int dpd_adam_tf_fused(float* p, float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, float gscale,
                       const dpd_adam_fuse* fuse, void* stream);
 
-/* apply_gradients INSIDE compute_gradients (single-GPU steps; train_multi_gpu_pc_compare_dist.py:277-302 with one tower): the weight-gradient
- * GEMM applies TF-form Adam (same expression as dpd_adam_tf, same bits) to the tile it has just produced, instead of storing it for an
- * optimizer launch that would read it back with p, m, v: the three matrices (99.9 % of the parameters) leave the optimizer kernel, which
- * keeps the biases and the output layer (dpd_adam_fuse.skip_w).  p / m / v: the matrix's parameters and moments, laid out like dW
- * ([Kin, Nout], 16-byte aligned); wt: optional transposed copy [Nout, Kin] of the NEW parameters (what dpd_weights_transpose would
- * make); *2: the second matrix of the pair call.  dW may be NULL (the gradient is then not stored at all).  DPD_F32 only in this round.
- * Not for data-parallel steps (the all-reduce stands between the gradient and its use).  Bit-identical and measured SLOWER than the
- * optimizer launch (DESIGN.md section 3.4 h): compiled into the ablation build only (dpd_has_adam_epilogue).                        */
-int dpd_has_adam_epilogue(void);   /* 1 in a library built with DPD_ABLATIONS (the form is a measured-and-rejected experiment: both calls
-                                     * below return DPD_E_UNSUPPORTED otherwise) */
-typedef struct dpd_adam_epi {
-    float *p, *m, *v, *wt;
-    float *p2, *m2, *v2, *wt2;
-    float lr_t, b1, b2, eps, gscale;
-} dpd_adam_epi;
-int dpd_decoder_bwd_weights_adam(int layer, const float* act, int lda, const float* g, int Qb, int Kin, int Nout, int dtype,
-                                 float* dW, float* db, void* ws, size_t ws_bytes, const dpd_planes* pl, const float* db_partials,
-                                 const dpd_adam_epi* ad, void* stream);
-int dpd_decoder_bwd_weights_pair_adam(const float* actA, const float* gA, float* dWA, const float* actB, const float* gB, float* dWB,
-                                      int lda, int Qb, int Kin, int Nout, int dtype, void* ws, size_t ws_bytes, const dpd_planes* pl,
-                                      float* dbA, const float* db_partials, const dpd_adam_epi* ad, void* stream);
-
-/* The same update with the schedule kept ON THE DEVICE, so that a captured (hipGraph) training step carries no per-step host
- * parameters.  state: 8 floats, caller-owned: [0] global step (int32 bits), [1] beta1_power, [2] beta2_power (the running
- * fp32 products TensorFlow keeps in the variables of those names), [3] lr_t, [4] learning rate of the step being taken.
- * Initialise to {0, 1, 1, 0, ...}.  dpd_adam_sched advances it by one step: lr = max(base_lr * decay_rate^floor(step /
- * decay_step), floor_lr) on the step counter before the increment (train_multi_gpu_pc_compare_dist.py:976-990), then
- * lr_t = lr sqrt(1 - beta2_power) / (1 - beta1_power).  dpd_adam_tf_dev reads lr_t from state[3].              */
-int dpd_adam_sched(float* state, float base_lr, int decay_step, float decay_rate, float floor_lr, float b1, float b2, void* stream);
+/* The same update with lr_t read from DEVICE memory (state[3] of an 8-float caller-owned buffer), so that a captured (hipGraph) step carries
+ * no per-step host parameter: the host writes state[3] before every replay (dpdist_amd/optim.py: TFAdam.prepare_replay).  */
 int dpd_adam_tf_dev(float* p, const float* g, float* m, float* v, size_t n, const float* state, float b1, float b2, float eps,
                     float gscale, void* stream);
 
@@ -468,11 +407,9 @@ int dpd_adam_tf_dev(float* p, const float* g, float* m, float* v, size_t n, cons
  *   transA = 0: A is [M,K] (lda);  1: A is stored [K,M].   transB = 0: B is [K,N];  1: B is [N,K].
  *   epilogue: 0 none, 1 +bias[n], 2 relu(+bias[n]), 3 multiply by (gate[m,n] > 0) (ldg = ldc).
  *   K, N, lda, ldb, ldc multiples of 4; split_k >= 1 (slabs in ws, reduced by a second kernel,
- *   epilogue applied after the reduction); tile: 0 = auto; register-staged kernels 1 = 128x128, 2 = 128x64,
- *   3 = 64x64; LDS-DMA ring kernels (K % 32 == 0, else 3 is used) 4 = 64x64/4-stage, 5 = 128x128/4-stage,
- *   6 = 128x64, 7 = 64x128, 8 = 64x64/3-stage, 9 = 128x128/3-stage, 10 = 128x128/5-stage, 11-14 multi-accumulator forms;
- *   register-streamed kernels (no LDS, no barriers; K % 32 == 0; csrc/gemm_rs.h): workgroup of 4 waves, wave tile
- *   30 = 64x64, 31 = 64x32, 32 = 32x64, 33 = 32x32, 34-36 = the same three with operands two K-tiles ahead, 37 = 8 waves. */
+ *   epilogue applied after the reduction); tile: 0 = auto (= 3); 3 = register-staged 64x64 (any K % 4 == 0); LDS-DMA ring
+ *   kernels (K % 32 == 0, else 3 is used) 8 = 64x64/3-stage, 9 = 128x128/3-stage; register-streamed kernels (no LDS, no
+ *   barriers; K % 32 == 0; csrc/gemm_rs.h): workgroup of 4 waves, wave tile 30 = 64x64, 31 = 64x32, 32 = 32x64, 33 = 32x32. */
 int dpd_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* Cout, int ldc, const float* bias, const float* gate, int epilogue, int split_k, int tile,
                  void* ws, size_t ws_bytes, void* stream);
@@ -496,13 +433,11 @@ int dpd_gemm_planes(int np, int a_fmt, int b_fmt, int M, int N, int K, const voi
 
 /* Tuning knob (process-wide, never needed for correctness): GEMM tile / split-K per
  * call site.  op: 0 fwd layer 1, 1 fwd layers 2-3, 2 bwd dH, 3 bwd dX, 4 bwd dW1, 5 bwd dW2/3, 6 / 7 bwd dH / dX with a
- * transposed weight copy, 8 bwd dW1 with the fused gather; 16 + op: one-plane (bf16) tile of gemm_x3.hip for that call site
- * (0 = automatic), 32: its grouped dW2/dW3 launch, 33: the grouped dW1/dW2/dW3 launch of dpd_decoder_bwd_weights_trio.  tile as in
- * dpd_gemm_f32 (0 = auto); split_k applies to ops 4, 5, 8 and, for the plane weight gradients (ops 20, 21, 32, 33): n > 1 = n K slices
- * per tile reduced inside the launch (last-arriving slice, slice order: deterministic), n < -1 = |n| fp32 slabs + a reduce launch,
- * 1 = off, 0 = automatic.  op 48 / 49: the chained persistent launch of the one-plane forward (layers 1 -> 2 -> 3) / data-gradient chain
- * (g3 -> g2 -> g1), see dpd_planes.sync: tile 0 = off (separate launches; the default: measured faster), 1 = automatic, 21 / 23 = force the
- * 256x128 / 128x128 tile.
+ * transposed weight copy; 16 + op: one-plane (bf16) tile of gemm_x3.hip for that call site (0 = automatic; 1-5 ring kernels, 13 =
+ * 192x128 at BK 64, 21 / 23 / 24 phase-staggered), 32: its grouped dW2/dW3 launch, 33: the grouped dW1/dW2/dW3 launch of
+ * dpd_decoder_bwd_weights_trio.  tile as in dpd_gemm_f32 (0 = auto); split_k applies to ops 4, 5 and, for the plane weight gradients
+ * (ops 20, 21, 32, 33): n > 1 = n K slices per tile reduced inside the launch (last-arriving slice, slice order: deterministic),
+ * n < -1 = |n| fp32 slabs + a reduce launch, 1 = off, 0 = automatic.
  * Defaults are the measured best.                                                                                        */
 int dpd_set_gemm_plan(int op, int tile, int split_k);
 

@@ -45,7 +45,7 @@ def test_header_compiles_as_c_and_cxx(tmp_path, cc, std, ext):
         pytest.skip(cc + " not installed")
     tu = tmp_path / ("tu" + ext)
     tu.write_text('#include "dpdist_capi.h"\n'
-                  'int use(const dpd_planes* p, const dpd_decoder_params* d, const dpd_small_grads* s, const dpd_gather* g)\n'
+                  'int use(const dpd_planes* p, const dpd_decoder_params* d, const dpd_small_grads* s, const dpd_asloss* g)\n'
                   '{ return p && d && s && g ? (int)DPD_BF16 + DPD_E_NULL + (int)sizeof(dpd_planes) : DPD_OK; }\n')
     r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                         "-I", os.path.join(ROOT, "include"), str(tu)], capture_output=True, text=True)
@@ -168,8 +168,7 @@ def test_asloss_engine_carve_is_a_partition_of_the_callers_buffer(lib, B, N, H, 
         pl = e.planes
         for name, size in (("X_rc", np_ * 2 * Q * KP), ("h1_rc", np_ * 2 * Q * H), ("h2_rc", np_ * 2 * Q * H), ("g3_rc", np_ * 2 * Q * H),
                            ("g2_rc", np_ * 2 * Q * H), ("g1_rc", np_ * 2 * Q * H), ("W1_r8", np_ * 2 * KP * H), ("W1_rc", np_ * 2 * KP * H),
-                           ("W2_r8", np_ * 2 * H * H), ("W3_r8", np_ * 2 * H * H), ("W2_rc", np_ * 2 * H * H), ("W3_rc", np_ * 2 * H * H),
-                           ("sync", 4096)):
+                           ("W2_r8", np_ * 2 * H * H), ("W3_r8", np_ * 2 * H * H), ("W2_rc", np_ * 2 * H * H), ("W3_rc", np_ * 2 * H * H)):
             spans["planes." + name] = size
         assert not pl.X_r8 and not pl.h1_r8 and not pl.g3_r8          # as-loss mode feeds no weight gradients: RC planes only
     else:

@@ -161,16 +161,10 @@ def test_patch_rows_backward_is_transpose(dev):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM building block
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 34, 35, 36, 37])
+@pytest.mark.parametrize("tile", [3, 8, 9, 30, 31, 32, 33])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
 def test_gemm_f32(dev, tile, mode):
     from dpdist_amd import lib as L, ops
-    if tile in (5, 6, 7, 10, 11, 12, 13, 14):
-        # ring configurations that no plan uses: compiled only into a DPD_ABLATIONS=1 build (A/B references of the tuning tools)
-        x = torch.zeros(64, 64, device=dev)
-        if L.load().dpd_gemm_f32(0, 0, 64, 64, 64, L.ptr(x), 64, L.ptr(x), 64, L.ptr(x), 64, None, None, 0, 1, tile, None, 0,
-                                 L.cur_stream()) == -3:
-            pytest.skip("tile %d is an ablation-build configuration" % tile)
     rng = np.random.default_rng(10)
     M, N, K = 328, 196, 224            # ragged in M and N against every tile size; asymmetric operands catch transposes
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -195,7 +189,7 @@ def test_gemm_layer1_shape_is_fmaf_exact(dev):
     rng = np.random.default_rng(11)
     A = rng.standard_normal((512, 2528)).astype(np.float32) * 0.05
     W = rng.standard_normal((2528, 1024)).astype(np.float32) * 0.3
-    c = ops.gemm_f32(_cu(A, dev), _cu(W, dev), tile=4).cpu().numpy()
+    c = ops.gemm_f32(_cu(A, dev), _cu(W, dev), tile=32).cpu().numpy()
     ref = A.astype(np.float64) @ W.astype(np.float64)
     assert np.abs(c - ref).max() <= 5e-5
 
@@ -546,18 +540,18 @@ def test_split_planes_reconstruct_exactly(dev):
     assert torch.equal(r8_as_rc, rc)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 13])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN", "TNr"])
 @pytest.mark.parametrize("np_", [3, 1])
 def test_gemm_planes(dev, np_, mode, tile):
     """Split-bf16 GEMM against fp64: the 3-plane / 6-term form must be at least as accurate as the exact-fp32 MFMA
     GEMM on the same operands (fp32-equivalent); the 1-plane form is a plain bf16 GEMM (2^-8 operand rounding)."""
     from dpdist_amd import lib as L, ops
-    if tile >= 8 and np_ == 3:
-        pytest.skip("BK = 64 tiles exist for one plane only (a 3-plane stage does not fit the LDS)")
+    if tile == 13 and np_ == 3:
+        pytest.skip("the BK = 64 tile exists for one plane only (a 3-plane stage does not fit the LDS)")
     if mode == "TNr" and tile not in (1, 2, 3, 5):
         pytest.skip("the transpose-read TN form (both operands as RC planes) exists for tiles 1, 2, 3, 5")
-    M, N, K = 200, 328, 576 if tile >= 8 else 544   # ragged M (clamped rows), N % 8 == 0, K a whole number of K-tiles
+    M, N, K = 200, 328, 576 if tile == 13 else 544   # ragged M (clamped rows), N % 8 == 0, K a whole number of K-tiles
     g = torch.Generator().manual_seed(tile * 10 + np_)
     A = torch.randn(M, K, generator=g).to(dev)
     B = torch.randn(K, N, generator=g).to(dev)
@@ -597,12 +591,12 @@ def _bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float64)
 
 
-@pytest.mark.parametrize("tile", [20, 21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("tile", [21, 23, 24])
 @pytest.mark.parametrize("mode", ["NN", "NT", "TN"])
 @pytest.mark.parametrize("K", [32, 64, 96, 128, 160, 544, 576, 2528])
 def test_gemm_planes_phase_staggered(dev, mode, tile, K):
     """gemm_p8_kernel (two wave groups one barrier apart, three whole K-tiles of LDS, zero chunks beyond a K that ends inside a
-    K-tile; tiles 20-23: one bf16 plane at BK = 64, tiles 24-26: three planes at BK = 32) against float64: for one plane the EXACT
+    K-tile; tiles 21 / 23: one bf16 plane at BK = 64, tile 24: three planes at BK = 32) against float64: for one plane the EXACT
     product of the bf16-rounded operands (fp32 accumulation is ~1e-6 relative: a chunk read before its LDS-DMA landed, a stale
     stage or a missing zero fill is an O(1) error), for three planes the fp32-equivalence bar of test_gemm_planes.
     K covers 1 .. 5 half/whole K-tiles (prologue / drain corner cases), the unrolled-by-three steady state with and without a
@@ -642,7 +636,7 @@ def test_gemm_planes_phase_staggered(dev, mode, tile, K):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("tile", [20, 21, 24])
+@pytest.mark.parametrize("tile", [21, 24])
 def test_gemm_planes_phase_staggered_full_size_is_stable(dev, tile):
     """The layer-1 shape of BASELINE config 3 (8192 x 1024 x 2528; tile 24: the B = 32 shape 4096 x 1024 x 2528 in three planes; one
     workgroup per CU) ten times under a memory-hungry side stream: identical bits every time and the right product."""
@@ -835,13 +829,13 @@ def test_bf16_step_vs_oracle_b64(dev):
         assert abs(np.linalg.norm(a) / (np.linalg.norm(b) + 1e-30) - 1.0) <= 0.02, n
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 5, 20, 22, 24])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 21, 23, 24])
 @pytest.mark.parametrize("np_", [3, 1])
 def test_gemm_planes_fused_outputs(dev, np_, tile):
     """The LDS-staged epilogue writes the result as operand planes: bit-identical to splitting the fp32 result."""
     from dpdist_amd import lib as L
     if tile >= 20 and (np_ == 3) != (tile >= 24):
-        pytest.skip("phase-staggered tiles 20-23 take one plane, 24-26 three")
+        pytest.skip("phase-staggered tiles 21 / 23 take one plane, 24 three")
     M, N, K, R8 = 320, 264, 96, 192
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).to(dev)
@@ -894,15 +888,11 @@ def test_patch_rows_planes_match_split(dev, np_):
     assert torch.equal(got_r8, want_r8)
 
 
-@pytest.mark.parametrize("fused_gather", [False, True])
-def test_prefetch_pipeline_is_bitwise_equivalent(dev, fused_gather, monkeypatch):
+def test_prefetch_pipeline_is_bitwise_equivalent(dev):
     """Running the next batch's encoder + gather on the side stream must not change a single bit of the weights
-    (except through the fp32 atomics of db1/db2, which are excluded by comparing the GEMM-produced tensors).
-    fused_gather (DPD_FUSED_GATHER=1): there the current step's backward reads mask / fv / xyz / rowinfo until dW1 is done, so
-    the WHOLE prefetched front end has to wait for it (round-2 advisor finding: only the gather waited)."""
+    (except through the fp32 atomics of db1/db2, which are excluded by comparing the GEMM-produced tensors)."""
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer
-    monkeypatch.setenv("DPD_FUSED_GATHER", "1" if fused_gather else "0")
     B = 8
     batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100 + i)) for i in range(4)]
     W0 = synth.make_weights("wide")
@@ -911,7 +901,6 @@ def test_prefetch_pipeline_is_bitwise_equivalent(dev, fused_gather, monkeypatch)
         P = DPDistParams(device=dev)
         P.load_tf_state_dict(W0)
         tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
-        assert tr.fused == fused_gather
         losses = []
         for i, (a, b, l) in enumerate(batches):
             nxt = batches[i + 1][:2] + (None,) if (use_prefetch and i + 1 < len(batches)) else None
@@ -967,7 +956,6 @@ def test_data_parallel_schedule_matches_plain_backward(dev, dt, buckets, backend
     one collective per bucket; exercised here with a single-rank process group) produces the same gradients as the plain
     schedule.  backend "rccl": ddp.DirectRcclReducer (librccl through ctypes: early buckets on a side stream behind events without
     the system fence, the last bucket on the compute stream itself); "torch": ddp.BucketReducer over torch.distributed."""
-    monkeypatch.setenv("DPD_DP_BUCKETS", buckets)
     monkeypatch.setenv("DPD_DP_BACKEND", backend)
     import torch.distributed as dist
     from dpdist_amd.model import DPDistParams
@@ -986,7 +974,7 @@ def test_data_parallel_schedule_matches_plain_backward(dev, dt, buckets, backend
             os.environ["DPD_FORCE_DIST"] = "1" if mode == "dp" else "0"
             P = DPDistParams(device=dev, compute_dtype=dt)
             P.load_tf_state_dict(W0)
-            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=(mode == "dp"))
+            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=(mode == "dp"), options={"dp_buckets": int(buckets)})
             assert (tr.reducer is not None and tr.reducer.active) == (mode == "dp")
             if mode == "dp":
                 assert type(tr.reducer).__name__ == ("DirectRcclReducer" if backend == "rccl" else "BucketReducer")
@@ -1021,9 +1009,8 @@ def _single_rank_group(dev, port):
     return own
 
 
-@pytest.mark.parametrize("backend,two,mode", [("rccl", "0", "allreduce"), ("rccl", "1", "allreduce"), ("rccl", "0", "zero1"),
-                                              ("torch", "0", "allreduce"), ("torch", "0", "zero1"), ("torch", "0", "rs_ag")])
-def test_reducer_startup_crosscheck_and_rank_count(dev, backend, two, mode, monkeypatch):
+@pytest.mark.parametrize("backend,mode", [("rccl", "allreduce"), ("rccl", "zero1"), ("torch", "allreduce"), ("torch", "zero1"), ("torch", "rs_ag")])
+def test_reducer_startup_crosscheck_and_rank_count(dev, backend, mode, monkeypatch):
     """ddp.make_reducer: every reducer form reduces a known integer pattern (exact in any summation order) with the trainer's call
     sequence and must return the closed-form sum BIT FOR BIT, next to a plain torch.distributed all-reduce of the same pattern;
     the direct reducer reports its rank count from ncclCommCount; the gradient buffer is left untouched.  (Single-rank group on a
@@ -1031,7 +1018,6 @@ def test_reducer_startup_crosscheck_and_rank_count(dev, backend, two, mode, monk
     import torch.distributed as dist
     from dpdist_amd import ddp
     monkeypatch.setenv("DPD_DP_BACKEND", backend)
-    monkeypatch.setenv("DPD_DP_TWO_COMMS", two)
     monkeypatch.setenv("DPD_DP_MODE", mode)
     own = _single_rank_group(dev, 29641)
     try:
@@ -1041,7 +1027,6 @@ def test_reducer_startup_crosscheck_and_rank_count(dev, backend, two, mode, monk
         assert red.active and red.backend == (backend if mode != "rs_ag" else "torch") and red.mode == mode
         assert red.crosscheck["ok"] and red.crosscheck["reducer_bitwise"] and red.crosscheck["torch_all_reduce_bitwise"]
         assert red.crosscheck["elements"] == 5000 and red.nranks == 1 and red.wire_bytes_per_step == 0
-        assert bool(getattr(red, "two_comms", False)) == (two == "1")
         assert torch.equal(flat, keep)
         red.measure = True                       # exposed-communication probe: event pairs around the compute stream's waits
         for _ in range(2):
@@ -1102,7 +1087,7 @@ def test_zero1_sharded_optimizer_step_is_bitwise_replicated_adam(dev, dt, backen
 @pytest.mark.parametrize("backend", ["rccl", "torch"])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_optimizer_on_the_collective_stream_is_the_joined_step(dev, dt, backend, monkeypatch):
-    """DPD_DP_ADAM_SIDE=1: in a data-parallel step Adam runs on the stream the collectives ran on and the compute stream is joined only
+    """adam_on_side: in a data-parallel step Adam runs on the stream the collectives ran on and the compute stream is joined only
     where the next step first reads the weights (after its encoder + window gather).  Four steps on alternating batches, with a
     memory-hungry kernel train on the compute stream in between, give the parameters, Adam slots and losses of the joined form
     (f32: bit for bit); reading the weights through the trainer (evaluate, tf_global_variables) joins by itself."""
@@ -1119,11 +1104,9 @@ def test_optimizer_on_the_collective_stream_is_the_joined_step(dev, dt, backend,
     res = {}
     try:
         for side in ("0", "1"):
-            monkeypatch.setenv("DPD_DP_ADAM_SIDE", side)
             P = DPDistParams(device=dev, compute_dtype=dt)
             P.load_tf_state_dict(W0)
-            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=True)
-            assert tr.adam_on_side == (side == "1")
+            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=True, adam_on_side=(side == "1"))
             losses = []
             for i in range(4):
                 losses.append(tr.step(*batches[i % 2]).clone())
@@ -1305,7 +1288,7 @@ def test_fused_as_loss_node_equals_module_contract(dev, golden_dir):
 def test_as_loss_node_on_persistent_planes(dev, dt, golden_dir, monkeypatch):
     """The as-loss node of the plane compute types (round 4): rows / h1 / h2 / g3 / g2 / g1 as bf16 RC planes written by their
     producers, the frozen weights' planes cached on the parameter object -- against the round-3 form that converted both operands of
-    every GEMM (DPD_ASLOSS_PLANES=0): same loss and input gradients (the planes hold the same bits); f32x3 also against the oracle's
+    every GEMM (asloss.PLANES = False): same loss and input gradients (the planes hold the same bits); f32x3 also against the oracle's
     float64 autograd at the bars of the exact type; two evaluations may be alive before either backward runs; a change of the
     weights re-derives the cached weight planes."""
     from dpdist_amd import model as M
@@ -1314,9 +1297,9 @@ def test_as_loss_node_on_persistent_planes(dev, dt, golden_dir, monkeypatch):
     B = 16
     pcA, pcB, _ = synth.s2_modelnet_shaped(B, 64, 100)
     res = {}
-    monkeypatch.setenv("DPD_ASLOSS_ENGINE", "0")          # the plane NODE (model._AsLossFn on ops.AsLossPlanes); the engine has its own tests
+    monkeypatch.setattr("dpdist_amd.asloss.ENGINE", False)          # the plane NODE (model._AsLossFn on ops.AsLossPlanes); the engine has its own tests
     for planes in ("0", "1"):
-        monkeypatch.setenv("DPD_ASLOSS_PLANES", planes)
+        monkeypatch.setattr("dpdist_amd.asloss.PLANES", planes == "1")
         mod = _model(dev, "wide")
         mod.params_.compute_dtype = dt
         fn = M.DPDistLoss(mod)
@@ -1382,46 +1365,10 @@ def test_out_asloss_equals_the_three_kernel_chain(dev, B, N, H):
     assert torch.equal(y2, y0) and torch.equal(pred2, p0)
 
 
-@pytest.mark.parametrize("dt,B", [("bf16", 64), ("f32x3", 32), ("bf16", 8), ("f32", 32), ("f32", 4)])
-def test_lds_window_gather_is_bitwise_the_row_wise_kernels(dev, dt, B, monkeypatch):
-    """The window gather of round 3 stages the cloud's scaled Fisher vector once per workgroup in LDS (planes: patch_rows_planes_lds_kernel,
-    fp32 rows: patch_rows_fwd_lds_kernel).  Same products, same rounding: X / the operand planes, mask and voxel ids are bit for bit those
-    of the row-wise kernels (DPD_GATHER_PLANES_V2 / DPD_GATHER_ROWS_V1), including rows whose query lies outside the grid and windows
-    that stick out of it."""
-    from dpdist_amd.model import DPDistParams
-    from dpdist_amd.trainer import DPDistTrainer
-    P = DPDistParams(device=dev, compute_dtype=dt)
-    P.load_tf_state_dict(synth.make_weights("wide"))
-    tr = DPDistTrainer(P, B, 64)
-    pcA, pcB, _ = [_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100, tilt_deg=20.0)]
-    pcA[0, :3] += 5.0                     # three queries outside the grid (mask 0)
-    pcB[-1, :5] = pcB[-1, :5] * 0.0 + 0.79      # and a few in a corner cell (windows clipped on three sides)
-    tr._take_front(pcA, pcB, None)
-    buf = tr._plane_mem if tr._planes is not None else tr.X
-
-    def run(old):
-        for k in ("DPD_GATHER_PLANES_V2", "DPD_GATHER_ROWS_V1"):
-            if old:
-                monkeypatch.setenv(k, "1")
-            else:
-                monkeypatch.delenv(k, raising=False)
-        buf.zero_(); tr.mask.fill_(-1.0); tr.vox.fill_(-1)
-        tr._gather()
-        torch.cuda.synchronize()
-        return buf.clone(), tr.mask.clone(), tr.vox.clone()
-
-    new, old = run(False), run(True)
-    assert int((new[1] == 0).sum()) >= 3 and int((new[0] != 0).sum()) > 0
-    for a, b in zip(new, old):        # bit patterns: the cloud whose points were moved out of the grid is NaN in both (the reference's 0/0)
-        ai = a.view(torch.int32) if a.dtype == torch.float32 else a
-        bi = b.view(torch.int32) if b.dtype == torch.float32 else b
-        assert torch.equal(ai, bi)
-
-
-def test_bf16_step_with_layer3_activation_as_a_plane(dev, monkeypatch):
+def test_bf16_step_with_layer3_activation_as_a_plane(dev):
     """DPD_BF16 training steps keep layer 3's activation as ONE bf16 plane (dpd_planes.h3_rc: written by the layer-3 GEMM, read by the
     fused output-layer kernel) instead of fp32.  It rounds the output layer's input like every other activation of this compute type:
-    against the fp32-h3 form (DPD_H3_PLANE=0) the losses of five steps agree to 2e-3 relative and the weights to the bf16 bar; the
+    against the fp32-h3 form (options["h3_plane"] = False) the losses of five steps agree to 2e-3 relative and the weights to the bf16 bar; the
     plane form is the one that runs by default, and evaluation-mode forwards (output layer wanted) still produce the fp32 h3."""
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer
@@ -1430,10 +1377,9 @@ def test_bf16_step_with_layer3_activation_as_a_plane(dev, monkeypatch):
     W0 = synth.make_weights("wide")
     res = {}
     for v in ("1", "0"):
-        monkeypatch.setenv("DPD_H3_PLANE", v)
         P = DPDistParams(device=dev, compute_dtype="bf16")
         P.load_tf_state_dict(W0)
-        tr = DPDistTrainer(P, B, 64)
+        tr = DPDistTrainer(P, B, 64, options={"h3_plane": v == "1"})
         losses = []
         for b in batches:
             losses.append(tr.step(*b).clone())
@@ -1449,48 +1395,11 @@ def test_bf16_step_with_layer3_activation_as_a_plane(dev, monkeypatch):
     assert np.abs(wa - wb).max() <= 2e-3          # five Adam steps of 1e-4: the signs of a few tiny gradients may differ, nothing more
 
 
-def test_adam_in_the_weight_gradient_epilogue_is_bitwise_the_optimizer_kernel(dev, monkeypatch):
-    """Single-GPU exact-fp32 steps apply Adam to W1p / W2 / W3 inside the epilogue of their weight-gradient GEMMs
-    (dpd_decoder_bwd_weights*_adam) and leave the optimizer launch the biases and the output layer.  Same adam_one on the same
-    gradient values: parameters, both moments, the transposed copies and the losses are bit for bit those of DPD_ADAM_IN_DW=0,
-    four steps long (the schedule's lr_t changes every step), also when the gradients are stored as well (DPD_KEEP_GRAD=1)."""
-    from dpdist_amd.model import DPDistParams
-    from dpdist_amd.trainer import DPDistTrainer
-    from dpdist_amd import lib as Lb
-    B = 32
-    batches = [tuple(_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 300 + i)) for i in range(4)]
-    W0 = synth.make_weights("wide")
-    outs = []
-    forms = [("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("0", "0", "1")]
-    if Lb.load().dpd_has_adam_epilogue() != 1:      # the epilogue form lives in the ablation build only (gemm_shared.h: DPD_ADAM_EPI)
-        forms = [f for f in forms if f[0] == "0"]
-    for in_dw, keep, early in forms:
-        # (the last form: Adam for W1p on a side stream right after dW1, under the dW2 + dW3 GEMM; opt-in as well)
-        monkeypatch.setenv("DPD_ADAM_IN_DW", in_dw)
-        monkeypatch.setenv("DPD_KEEP_GRAD", keep)
-        monkeypatch.setenv("DPD_ADAM_W1_EARLY", early)
-        P = DPDistParams(device=dev)
-        P.load_tf_state_dict(W0)
-        tr = DPDistTrainer(P, B, 64)
-        assert tr.adam_in_dw == (in_dw == "1") and tr.adam_w1_early == (early == "1")
-        losses = [tr.step(*b).clone() for b in batches]
-        torch.cuda.synchronize()
-        outs.append((P.flat.detach().clone(), tr.m_state.clone(), tr.v_state.clone(), tr.W2T.clone(), tr.W3T.clone(), torch.stack(losses),
-                     tr.grad.clone()))
-    ref = outs[0]
-    for o in outs[1:]:
-        for a, b in zip(ref[:6], o[:6]):
-            assert torch.equal(a, b)
-    if len(outs) == 4:
-        assert torch.equal(ref[6], outs[2][6])          # DPD_KEEP_GRAD=1: the stored gradients are the ones the kernel form stores
-    assert torch.equal(ref[3], P.view("W2", ref[0]).t().contiguous())     # and the transposed copy is the transpose of the new W2
-
-
 @pytest.mark.parametrize("dt", ["f32x3", "bf16"])
 def test_plane_step_without_fp32_copies_is_bitwise_the_step_with_them(dev, dt, monkeypatch):
     """Plane compute types (round 3): fp32 h1 / h2 / g1 / g2 / g3 are not written at all -- layers 2/3 and the weight gradients read
     the bf16 planes, the backward's ReLU gate is taken from the plane (EPI_GATE / gate16), g3 leaves the fused output-layer backward
-    as planes.  DPD_KEEP_F32_H=1 keeps the copies (and the separate g3 conversion launch): same planes, same GEMM results (up to the order of the
+    as planes.  options["keep_f32_h"] keeps the copies (and the separate g3 conversion launch): same planes, same GEMM results (up to the order of the
     fp32-atomic bias-gradient sums these compute types use either way), three optimizer steps long; also through the data-parallel kernel order (single-rank RCCL group), whose weight-gradient calls differ."""
     import torch.distributed as dist
     from dpdist_amd.model import DPDistParams
@@ -1507,11 +1416,10 @@ def test_plane_step_without_fp32_copies_is_bitwise_the_step_with_them(dev, dt, m
         for dp in (False, True):
             outs = []
             for keep in ("1", "0"):
-                monkeypatch.setenv("DPD_KEEP_F32_H", keep)
                 monkeypatch.setenv("DPD_FORCE_DIST", "1" if dp else "0")
                 P = DPDistParams(device=dev, compute_dtype=dt)
                 P.load_tf_state_dict(W0)
-                tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=dp)
+                tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=dp, options={"keep_f32_h": keep == "1"})
                 assert (tr.h1 is None) == (keep == "0") and (tr.g3 is None) == (keep == "0")
                 losses = [tr.step(*b).clone() for b in batches]
                 torch.cuda.synchronize()
@@ -1589,112 +1497,6 @@ def test_integration_md_stub_runs_as_written(dev, golden_dir, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------ fused window gather (K2)
-@pytest.mark.parametrize("m,k", [(8, 5), (5, 3)])
-def test_fused_gather_is_bitwise_the_materialised_rows(dev, m, k):
-    """Layer 1 and dW1 with the window gather fused into the GEMM's A operand (csrc/gemm_rs.h, ASRC 1 / 2) against the SAME
-    register-streamed kernels run on the materialised X [Q,KP] of dpd_patch_rows_fwd (itself bit-exact against the oracle,
-    test_patch_rows_bit_exact): identical contraction order -> identical bits.  Boundary clouds put queries on cell edges,
-    outside the cube (masked rows gather voxel 0) and next to the grid border (out-of-grid neighbours = zero padding)."""
-    from dpdist_amd import lib as L, ops
-    lib = L.load()
-    B, N, H = 4, 64, 128
-    pcA, pcB = synth.boundary_cloud(B, N, seed=7)
-    pcA2, pcB2 = synth.s1_random_patches(B, N, 3)
-    pcA = np.concatenate([pcA[:2], pcA2[:2]]); pcB = np.concatenate([pcB[:2], pcB2[:2]])
-    a, b = _cu(pcA, dev), _cu(pcB, dev)
-    C, Q, G = 2 * B, 2 * B * N, m ** 3
-    KP = ops.padded_width(k)
-    # unfused reference path
-    pts0, q0 = ops.stack_clouds(a, b, None)
-    fv0 = ops.mfv3d_fwd(pts0, m, 0.125)
-    X, mask0, vox0 = ops.patch_rows_fwd(q0, fv0, m, k, KP)
-    # fused sources
-    fvx = torch.empty(C * G * 20 + Q * 4, device=dev)
-    fv, xyz = fvx[:C * G * 20].view(C, G, 20), fvx[C * G * 20:].view(Q, 4)
-    pts, mask, vox = torch.empty(C, N, 3, device=dev), torch.empty(Q, device=dev), torch.empty(Q, device=dev, dtype=torch.int32)
-    rowinfo = torch.empty(Q, 2, device=dev, dtype=torch.int32)
-    ktab = torch.empty(KP // 4, 2, device=dev, dtype=torch.int32)
-    L.check(lib.dpd_gather_table(m, k, KP, L.ptr(ktab), L.cur_stream()), "dpd_gather_table")
-    L.check(lib.dpd_front(L.ptr(a), L.ptr(b), None, B, N, m, k, L.ptr(pts), None, L.ptr(mask), L.ptr(vox), L.ptr(xyz), L.ptr(rowinfo),
-                          L.cur_stream()), "dpd_front")
-    fv.copy_(ops.mfv3d_fwd(pts, m, 0.125))
-    assert torch.equal(pts, pts0) and torch.equal(mask, mask0) and torch.equal(vox, vox0)
-    E = k ** 3 * 20
-    assert torch.equal(xyz[:, :3], X[:, E:E + 3]) and not xyz[:, 3].any()
-    g = torch.Generator().manual_seed(3)
-    W = [(torch.randn(KP, H, generator=g) * 0.3).to(dev), (torch.randn(H, H, generator=g) * 0.1).to(dev),
-         (torch.randn(H, H, generator=g) * 0.1).to(dev), (torch.randn(H, 3, generator=g) * 0.3).to(dev)]
-    bs = [torch.randn(H, generator=g).to(dev) * 0.1 for _ in range(3)] + [torch.randn(3, generator=g).to(dev)]
-    params = (W[0], bs[0], W[1], bs[1], W[2], bs[2], W[3], bs[3])
-    gs = L.Gather(fv.data_ptr(), xyz.data_ptr(), rowinfo.data_ptr(), ktab.data_ptr(), C, G)
-    h = [torch.empty(Q, H, device=dev) for _ in range(3)]
-    y, pred = torch.empty(Q, 3, device=dev), torch.empty(Q, 3, device=dev)
-    L.check(lib.dpd_decoder_fwd_gather(gs, L.ptr(mask), Q, KP, H, L.make_params(*params), L.ptr(h[0]), L.ptr(h[1]), L.ptr(h[2]), L.ptr(y),
-                                       L.ptr(pred), L.cur_stream()), "dpd_decoder_fwd_gather")
-    ref1 = ops.gemm_f32(X, W[0], bias=bs[0], epilogue=2, tile=32)
-    assert torch.equal(h[0], ref1)
-    h1r, h2r, h3r, yr, predr = ops.decoder_fwd(X, mask0, params, H)
-    assert torch.equal(pred, predr) and torch.equal(h[2], h3r)
-    # dW1 = X^T g1 over the first Qb rows
-    Qb = Q // 2
-    g1 = torch.randn(Qb, H, generator=g).to(dev)
-    dW = torch.empty(KP, H, device=dev)
-    for op_tile, split in ((33, 1), (30, 1), (31, 2)):     # wave tiles 32x32 / 64x64 / 64x32, with and without split-K slabs
-        ops.set_gemm_plan(8, op_tile, split)
-        ws = torch.empty(max(split, 1) * KP * H, device=dev)
-        dW = torch.empty(KP, H, device=dev)
-        L.check(lib.dpd_decoder_bwd_weights_gather(gs, L.ptr(g1), Qb, KP, H, L.ptr(dW), L.ptr(ws), ws.numel() * 4, L.cur_stream()),
-                "dpd_decoder_bwd_weights_gather")
-        refd = ops.gemm_f32(X[:Qb], g1, transA=True, tile=33, split_k=split)
-        assert torch.equal(dW, refd), (op_tile, split)
-    ops.set_gemm_plan(8, 30, 3)
-    assert not dW[E + 3:].any()                       # zero-pad columns of X -> zero rows of dW1
-
-
-def test_fused_trainer_matches_unfused(dev, monkeypatch):
-    """The default f32 trainer (fused gather, no X buffer) and the DPD_FUSED_GATHER=0 trainer produce the same weights."""
-    from dpdist_amd.model import DPDistParams
-    from dpdist_amd.trainer import DPDistTrainer
-    B = 4
-    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
-    outs = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DPD_FUSED_GATHER", fused)
-        P = DPDistParams(device=dev)
-        P.load_tf_state_dict(synth.make_weights("wide"))
-        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
-        assert tr.fused == (fused == "1") and (tr.X is None) == tr.fused
-        losses = [tr.step(pcA, pcB, lab).clone() for _ in range(3)]
-        outs.append((torch.stack(losses), P.flat.detach().clone()))
-    assert torch.equal(outs[0][0][0], outs[1][0][0])                       # first step: same bits
-    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-6
-    assert (outs[0][1] - outs[1][1]).abs().mean().item() <= 1e-6         # later steps: db1/db2 atomics order only
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode,tile,shape", [("TN", 33, (2528, 1024, 2048)), ("TN", 33, (1024, 1024, 2048)), ("NN", 32, (4096, 1024, 1024)),
-                                             ("TN", 33, (2496, 1024, 512))])
-def test_xcd_blocked_tile_map_is_bitwise_the_default_map(dev, mode, tile, shape):
-    """dpd_set_gemm_plan(40, 2): the 2 x 4 XCD-blocked block -> tile map of the register-streamed fp32 GEMMs (measured: no gain, opt-in)
-    computes every tile exactly once -- same bits as the default map (a k-ordered fmaf chain per element); shapes whose tile grid
-    is not divisible by 2 x 4 keep the default map."""
-    from dpdist_amd import ops
-    M, N, K = shape
-    g = torch.Generator().manual_seed(M + K)
-    A = torch.randn((K, M) if mode == "TN" else (M, K), generator=g).to(dev)
-    Bm = torch.randn(K, N, generator=g).to(dev)
-    try:
-        ops.set_gemm_plan(40, 0, 1)
-        ref = ops.gemm_f32(A, Bm, transA=(mode == "TN"), tile=tile)
-        ops.set_gemm_plan(40, 2, 1)
-        got = ops.gemm_f32(A, Bm, transA=(mode == "TN"), tile=tile)
-    finally:
-        ops.set_gemm_plan(40, 0, 1)
-    assert torch.equal(ref, got)
-    exact = (A.double().t() if mode == "TN" else A.double()) @ Bm.double()
-    assert (got.double() - exact).abs().max().item() <= 2e-4 * exact.abs().max().item()
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [8, 32, 64])
 @pytest.mark.parametrize("dt", ["f32x3", "bf16"])
@@ -1709,12 +1511,11 @@ def test_plane_weight_gradients_in_one_grouped_launch(dev, dt, B, monkeypatch):
     res = {}
     try:
         for name, trio, tile, split in (("apart", "0", 0, 1), ("trio", "1", 0, 1), ("trio64", "1", 3, 1), ("trio_split2", "1", 2, 2),
-                                        ("trio192", "1", 13, 1), ("trio_n192", "1", 14, 1)):
-            monkeypatch.setenv("DPD_DW_TRIO", trio)
+                                        ("trio192", "1", 13, 1)):
             ops.set_gemm_plan(33, tile, split)
             P = DPDistParams(device=dev, compute_dtype=dt)
             P.load_tf_state_dict(synth.make_weights("wide"))
-            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False, options={"dw_trio": trio == "1"})
             assert tr._trio == (trio == "1")
             grads = []
             for rep in range(2):
@@ -1730,7 +1531,7 @@ def test_plane_weight_gradients_in_one_grouped_launch(dev, dt, B, monkeypatch):
             res[name] = (grads[0], losses)
     finally:
         ops.set_gemm_plan(33, 0, 1)
-    for name in ("trio", "trio64", "trio_split2", "trio192", "trio_n192"):
+    for name in ("trio", "trio64", "trio_split2", "trio192"):
         for n in ("W1p", "W2", "W3"):
             a, b = res[name][0][n], res["apart"][0][n]
             assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-9, (name, n)
@@ -1868,10 +1669,9 @@ def test_two_launch_front_end_in_the_trainer(dev, monkeypatch, dt):
     pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("DPD_FRONT2", flag)
         P = DPDistParams(device=dev, compute_dtype=dt)
         P.load_tf_state_dict(synth.make_weights("wide"))
-        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False, options={"front2": flag == "1"})
         assert tr.front2 == (flag == "1")
         losses = [tr.step(pcA, pcB, lab).clone() for _ in range(3)]
         ev = tr.evaluate(pcA, pcB, lab)[1].clone()
@@ -1889,16 +1689,15 @@ def test_two_launch_front_end_in_the_trainer(dev, monkeypatch, dt):
 @pytest.mark.parametrize("mlp", [(1024, 1024, 1024), (256, 256, 256)])
 def test_output_layer_forward_inside_its_backward_is_bitwise(dev, monkeypatch, mlp, B):
     """Training step: y / pred of BOTH directions computed inside out_bwd_fused4_kernel (dpd_small_grads.fwd_y, no out_fwd launch)
-    against the separate output-layer forward (DPD_FUSE_OUT=0): same y, pred, losses, gradients and weights, bit for bit."""
+    against the separate output-layer forward (options["fuse_out"] = False): same y, pred, losses, gradients and weights, bit for bit."""
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer
     pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("DPD_FUSE_OUT", flag)
         P = DPDistParams(mlp=mlp, device=dev)
         P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
-        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False, options={"fuse_out": flag == "1"})
         assert tr.fuse_out == (flag == "1")
         losses = [tr.step(pcA, pcB, lab).clone() for _ in range(3)]
         torch.cuda.synchronize()
@@ -1935,7 +1734,7 @@ def test_one_launch_optimizer_writes_the_weight_planes(dev, dt, mlp):
 @pytest.mark.parametrize("mlp", [(1024, 1024, 1024), (64, 64, 64), (256, 256, 256)])
 def test_one_launch_optimizer_is_bitwise_the_three_launches(dev, monkeypatch, mlp):
     """dpd_adam_tf_fused (Adam + transposed weight copies + the reduction of the output layer's block partials in ONE launch)
-    against DPD_FUSED_ADAM=0 (dpd_adam_tf, dpd_weights_transpose, small_grads_reduce): same weights, moments, gradients,
+    against options["fused_adam"] = False (dpd_adam_tf, dpd_weights_transpose, small_grads_reduce): same weights, moments, gradients,
     transposed copies and losses, bit for bit, over four steps."""
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer
@@ -1943,10 +1742,9 @@ def test_one_launch_optimizer_is_bitwise_the_three_launches(dev, monkeypatch, ml
     pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
     outs = []
     for fused in ("1", "0"):
-        monkeypatch.setenv("DPD_FUSED_ADAM", fused)
         P = DPDistParams(mlp=mlp, device=dev)
         P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
-        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False, options={"fused_adam": fused == "1"})
         assert tr.fused_adam == (fused == "1")
         assert tr._tail_ok == (mlp[0] % 256 == 0)            # the block-partial tail really takes part at H = 1024 / 256
         losses = [tr.step(pcA, pcB, lab).clone() for _ in range(4)]
@@ -2032,95 +1830,6 @@ def test_gemm_tail_split(dev, shape):
         assert same[:first_cut].all() and first_cut % 64 == 0
 
 
-# ------------------------------------------------------------------------------------------------ chained persistent launches (round 5)
-def _chain_run(tr, pcA, pcB, lab, reps=1):
-    outs = []
-    for _ in range(reps):
-        tr._take_front(pcA, pcB, None)
-        tr._decode(skip_out=True)
-        tr.backward(lab.reshape(-1))
-        torch.cuda.synchronize()
-        outs.append((tr._plane_mem[:-4096].clone(), tr.grad.clone(), tr.loss.clone()))
-    return outs
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B,tile", [(64, 21), (32, 23), (64, 23), (128, 21)])
-def test_chained_decoder_launches_are_bitwise_the_separate_launches(dev, B, tile):
-    """gemm_chain_kernel: layers 1 -> 2 -> 3 of the bf16 forward and the data-gradient chain g3 -> g2 -> g1 as ONE persistent launch each
-    (ticket queues, per-band arrival words, write-through plane stores) against the same GEMMs launched apart: every operand plane
-    (X, h1, h2, h3, g3, g2, g1: the whole plane allocation) bit for bit, under an uneven memory load on a second stream, five times over;
-    the ticket / arrival words are left zero and no poll gave up."""
-    from dpdist_amd import lib as L, ops
-    from dpdist_amd.model import DPDistParams
-    from dpdist_amd.trainer import DPDistTrainer
-    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
-    res = {}
-    side = torch.cuda.Stream()
-    junk = torch.empty(64 << 20, device=dev, dtype=torch.float32)
-    try:
-        for name, mode in (("apart", 0), ("chained", tile)):
-            ops.set_gemm_plan(48, mode, 0)
-            ops.set_gemm_plan(49, mode, 0)
-            P = DPDistParams(device=dev, compute_dtype="bf16")
-            P.load_tf_state_dict(synth.make_weights("wide"))
-            tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
-            if name == "chained":
-                with torch.cuda.stream(side):      # uneven load: a bandwidth hog that comes and goes while the chained launches run
-                    for i in range(40):
-                        junk[: (8 << 20) * (1 + i % 5)].mul_(1.0001)
-            res[name] = _chain_run(tr, pcA, pcB, lab, reps=5 if name == "chained" else 1)
-            side.synchronize()
-            if name == "chained":
-                assert L.load().dpd_planes_sync_status(tr._planes, L.cur_stream()) == 0
-                words = tr._plane_mem[-4096:].view(torch.int32)
-                assert int(words.abs().sum().item()) == 0, words.nonzero().flatten().tolist()
-    finally:
-        ops.set_gemm_plan(48, 0, 0)
-        ops.set_gemm_plan(49, 0, 0)
-    ref = res["apart"][0]
-    for i, got in enumerate(res["chained"]):
-        assert torch.equal(got[0], ref[0]), (i, int((got[0] != ref[0]).sum().item()))
-        assert torch.equal(got[2], ref[2]), i
-        # weight gradients: the same operand planes feed the same grouped launch; only the bias sums of the dH epilogues are fp32 atomics
-        assert (got[1] - ref[1]).abs().max().item() <= 2e-6 * ref[1].abs().max().item() + 1e-9
-
-
-@pytest.mark.gpu
-def test_chained_launch_reports_dirty_sync_words(dev):
-    """The ticket / arrival words must be zero at launch: garbage there is reported (the launch ends, dpd_planes_sync_status or the words
-    say so) instead of hanging, and dpd_planes_sync_reset (or the next window gather) makes the planes usable again."""
-    from dpdist_amd import lib as L, ops
-    from dpdist_amd.model import DPDistParams
-    from dpdist_amd.trainer import DPDistTrainer
-    B = 64
-    pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
-    P = DPDistParams(device=dev, compute_dtype="bf16")
-    P.load_tf_state_dict(synth.make_weights("wide"))
-    tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
-    ref = _chain_run(tr, pcA, pcB, lab)[0]                            # (separate launches: the default)
-    ops.set_gemm_plan(48, 1, 0)
-    ops.set_gemm_plan(49, 1, 0)
-    try:
-        _dirty_words_case(tr, pcA, pcB, lab, ref, L)
-    finally:
-        ops.set_gemm_plan(48, 0, 0)
-        ops.set_gemm_plan(49, 0, 0)
-
-
-def _dirty_words_case(tr, pcA, pcB, lab, ref, L):
-    tr._take_front(pcA, pcB, None)
-    tr._plane_mem[-4096:].view(torch.int32)[:256:32] = 1 << 30     # every ticket queue looks exhausted: no tile is computed
-    tr._plane_mem[: 1 << 20] = 0                                      # (poison a piece of what the forward should have rewritten)
-    tr._decode(skip_out=True)
-    torch.cuda.synchronize()
-    words = tr._plane_mem[-4096:].view(torch.int32)
-    assert int(words[:256].abs().sum().item()) == 0                   # the last workgroup out still cleans up
-    got = _chain_run(tr, pcA, pcB, lab)[0]                            # the next step (its gather zeroes the words) is right again
-    assert torch.equal(got[0], ref[0])
-    assert L.load().dpd_planes_sync_status(tr._planes, L.cur_stream()) == 0
-
-
 # ------------------------------------------------------------------------------------------------ the headline workload's backward (round 5)
 _BENCH_SHAPE_ORACLE = {}
 
@@ -2193,7 +1902,7 @@ def test_training_step_at_the_bench_shape_vs_oracle(dev, dt, B):
 @pytest.mark.parametrize("dt", ["f32", "f32x3", "bf16"])
 def test_as_loss_engine_is_bitwise_the_entry_by_entry_node(dev, dt, monkeypatch):
     """dpd_asloss_forward / dpd_asloss_backward (ONE foreign call per direction on an engine's persistent buffers) against the autograd
-    node that drives the C ABI entry by entry (DPD_ASLOSS_ENGINE=0): loss and both input gradients BIT FOR BIT at the registration
+    node that drives the C ABI entry by entry (asloss.ENGINE = False): loss and both input gradients BIT FOR BIT at the registration
     batch; forward-only evaluations under no_grad; several evaluations alive before their backwards (each holds its own engine, the
     fifth falls back to the allocating path); a node dropped without a backward frees its engine; a second backward through the same
     node works while its engine has not been re-used and raises once it has."""
@@ -2203,7 +1912,7 @@ def test_as_loss_engine_is_bitwise_the_entry_by_entry_node(dev, dt, monkeypatch)
     pcA, pcB, _ = synth.s2_modelnet_shaped(B, 64, 100)
     res = {}
     for eng in ("0", "1"):
-        monkeypatch.setenv("DPD_ASLOSS_ENGINE", eng)
+        monkeypatch.setattr("dpdist_amd.asloss.ENGINE", eng == "1")
         mod = _model(dev, "wide")
         mod.params_.compute_dtype = dt
         fn = M.DPDistLoss(mod)
@@ -2290,6 +1999,38 @@ def test_as_loss_engine_c_entry_forward_backward(dev):
         assert torch.equal(out[0], loss.detach()) and torch.equal(g1, gA) and torch.equal(g2, gB), dt
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,m,k", [(16, 64, 8, 5), (3, 100, 8, 5), (5, 33, 8, 5), (2, 64, 5, 3), (32, 64, 8, 5)])
+def test_as_loss_tail_in_three_launches_is_bitwise_the_six(dev, B, N, m, k):
+    """dpd_asloss_tail (round 6: [window-gather backward || encoder statistics] -> combine -> apply + both input gradients) against
+    dpd_patch_rows_bwd + dpd_mfv3d_bwd + dpd_asloss_combine on the same dX: the same device routines in another launch shape, so gA / gB
+    and the dfv scratch agree bit for bit, with and without an upstream scale; a cloud of fewer than 8 points is refused (the caller falls back)."""
+    from dpdist_amd import lib as L, ops
+    lib = L.load()
+    C, Q, KP = 2 * B, 2 * B * N, ops.padded_width(k)
+    pcA, pcB, _ = synth.s2_modelnet_shaped(B, N, 11)
+    pts = _cu(np.concatenate([pcA, pcB]), dev)
+    q = _cu(np.concatenate([pcB, pcA]), dev)
+    q[0, :2] += 5.0                                   # two queries outside the grid
+    fv = ops.mfv3d_fwd(pts, m, 0.125)
+    _, _, vox = ops.patch_rows_fwd(q, fv, m, k)
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    dX = (torch.randn(Q, KP, generator=g) * 1e-2).to(dev)
+    for scale in (None, torch.tensor([0.37], device=dev)):
+        _, dfv = ops.patch_rows_bwd(dX, vox, C, N, m, k, want_dq=False)
+        dpts = ops.mfv3d_bwd(pts, dfv, m, 0.125)
+        gA, gB = ops.asloss_combine(dpts, dX, scale, B, N, k)
+        ws = torch.empty(lib.dpd_mfv3d_bwd_workspace_bytes(C, m) // 4, device=dev)
+        dfv2 = torch.full_like(dfv, float("nan"))
+        gA2, gB2 = torch.full_like(gA, float("nan")), torch.full_like(gB, float("nan"))
+        L.check(lib.dpd_asloss_tail(L.ptr(dX), L.ptr(vox), L.ptr(pts), L.ptr(scale), B, N, m, k, KP, 0.125, L.ptr(dfv2), L.ptr(ws), ws.numel() * 4,
+                                    L.ptr(gA2), L.ptr(gB2), L.cur_stream()), "dpd_asloss_tail")
+        assert torch.equal(dfv2, dfv) and torch.equal(gA2, gA) and torch.equal(gB2, gB), (B, N, scale)
+    small = torch.zeros(2, 4, 3, device=dev)
+    assert lib.dpd_asloss_tail(L.ptr(dX), L.ptr(vox), L.ptr(small), None, 1, 4, m, k, KP, 0.125, L.ptr(dfv2), L.ptr(ws), ws.numel() * 4,
+                               L.ptr(gA2), L.ptr(gB2), L.cur_stream()) == -3
+
+
 # ------------------------------------------------------------------------------------------------ data-parallel schedule by measurement (round 5)
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
@@ -2371,18 +2112,17 @@ def test_data_parallel_schedule_is_selected_by_measurement(dev, dt, monkeypatch)
 def test_plane_weight_gradient_pair_on_a_narrow_decoder(dev, B, monkeypatch):
     """with a narrow decoder (H = 64) and >= 2048 gradient rows the automatic in-launch split-K of the grouped dW2 + dW3 launch
     asked for more tile-padded slab space than the base workspace holds and the call failed with DPD_E_WORKSPACE.  The split is now fitted
-    to the slab region (down to no split at all): the separate-launch backward (DPD_DW_TRIO=0: dW1, then the pair) runs and its weight
+    to the slab region (down to no split at all): the separate-launch backward (options["dw_trio"] = False: dW1, then the pair) runs and its weight
     gradients agree with the exact-fp32 trainer's to bf16 accuracy."""
     from dpdist_amd.model import DPDistParams
     from dpdist_amd.trainer import DPDistTrainer
-    monkeypatch.setenv("DPD_DW_TRIO", "0")
     mlp = (64, 64, 64)
     pcA, pcB, lab = (_cu(x, dev) for x in synth.s2_modelnet_shaped(B, 64, 100))
     grads = {}
     for dt in ("f32", "bf16"):
         P = DPDistParams(mlp=mlp, device=dev, compute_dtype=dt)
         P.load_tf_state_dict(synth.make_weights("wide", mlp=mlp))
-        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False)
+        tr = DPDistTrainer(P, B, base_lr=1e-3, distributed=False, options={"dw_trio": False})
         tr._take_front(pcA, pcB, None)
         tr._decode()
         tr.backward(lab.reshape(-1))
@@ -2546,7 +2286,7 @@ def test_as_loss_engine_on_ragged_shapes(dev, dt, B, N, monkeypatch):
     pcA, pcB, _ = synth.s2_modelnet_shaped(B, N, 11)
     res = {}
     for eng in ("0", "1"):
-        monkeypatch.setenv("DPD_ASLOSS_ENGINE", eng)
+        monkeypatch.setattr("dpdist_amd.asloss.ENGINE", eng == "1")
         mod = _model(dev, "wide")
         mod.params_.compute_dtype = dt
         a, b = _cu(pcA, dev).requires_grad_(True), _cu(pcB, dev).requires_grad_(True)

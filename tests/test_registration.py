@@ -457,17 +457,15 @@ def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(mo
     dev = torch.device("cuda:0")
 
     def run(engine, graph, fused="1", native="1"):
-        monkeypatch.setenv("DPD_ASLOSS_ENGINE", engine)
-        monkeypatch.setenv("DPD_REG_GRAPH", graph)
-        monkeypatch.setenv("DPD_POSE_FUSED", fused)
-        monkeypatch.setenv("DPD_POSE_NATIVE", native)
+        monkeypatch.setattr("dpdist_amd.asloss.ENGINE", engine == "1")
         torch.manual_seed(0)
         model = DPDistModel(device=dev)
         model.load_tf_state_dict(synth.make_weights("wide"))
         net = PoseNet().to(dev)
         torch.manual_seed(1000)
         rng = np.random.default_rng(0)
-        reg = IterativeRegistration(net, DPDistLoss(model), lr=1e-4, max_loops=8, distributed=False)
+        reg = IterativeRegistration(net, DPDistLoss(model), lr=1e-4, max_loops=8, distributed=False, graph=(graph == "1"),
+                                    fused_pose=(fused == "1"), native_refine=(native == "1"))
         losses = []
         for _ in range(12):
             src, tmpl, _ = synth.registration_pairs(16, 64, rng=rng)

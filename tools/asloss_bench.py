@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=60)     # the chip needs ~25 ms under load to reach its steady clock (tools/ramp_probe.py)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"])
+    ap.add_argument("--engine", type=int, default=1, help="0 = the entry-by-entry autograd node (dpdist_amd.asloss.ENGINE = False)")
     ap.add_argument("--plan", default="", help="GEMM plan overrides, e.g. '7:30' = op:tile[:split_k] (include/dpdist_capi.h: dpd_set_gemm_plan)")
     a = ap.parse_args()
-    from dpdist_amd import lib as Lb
+    from dpdist_amd import asloss, lib as Lb
+    asloss.ENGINE = bool(a.engine)
     for item in filter(None, a.plan.split(",")):
         f = [int(x) for x in item.split(":")]
         Lb.check(Lb.load().dpd_set_gemm_plan(f[0], f[1], f[2] if len(f) > 2 else 1), "dpd_set_gemm_plan")
@@ -58,7 +60,7 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, l
 
-    engine = os.environ.get("DPD_ASLOSS_ENGINE", "1") == "1"
+    engine = bool(a.engine)
     el, l = run(step)
     print(json.dumps({"mode": "as-loss (fwd + bwd to inputs)", "engine": engine, "batch": a.batch, "dtype": a.dtype,
                       "ms_per_step": round(el / a.steps * 1e3, 4), "query_points_per_sec": round(2 * a.batch * 64 * a.steps / el, 1),

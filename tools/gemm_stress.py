@@ -38,7 +38,7 @@ def main():
         tol = 5e-6 * K ** 0.5 * 16
         At, Bt = A.t().contiguous(), B.t().contiguous()
         cases = []
-        for tile in (8, 9, 4):      # (5, 6, 7, 10-14 exist in a DPD_ABLATIONS=1 build only)
+        for tile in (8, 9, 32):
             if mode == "NN":
                 cases.append(("f32 tile %d" % tile, lambda t=tile: ops.gemm_f32(A, B, tile=t)))
             elif mode == "NT":
@@ -94,12 +94,11 @@ def main():
     base = None
     for name, env, plans in (("apart, whole K", "0", ((20, 0, 1), (32, 3, 1))), ("grouped 192x128", "1", ((33, 13, 1),)), ("grouped 128x128", "1", ((33, 2, 1),)),
                              ("grouped 128x128 split-K 2 in launch", "1", ((33, 2, 2),)), ("apart, dW1 split-K 3 + pair split-K 2 in launch", "0", ((20, 2, 3), (32, 2, 2)))):
-        os.environ["DPD_DW_TRIO"] = env
         for op, tile, split in plans:
             ops.set_gemm_plan(op, tile, split)
         P = DPDistParams(device=dev, compute_dtype="bf16")
         P.load_tf_state_dict(synth.make_weights("wide"))
-        tr = DPDistTrainer(P, B, distributed=False)
+        tr = DPDistTrainer(P, B, distributed=False, options={"dw_trio": env == "1"})
         first, ndiff = None, 0
         for it in range(max(20, a.iters // 4)):
             if it % 2 == 0:
@@ -123,7 +122,6 @@ def main():
         bad += 0 if ok else 1
         for op, tile, split in plans:
             ops.set_gemm_plan(op, 0, 1 if op == 33 else 0)
-    os.environ.pop("DPD_DW_TRIO", None)
     print("RESULT:", "clean" if bad == 0 else "%d bad results" % bad)
     return 1 if bad else 0
 

@@ -17,7 +17,8 @@ NOCPU="--no-cpu-baseline"
 SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes"
 export TMPDIR=/tmp
 # the profiler passes must see the training step only: no spin-up GEMMs (bench.py: spinup_ms) in the traces
-PROF="env DPD_BENCH_SPINUP_MS=0 rocprofv3"
+PROF="rocprofv3"
+NOSPIN="--spinup-ms 0"
 cd /tmp
 $PROF --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes > $OUT/bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -87,7 +88,7 @@ hipcc --offload-arch=gfx950 -O3 $R/tools/ldsdma_bw.hip -o /tmp/ldsdma_bw 2>/dev/
     env $e MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 $B --steps 200 --warmup 30 $NOCPU --no-other-dtypes --no-roofline 2>/dev/null | tail -1 | line "$e" ; done; } > $OUT/dp_single_rank.txt 2>&1
 # the N > 1 skeleton on one GPU: watchdog -> fallback (injected hang), and the healthy forced-distributed line with its `dp` object
 ( cd $R; DPD_FORCE_DIST=1 DPD_WD_INJECT_HANG=timed DPD_WD_LIMITS=timed=8 MASTER_PORT=29531 $B --steps 20 --warmup 5 $NOCPU --no-other-dtypes 2> $OUT/watchdog_fallback.err | tail -1 > $OUT/watchdog_fallback.json
-  DPD_FORCE_DIST=1 DPD_BENCH_CFG4=1 DPD_DP_ADAM_SIDE=1 MASTER_PORT=29533 $B --steps 50 --warmup 10 $NOCPU 2>/dev/null | tail -1 > $OUT/bench_forced_dist_cfg4.json )
+  DPD_FORCE_DIST=1 MASTER_PORT=29533 $B --cfg4 --steps 50 --warmup 10 $NOCPU 2>/dev/null | tail -1 > $OUT/bench_forced_dist_cfg4.json )
 # row f2 / config 5 with the data-parallel plumbing on (single rank): DPDist trained, frozen, pose network registered
 ( cd $R; DPD_FORCE_DIST=1 MASTER_PORT=29535 timeout 900 python tools/registration_demo.py --loss ours 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/registration_demo.txt )
 python $R/tools/summarize_profiles.py $TAG

@@ -48,7 +48,7 @@ def main():
             sys.stderr.write("registration_demo --gpus %d: only %d GPU(s) visible\n" % (a.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0))
             raise SystemExit(2)
         raise SystemExit(bench.spawn_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                           timeout_s=float(os.environ.get("DPD_SPAWN_TIMEOUT", "3600"))))
+                                           timeout_s=3600.0))
     use_dist = world > 1 or os.environ.get("DPD_FORCE_DIST") == "1"
     from dpdist_amd import launch
     if use_dist:

@@ -81,7 +81,7 @@ def run(mode, M, N, K, np_, tile, iters=20):
 
 
 if __name__ == "__main__":
-    tiles = [int(t) for t in sys.argv[1:]] or [1, 2, 6, 7]
+    tiles = [int(t) for t in sys.argv[1:]] or [1, 2, 21, 24]
     import os
     quick = os.environ.get("QUICK")
     if os.environ.get("B64"):
