@@ -64,8 +64,8 @@ def main():
     if hasattr(lib, "dpd_asloss_tail"):
         gA2, gB2 = torch.empty_like(gA), torch.empty_like(gB)
         tail()
-        timed("tail_fused_us", lambda: L.check(lib.dpd_asloss_tail(L.ptr(dX), L.ptr(vox), L.ptr(pts), None, B, N, m, k, KP, sigma, L.ptr(gA2), L.ptr(gB2),
-                                                               L.ptr(ws), ws.numel() * 4, s), "tail"))
+        timed("tail_fused_us", lambda: L.check(lib.dpd_asloss_tail(L.ptr(dX), L.ptr(vox), L.ptr(pts), None, B, N, m, k, KP, sigma, L.ptr(dfv), L.ptr(ws),
+                                                               ws.numel() * 4, L.ptr(gA2), L.ptr(gB2), s), "tail"))
         out["fused_max_abs_diff"] = float(max((gA2 - gA).abs().max(), (gB2 - gB).abs().max()))
     print(json.dumps(out))
 

@@ -23,28 +23,33 @@ def copy(a, b):
         shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (tag, b)))
 
 
-for a, b in (("bench.json", "bench.json"), ("bench_f32x3.json", "bench_f32x3.json"), ("bench_bf16.json", "bench_bf16.json"),
-             ("bench_bf16_b64.json", "bench_bf16_b64.json"), ("bench_f32_b64.json", "bench_f32_b64.json"),
-             ("x3_bench.txt", "x3_bench.txt"), ("gemm_bench.txt", "gemm_bench.txt"), ("variants.txt", "variants.txt"),
-             ("determinism.txt", "determinism.txt"), ("bench_driver_flags.json", "bench_driver_flags.json"),
-             ("asloss_bench.txt", "asloss_bench.txt"), ("ramp_probe.txt", "ramp_probe.txt"), ("host_rate.txt", "host_rate.txt"),
-             ("ldsdma_bw.txt", "ldsdma_bw.txt"), ("dp_single_rank.txt", "dp_single_rank.txt"), ("step_timeline.txt", "step_timeline.txt"),
-             ("x3_bench_p8.txt", "x3_bench_p8.txt"), ("gather_bench.txt", "gather_bench.txt"), ("event_cost.txt", "event_cost.txt"),
-             ("launch_floor.txt", "launch_floor.txt"), ("bf16_trio_sweep.txt", "bf16_trio_sweep.txt"), ("bf16_bwd_sweep.txt", "bf16_bwd_sweep.txt"),
-             ("bf16_plan_sweep.txt", "bf16_plan_sweep.txt"), ("trio_other_configs.txt", "trio_other_configs.txt"), ("xcd_band_ab.txt", "xcd_band_ab.txt"),
-             ("overlap_probe_bf16.txt", "overlap_probe_bf16.txt"), ("watchdog_fallback.json", "watchdog_fallback.json"),
-             ("watchdog_fallback.err", "watchdog_fallback.err"), ("bench_forced_dist_cfg4.json", "bench_forced_dist_cfg4.json"),
-             ("registration_demo.txt", "registration_demo.txt"), ("mfv_stamps.txt", "mfv_stamps.txt"), ("chain_bench.txt", "chain_bench.txt"),
-             ("asloss_engine_ab.txt", "asloss_engine_ab.txt"), ("registration_engine_ab.txt", "registration_engine_ab.txt")):
-    copy(a, b)
+# every top-level text / json artefact of the round, as written
+if os.path.isdir(src):
+    for name in sorted(os.listdir(src)):
+        if os.path.isfile(os.path.join(src, name)) and name.endswith((".json", ".txt", ".err")) and not name.endswith(".out"):
+            copy(name, name)
 
 # per-kernel stats (our kernels only), one file per compute type
-for sub, out in (("stats", "kernel_stats.csv"), ("stats_f32x3", "kernel_stats_f32x3.csv"), ("stats_bf16", "kernel_stats_bf16.csv"),
-                 ("stats_bf16_b64", "kernel_stats_bf16_b64.csv")):
+raw = os.path.join(dst, "raw")
+os.makedirs(raw, exist_ok=True)
+subs = sorted(d for d in (os.listdir(src) if os.path.isdir(src) else []) if d.startswith("stats") and os.path.isdir(os.path.join(src, d)))
+for sub in subs:
+    out = "kernel_stats%s.csv" % sub[len("stats"):]
+    # the raw rocprofv3 stats (every kernel, torch's and RCCL's included) and the first 200 launches of the trace, so that the condensed
+    # file below can be re-derived without gpurun_out/
+    for kind, keep in (("kernel_stats", None), ("kernel_trace", 201)):
+        f0 = os.path.join(src, sub, "%s_%s.csv" % (tag, kind))
+        if os.path.exists(f0):
+            with open(f0) as fi, open(os.path.join(raw, "%s_%s_%s.csv" % (tag, sub, kind)), "w") as fo:
+                for n, line in enumerate(fi):
+                    if keep is not None and n >= keep:
+                        break
+                    fo.write(line)
     f = os.path.join(src, sub, "%s_kernel_stats.csv" % tag)
     if not os.path.exists(f):
         continue
-    rows = [r for r in csv.DictReader(open(f)) if mine(r["Name"])]
+    # (the registration step also runs torch / hipBLASLt kernels -- the pose network's backward: every kernel is listed there)
+    rows = [r for r in csv.DictReader(open(f)) if mine(r["Name"]) or "registration" in sub]
     with open(os.path.join(dst, "%s_%s" % (tag, out)), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent"])
@@ -85,7 +90,5 @@ def pmc_summary(prefix, stats_sub, out_name):
 
 
 pmc_summary("pmc_", "stats", "pmc_summary.csv")
-pmc_summary("pmc_f32x3_", "stats_f32x3", "pmc_summary_f32x3.csv")
-pmc_summary("pmc_bf16_", "stats_bf16", "pmc_summary_bf16.csv")
 pmc_summary("pmc_bf16_b64_", "stats_bf16_b64", "pmc_summary_bf16_b64.csv")
 print("wrote", sorted(x for x in os.listdir(dst) if x.startswith(tag)))
