@@ -150,7 +150,7 @@ def supervise(argv, rank, world, log=sys.stderr):
                 pass
     else:                   # a directory name can repeat (PID and port reuse): markers of a launch long gone must not decide this one.  The ranks
         for f in os.listdir(d):    # of one launch start within seconds of each other, so nothing of THIS launch is two minutes old yet
-            if f.split(".")[0] in ("fail", "port", "ok"):
+            if f.split(".")[0] in ("fail", "port", "ok", "reported"):
                 try:
                     if os.path.getmtime(os.path.join(d, f)) < time.time() - 120.0:
                         os.unlink(os.path.join(d, f))
@@ -220,9 +220,18 @@ def supervise(argv, rank, world, log=sys.stderr):
         if attempt == 1 and os.environ.get("DPD_DP_BACKEND", "rccl") == "torch" and os.environ.get("DPD_WD_RETRY_SAME", "0") != "1":
             # the conservative backend itself failed: a retry would run the same thing again
             break
+    # Rank 0's line must be out before ANY supervisor exits with a failure code: the launcher (bench.spawn_ranks, torchrun) stops the
+    # other ranks the moment one of them fails, and a rank-0 supervisor stopped before its print loses the only record of the launch
+    # (seen under host load in tests/test_ddp_gloo.py: the line was missing once in three runs)
+    reported = os.path.join(d, "reported")
     if rank == 0:
         print(json.dumps({"metric": "query-points/sec (DPDist fwd+bwd)", "value": None, "unit": "query-points/sec", "n_gpus": world,
                           "error": "data-parallel launch failed on both collective backends", "watchdog": history}), flush=True)
+        _write_atomic(reported, "%.3f\n" % time.time())
+    else:
+        t0 = time.time()
+        while not os.path.exists(reported) and time.time() - t0 < 15.0:
+            time.sleep(0.05)
     return 3
 
 

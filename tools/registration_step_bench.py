@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--loops", type=int, default=8)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--forms", default="eager_torch,eager_fused,eager_native,graph_fused,graph")
+    ap.add_argument("--train-only", action="store_true", help="profiler runs: exactly 8 + 3 * steps training steps per form, nothing else")
     a = ap.parse_args()
     from dpdist_amd import synth
     from dpdist_amd.model import DPDistLoss, DPDistModel
@@ -64,6 +65,10 @@ def main():
         for i in range(8):
             reg.train_step(*pool[i % len(pool)])
         ms = min(timed(lambda i: reg.train_step(*pool[i % len(pool)]), a.steps) for _ in range(3))
+        if a.train_only:
+            print(form, json.dumps({"train_ms_per_step": round(ms, 4), "training_steps_run": 8 + 3 * a.steps}), flush=True)
+            reg.close()
+            continue
         for i in range(4):
             reg.evaluate(*pool[i % len(pool)])
         ms_eval = min(timed(lambda i: reg.evaluate(*pool[i % len(pool)]), a.steps) for _ in range(2))
@@ -85,6 +90,8 @@ def main():
         reg.close()
         print(form, json.dumps(out[form]), flush=True)
 
+    if a.train_only:
+        return
     # the DPDist share: one as-loss forward + backward at this shape, on its own
     model, _ = harness(False, True)
     fn = DPDistLoss(model)

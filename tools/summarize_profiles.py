@@ -91,4 +91,32 @@ def pmc_summary(prefix, stats_sub, out_name):
 
 pmc_summary("pmc_", "stats", "pmc_summary.csv")
 pmc_summary("pmc_bf16_b64_", "stats_bf16_b64", "pmc_summary_bf16_b64.csv")
+
+# config 5: where a registration step's GPU time goes (eager form of the default path = what the captured graph replays), per training step
+f = os.path.join(src, "stats_registration", "%s_kernel_stats.csv" % tag)
+if os.path.exists(f):
+    steps = 8 + 3 * 50      # tools/registration_step_bench.py --steps 50 --train-only
+    groups = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        n = r["Name"]
+        if "dpd::pose_" in n:
+            g = "pose chain + refinement pose network (csrc/pose.hip)"
+        elif "dpd::adam" in n:
+            g = "TF-form Adam (dpd_adam_tf)"
+        elif "dpd::" in n:
+            g = "DPDist forward + backward (as-loss engine)"
+        elif n.startswith("Cijk_"):
+            g = "training evaluation: pose network GEMMs (hipBLASLt, fwd + bwd)"
+        else:
+            g = "training evaluation: torch element-wise / reductions / copies"
+        groups[g][0] += float(r["TotalDurationNs"]) / 1e3
+        groups[g][1] += int(r["Calls"])
+    tot = sum(v[0] for v in groups.values())
+    with open(os.path.join(dst, "%s_registration_breakdown.txt" % tag), "w") as fh:
+        fh.write("# kernel time per registration TRAINING step (B=16, 64 points, 8 loops; %d steps under rocprofv3, eager form of the default path)\n" % steps)
+        fh.write("# %-75s %10s %10s %8s\n" % ("group", "us/step", "launches", "share"))
+        for g, (us, calls) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+            fh.write("%-77s %10.1f %10.1f %7.1f%%\n" % (g, us / steps, calls / steps, 100 * us / tot))
+        fh.write("%-77s %10.1f\n" % ("total kernel time per step", tot / steps))
+        fh.write("# wall clock per step: see %s_registration_step_bench.txt (eager_native; the captured graph replays these kernels)\n" % tag)
 print("wrote", sorted(x for x in os.listdir(dst) if x.startswith(tag)))
