@@ -255,6 +255,54 @@ def pmc_traffic(kernel_substr, suffix=""):
     return (tot / n if n else None), os.path.relpath(files[-1], root)
 
 
+def pmc_traffic_live(kernel_substr, bench_args, timeout_s=75.0):
+    """Fabric-side bytes per launch of a kernel family, MEASURED NOW: two child runs of this file under `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` (separate passes: the two do not fit one; --kernel-trace only, the combination MI355X_MICROARCH.md prescribes), a few
+    steps each, no roofline / CPU legs in the children.  2 x FETCH_SIZE (gfx950 tallies 128-byte requests at 64 B) + WRITE_SIZE, launch-
+    weighted over the family.  Returns (bytes per launch or None, note).  Never raises; bounded by timeout_s per pass."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
+    me = os.path.abspath(__file__)
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="dpd_pmc_", dir="/tmp")
+    try:
+        for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, cname)
+            cmd = [exe, "--pmc", cname, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, me,
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-other-dtypes", "--spinup-ms", "0"] + list(bench_args)
+            env = dict(os.environ, TMPDIR="/tmp", DPD_WD="0")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DPD_FORCE_DIST"):
+                env.pop(k, None)
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s did not finish in %.0f s" % (cname, timeout_s)
+            hits = []
+            for root_, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for r in csv.DictReader(open(os.path.join(root_, f))):
+                            if r.get("Counter_Name") == cname and any(x in r.get("Kernel_Name", "") for x in subs):
+                                hits.append(float(r["Counter_Value"]))
+            if not hits:
+                return None, "no %s rows for %s" % (cname, "/".join(subs))
+            vals[cname] = sum(hits) / len(hits)          # KiB per launch, launch-weighted (one row per dispatch)
+    except Exception as e:      # noqa: BLE001 -- a measurement aid must never take the bench line down
+        return None, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0, (
+        "MEASURED in this run: two child passes of this command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (--kernel-trace only, 3 steps "
+        "each); bytes per launch at the L2's fabric side (2 x FETCH_SIZE: gfx950 correction, + WRITE_SIZE; Infinity-Cache hits included), mean over "
+        "the family's dispatches")
+
+
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E, 8 TB/s
 ACHIEVABLE_HBM_GBPS = 6300.0    # what a pure streaming kernel sustains on this chip (same guide; our Adam kernel reaches it)
 # stage tag of the library's in-stream profiler (include/dpdist_capi.h: dpd_prof_collect_stage) -> (name, kernel-name substrings in the
@@ -522,6 +570,8 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=40.0, help="device spin-up before the timed region (0 = off: profiler passes)")
     ap.add_argument("--trace", action="store_true", help="diagnostic: per-10-step times of the timed region (adds syncs)")
     ap.add_argument("--cfg4", action="store_true", help="with DPD_FORCE_DIST=1: also run the config-4 legs on one GPU")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 child passes "
+                                                               "(profiler runs of this file: a profiler cannot nest)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -956,20 +1006,37 @@ def main():
                                     "f32x3": (6, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<3,...> (6 x v_mfma_f32_32x32x16_bf16 per product, LDS-DMA ring)"),
                                     "bf16": (1, PEAK_BF16_MFMA_TFLOPS, "gemm_x3_kernel<1,...> (v_mfma_f32_32x32x16_bf16, LDS-DMA ring)")}[a.dtype]
                 sfx = {"f32": "", "f32x3": "_f32x3", "bf16": "_bf16"}[a.dtype] if B == 32 else ("_bf16_b64" if (a.dtype, B) == ("bf16", 64) else "_none")
-                traffic, tsrc = pmc_traffic(("gemm_rs_kernel",) if a.dtype == "f32" else ("gemm_p8_kernel", "gemm_x3_kernel"), sfx)
+                fam = ("gemm_rs_kernel",) if a.dtype == "f32" else ("gemm_p8_kernel", "gemm_x3_kernel")
+                traffic, tsrc = pmc_traffic(fam, sfx)
+                committed = traffic
+                live_note = None
+                if not a.no_live_pmc and world == 1 and not use_dist:
+                    # the headline's own PMC passes, now: the timed region is over, the GPU is ours (the children allocate their own trainer)
+                    hb.beat("profile:live PMC passes")
+                    torch.cuda.synchronize()
+                    t_pmc = time.perf_counter()
+                    live, live_note = pmc_traffic_live(fam, ["--dtype", a.dtype, "--batch", str(B)] + (["--plan", a.plan] if a.plan else []))
+                    if live:
+                        traffic = live
+                    live_s = round(time.perf_counter() - t_pmc, 1)
                 roof = {"bound": "mfma", "kernel": kern,
                         "achieved": round(ach * mult, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach * mult / peak, 4),
                         "traffic": round(traffic) if traffic else None,
-                        "traffic_note": ("NOT measured in this run: read from the COMMITTED PMC pass %s (separate rocprofv3 --pmc FETCH_SIZE / "
-                                         "WRITE_SIZE runs of this command); bytes per launch at the L2's fabric side (2 x FETCH_SIZE + "
-                                         "WRITE_SIZE, Infinity-Cache hits included), launch-weighted over the family" % tsrc) if traffic else
-                                        "PMC passes are separate rocprofv3 runs: profiles/",
+                        "traffic_note": (live_note if (live_note and traffic is not committed) else
+                                         ("NOT measured in this run%s: read from the COMMITTED PMC pass %s (separate rocprofv3 --pmc FETCH_SIZE / "
+                                          "WRITE_SIZE runs of this command); bytes per launch at the L2's fabric side (2 x FETCH_SIZE + "
+                                          "WRITE_SIZE, Infinity-Cache hits included), launch-weighted over the family"
+                                          % (" (%s)" % live_note if live_note else "", tsrc)) if traffic else
+                                         "PMC passes are separate rocprofv3 runs: profiles/"),
                         "algorithmic_bytes_per_launch": round(gemm_bytes_per_step(B, N, 2528, 1024, a.dtype) / (launches / a.steps)),
                         "algorithmic_tflops": round(ach, 2),
                         "launches_per_step": launches // a.steps, "avg_launch_us": round(ms.value * 1e3 / launches, 2),
                         "alg_gflop_per_launch": round(alg / (launches / a.steps) / 1e9, 3),
                         "gemm_ms_per_step": round(ms.value / a.steps, 4)}
+                if live_note is not None:
+                    roof["traffic_committed_summary"] = round(committed) if committed else None
+                    roof["live_pmc_seconds"] = live_s
                 # the DOMINANT kernel alone (the family above also holds the weight-gradient kernel): the forward layers and the data
                 # gradients are one kernel in f32 (gemm_rs_kernel<true, false, ...>, NN products on transposed weight copies)
                 n0, ms0 = best_nn

@@ -2204,6 +2204,9 @@ def test_bench_line_on_one_gpu(dev):
     assert abs(rec["value"] - 2 * 32 * 64 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
     roof = rec["roofline"]
     assert roof["bound"] == "mfma" and 0.5 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # roofline.traffic is measured IN this run (two rocprofv3 --pmc child passes): at least the algorithmic bytes, at most ten times them
+    assert roof["traffic_note"].startswith("MEASURED in this run"), roof["traffic_note"]
+    assert roof["algorithmic_bytes_per_launch"] <= roof["traffic"] <= 10 * roof["algorithmic_bytes_per_launch"], roof
     fo = rec["fwd_only"]
     assert fo["batch"] == 32 and fo["dtype"] == "f32" and 0 < fo["ms_per_eval"] < rec["ms_per_step"] and 0.3 < fo["gemm_frac_of_peak"] <= 1.0
     assert abs(fo["value"] - 2 * 32 * 64 / (fo["ms_per_eval"] * 1e-3)) <= 1e-3 * fo["value"]

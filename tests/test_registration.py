@@ -456,7 +456,7 @@ def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(mo
     from dpdist_amd.registration import IterativeRegistration
     dev = torch.device("cuda:0")
 
-    def run(engine, graph, fused="1", native="1"):
+    def run(engine, graph, fused="1", native="1", concat=True):
         monkeypatch.setattr("dpdist_amd.asloss.ENGINE", engine == "1")
         torch.manual_seed(0)
         model = DPDistModel(device=dev)
@@ -465,7 +465,7 @@ def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(mo
         torch.manual_seed(1000)
         rng = np.random.default_rng(0)
         reg = IterativeRegistration(net, DPDistLoss(model), lr=1e-4, max_loops=8, distributed=False, graph=(graph == "1"),
-                                    fused_pose=(fused == "1"), native_refine=(native == "1"))
+                                    fused_pose=(fused == "1"), native_refine=(native == "1"), concat_grads=concat)
         losses = []
         for _ in range(12):
             src, tmpl, _ = synth.registration_pairs(16, 64, rng=rng)
@@ -486,6 +486,9 @@ def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(mo
         return h.hexdigest(), tuple(l.item() for l in losses) + (el.item(),), used
 
     a, b, c, d, e = run("1", "1"), run("1", "1"), run("1", "0"), run("0", "0"), run("0", "1")
+    # gradients accumulated into 18 views of a zeroed flat buffer (autograd's default) instead of written by one concatenation: 0 + g == g
+    acc = run("1", "1", concat=False)
+    assert acc[:2] == a[:2], (acc, a)
     assert a[2] and c[2] and not d[2] and not e[2]      # the engine really ran where it should and not where it should not
     assert a[:2] == b[:2] == c[:2] == d[:2] == e[:2], (a, b, c, d, e)
     # the torch pose algebra (~115 launches per loop) instead of csrc/pose.hip (1): the same step up to fp32 rounding of the pose chain

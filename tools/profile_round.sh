@@ -14,10 +14,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 B="python $R/bench.py"
-NOCPU="--no-cpu-baseline"
+NOCPU="--no-cpu-baseline --no-live-pmc"
 # the profiler passes must see the training step only: no spin-up GEMMs (bench.py: spinup_ms) in the traces
-SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes --spinup-ms 0"
-LONG="--steps 20 --warmup 5 --no-cpu-baseline --no-other-dtypes --spinup-ms 0"
+SHORT="--steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-other-dtypes --spinup-ms 0 --no-live-pmc"
+LONG="--steps 20 --warmup 5 --no-cpu-baseline --no-other-dtypes --spinup-ms 0 --no-live-pmc"
 export TMPDIR=/tmp
 cd /tmp
 stats() { rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1 -o $TAG -- "${@:2}" > $OUT/$1.out 2>&1; }
