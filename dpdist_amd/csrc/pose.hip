@@ -281,8 +281,23 @@ __device__ __forceinline__ void store_relu_tile(float* __restrict__ hout, int pt
 
 // models/ipcr_model.py:198-233: cloud c (< nA: ptsA[c], else ptsB[c - nA]) -> f[(row0 + c), slice*128 .. +128) = max over the points of
 // relu(W5 relu(W4 relu(W3 relu(W2 relu(W1 p + b1) + b2) + b3) + b4) + b5)
+// TRAIN (the training evaluation, dpd_pose_point_fwd_train): the slice-0 workgroup of a cloud also stores the four hidden activations, and every
+// workgroup the TIE MASK of its 128 columns -- bit p of ties[cloud][column] is set iff point p attains the column's maximum and that maximum
+// is positive (relu' = 0 at 0): what the gradient of reduce_max needs (tf.reduce_max / torch.amax share it evenly among ties).  N <= 64.
+struct PointSave {
+    float* h[4];                    // [clouds * N, 64] x 3, [clouds * N, 128]
+    unsigned long long* ties;       // [clouds, OUT]
+};
+template <bool TRAIN>
+__device__ __forceinline__ void save_rows(float* __restrict__ dst, const float* __restrict__ src_lds, int np, int W, int stride, int t) {
+    for (int e = t; e < np * (W / 4); e += 256) {
+        const int r = e / (W / 4), c4 = e % (W / 4);
+        *reinterpret_cast<float4*>(dst + (size_t)r * W + 4 * c4) = *reinterpret_cast<const float4*>(src_lds + r * stride + 4 * c4);
+    }
+}
+template <bool TRAIN>
 __global__ __launch_bounds__(256) void pose_point_kernel(const float* __restrict__ ptsA, const float* __restrict__ ptsB, int nA, int N,
-                                                         PointNetW net, int OUT, int row0, float* __restrict__ f) {
+                                                         PointNetW net, int OUT, int row0, float* __restrict__ f, PointSave sv) {
     extern __shared__ float lds[];
     const int c = blockIdx.x, slice = blockIdx.y, t = threadIdx.x, og = t & 15, pg = t >> 4, l = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -320,15 +335,18 @@ __global__ __launch_bounds__(256) void pose_point_kernel(const float* __restrict
             }
         }
         __syncthreads();
+        if (TRAIN && slice == 0) save_rows<TRAIN>(sv.h[0] + ((size_t)(row0 + c) * N + p0) * 64, lds + kHA, np, 64, kS64, t);
         f32x16 c0, c1;
         // layer 2: hA -> hB (64 wide): wave = (point tile wv & 1, output tile wv >> 1)
         mfma_layer<64, 1>(lds + kHA, lds + kW2, lds[kBias + 64 + (wv >> 1) * 32 + (l & 31)], wv & 1, (wv >> 1) * 32, c0, c1);
         store_relu_tile<64>(lds + kHB, wv & 1, wv >> 1, c0);
         __syncthreads();
+        if (TRAIN && slice == 0) save_rows<TRAIN>(sv.h[1] + ((size_t)(row0 + c) * N + p0) * 64, lds + kHB, np, 64, kS64, t);
         // layer 3: hB -> hA
         mfma_layer<64, 1>(lds + kHB, lds + kW3, lds[kBias + 128 + (wv >> 1) * 32 + (l & 31)], wv & 1, (wv >> 1) * 32, c0, c1);
         store_relu_tile<64>(lds + kHA, wv & 1, wv >> 1, c0);
         __syncthreads();                                       // W2 | W3 are done with: the second half of W5's slice takes their place,
+        if (TRAIN && slice == 0) save_rows<TRAIN>(sv.h[2] + ((size_t)(row0 + c) * N + p0) * 64, lds + kHA, np, 64, kS64, t);
         dma_weights<128, 64>(W5s + 64 * 128, lds_base, kW5b, wv, l);      // in flight under layer 4
         // layer 4: hA -> hB (128 wide): wave = output tile wv, both point tiles
         mfma_layer<64, 2>(lds + kHA, lds + kW4, lds[kBias + 192 + wv * 32 + (l & 31)], 0, wv * 32, c0, c1);
@@ -336,12 +354,31 @@ __global__ __launch_bounds__(256) void pose_point_kernel(const float* __restrict
         store_relu_tile<128>(lds + kHB, 1, wv, c1);
         dma_wait();
         __syncthreads();
+        if (TRAIN && slice == 0) save_rows<TRAIN>(sv.h[3] + ((size_t)(row0 + c) * N + p0) * 128, lds + kHB, np, 128, kS128, t);
         // layer 5 (slice): waves 0, 1 on the first half of the slice, 2, 3 on the second; max over this lane's valid points
         mfma_layer<128, 2>(lds + kHB, lds + (wv < 2 ? kW5a : kW5b), lds[kBias + 320 + wv * 32 + (l & 31)], 0, (wv & 1) * 32, c0, c1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (mfma_row(r, l) < np) vmax = fmaxf(vmax, c0[r]);          // = max(relu(.)): vmax starts at 0
             if (32 + mfma_row(r, l) < np) vmax = fmaxf(vmax, c1[r]);
+        }
+        if (TRAIN) {        // (N <= kPP: one pass, the accumulators of every point are still in registers)
+            __syncthreads();
+            float* red = lds + kHA;
+            red[(l >> 5) * kSlice + wv * 32 + (l & 31)] = vmax;
+            __syncthreads();
+            const int col = wv * 32 + (l & 31);
+            const float m = fmaxf(red[col], red[kSlice + col]);
+            unsigned lo = 0, hi = 0;                           // rows 0..31 come from c0, rows 32..63 from c1
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, l);
+                if (row < np && m > 0.f && c0[r] == m) lo |= 1u << row;
+                if (32 + row < np && m > 0.f && c1[r] == m) hi |= 1u << row;
+            }
+            lo |= (unsigned)__shfl_xor((int)lo, 32, 64);       // the two lane halves hold the other rows of the same column
+            hi |= (unsigned)__shfl_xor((int)hi, 32, 64);
+            if ((l >> 5) == 0) sv.ties[(size_t)(row0 + c) * OUT + slice * kSlice + col] = ((unsigned long long)hi << 32) | lo;
         }
     }
     __syncthreads();
@@ -472,7 +509,7 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
     hipStream_t s = (hipStream_t)stream;
     const float lim_rad = (float)(3.14159265358979323846 / 180.0 * (double)lim_rot_deg);
     const size_t lds = (size_t)kPointLds * sizeof(float);
-    if (int rc = ensure_dyn_lds(g_point_lds, (const void*)pose_point_kernel, lds)) return rc;
+    if (int rc = ensure_dyn_lds(g_point_lds, (const void*)pose_point_kernel<false>, lds)) return rc;
     PointNetW pw{};
     for (int i = 0; i < 5; ++i) { pw.W[i] = net->Wp[i]; pw.b[i] = net->bp[i]; }
     for (int it = 0; it < loops; ++it) {
@@ -483,10 +520,10 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
         float* Tn = last ? T_out : w.T[it & 1];
         // shared MLP + max pool: source features every loop; the template's once (the template never moves)
         if (it == 0) {
-            DPD_LAUNCH(pose_point_kernel, dim3((unsigned)(2 * B), (unsigned)(OUT / kSlice)), dim3(256), lds, s, cur, tmpl, B, N, pw, OUT, 0, w.f);
+            DPD_LAUNCH(pose_point_kernel<false>, dim3((unsigned)(2 * B), (unsigned)(OUT / kSlice)), dim3(256), lds, s, cur, tmpl, B, N, pw, OUT, 0, w.f, PointSave{});
         } else {
-            DPD_LAUNCH(pose_point_kernel, dim3((unsigned)B, (unsigned)(OUT / kSlice)), dim3(256), lds, s, cur, (const float*)nullptr, B, N, pw, OUT, 0,
-                       w.f);
+            DPD_LAUNCH(pose_point_kernel<false>, dim3((unsigned)B, (unsigned)(OUT / kSlice)), dim3(256), lds, s, cur, (const float*)nullptr, B, N, pw, OUT, 0,
+                       w.f, PointSave{});
         }
         DPD_CHECK_LAUNCH();
         const unsigned ry = (unsigned)((B + 15) / 16);
@@ -508,5 +545,555 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
                    Tn, (const float*)w.h3, net->Wh[3], net->bh[3], 256, pred_out ? pred_out + (size_t)it * B * 7 : (float*)nullptr);
         DPD_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ pose network, training evaluation (round 6)
+// The training evaluation of a registration step (pcrnet-registration/iterative_PCRNet_ours.py:442-470) differentiates the pose network
+// w.r.t. its WEIGHTS only (the refined source cloud is a constant of the step).  Shared MLP + max pool (models/ipcr_model.py:198-233) here:
+//   dpd_pose_point_fwd_train   the forward kernel above with its hidden activations and the max pool's tie masks stored
+//   dpd_pose_point_bwd         d features [clouds, OUT] -> dW1..dW5, db1..db5 (TF / torch autodiff of five 1x1 convolutions, ReLU, reduce_max)
+// The max pool makes the last layer's gradient SPARSE: per (cloud, column) only the points that attain a positive maximum carry gradient
+// (evenly shared among ties, like tf.reduce_max), i.e. one 128-vector per (cloud, column) instead of a [points, 1024] matrix:
+//   pose_bwd_w5_kernel      wave = output column c: dW5[c, :] = sum over clouds of coef * h4[tied point, :], db5[c] = sum of the column's gradient
+//   pose_bwd_dh4_kernel     wave = point: the gradient of layer 4's output from the tie masks (columns in ascending order: deterministic)
+//   pose_bwd_cloud_kernel   workgroup = cloud: layers 4..1 densely in LDS (64 points: ~2 MFLOP per cloud); per-cloud partial weight gradients
+//   pose_bwd_reduce_kernel  sums the partials over the clouds in cloud order
+// Plain fp32 FMA; every sum has a fixed order (bitwise reproducible).
+namespace dpd {
+
+constexpr int kPart = 128 * 64 + 128 + 64 * 64 + 64 + 64 * 64 + 64 + 64 * 3 + 64;      // dW4 | db4 | dW3 | db3 | dW2 | db2 | dW1 | db1 per cloud
+
+__global__ __launch_bounds__(256) void pose_bwd_w5_kernel(const float* __restrict__ df, const unsigned long long* __restrict__ ties,
+                                                           const float* __restrict__ h4, int C, int N, int OUT, float* __restrict__ dW5,
+                                                           float* __restrict__ db5) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (c >= OUT) return;
+    float a0 = 0.f, a1 = 0.f, bsum = 0.f;
+    for (int cl0 = 0; cl0 < C; cl0 += 64) {
+        // lane = cloud: the column's tie mask and gradient of 64 clouds in ONE load each, so that the row loads below do not wait on them
+        const int mine = cl0 + l;
+        const unsigned long long mybits = mine < C ? ties[(size_t)mine * OUT + c] : 0ull;
+        const float myg = (mine < C && mybits) ? df[(size_t)mine * OUT + c] : 0.f;
+        const float mycoef = mybits ? myg / (float)__popcll(mybits) : 0.f;
+        const int myfirst = mybits ? __ffsll((long long)mybits) - 1 : 0;
+        const bool multi = mybits & (mybits - 1);
+        const int n = min(64, C - cl0);
+        for (int k0 = 0; k0 < n; k0 += 8) {          // eight clouds at a time: their (single) tied rows are requested together
+            float2 h[8];
+            float cf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(k0 + u, n - 1);
+                cf[u] = (k0 + u < n) ? __shfl(mycoef, k, 64) : 0.f;
+                const int p = __shfl(myfirst, k, 64);
+                h[u] = *reinterpret_cast<const float2*>(h4 + ((size_t)(cl0 + k) * N + p) * 128 + 2 * l);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0 += cf[u] * h[u].x; a1 += cf[u] * h[u].y; }      // (a cloud without a positive maximum: coef 0)
+        }
+        // further tied points of a column (duplicated points): rare, one at a time, after the first ones, in cloud / point order
+        unsigned long long any = __ballot(multi);
+        while (any) {
+            const int k = __ffsll((long long)any) - 1;
+            any &= any - 1;
+            unsigned lo = (unsigned)__shfl((int)(unsigned)(mybits & 0xffffffffull), k, 64), hi = (unsigned)__shfl((int)(unsigned)(mybits >> 32), k, 64);
+            unsigned long long bits = ((unsigned long long)hi << 32) | lo;
+            const float coef = __shfl(mycoef, k, 64);
+            bits &= bits - 1;                        // the first point was taken above
+            while (bits) {
+                const int p = __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const float2 hh = *reinterpret_cast<const float2*>(h4 + ((size_t)(cl0 + k) * N + p) * 128 + 2 * l);
+                a0 += coef * hh.x;
+                a1 += coef * hh.y;
+            }
+        }
+        // db5[c] = sum of the column's gradient over the clouds in which the maximum is positive: lane sums in a fixed tree
+        float g = myg;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+        bsum += g;
+    }
+    *reinterpret_cast<float2*>(dW5 + (size_t)c * 128 + 2 * l) = make_float2(a0, a1);
+    if (l == 0) db5[c] = bsum;
+}
+
+constexpr int kBT = 1024;      // threads of the per-cloud backward workgroup
+
+// out[p][j] (4 columns per thread) = [hprev[p][j] > 0] * sum_o g[p][o] W[o][j]   (dX of a layer whose weight W [KO, KI] row-major sits in LDS)
+// thread = (p = t / 16, column quad t % 16); KI = 64
+template <int KO>
+__device__ __forceinline__ void bwd_dx64(const float* __restrict__ g, int gs, const float* __restrict__ Wl, const float* __restrict__ hprev,
+                                         float* __restrict__ out, int os, int np, int t) {
+    const int p = t >> 4, j0 = (t & 15) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int o = 0; o < KO; ++o) {
+        const float a = g[p * gs + o];
+        const float4 w = *reinterpret_cast<const float4*>(Wl + o * 64 + j0);
+        acc.x += a * w.x; acc.y += a * w.y; acc.z += a * w.z; acc.w += a * w.w;
+    }
+    const bool live = p < np;
+    out[p * os + j0] = (live && hprev[p * os + j0] > 0.f) ? acc.x : 0.f;
+    out[p * os + j0 + 1] = (live && hprev[p * os + j0 + 1] > 0.f) ? acc.y : 0.f;
+    out[p * os + j0 + 2] = (live && hprev[p * os + j0 + 2] > 0.f) ? acc.z : 0.f;
+    out[p * os + j0 + 3] = (live && hprev[p * os + j0 + 3] > 0.f) ? acc.w : 0.f;
+}
+
+// dW[o][i] = sum_p g[p][o] h[p][i] (p ascending), db[o] = sum_p g[p][o]; KI = 64; thread = (output row o, NI consecutive inputs)
+template <int KO>
+__device__ __forceinline__ void bwd_dw64(const float* __restrict__ g, int gs, const float* __restrict__ h, int hs, int np, float* __restrict__ dW,
+                                         float* __restrict__ db, int t) {
+    constexpr int NI = KO * 64 / kBT;       // 8 (KO = 128) or 4 (KO = 64)
+    constexpr int TPO = 64 / NI;
+    const int o = t / TPO, i0 = (t % TPO) * NI;
+    float acc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+    float bs = 0.f;
+    for (int p = 0; p < np; ++p) {
+        const float a = g[p * gs + o];
+        bs += a;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += a * h[p * hs + i0 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dW[o * 64 + i0 + i] = acc[i];
+    if (i0 == 0) db[o] = bs;
+}
+
+constexpr int kBS128 = 129, kBS64 = 65;      // odd LDS strides: a column read down the points touches every bank once
+// LDS (floats): g4 [64][129] | hA, hB, gA, gB [64][65] each | W [128 x 64] | points [64][4]
+constexpr int kBwdG4 = 0, kBwdHA = 64 * kBS128, kBwdGA = kBwdHA + 64 * kBS64, kBwdGB = kBwdGA + 64 * kBS64, kBwdHB = kBwdGB + 64 * kBS64,
+              kBwdW = kBwdHB + 64 * kBS64, kBwdPts = kBwdW + 128 * 64, kBwdLds = kBwdPts + 256;
+static_assert(kBwdLds * 4 <= 160 * 1024 && (kBwdW % 4) == 0, "LDS budget / alignment");
+
+__device__ __forceinline__ void lds_rows64(float* __restrict__ dst, const float* __restrict__ src, int np, int t) {      // [np][64] global -> [64][65]
+    for (int e = t; e < 64 * 16; e += kBT) {
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        const float4 v = r < np ? *reinterpret_cast<const float4*>(src + (size_t)r * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[r * kBS64 + c4] = v.x; dst[r * kBS64 + c4 + 1] = v.y; dst[r * kBS64 + c4 + 2] = v.z; dst[r * kBS64 + c4 + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void lds_weights(float* __restrict__ dst, const float* __restrict__ W, int n, int t) {        // n floats, n % 4 == 0
+    for (int e = t * 4; e < n; e += kBT * 4) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(W + e);
+}
+
+// g4[cloud, p, :] = [h4 > 0] * sum over the columns whose maximum point p attains of coef * W5[column, :], columns in ascending order
+// (deterministic).  Workgroup = (cloud, four points), wave = point, lane = two of the 128 inputs.  (A) lane l tests column 64 g + l for
+// g = 0..15 and the sixteen ballots go to LDS: the point's hit list is known before the first weight row is requested, so (B) the rows (512
+// contiguous bytes of W5 each, one float2 per lane, L2-resident) are requested SIXTEEN at a time.  (Testing and loading column by column
+// inside the per-cloud kernel made every hit a dependent L2 round trip: 150 us.)  A few "critical" points attain most maxima: one wave per
+// point on clouds * 16 workgroups spreads that skew over the chip.
+__global__ __launch_bounds__(256) void pose_bwd_dh4_kernel(const float* __restrict__ df, const unsigned long long* __restrict__ ties,
+                                                            const float* __restrict__ W5, const float* __restrict__ h4, int N, int OUT,
+                                                            float* __restrict__ g4g) {
+    __shared__ unsigned long long sbits[1024];
+    __shared__ float coef[1024];
+    __shared__ unsigned long long smask_all[4 * 16];
+    const int c = blockIdx.x >> 4, t = threadIdx.x, wv = t >> 6, l = t & 63;
+    const int p = (blockIdx.x & 15) * 4 + wv;
+    for (int col = t; col < OUT; col += 256) {
+        const unsigned long long b = ties[(size_t)c * OUT + col];
+        sbits[col] = b;
+        coef[col] = b ? df[(size_t)c * OUT + col] / (float)__popcll(b) : 0.f;
+    }
+    __syncthreads();
+    if (p >= N) return;
+    unsigned long long* smask = smask_all + wv * 16;
+    const int ng = OUT / 64;
+    for (int g = 0; g < ng; ++g) {
+        const unsigned long long m = __ballot((sbits[g * 64 + l] >> p) & 1ull);
+        if (l == 0) smask[g] = m;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float a0 = 0.f, a1 = 0.f;
+    int g = 0;
+    unsigned long long m = smask[0];
+    for (;;) {
+        int cols[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            while (!m && g < ng - 1) m = smask[++g];
+            if (m) { cols[u] = g * 64 + __ffsll((long long)m) - 1; m &= m - 1; }
+            else cols[u] = -1;
+        }
+        if (cols[0] < 0) break;
+        float2 w[16];
+        float cf[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int cc = cols[u] < 0 ? cols[0] : cols[u];           // (a padding slot re-reads the batch's first row: a cache hit)
+            cf[u] = cols[u] < 0 ? 0.f : coef[cc];
+            w[u] = *reinterpret_cast<const float2*>(W5 + (size_t)cc * 128 + 2 * l);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a0 += cf[u] * w[u].x; a1 += cf[u] * w[u].y; }
+        if (cols[15] < 0) break;
+    }
+    const float2 hv = *reinterpret_cast<const float2*>(h4 + ((size_t)c * N + p) * 128 + 2 * l);
+    *reinterpret_cast<float2*>(g4g + ((size_t)c * N + p) * 128 + 2 * l) = make_float2(hv.x > 0.f ? a0 : 0.f, hv.y > 0.f ? a1 : 0.f);
+}
+
+__global__ __launch_bounds__(kBT) void pose_bwd_cloud_kernel(const float* __restrict__ ptsA, const float* __restrict__ ptsB, int nA, int N,
+                                                              PointNetW net, const float* __restrict__ g4g, PointSave sv,
+                                                              float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* g4 = lds + kBwdG4;
+    float* hA = lds + kBwdHA;                // activations of the layer below the one being differentiated
+    float* gA = lds + kBwdGA;                // its gradient (ping)
+    float* gB = lds + kBwdGB;                // (pong)
+    float* hB = lds + kBwdHB;
+    float* Wl = lds + kBwdW;
+    float* sp = lds + kBwdPts;
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int np = N;
+    const float* pts = c < nA ? ptsA + (size_t)c * N * 3 : ptsB + (size_t)(c - nA) * N * 3;
+    float* out = part + (size_t)c * kPart;
+    // h3, W4, the points
+    lds_rows64(hA, sv.h[2] + (size_t)c * N * 64, np, t);
+    lds_weights(Wl, net.W[3], 128 * 64, t);
+    if (t < 192) sp[(t / 3) * 4 + t % 3] = (t / 3) < np ? pts[t] : 0.f;
+    __syncthreads();
+    // g4 = dh4 * [h4 > 0] of this cloud (pose_bwd_dh4_kernel)
+    for (int e = t; e < 64 * 32; e += kBT) {
+        const int r = e >> 5, c4 = (e & 31) * 4;
+        const float4 v = r < np ? *reinterpret_cast<const float4*>(g4g + ((size_t)c * N + r) * 128 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g4[r * kBS128 + c4] = v.x; g4[r * kBS128 + c4 + 1] = v.y; g4[r * kBS128 + c4 + 2] = v.z; g4[r * kBS128 + c4 + 3] = v.w;
+    }
+    __syncthreads();
+    // layer 4 (128 x 64): dW4 / db4 from (g4, h3); g3 = (g4 W4) * [h3 > 0] -> gA
+    bwd_dw64<128>(g4, kBS128, hA, kBS64, np, out, out + 128 * 64, t);
+    bwd_dx64<128>(g4, kBS128, Wl, hA, gA, kBS64, np, t);
+    __syncthreads();
+    // layer 3 (64 x 64): h2 -> hB, W3 -> Wl; dW3 / db3 from (g3, h2); g2 = (g3 W3) * [h2 > 0] -> gB
+    lds_rows64(hB, sv.h[1] + (size_t)c * N * 64, np, t);
+    lds_weights(Wl, net.W[2], 64 * 64, t);
+    __syncthreads();
+    float* o3 = out + 128 * 64 + 128;
+    bwd_dw64<64>(gA, kBS64, hB, kBS64, np, o3, o3 + 64 * 64, t);
+    bwd_dx64<64>(gA, kBS64, Wl, hB, gB, kBS64, np, t);
+    __syncthreads();
+    // layer 2 (64 x 64): h1 -> hA, W2 -> Wl; dW2 / db2 from (g2, h1); g1 = (g2 W2) * [h1 > 0] -> gA
+    lds_rows64(hA, sv.h[0] + (size_t)c * N * 64, np, t);
+    lds_weights(Wl, net.W[1], 64 * 64, t);
+    __syncthreads();
+    float* o2 = o3 + 64 * 64 + 64;
+    bwd_dw64<64>(gB, kBS64, hA, kBS64, np, o2, o2 + 64 * 64, t);
+    bwd_dx64<64>(gB, kBS64, Wl, hA, gA, kBS64, np, t);
+    __syncthreads();
+    // layer 1 (64 x 3): dW1[o][i] = sum_p g1[p][o] pts[p][i], db1
+    float* o1 = o2 + 64 * 64 + 64;
+    if (t < 64) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, bs = 0.f;
+        for (int p = 0; p < np; ++p) {
+            const float a = gA[p * kBS64 + t];
+            bs += a; a0 += a * sp[p * 4]; a1 += a * sp[p * 4 + 1]; a2 += a * sp[p * 4 + 2];
+        }
+        o1[t * 3] = a0; o1[t * 3 + 1] = a1; o1[t * 3 + 2] = a2;
+        o1[192 + t] = bs;
+    }
+}
+
+__global__ __launch_bounds__(256) void pose_bwd_reduce_kernel(const float* __restrict__ part, int C, float* __restrict__ dW4, float* __restrict__ db4,
+                                                               float* __restrict__ dW3, float* __restrict__ db3, float* __restrict__ dW2,
+                                                               float* __restrict__ db2, float* __restrict__ dW1, float* __restrict__ db1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kPart) return;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += part[(size_t)c * kPart + i];
+    int k = i;
+    if (k < 128 * 64) { dW4[k] = s; return; }
+    k -= 128 * 64;
+    if (k < 128) { db4[k] = s; return; }
+    k -= 128;
+    if (k < 64 * 64) { dW3[k] = s; return; }
+    k -= 64 * 64;
+    if (k < 64) { db3[k] = s; return; }
+    k -= 64;
+    if (k < 64 * 64) { dW2[k] = s; return; }
+    k -= 64 * 64;
+    if (k < 64) { db2[k] = s; return; }
+    k -= 64;
+    if (k < 192) { dW1[k] = s; return; }
+    k -= 192;
+    db1[k] = s;
+}
+
+}  // namespace dpd
+
+namespace {
+dpd::LdsOptIn g_point_train_lds, g_point_bwd_lds;
+int check_point_net(const dpd_pose_net* net) {
+    if (!net) return DPD_E_NULL;
+    for (int i = 0; i < 5; ++i)
+        if (!net->Wp[i] || !net->bp[i]) return DPD_E_NULL;
+    if (net->out_features != 1024) return DPD_E_UNSUPPORTED;
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t dpd_pose_point_bwd_workspace_bytes(int clouds) {      // per-cloud partial weight gradients + g4 [clouds * 64, 128]
+    return clouds > 0 ? (size_t)clouds * (dpd::kPart + 64 * 128) * sizeof(float) : 0;
+}
+
+extern "C" int dpd_pose_point_fwd_train(const dpd_pose_net* net, const float* ptsA, const float* ptsB, int nA, int nB, int N, float* f,
+                                        float* h1, float* h2, float* h3, float* h4, unsigned long long* ties, void* stream) {
+    using namespace dpd;
+    if (int rc = check_point_net(net)) return rc;
+    if (!ptsA || (nB > 0 && !ptsB) || !f || !h1 || !h2 || !h3 || !h4 || !ties) return DPD_E_NULL;
+    if (nA <= 0 || nB < 0 || N <= 0) return DPD_E_DIM;
+    if (N > kPP) return DPD_E_UNSUPPORTED;                 // the tie mask is one 64-bit word per (cloud, column)
+    if ((((uintptr_t)h1 | (uintptr_t)h2 | (uintptr_t)h3 | (uintptr_t)h4) & 15) != 0) return DPD_E_UNSUPPORTED;
+    const int OUT = net->out_features;
+    const size_t lds = (size_t)kPointLds * sizeof(float);
+    if (int rc = ensure_dyn_lds(g_point_train_lds, (const void*)pose_point_kernel<true>, lds)) return rc;
+    PointNetW pw{};
+    for (int i = 0; i < 5; ++i) { pw.W[i] = net->Wp[i]; pw.b[i] = net->bp[i]; }
+    PointSave sv{{h1, h2, h3, h4}, ties};
+    DPD_LAUNCH(pose_point_kernel<true>, dim3((unsigned)(nA + nB), (unsigned)(OUT / kSlice)), dim3(256), lds, (hipStream_t)stream, ptsA, ptsB, nA, N, pw,
+               OUT, 0, f, sv);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dpd_pose_point_bwd(const dpd_pose_net* net, const float* ptsA, const float* ptsB, int nA, int nB, int N, const float* df,
+                                  const float* h1, const float* h2, const float* h3, const float* h4, const unsigned long long* ties,
+                                  float* const* dW, float* const* db, void* ws, size_t ws_bytes, void* stream) {
+    using namespace dpd;
+    if (int rc = check_point_net(net)) return rc;
+    if (!ptsA || (nB > 0 && !ptsB) || !df || !h1 || !h2 || !h3 || !h4 || !ties || !dW || !db || !ws) return DPD_E_NULL;
+    for (int i = 0; i < 5; ++i)
+        if (!dW[i] || !db[i]) return DPD_E_NULL;
+    if (nA <= 0 || nB < 0 || N <= 0) return DPD_E_DIM;
+    if (N > kPP) return DPD_E_UNSUPPORTED;
+    const int C = nA + nB, OUT = net->out_features;
+    if (ws_bytes < dpd_pose_point_bwd_workspace_bytes(C)) return DPD_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    PointNetW pw{};
+    for (int i = 0; i < 5; ++i) { pw.W[i] = net->Wp[i]; pw.b[i] = net->bp[i]; }
+    PointSave sv{{const_cast<float*>(h1), const_cast<float*>(h2), const_cast<float*>(h3), const_cast<float*>(h4)},
+                 const_cast<unsigned long long*>(ties)};
+    DPD_LAUNCH(pose_bwd_w5_kernel, dim3((unsigned)((OUT + 3) / 4)), dim3(256), 0, s, df, ties, h4, C, N, OUT, dW[4], db[4]);
+    DPD_CHECK_LAUNCH();
+    const size_t lds = (size_t)kBwdLds * sizeof(float);
+    if (int rc = ensure_dyn_lds(g_point_bwd_lds, (const void*)pose_bwd_cloud_kernel, lds)) return rc;
+    float* g4g = (float*)ws + (size_t)C * kPart;                   // [C * N, 128]
+    DPD_LAUNCH(pose_bwd_dh4_kernel, dim3((unsigned)(C * 16)), dim3(256), 0, s, df, ties, net->Wp[4], h4, N, OUT, g4g);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_bwd_cloud_kernel, dim3((unsigned)C), dim3(kBT), lds, s, ptsA, ptsB, nA, N, pw, (const float*)g4g, sv, (float*)ws);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_bwd_reduce_kernel, dim3((unsigned)((kPart + 255) / 256)), dim3(256), 0, s, (const float*)ws, C, dW[3], db[3], dW[2], db[2], dW[1], db[1],
+               dW[0], db[0]);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ pose network head, training evaluation (round 6)
+// models/ipcr_model.py:273-284: fc 2048 -> 1024 -> 512 -> 256 (ReLU each, dropout on the last) -> 7, and TF / torch autodiff of it:
+//   forward   pose_fc_kernel (above) x 3 with the hidden activations kept, pose_fc4_fwd_kernel
+//   backward  pose_fc4_bwd_kernel: gradient of the 256-wide activation (dropout mask and ReLU gate applied) + dW4 / db4
+//             per wide layer: pose_fc_dw_kernel (dW = g^T x, db: 16 terms per entry, bound by the 8 MB it writes for fc1) and
+//             pose_fc_dx_kernel (gx = (g W) * [x > 0] on v_mfma_f32_16x16x4_f32; the weight is streamed once, 64 input columns per workgroup)
+namespace dpd {
+
+// pred[b][o] = sum_k h3[b][k] W4[o][k] + b4[o], o < 7, K4 = 256: one wave per row
+__global__ __launch_bounds__(64) void pose_fc4_fwd_kernel(const float* __restrict__ h3, const float* __restrict__ W4, const float* __restrict__ b4,
+                                                           int K4, float* __restrict__ pred) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = l; k < K4; k += 64) {
+        const float x = h3[(size_t)b * K4 + k];
+#pragma unroll
+        for (int o = 0; o < 7; ++o) acc[o] += x * W4[(size_t)o * K4 + k];
+    }
+#pragma unroll
+    for (int o = 0; o < 7; ++o) {
+        float v = acc[o];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+        if (l == 0) pred[(size_t)b * 7 + o] = v + b4[o];
+    }
+}
+
+// blocks [0, B): g3[b][k] = (sum_o dpred[b][o] W4[o][k]) * mask[b][k] * [h3[b][k] > 0]; block B: dW4[o][k] = sum_b dpred[b][o] h3[b][k], db4
+__global__ __launch_bounds__(256) void pose_fc4_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ W4, const float* __restrict__ h3,
+                                                            const float* __restrict__ mask, int B, int K4, float* __restrict__ g3,
+                                                            float* __restrict__ dW4, float* __restrict__ db4) {
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x < B) {
+        const int b = blockIdx.x;
+        float d[7];
+#pragma unroll
+        for (int o = 0; o < 7; ++o) d[o] = dpred[(size_t)b * 7 + o];
+        for (int k = t; k < K4; k += 256) {
+            float v = 0.f;
+#pragma unroll
+            for (int o = 0; o < 7; ++o) v += d[o] * W4[(size_t)o * K4 + k];
+            if (mask) v *= mask[(size_t)b * K4 + k];
+            g3[(size_t)b * K4 + k] = h3[(size_t)b * K4 + k] > 0.f ? v : 0.f;
+        }
+        return;
+    }
+    for (int e = t; e < 7 * K4; e += 256) {
+        const int o = e / K4, k = e % K4;
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) v += dpred[(size_t)b * 7 + o] * h3[(size_t)b * K4 + k];
+        dW4[e] = v;
+    }
+    if (t < 7) {
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) v += dpred[(size_t)b * 7 + t];
+        db4[t] = v;
+    }
+}
+
+// dW[j][k] = sum_r g[r][j] x[r][k] (r ascending), db[j] = sum_r g[r][j].  x = [xA (KA columns) | xB (K - KA)] like pose_fc_kernel's input.
+// block = 16 output rows x 256 columns: thread = (four rows j, one float4 of columns)
+__global__ __launch_bounds__(256) void pose_fc_dw_kernel(const float* __restrict__ g, const float* __restrict__ xA, const float* __restrict__ xB,
+                                                          int KA, int J, int K, int R, float* __restrict__ dW, float* __restrict__ db) {
+    const int t = threadIdx.x, kq = t & 63, jg = t >> 6;
+    const int k = blockIdx.x * 256 + 4 * kq, j0 = blockIdx.y * 16 + 4 * jg;
+    if (k >= K) return;
+    const float* x = k < KA ? xA + k : xB + (k - KA);
+    const int ldx = k < KA ? KA : K - KA;
+    float4 acc[4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < R; ++r) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx);
+        const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)r * J + j0);
+        const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[u].x += gg[u] * xv.x; acc[u].y += gg[u] * xv.y; acc[u].z += gg[u] * xv.z; acc[u].w += gg[u] * xv.w;
+            bs[u] += gg[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(dW + (size_t)(j0 + u) * K + k) = acc[u];
+    if (blockIdx.x == 0 && kq == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) db[j0 + u] = bs[u];
+    }
+}
+
+// gx[r][k] = (sum_j g[r][j] W[j][k]) * [xprev[r][k] > 0] for <= 16 rows per blockIdx.y and the 64 columns k0 .. k0 + 63 of blockIdx.x.
+// Eight waves share the reduction (wave w: j in [w J / 8, (w + 1) J / 8), NIT = J / 32 steps of four j); per step a lane loads ONE float4 of W
+// (row j0 + lane / 16, columns k0 + 4 (lane % 16) .. + 3) and one g value (row r0 + lane % 16, column j0 + lane / 16) and issues four
+// v_mfma_f32_16x16x4_f32: A_e[i][kk] = W[j0 + kk][k0 + 4 i + e], B[kk][n] = g[r0 + n][j0 + kk] -> C_e[i][n] = partial gx[r0 + n][k0 + 4 i + e].
+// A lane then holds the 16 consecutive columns k0 + 16 (lane / 16) .. + 15 of row r0 + lane % 16; the eight partial tiles are added in wave
+// order through LDS (deterministic).  xprev == NULL: no gate (the pooled features).  out rows: row r -> out + r * ldo (+ column k); for the
+// first layer the columns >= split go to the rows of the second cloud set: out[(R + r) * ldo + k - split].
+template <int NIT>
+__global__ __launch_bounds__(512) void pose_fc_dx_kernel(const float* __restrict__ g, const float* __restrict__ W, const float* __restrict__ xprev,
+                                                          int K, int R, float* __restrict__ out, int ldo, int split) {
+    constexpr int J = NIT * 32;
+    __shared__ float part[8][1024];
+    const int k0 = blockIdx.x * 64, r0 = blockIdx.y * 16, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int n = l & 15, kk = l >> 4;
+    const int row = min(r0 + n, R - 1);
+    const int jw = wv * (J / 8);
+    float4 wr[NIT];
+    float gr[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        wr[i] = *reinterpret_cast<const float4*>(W + (size_t)(jw + 4 * i + kk) * K + k0 + 4 * n);
+        gr[i] = g[(size_t)row * J + jw + 4 * i + kk];
+    }
+    f32x4 c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].x, gr[i], c[0], 0, 0, 0);
+        c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].y, gr[i], c[1], 0, 0, 0);
+        c[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].z, gr[i], c[2], 0, 0, 0);
+        c[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].w, gr[i], c[3], 0, 0, 0);
+    }
+    // lane l holds C_e[i = 4 (l / 16) + r][n = l % 16]: column k0 + 16 (l / 16) + 4 r + e of row n
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[wv][l * 16 + 4 * r + e] = c[e][r];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 1024; idx += 512) {
+        float v = part[0][idx];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v += part[q][idx];
+        const int ll = idx >> 4, off = idx & 15;
+        const int rr = r0 + (ll & 15), k = k0 + 16 * (ll >> 4) + off;
+        if (rr < R) {
+            if (xprev && !(xprev[(size_t)rr * K + k] > 0.f)) v = 0.f;
+            if (k < split) out[(size_t)rr * ldo + k] = v;
+            else out[(size_t)(R + rr) * ldo + k - split] = v;
+        }
+    }
+}
+
+}  // namespace dpd
+
+extern "C" int dpd_pose_head_fwd_train(const dpd_pose_net* net, const float* f, int B, const float* drop_mask, float* h1, float* h2, float* h3,
+                                       float* pred, void* stream) {
+    using namespace dpd;
+    if (!net || !f || !h1 || !h2 || !h3 || !pred) return DPD_E_NULL;
+    for (int i = 0; i < 4; ++i)
+        if (!net->Wh[i] || !net->bh[i]) return DPD_E_NULL;
+    if (B <= 0) return DPD_E_DIM;
+    if (net->out_features != 1024) return DPD_E_UNSUPPORTED;
+    const int OUT = 1024;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned ry = (unsigned)((B + 15) / 16);
+    DPD_LAUNCH(pose_fc_kernel<8>, dim3(1024 / 16, ry), dim3(1024), 0, s, f, f + (size_t)B * OUT, OUT, net->Wh[0], net->bh[0], 1024, B, 1,
+               (const float*)nullptr, h1);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_fc_kernel<4>, dim3(512 / 16, ry), dim3(1024), 0, s, (const float*)h1, (const float*)nullptr, 1024, net->Wh[1], net->bh[1], 512, B, 1,
+               (const float*)nullptr, h2);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_fc_kernel<2>, dim3(256 / 16, ry), dim3(1024), 0, s, (const float*)h2, (const float*)nullptr, 512, net->Wh[2], net->bh[2], 256, B, 1,
+               drop_mask, h3);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_fc4_fwd_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)h3, net->Wh[3], net->bh[3], 256, pred);
+    DPD_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" size_t dpd_pose_head_bwd_workspace_bytes(int B) { return B > 0 ? (size_t)B * (256 + 512 + 1024) * sizeof(float) : 0; }
+
+extern "C" int dpd_pose_head_bwd(const dpd_pose_net* net, const float* f, int B, const float* drop_mask, const float* h1, const float* h2,
+                                 const float* h3, const float* dpred, float* const* dW, float* const* db, float* df, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    using namespace dpd;
+    if (!net || !f || !h1 || !h2 || !h3 || !dpred || !dW || !db || !df || !ws) return DPD_E_NULL;
+    for (int i = 0; i < 4; ++i)
+        if (!net->Wh[i] || !dW[i] || !db[i]) return DPD_E_NULL;
+    if (B <= 0) return DPD_E_DIM;
+    if (net->out_features != 1024) return DPD_E_UNSUPPORTED;
+    if (ws_bytes < dpd_pose_head_bwd_workspace_bytes(B)) return DPD_E_WORKSPACE;
+    const int OUT = 1024;
+    hipStream_t s = (hipStream_t)stream;
+    float* g3 = (float*)ws;                  // [B, 256]
+    float* g2 = g3 + (size_t)B * 256;        // [B, 512]
+    float* g1 = g2 + (size_t)B * 512;        // [B, 1024]
+    const unsigned ry = (unsigned)((B + 15) / 16);
+    DPD_LAUNCH(pose_fc4_bwd_kernel, dim3((unsigned)B + 1), dim3(256), 0, s, dpred, net->Wh[3], h3, drop_mask, B, 256, g3, dW[3], db[3]);
+    DPD_CHECK_LAUNCH();
+    // fc3: W [256, 512]
+    DPD_LAUNCH(pose_fc_dw_kernel, dim3(512 / 256, 256 / 16), dim3(256), 0, s, (const float*)g3, h2, (const float*)nullptr, 512, 256, 512, B, dW[2], db[2]);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_fc_dx_kernel<8>, dim3(512 / 64, ry), dim3(512), 0, s, (const float*)g3, net->Wh[2], h2, 512, B, g2, 512, 512);
+    DPD_CHECK_LAUNCH();
+    // fc2: W [512, 1024]
+    DPD_LAUNCH(pose_fc_dw_kernel, dim3(1024 / 256, 512 / 16), dim3(256), 0, s, (const float*)g2, h1, (const float*)nullptr, 1024, 512, 1024, B, dW[1], db[1]);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_fc_dx_kernel<16>, dim3(1024 / 64, ry), dim3(512), 0, s, (const float*)g2, net->Wh[1], h1, 1024, B, g1, 1024, 1024);
+    DPD_CHECK_LAUNCH();
+    // fc1: W [1024, 2048], input = [features of the first B clouds | of the second B clouds]; its dX is d features [2B, 1024] (no gate)
+    DPD_LAUNCH(pose_fc_dw_kernel, dim3(2048 / 256, 1024 / 16), dim3(256), 0, s, (const float*)g1, f, f + (size_t)B * OUT, OUT, 1024, 2048, B, dW[0], db[0]);
+    DPD_CHECK_LAUNCH();
+    DPD_LAUNCH(pose_fc_dx_kernel<32>, dim3(2048 / 64, ry), dim3(512), 0, s, (const float*)g1, net->Wh[0], (const float*)nullptr, 2048, B, df, OUT, OUT);
+    DPD_CHECK_LAUNCH();
     return 0;
 }

@@ -88,6 +88,14 @@ SIGNATURES = {
     "dpd_pose_refine_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpd_pose_refine": (c_int, [POINTER(PoseNetW), c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
+    "dpd_pose_point_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "dpd_pose_point_fwd_train": (c_int, [POINTER(PoseNetW), c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
+    "dpd_pose_point_bwd": (c_int, [POINTER(PoseNetW), c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6 +
+                           [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "dpd_pose_head_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "dpd_pose_head_fwd_train": (c_int, [POINTER(PoseNetW), c_void_p, c_int] + [c_void_p] * 6),
+    "dpd_pose_head_bwd": (c_int, [POINTER(PoseNetW), c_void_p, c_int] + [c_void_p] * 5 + [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p,
+                                                                                           c_size_t, c_void_p]),
     "dpd_planes_bytes": (c_size_t, [c_int] * 6),
     "dpd_planes_carve": (c_int, [c_void_p, c_size_t] + [c_int] * 6 + [POINTER(Planes)]),
     "dpd_weights_to_planes": (c_int, [POINTER(DecoderParams), c_int, c_int, POINTER(Planes), c_void_p]),

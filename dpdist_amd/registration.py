@@ -42,8 +42,127 @@ def quat_normalize(pred, rot_lim=45.0):
     return torch.cat([torch.tanh(t) * 0.1, torch.cos(ang / 2), axis * torch.sin(ang / 2)], -1)
 
 
+class _PointFeaturesFn(torch.autograd.Function):
+    """Shared MLP + max pool of the pose network (models/ipcr_model.py:198-233) with its weight gradients on the library
+    (include/dpdist_capi.h: dpd_pose_point_fwd_train / dpd_pose_point_bwd; csrc/pose.hip): one launch forward, three backward, instead of
+    ~16 forward and ~45 backward launches of torch / hipBLASLt kernels at batch 16.  The clouds carry no gradient (the refined source of a
+    registration step is a constant of the step, iterative_PCRNet_ours.py:442-470).  Same mathematics as `point(...).amax(1)` -- gradient of
+    the max pool shared evenly among ties like tf.reduce_max -- in another fp32 summation order."""
+
+    @staticmethod
+    def forward(ctx, clouds, *wb):
+        from ctypes import byref
+        from . import lib as L
+        C, N, _ = clouds.shape
+        L.req(clouds, name="clouds", shape=(C, N, 3))
+        w = L.PoseNetW()
+        for i in range(5):
+            w.Wp[i], w.bp[i] = L.req(wb[2 * i], name="weight").data_ptr(), L.req(wb[2 * i + 1], name="bias").data_ptr()
+        w.out_features = wb[8].shape[0]
+        dev = clouds.device
+        f = torch.empty(C, w.out_features, device=dev, dtype=torch.float32)
+        h = [torch.empty(C * N, k, device=dev, dtype=torch.float32) for k in (64, 64, 64, 128)]
+        ties = torch.empty(C, w.out_features, device=dev, dtype=torch.int64)
+        L.check(L.load().dpd_pose_point_fwd_train(byref(w), L.ptr(clouds), None, C, 0, N, L.ptr(f), L.ptr(h[0]), L.ptr(h[1]), L.ptr(h[2]), L.ptr(h[3]),
+                                                  ties.data_ptr(), L.cur_stream()), "dpd_pose_point_fwd_train")
+        ctx.save_for_backward(clouds, ties, *h, *wb)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        import ctypes
+        from ctypes import byref
+        from . import lib as L
+        clouds, ties, h1, h2, h3, h4 = ctx.saved_tensors[:6]
+        wb = ctx.saved_tensors[6:]
+        C, N, _ = clouds.shape
+        w = L.PoseNetW()
+        for i in range(5):
+            w.Wp[i], w.bp[i] = wb[2 * i].data_ptr(), wb[2 * i + 1].data_ptr()
+        w.out_features = wb[8].shape[0]
+        df = df.contiguous()
+        grads = [torch.empty_like(t) for t in wb]
+        dW = (ctypes.c_void_p * 5)(*[grads[2 * i].data_ptr() for i in range(5)])
+        db = (ctypes.c_void_p * 5)(*[grads[2 * i + 1].data_ptr() for i in range(5)])
+        lib = L.load()
+        nbytes = lib.dpd_pose_point_bwd_workspace_bytes(C)
+        ws = torch.empty(nbytes // 4, device=clouds.device, dtype=torch.float32)
+        L.check(lib.dpd_pose_point_bwd(byref(w), L.ptr(clouds), None, C, 0, N, L.ptr(df), L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(h4), ties.data_ptr(),
+                                       dW, db, L.ptr(ws), nbytes, L.cur_stream()), "dpd_pose_point_bwd")
+        return (None,) + tuple(grads)
+
+
+class _PoseNetRawFn(torch.autograd.Function):
+    """The whole pose network of a training evaluation -- shared MLP + max pool (_PointFeaturesFn's kernels) and the head (models/ipcr_model.py:
+    273-284) -- as ONE autograd node on the library: five launches forward (dpd_pose_point_fwd_train, dpd_pose_head_fwd_train), eleven backward
+    (dpd_pose_head_bwd, dpd_pose_point_bwd), gradients w.r.t. the 18 weight tensors only.  `mask` [B,256]: the dropout mask (0 or 1 / keep)
+    drawn by the caller, or None (evaluation mode)."""
+
+    @staticmethod
+    def forward(ctx, clouds, mask, *wb):
+        from ctypes import byref
+        from . import lib as L
+        C, N, _ = clouds.shape
+        B = C // 2
+        L.req(clouds, name="clouds", shape=(C, N, 3))
+        if mask is not None:
+            L.req(mask, name="mask", shape=(B, 256))
+        w = L.PoseNetW()
+        for i in range(5):
+            w.Wp[i], w.bp[i] = L.req(wb[2 * i], name="weight").data_ptr(), L.req(wb[2 * i + 1], name="bias").data_ptr()
+        for i in range(4):
+            w.Wh[i], w.bh[i] = L.req(wb[10 + 2 * i], name="weight").data_ptr(), L.req(wb[11 + 2 * i], name="bias").data_ptr()
+        w.out_features = wb[8].shape[0]
+        dev, lib, st = clouds.device, L.load(), L.cur_stream()
+        e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)      # noqa: E731
+        f = e(C, w.out_features)
+        h = [e(C * N, k) for k in (64, 64, 64, 128)]
+        ties = torch.empty(C, w.out_features, device=dev, dtype=torch.int64)
+        L.check(lib.dpd_pose_point_fwd_train(byref(w), L.ptr(clouds), None, C, 0, N, L.ptr(f), L.ptr(h[0]), L.ptr(h[1]), L.ptr(h[2]), L.ptr(h[3]),
+                                             ties.data_ptr(), st), "dpd_pose_point_fwd_train")
+        a1, a2, a3, pred = e(B, 1024), e(B, 512), e(B, 256), e(B, 7)
+        L.check(lib.dpd_pose_head_fwd_train(byref(w), L.ptr(f), B, L.ptr(mask), L.ptr(a1), L.ptr(a2), L.ptr(a3), L.ptr(pred), st),
+                "dpd_pose_head_fwd_train")
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(clouds, ties, f, a1, a2, a3, *h, *wb, *([mask] if mask is not None else []))
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        import ctypes
+        from ctypes import byref
+        from . import lib as L
+        sv = ctx.saved_tensors
+        clouds, ties, f, a1, a2, a3, h1, h2, h3, h4 = sv[:10]
+        wb = sv[10:28]
+        mask = sv[28] if ctx.has_mask else None
+        C, N, _ = clouds.shape
+        B = C // 2
+        w = L.PoseNetW()
+        for i in range(5):
+            w.Wp[i], w.bp[i] = wb[2 * i].data_ptr(), wb[2 * i + 1].data_ptr()
+        for i in range(4):
+            w.Wh[i], w.bh[i] = wb[10 + 2 * i].data_ptr(), wb[11 + 2 * i].data_ptr()
+        w.out_features = wb[8].shape[0]
+        dev, lib, st = clouds.device, L.load(), L.cur_stream()
+        dpred = dpred.contiguous()
+        grads = [torch.empty_like(t) for t in wb]
+        vp = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])      # noqa: E731
+        df = torch.empty_like(f)
+        nb = lib.dpd_pose_head_bwd_workspace_bytes(B)
+        ws = torch.empty(nb // 4, device=dev, dtype=torch.float32)
+        L.check(lib.dpd_pose_head_bwd(byref(w), L.ptr(f), B, L.ptr(mask), L.ptr(a1), L.ptr(a2), L.ptr(a3), L.ptr(dpred), vp(grads[10::2]), vp(grads[11::2]),
+                                      L.ptr(df), L.ptr(ws), nb, st), "dpd_pose_head_bwd")
+        nb2 = lib.dpd_pose_point_bwd_workspace_bytes(C)
+        ws2 = torch.empty(nb2 // 4, device=dev, dtype=torch.float32)
+        L.check(lib.dpd_pose_point_bwd(byref(w), L.ptr(clouds), None, C, 0, N, L.ptr(df), L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(h4), ties.data_ptr(),
+                                       vp(grads[0:10:2]), vp(grads[1:10:2]), L.ptr(ws2), nb2, st), "dpd_pose_point_bwd")
+        return (None, None) + tuple(grads)
+
+
 class PoseNet(nn.Module):
     """models/ipcr_model.py:198-233 + :273-284 (1xW convs == per-point linear layers)."""
+    native_train = True      # the training evaluation's shared MLP + max pool on the library (_PointFeaturesFn) when the shape allows it
 
     def __init__(self, out_features=1024, lim_rot=45.0, keep_prob=0.7):
         super().__init__()
@@ -77,15 +196,43 @@ class PoseNet(nn.Module):
             l.weight.copy_(torch.as_tensor(np.asarray(sd["fc%d/weights" % i]), dtype=torch.float32).t())
             l.bias.copy_(torch.as_tensor(np.asarray(sd["fc%d/biases" % i]), dtype=torch.float32))
 
+    def _pooled(self, clouds):
+        """shared MLP + max pool over the points of every cloud: [C, N, 3] -> [C, out_features]"""
+        lin = [m for m in self.point if isinstance(m, nn.Linear)]
+        if (self.native_train and torch.is_grad_enabled() and clouds.is_cuda and clouds.dtype == torch.float32 and not clouds.requires_grad
+                and clouds.shape[1] <= 64 and [(m.in_features, m.out_features) for m in lin] == [(3, 64), (64, 64), (64, 64), (64, 128), (128, 1024)]
+                and any(p.requires_grad for m in lin for p in (m.weight, m.bias))):
+            return _PointFeaturesFn.apply(clouds.contiguous(), *[t for m in lin for t in (m.weight, m.bias)])
+        return self.point(clouds).amax(1)
+
     def features(self, source, template):
         """ipcr_model.pointnet (:198-233): (source_global_feature, template_global_feature), each [B, out_features]."""
-        f = self.point(torch.cat([source, template], 0)).amax(1)
+        f = self._pooled(torch.cat([source, template], 0))
         B = source.shape[0]
         return f[:B], f[B:]
 
+    def _native_raw_ok(self, clouds):
+        lin_p = [m for m in self.point if isinstance(m, nn.Linear)]
+        lin_h = [m for m in self.head if isinstance(m, nn.Linear)]
+        return (self.native_train and torch.is_grad_enabled() and clouds.is_cuda and clouds.dtype == torch.float32 and not clouds.requires_grad
+                and clouds.shape[1] <= 64 and [(m.in_features, m.out_features) for m in lin_p] == [(3, 64), (64, 64), (64, 64), (64, 128), (128, 1024)]
+                and [(m.in_features, m.out_features) for m in lin_h] == [(2048, 1024), (1024, 512), (512, 256), (256, 7)]
+                and any(p.requires_grad for p in self.parameters()))
+
     def raw(self, source, template):
         """get_pose's fc4 output (:273-284) BEFORE quat_normalize: [B,7] = (t, angle, axis)."""
-        f = self.point(torch.cat([source, template], 0)).amax(1)            # max pool over the points
+        clouds = torch.cat([source, template], 0)
+        if self._native_raw_ok(clouds):
+            # the training evaluation on the library (one autograd node): the dropout mask is drawn here (torch's Philox stream, as the
+            # refinements' masks are), everything else is csrc/pose.hip
+            mask = None
+            drop = next((m for m in self.head if isinstance(m, nn.Dropout)), None)
+            if self.training and drop is not None and drop.p > 0:
+                keep = 1.0 - drop.p
+                mask = torch.empty(source.shape[0], 256, device=source.device).bernoulli_(keep).div_(keep)
+            lin = [m for m in self.point if isinstance(m, nn.Linear)] + [m for m in self.head if isinstance(m, nn.Linear)]
+            return _PoseNetRawFn.apply(clouds.contiguous(), mask, *[t for m in lin for t in (m.weight, m.bias)])
+        f = self._pooled(clouds)                                            # max pool over the points
         B = source.shape[0]
         return self.head(torch.cat([f[:B], f[B:]], 1))
 

@@ -362,6 +362,33 @@ size_t dpd_pose_refine_workspace_bytes(int B, int N, int out_features);
 int dpd_pose_refine(const dpd_pose_net* net, const float* src, const float* tmpl, int B, int N, int loops, float lim_rot_deg,
                     const float* drop_mask, void* ws, size_t ws_bytes, float* moved, float* T_out, float* pred_out, void* stream);
 
+/* The TRAINING evaluation of the pose network's shared MLP + max pool (models/ipcr_model.py:198-233 inside the step of
+ * pcrnet-registration/iterative_PCRNet_ours.py:442-470, which differentiates the network w.r.t. its weights only): forward with what the
+ * backward needs, and TF / torch autodiff of the five 1x1 convolutions, their ReLUs and tf.reduce_max.
+ *   dpd_pose_point_fwd_train: clouds ptsA [nA,N,3] then ptsB [nB,N,3] (nB may be 0) -> f [nA+nB, out_features]; stored for the backward:
+ *     h1, h2, h3 [(nA+nB) N, 64], h4 [(nA+nB) N, 128] (16-byte aligned) and ties [nA+nB, out_features] x 8 bytes: bit p set <=> point p
+ *     attains the column's maximum and that maximum is positive (the gradient of reduce_max is shared evenly among ties).  N <= 64.
+ *   dpd_pose_point_bwd: df [nA+nB, out_features] -> dW[i], db[i] (i = 0..4, shapes of net->Wp / bp; overwritten).  ws:
+ *     dpd_pose_point_bwd_workspace_bytes(nA + nB) bytes.  Deterministic (every sum in a fixed order).  The head's fields of `net` are not read. */
+size_t dpd_pose_point_bwd_workspace_bytes(int clouds);
+int dpd_pose_point_fwd_train(const dpd_pose_net* net, const float* ptsA, const float* ptsB, int nA, int nB, int N, float* f, float* h1, float* h2,
+                             float* h3, float* h4, unsigned long long* ties, void* stream);
+int dpd_pose_point_bwd(const dpd_pose_net* net, const float* ptsA, const float* ptsB, int nA, int nB, int N, const float* df, const float* h1,
+                       const float* h2, const float* h3, const float* h4, const unsigned long long* ties, float* const* dW, float* const* db,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* The head of the same training evaluation (models/ipcr_model.py:273-284: fc 2 x out_features -> 1024 -> 512 -> 256, ReLU each, dropout on the
+ * last, -> 7) and its autodiff.  f [2B, out_features] = the pooled features (rows < B: first cloud set, rows >= B: second; the head reads
+ * their concatenation without materialising it); drop_mask [B,256] (0 or 1/keep) or NULL.
+ *   dpd_pose_head_fwd_train: -> h1 [B,1024], h2 [B,512], h3 [B,256] (after the mask), pred [B,7] (the network's raw output).
+ *   dpd_pose_head_bwd: dpred [B,7] -> dW[i], db[i] (i = 0..3, shapes of net->Wh / bh; overwritten) and df [2B, out_features];
+ *     ws: dpd_pose_head_bwd_workspace_bytes(B).  Deterministic.  The shared MLP's fields of `net` are not read.                               */
+size_t dpd_pose_head_bwd_workspace_bytes(int B);
+int dpd_pose_head_fwd_train(const dpd_pose_net* net, const float* f, int B, const float* drop_mask, float* h1, float* h2, float* h3, float* pred,
+                            void* stream);
+int dpd_pose_head_bwd(const dpd_pose_net* net, const float* f, int B, const float* drop_mask, const float* h1, const float* h2, const float* h3,
+                      const float* dpred, float* const* dW, float* const* db, float* df, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * tf.train.AdamOptimizer step (epsilon-hat form), train_multi_gpu_pc_compare_dist.py:216,301:
  *   g' = g * gscale;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr_t m / (sqrt(v)+eps)

@@ -591,3 +591,131 @@ def test_fused_pose_kernels_match_the_torch_algebra(lim):
     with pytest.raises(RuntimeError, match="forward-only"):
         pg2 = pred.to(dev).requires_grad_(True)
         pose_apply(pg2, src.to(dev), None, lim, 0)[1].sum().backward()
+
+
+def _native_pool_selection(net, clouds):
+    """The max pool's selection as the LIBRARY's forward made it: sel [C,N,1024] float64 with 1 / (number of tied points) at the points that
+    attain a column's positive maximum (dpd_pose_point_fwd_train's tie masks).  A float64 reference must pool with THIS selection: where two
+    points of a cloud are equal to fp32 rounding, the library's fp32-MFMA forward and torch's GEMM may each call a different one the
+    maximum (seen: 1 column of 18765) -- both are right for their own values, and the gradient of max is discontinuous there."""
+    from ctypes import byref
+    from dpdist_amd import lib as L
+    C, N, _ = clouds.shape
+    lin = [m for m in net.point if isinstance(m, torch.nn.Linear)]
+    w = L.PoseNetW()
+    for i, m in enumerate(lin):
+        w.Wp[i], w.bp[i] = m.weight.data_ptr(), m.bias.data_ptr()
+    w.out_features = 1024
+    dev = clouds.device
+    e = lambda *sh: torch.empty(*sh, device=dev)      # noqa: E731
+    f, h = e(C, 1024), [e(C * N, k) for k in (64, 64, 64, 128)]
+    ties = torch.empty(C, 1024, device=dev, dtype=torch.int64)
+    L.check(L.load().dpd_pose_point_fwd_train(byref(w), L.ptr(clouds.contiguous()), None, C, 0, N, L.ptr(f), L.ptr(h[0]), L.ptr(h[1]), L.ptr(h[2]),
+                                              L.ptr(h[3]), ties.data_ptr(), L.cur_stream()), "dpd_pose_point_fwd_train")
+    bits = torch.stack([(ties >> b) & 1 for b in range(N)], 1).double()          # [C, N, 1024]
+    return bits / bits.sum(1, keepdim=True).clamp_min(1.0), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,N,dup", [(32, 64, False), (5, 50, False), (6, 64, True), (1, 8, False)])
+def test_pose_point_network_training_evaluation_on_the_library(C, N, dup):
+    """dpd_pose_point_fwd_train / dpd_pose_point_bwd (the pose network's shared MLP + max pool with its weight gradients: one launch forward,
+    three backward) against torch autograd of the same layers in float64: features and all ten gradients; `dup` duplicates points inside
+    the clouds, so that several points attain a column's maximum and the max pool's gradient must be SHARED among them (tf.reduce_max /
+    torch.amax); and two calls give the same bits (every sum has a fixed order)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = PoseNet().to(dev)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.bias.normal_(0.0, 0.05)
+    src, tmpl, _ = synth.registration_pairs(max(1, C), N, seed=9)
+    clouds = torch.tensor(np.concatenate([src, tmpl])[:C], device=dev)
+    if dup:
+        clouds[:, N // 2:] = clouds[:, :N - N // 2]              # every point twice: every positive maximum is attained (at least) twice
+    g = torch.Generator().manual_seed(5)
+    up = torch.randn(C, 1024, generator=g).to(dev)
+    params = [p for m in net.point if isinstance(m, torch.nn.Linear) for p in (m.weight, m.bias)]
+
+    def run(native):
+        net.native_train = native
+        for p in params:
+            p.grad = None
+        f = net._pooled(clouds)
+        (f * up).sum().backward()
+        return f.detach().clone(), [p.grad.clone() for p in params]
+
+    f_nat, g_nat = run(True)
+    f_nat2, g_nat2 = run(True)
+    assert torch.equal(f_nat, f_nat2) and all(torch.equal(a, b) for a, b in zip(g_nat, g_nat2))
+    f_t, g_t = run(False)
+    assert (f_nat - f_t).abs().max().item() <= 2e-5 * max(1.0, f_t.abs().max().item())
+    # float64 reference
+    net64 = PoseNet().double().to(dev)
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    p64 = [p for m in net64.point if isinstance(m, torch.nn.Linear) for p in (m.weight, m.bias)]
+    z64 = net64.point(clouds.double())
+    sel, _ = _native_pool_selection(net, clouds)
+    f64 = (z64 * sel).sum(1)                                     # the max pool with the library's selection (see the helper)
+    assert (f64 - z64.amax(1)).abs().max().item() <= 1e-5        # ... which IS the maximum up to fp32 rounding
+    (f64 * up.double()).sum().backward()
+    assert (f_nat.double() - f64).abs().max().item() <= 2e-5 * max(1.0, f64.abs().max().item())
+    for name, a, r in zip(["W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4", "W5", "b5"], g_nat, (p.grad for p in p64)):
+        scale = max(1e-6, r.abs().max().item())
+        # (a ReLU gate that is +-1e-8 in float64 and exactly 0 in fp32 can still move single entries: 1e-3 of the tensor's largest entry)
+        assert (a.double() - r).abs().max().item() <= 1e-3 * scale, (name, (a.double() - r).abs().max().item(), scale)
+    if dup:
+        assert float((f_nat > 0).float().mean()) > 0.05          # positive maxima exist, i.e. ties really carried gradient
+    net.native_train = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,with_mask", [(16, 64, True), (16, 64, False), (5, 50, True), (33, 64, True)])
+def test_pose_network_training_evaluation_is_one_node_on_the_library(B, N, with_mask):
+    """_PoseNetRawFn (shared MLP + max pool + head, forward and weight gradients on csrc/pose.hip) against the same network in torch, float64,
+    with the SAME dropout mask: raw output [B,7] and all 18 gradients; ragged batch / more than one row group of the head (B = 33)."""
+    from dpdist_amd.registration import _PoseNetRawFn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    net = PoseNet().to(dev)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.bias.normal_(0.0, 0.05)
+    src, tmpl, _ = synth.registration_pairs(B, N, seed=3)
+    clouds = torch.tensor(np.concatenate([src, tmpl]), device=dev)
+    g = torch.Generator().manual_seed(7)
+    mask = (torch.rand(B, 256, generator=g) < 0.7).float().div(0.7).to(dev) if with_mask else None
+    up = torch.randn(B, 7, generator=g).to(dev)
+    lin = [m for m in net.point if isinstance(m, torch.nn.Linear)] + [m for m in net.head if isinstance(m, torch.nn.Linear)]
+    params = [t for m in lin for t in (m.weight, m.bias)]
+    pred = _PoseNetRawFn.apply(clouds, mask, *params)
+    grads = torch.autograd.grad((pred * up).sum(), params)
+    pred2 = _PoseNetRawFn.apply(clouds, mask, *params)
+    grads2 = torch.autograd.grad((pred2 * up).sum(), params)
+    assert torch.equal(pred, pred2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))          # fixed summation orders
+    net64 = PoseNet().double().to(dev)
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    lin64 = [m for m in net64.point if isinstance(m, torch.nn.Linear)] + [m for m in net64.head if isinstance(m, torch.nn.Linear)]
+    p64 = [t for m in lin64 for t in (m.weight, m.bias)]
+    sel, _ = _native_pool_selection(net, clouds)
+    f = (net64.point(clouds.double()) * sel).sum(1)             # the max pool with the library's selection (see the helper)
+    h = net64.head[:6](torch.cat([f[:B], f[B:]], 1))
+    if mask is not None:
+        h = h * mask.double()
+    ref = net64.head[7](h)
+    gref = torch.autograd.grad((ref * up.double()).sum(), p64)
+    assert (pred.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    for i, (a, r) in enumerate(zip(grads, gref)):
+        scale = max(1e-6, r.abs().max().item())
+        assert (a.double() - r).abs().max().item() <= 1e-3 * scale, (i, (a.double() - r).abs().max().item(), scale)
+    # and through the module: train mode takes this node (a drawn mask), evaluation mode too (no mask); torch when switched off
+    net.train()
+    out = net.raw(clouds[:B], clouds[B:])
+    assert type(out.grad_fn).__name__ == "_PoseNetRawFnBackward"
+    net.native_train = False
+    out_t = net.eval().raw(clouds[:B], clouds[B:])
+    net.native_train = True
+    out_n = net.raw(clouds[:B], clouds[B:])
+    assert type(out_t.grad_fn).__name__ != "_PoseNetRawFnBackward" and (out_t - out_n).abs().max().item() <= 2e-5 * max(1.0, out_t.abs().max().item())
