@@ -556,10 +556,11 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
 // The max pool makes the last layer's gradient SPARSE: per (cloud, column) only the points that attain a positive maximum carry gradient
 // (evenly shared among ties, like tf.reduce_max), i.e. one 128-vector per (cloud, column) instead of a [points, 1024] matrix:
 //   pose_bwd_w5_kernel      wave = output column c: dW5[c, :] = sum over clouds of coef * h4[tied point, :], db5[c] = sum of the column's gradient
-//   pose_bwd_dh4_kernel     wave = point: the gradient of layer 4's output from the tie masks (columns in ascending order: deterministic)
-//   pose_bwd_cloud_kernel   workgroup = cloud: layers 4..1 densely in LDS (64 points: ~2 MFLOP per cloud); per-cloud partial weight gradients
+//   pose_bwd_dh4_kernel     the gradient of layer 4's output, g4 = S W5 with the selection matrix S built from the tie masks, on the fp32
+//                           matrix cores (workgroup = cloud x 32x32 tile, wave = 128 columns): independent of how the maxima spread over points
+//   pose_bwd_cloud_kernel   workgroup = cloud: layers 4..1 on v_mfma_f32_32x32x2_f32 out of LDS; per-cloud partial weight gradients
 //   pose_bwd_reduce_kernel  sums the partials over the clouds in cloud order
-// Plain fp32 FMA; every sum has a fixed order (bitwise reproducible).
+// fp32 throughout (MFMA fp32 = an fmaf chain per element); every sum has a fixed order (bitwise reproducible).
 namespace dpd {
 
 constexpr int kPart = 128 * 64 + 128 + 64 * 64 + 64 + 64 * 64 + 64 + 64 * 3 + 64;      // dW4 | db4 | dW3 | db3 | dW2 | db2 | dW1 | db1 per cloud
@@ -619,176 +620,224 @@ __global__ __launch_bounds__(256) void pose_bwd_w5_kernel(const float* __restric
     if (l == 0) db5[c] = bsum;
 }
 
-constexpr int kBT = 1024;      // threads of the per-cloud backward workgroup
-
-// out[p][j] (4 columns per thread) = [hprev[p][j] > 0] * sum_o g[p][o] W[o][j]   (dX of a layer whose weight W [KO, KI] row-major sits in LDS)
-// thread = (p = t / 16, column quad t % 16); KI = 64
-template <int KO>
-__device__ __forceinline__ void bwd_dx64(const float* __restrict__ g, int gs, const float* __restrict__ Wl, const float* __restrict__ hprev,
-                                         float* __restrict__ out, int os, int np, int t) {
-    const int p = t >> 4, j0 = (t & 15) * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int o = 0; o < KO; ++o) {
-        const float a = g[p * gs + o];
-        const float4 w = *reinterpret_cast<const float4*>(Wl + o * 64 + j0);
-        acc.x += a * w.x; acc.y += a * w.y; acc.z += a * w.z; acc.w += a * w.w;
-    }
-    const bool live = p < np;
-    out[p * os + j0] = (live && hprev[p * os + j0] > 0.f) ? acc.x : 0.f;
-    out[p * os + j0 + 1] = (live && hprev[p * os + j0 + 1] > 0.f) ? acc.y : 0.f;
-    out[p * os + j0 + 2] = (live && hprev[p * os + j0 + 2] > 0.f) ? acc.z : 0.f;
-    out[p * os + j0 + 3] = (live && hprev[p * os + j0 + 3] > 0.f) ? acc.w : 0.f;
-}
-
-// dW[o][i] = sum_p g[p][o] h[p][i] (p ascending), db[o] = sum_p g[p][o]; KI = 64; thread = (output row o, NI consecutive inputs)
-template <int KO>
-__device__ __forceinline__ void bwd_dw64(const float* __restrict__ g, int gs, const float* __restrict__ h, int hs, int np, float* __restrict__ dW,
-                                         float* __restrict__ db, int t) {
-    constexpr int NI = KO * 64 / kBT;       // 8 (KO = 128) or 4 (KO = 64)
-    constexpr int TPO = 64 / NI;
-    const int o = t / TPO, i0 = (t % TPO) * NI;
-    float acc[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) acc[i] = 0.f;
-    float bs = 0.f;
-    for (int p = 0; p < np; ++p) {
-        const float a = g[p * gs + o];
-        bs += a;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] += a * h[p * hs + i0 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) dW[o * 64 + i0 + i] = acc[i];
-    if (i0 == 0) db[o] = bs;
-}
-
-constexpr int kBS128 = 129, kBS64 = 65;      // odd LDS strides: a column read down the points touches every bank once
-// LDS (floats): g4 [64][129] | hA, hB, gA, gB [64][65] each | W [128 x 64] | points [64][4]
-constexpr int kBwdG4 = 0, kBwdHA = 64 * kBS128, kBwdGA = kBwdHA + 64 * kBS64, kBwdGB = kBwdGA + 64 * kBS64, kBwdHB = kBwdGB + 64 * kBS64,
-              kBwdW = kBwdHB + 64 * kBS64, kBwdPts = kBwdW + 128 * 64, kBwdLds = kBwdPts + 256;
-static_assert(kBwdLds * 4 <= 160 * 1024 && (kBwdW % 4) == 0, "LDS budget / alignment");
-
-__device__ __forceinline__ void lds_rows64(float* __restrict__ dst, const float* __restrict__ src, int np, int t) {      // [np][64] global -> [64][65]
-    for (int e = t; e < 64 * 16; e += kBT) {
-        const int r = e >> 4, c4 = (e & 15) * 4;
-        const float4 v = r < np ? *reinterpret_cast<const float4*>(src + (size_t)r * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[r * kBS64 + c4] = v.x; dst[r * kBS64 + c4 + 1] = v.y; dst[r * kBS64 + c4 + 2] = v.z; dst[r * kBS64 + c4 + 3] = v.w;
-    }
-}
-__device__ __forceinline__ void lds_weights(float* __restrict__ dst, const float* __restrict__ W, int n, int t) {        // n floats, n % 4 == 0
-    for (int e = t * 4; e < n; e += kBT * 4) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(W + e);
-}
-
-// g4[cloud, p, :] = [h4 > 0] * sum over the columns whose maximum point p attains of coef * W5[column, :], columns in ascending order
-// (deterministic).  Workgroup = (cloud, four points), wave = point, lane = two of the 128 inputs.  (A) lane l tests column 64 g + l for
-// g = 0..15 and the sixteen ballots go to LDS: the point's hit list is known before the first weight row is requested, so (B) the rows (512
-// contiguous bytes of W5 each, one float2 per lane, L2-resident) are requested SIXTEEN at a time.  (Testing and loading column by column
-// inside the per-cloud kernel made every hit a dependent L2 round trip: 150 us.)  A few "critical" points attain most maxima: one wave per
-// point on clouds * 16 workgroups spreads that skew over the chip.
-__global__ __launch_bounds__(256) void pose_bwd_dh4_kernel(const float* __restrict__ df, const unsigned long long* __restrict__ ties,
+// g4[cloud, p, :] = [h4 > 0] * sum over the columns whose maximum point p attains of coef * W5[column, :], coef = df / (number of tied points).
+// As a product on the fp32 matrix cores: g4 = S W5 with S [64 points][1024 columns] holding coef[col] at the point(s) that attain column col's
+// maximum -- one nonzero per column -- so the zeros cost 16.8 MFLOP per cloud and NOTHING depends on how the maxima are spread over the points.
+// (The sparse forms walked each point's hit list: a few "critical" points attain hundreds of columns while most attain none, and every batch of
+// weight rows was a dependent L2 round trip -- 30 us with a wave per point, 39-47 us with a workgroup per point.)
+// Workgroup = (cloud, 32 points x 32 inputs tile), eight waves, wave w = columns 128 w .. + 127: the A operand is built in registers from the tie
+// word and the coefficient of its column (LDS broadcasts), the B operand W5[col][n0 + lane % 32] is read straight from global memory (coalesced:
+// v_mfma_f32_32x32x2_f32 wants one k per lane half), all 64 of them requested before the first product.  The eight partial tiles are added in
+// wave order: columns ascending, deterministic; adding an exact zero changes nothing, so this IS the ascending-column sum of the sparse forms.
+__global__ __launch_bounds__(512) void pose_bwd_dh4_kernel(const float* __restrict__ df, const unsigned long long* __restrict__ ties,
                                                             const float* __restrict__ W5, const float* __restrict__ h4, int N, int OUT,
                                                             float* __restrict__ g4g) {
-    __shared__ unsigned long long sbits[1024];
-    __shared__ float coef[1024];
-    __shared__ unsigned long long smask_all[4 * 16];
-    const int c = blockIdx.x >> 4, t = threadIdx.x, wv = t >> 6, l = t & 63;
-    const int p = (blockIdx.x & 15) * 4 + wv;
-    for (int col = t; col < OUT; col += 256) {
-        const unsigned long long b = ties[(size_t)c * OUT + col];
-        sbits[col] = b;
-        coef[col] = b ? df[(size_t)c * OUT + col] / (float)__popcll(b) : 0.f;
+    __shared__ unsigned long long sT[1024];
+    __shared__ float sC[1024];
+    __shared__ float part[8][1024];
+    const int c = blockIdx.x >> 3, tile = blockIdx.x & 7, m0 = (tile >> 2) * 32, n0 = (tile & 3) * 32;
+    const int t = threadIdx.x, wv = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
+    const int kb = wv * 128;
+    // every global load of the kernel is requested here, together
+    float w[64];
+    const float* wp = W5 + (size_t)(kb + h) * 128 + n0 + i;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) w[j] = wp[(size_t)j * 256];
+    unsigned long long tb[2];
+    float dv[2], hv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int col = q * 512 + t;
+        tb[q] = ties[(size_t)c * OUT + col];
+        dv[q] = df[(size_t)c * OUT + col];
+        const int pr = m0 + (col >> 5);                       // (the epilogue's element: row col / 32 of the tile, input n0 + col % 32)
+        hv[q] = pr < N ? h4[((size_t)c * N + pr) * 128 + n0 + (col & 31)] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        sT[q * 512 + t] = tb[q];
+        sC[q * 512 + t] = tb[q] ? dv[q] / (float)__popcll(tb[q]) : 0.f;
     }
     __syncthreads();
-    if (p >= N) return;
-    unsigned long long* smask = smask_all + wv * 16;
-    const int ng = OUT / 64;
-    for (int g = 0; g < ng; ++g) {
-        const unsigned long long m = __ballot((sbits[g * 64 + l] >> p) & 1ull);
-        if (l == 0) smask[g] = m;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int sh = m0 + i;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const int col = kb + 2 * j + h;
+        const float a = ((sT[col] >> sh) & 1ull) ? sC[col] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[j], acc, 0, 0, 0);
     }
-    __builtin_amdgcn_wave_barrier();
-    float a0 = 0.f, a1 = 0.f;
-    int g = 0;
-    unsigned long long m = smask[0];
-    for (;;) {
-        int cols[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            while (!m && g < ng - 1) m = smask[++g];
-            if (m) { cols[u] = g * 64 + __ffsll((long long)m) - 1; m &= m - 1; }
-            else cols[u] = -1;
-        }
-        if (cols[0] < 0) break;
-        float2 w[16];
-        float cf[16];
+    for (int r = 0; r < 16; ++r) part[wv][mfma_row(r, l) * 32 + i] = acc[r];
+    __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int cc = cols[u] < 0 ? cols[0] : cols[u];           // (a padding slot re-reads the batch's first row: a cache hit)
-            cf[u] = cols[u] < 0 ? 0.f : coef[cc];
-            w[u] = *reinterpret_cast<const float2*>(W5 + (size_t)cc * 128 + 2 * l);
-        }
+    for (int q = 0; q < 2; ++q) {
+        const int o = q * 512 + t, pr = m0 + (o >> 5);
+        float sum = part[0][o];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { a0 += cf[u] * w[u].x; a1 += cf[u] * w[u].y; }
-        if (cols[15] < 0) break;
+        for (int u = 1; u < 8; ++u) sum += part[u][o];
+        if (pr < N) g4g[((size_t)c * N + pr) * 128 + n0 + (o & 31)] = hv[q] > 0.f ? sum : 0.f;
     }
-    const float2 hv = *reinterpret_cast<const float2*>(h4 + ((size_t)c * N + p) * 128 + 2 * l);
-    *reinterpret_cast<float2*>(g4g + ((size_t)c * N + p) * 128 + 2 * l) = make_float2(hv.x > 0.f ? a0 : 0.f, hv.y > 0.f ? a1 : 0.f);
+}
+
+// ---- layers 4..1 of one cloud on the fp32 matrix cores.  Every product is C[m][n] = sum_k A[m][k] B[n][k] with BOTH operands k-contiguous in
+// LDS (rows padded by 4 floats: conflict-free 16-byte reads), so each tensor is kept in the orientation(s) its products contract over:
+//   dW_l [o][i] = sum_p g_l[p][o] h_{l-1}[p][i]      A = g_l^T [o][p], B = h_{l-1}^T [i][p]
+//   dh   [p][i] = sum_o g_l[p][o] W_l[o][i]          A = g_l [p][o],   B = W_l^T [i][o];   g_{l-1} = dh * [h_{l-1} > 0]
+// 32x32 output tiles of v_mfma_f32_32x32x2_f32 (an exact fp32 fmaf chain per element, k ascending), four waves.  The FMA form of this kernel
+// (one output row per thread, operands re-read from LDS for every multiply) was LDS-bandwidth bound at 45 us.
+template <int K>
+__device__ __forceinline__ f32x16 bwd_mm_tile(const float* __restrict__ A, int sa, const float* __restrict__ Bm, int sb, int m0, int n0) {
+    const int l = threadIdx.x & 63, i = l & 31, h = l >> 5;
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    const float* ap = A + (m0 + i) * sa + 4 * h;
+    const float* bp = Bm + (n0 + i) * sb + 4 * h;
+#pragma unroll 4
+    for (int k = 0; k < K; k += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + k);
+        const float4 b = *reinterpret_cast<const float4*>(bp + k);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+    }
+    return c;
+}
+// (the k order inside a step of 8 is 4 h + e for lane half h: the two halves of the wave supply the two k of each 32x32x2 product)
+
+constexpr int kBT = 256;       // threads of the per-cloud backward workgroup (four waves)
+constexpr int kP64 = 68, kP128 = 132;
+// LDS (floats): G [64 p][132] | GT [128 o][68] | HT [64 i][68] | WT [64 i][132] | GA [64][68] | GAT [64][68] | points [64][4]
+//   layer 4: G = g4, GT = g4^T, HT = h3^T, WT = W4^T -> dW4, g3 (GA, GAT)
+//   layer 3: HT = h2^T, WT = W3^T (stride 68)         -> dW3, g2 (G as [64][68], GT as [64][68])
+//   layer 2: HT = h1^T, WT = W2^T                     -> dW2, g1 (GA)
+constexpr int kMG = 0, kMGT = kMG + 64 * kP128, kMHT = kMGT + 128 * kP64, kMWT = kMHT + 64 * kP64, kMGA = kMWT + 64 * kP128, kMGAT = kMGA + 64 * kP64,
+              kMPts = kMGAT + 64 * kP64, kBwdLds = kMPts + 256;
+static_assert(kBwdLds * 4 <= 160 * 1024, "LDS budget");
+
+// src [rows][cols] row-major in global memory (rows < nrow valid, else zero) -> dst[c][r] (transposed, stride ds), and optionally dst2[r][c]
+__device__ __forceinline__ void lds_load_t(const float* __restrict__ src, int nrow, int rows, int cols, float* __restrict__ dstT, int dsT,
+                                           float* __restrict__ dst, int ds, int t) {
+    const int c4n = cols / 4;
+    for (int e = t; e < rows * c4n; e += kBT) {
+        const int r = e / c4n, c4 = (e % c4n) * 4;
+        const float4 v = r < nrow ? *reinterpret_cast<const float4*>(src + (size_t)r * cols + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dstT[(c4 + 0) * dsT + r] = v.x; dstT[(c4 + 1) * dsT + r] = v.y; dstT[(c4 + 2) * dsT + r] = v.z; dstT[(c4 + 3) * dsT + r] = v.w;
+        if (dst) *reinterpret_cast<float4*>(dst + r * ds + c4) = v;
+    }
+}
+
+// the same for a [64][64] matrix in two steps, so that the NEXT layer's operands are requested before this layer's products and written to LDS
+// after them (a dependent global round trip per layer otherwise): thread t holds rows r = t / 16 + 16 q (q = 0..3), columns 4 (t % 16) .. + 3
+struct Pre64 {
+    float4 v[4];
+};
+__device__ __forceinline__ Pre64 pre64_load(const float* __restrict__ src, int nrow, int t) {
+    Pre64 x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (t >> 4) + 16 * q, c4 = (t & 15) * 4;
+        x.v[q] = r < nrow ? *reinterpret_cast<const float4*>(src + (size_t)r * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return x;
+}
+__device__ __forceinline__ void pre64_store_t(const Pre64& x, float* __restrict__ dstT, int t) {      // dstT[c][r], stride 68
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (t >> 4) + 16 * q, c4 = (t & 15) * 4;
+        dstT[(c4 + 0) * kP64 + r] = x.v[q].x; dstT[(c4 + 1) * kP64 + r] = x.v[q].y; dstT[(c4 + 2) * kP64 + r] = x.v[q].z; dstT[(c4 + 3) * kP64 + r] = x.v[q].w;
+    }
+}
+
+// dW tile(s) of this wave -> the cloud's partial record; db[o] = sum_p g[p][o] by the first KO threads (G^T rows are contiguous in p)
+template <int KO>
+__device__ __forceinline__ void bwd_layer_dw(const float* __restrict__ GT, const float* __restrict__ HT, float* __restrict__ dW, float* __restrict__ db,
+                                             int np, int t) {
+    const int wv = t >> 6, l = t & 63;
+    constexpr int TILES = (KO / 32) * 2;                  // 32x32 tiles of dW [KO][64]
+    for (int tile = wv; tile < TILES; tile += 4) {
+        const int m0 = (tile >> 1) * 32, n0 = (tile & 1) * 32;
+        const f32x16 c = bwd_mm_tile<64>(GT, kP64, HT, kP64, m0, n0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[(m0 + mfma_row(r, l)) * 64 + n0 + (l & 31)] = c[r];
+    }
+    if (t < KO) {
+        float s = 0.f;
+        for (int p = 0; p < np; ++p) s += GT[t * kP64 + p];
+        db[t] = s;
+    }
+}
+
+// g_prev = (g W) * [h_prev > 0]: tile (wave) of [64 p][64 i]; written as [p][i] (stride so) and transposed [i][p] (stride 68)
+template <int KO>
+__device__ __forceinline__ void bwd_layer_dx(const float* __restrict__ G, int sg, const float* __restrict__ WT, int sw, const float* __restrict__ HT,
+                                             float* __restrict__ out, int so, float* __restrict__ outT, int t) {
+    const int wv = t >> 6, l = t & 63;
+    const int m0 = (wv >> 1) * 32, n0 = (wv & 1) * 32;
+    const f32x16 c = bwd_mm_tile<KO>(G, sg, WT, sw, m0, n0);
+    const int col = n0 + (l & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + mfma_row(r, l);
+        const float v = HT[col * kP64 + row] > 0.f ? c[r] : 0.f;       // (rows >= np: h = 0 there, so g = 0)
+        out[row * so + col] = v;
+        if (outT) outT[col * kP64 + row] = v;
+    }
 }
 
 __global__ __launch_bounds__(kBT) void pose_bwd_cloud_kernel(const float* __restrict__ ptsA, const float* __restrict__ ptsB, int nA, int N,
                                                               PointNetW net, const float* __restrict__ g4g, PointSave sv,
                                                               float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* g4 = lds + kBwdG4;
-    float* hA = lds + kBwdHA;                // activations of the layer below the one being differentiated
-    float* gA = lds + kBwdGA;                // its gradient (ping)
-    float* gB = lds + kBwdGB;                // (pong)
-    float* hB = lds + kBwdHB;
-    float* Wl = lds + kBwdW;
-    float* sp = lds + kBwdPts;
+    float* G = lds + kMG;
+    float* GT = lds + kMGT;
+    float* HT = lds + kMHT;
+    float* WT = lds + kMWT;
+    float* GA = lds + kMGA;
+    float* GAT = lds + kMGAT;
+    float* sp = lds + kMPts;
     const int c = blockIdx.x, t = threadIdx.x;
     const int np = N;
     const float* pts = c < nA ? ptsA + (size_t)c * N * 3 : ptsB + (size_t)(c - nA) * N * 3;
     float* out = part + (size_t)c * kPart;
-    // h3, W4, the points
-    lds_rows64(hA, sv.h[2] + (size_t)c * N * 64, np, t);
-    lds_weights(Wl, net.W[3], 128 * 64, t);
+    // layer 4 (W4 [128 o][64 i]): g4 -> G [p][o], GT [o][p]; h3 -> HT [i][p]; W4 -> WT [i][o]
+    lds_load_t(g4g + (size_t)c * N * 128, np, 64, 128, GT, kP64, G, kP128, t);
+    lds_load_t(sv.h[2] + (size_t)c * N * 64, np, 64, 64, HT, kP64, nullptr, 0, t);
+    lds_load_t(net.W[3], 128, 128, 64, WT, kP128, nullptr, 0, t);
     if (t < 192) sp[(t / 3) * 4 + t % 3] = (t / 3) < np ? pts[t] : 0.f;
+    Pre64 ph = pre64_load(sv.h[1] + (size_t)c * N * 64, np, t), pw = pre64_load(net.W[2], 64, t);      // layer 3's operands, in flight
     __syncthreads();
-    // g4 = dh4 * [h4 > 0] of this cloud (pose_bwd_dh4_kernel)
-    for (int e = t; e < 64 * 32; e += kBT) {
-        const int r = e >> 5, c4 = (e & 31) * 4;
-        const float4 v = r < np ? *reinterpret_cast<const float4*>(g4g + ((size_t)c * N + r) * 128 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        g4[r * kBS128 + c4] = v.x; g4[r * kBS128 + c4 + 1] = v.y; g4[r * kBS128 + c4 + 2] = v.z; g4[r * kBS128 + c4 + 3] = v.w;
-    }
+    bwd_layer_dw<128>(GT, HT, out, out + 128 * 64, np, t);
+    bwd_layer_dx<128>(G, kP128, WT, kP128, HT, GA, kP64, GAT, t);                      // g3 -> GA [p][o3], GAT [o3][p]
     __syncthreads();
-    // layer 4 (128 x 64): dW4 / db4 from (g4, h3); g3 = (g4 W4) * [h3 > 0] -> gA
-    bwd_dw64<128>(g4, kBS128, hA, kBS64, np, out, out + 128 * 64, t);
-    bwd_dx64<128>(g4, kBS128, Wl, hA, gA, kBS64, np, t);
-    __syncthreads();
-    // layer 3 (64 x 64): h2 -> hB, W3 -> Wl; dW3 / db3 from (g3, h2); g2 = (g3 W3) * [h2 > 0] -> gB
-    lds_rows64(hB, sv.h[1] + (size_t)c * N * 64, np, t);
-    lds_weights(Wl, net.W[2], 64 * 64, t);
+    // layer 3 (W3 [64][64]): h2 -> HT, W3 -> WT (stride 68)
+    pre64_store_t(ph, HT, t);
+    pre64_store_t(pw, WT, t);
+    ph = pre64_load(sv.h[0] + (size_t)c * N * 64, np, t);                                              // layer 2's
+    pw = pre64_load(net.W[1], 64, t);
     __syncthreads();
     float* o3 = out + 128 * 64 + 128;
-    bwd_dw64<64>(gA, kBS64, hB, kBS64, np, o3, o3 + 64 * 64, t);
-    bwd_dx64<64>(gA, kBS64, Wl, hB, gB, kBS64, np, t);
+    bwd_layer_dw<64>(GAT, HT, o3, o3 + 64 * 64, np, t);
+    bwd_layer_dx<64>(GA, kP64, WT, kP64, HT, G, kP64, GT, t);                          // g2 -> G [p][o2] (stride 68), GT [o2][p]
     __syncthreads();
-    // layer 2 (64 x 64): h1 -> hA, W2 -> Wl; dW2 / db2 from (g2, h1); g1 = (g2 W2) * [h1 > 0] -> gA
-    lds_rows64(hA, sv.h[0] + (size_t)c * N * 64, np, t);
-    lds_weights(Wl, net.W[1], 64 * 64, t);
+    // layer 2 (W2 [64][64]): h1 -> HT, W2 -> WT
+    pre64_store_t(ph, HT, t);
+    pre64_store_t(pw, WT, t);
     __syncthreads();
     float* o2 = o3 + 64 * 64 + 64;
-    bwd_dw64<64>(gB, kBS64, hA, kBS64, np, o2, o2 + 64 * 64, t);
-    bwd_dx64<64>(gB, kBS64, Wl, hA, gA, kBS64, np, t);
+    bwd_layer_dw<64>(GT, HT, o2, o2 + 64 * 64, np, t);
+    bwd_layer_dx<64>(G, kP64, WT, kP64, HT, GA, kP64, nullptr, t);                     // g1 -> GA [p][o1]
     __syncthreads();
     // layer 1 (64 x 3): dW1[o][i] = sum_p g1[p][o] pts[p][i], db1
     float* o1 = o2 + 64 * 64 + 64;
     if (t < 64) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, bs = 0.f;
         for (int p = 0; p < np; ++p) {
-            const float a = gA[p * kBS64 + t];
+            const float a = GA[p * kP64 + t];
             bs += a; a0 += a * sp[p * 4]; a1 += a * sp[p * 4 + 1]; a2 += a * sp[p * 4 + 2];
         }
         o1[t * 3] = a0; o1[t * 3 + 1] = a1; o1[t * 3 + 2] = a2;
@@ -802,7 +851,15 @@ __global__ __launch_bounds__(256) void pose_bwd_reduce_kernel(const float* __res
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kPart) return;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += part[(size_t)c * kPart + i];
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {                       // eight clouds' records requested together; added in cloud order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * kPart + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < C; ++c) s += part[(size_t)c * kPart + i];
     int k = i;
     if (k < 128 * 64) { dW4[k] = s; return; }
     k -= 128 * 64;
@@ -880,7 +937,7 @@ extern "C" int dpd_pose_point_bwd(const dpd_pose_net* net, const float* ptsA, co
     const size_t lds = (size_t)kBwdLds * sizeof(float);
     if (int rc = ensure_dyn_lds(g_point_bwd_lds, (const void*)pose_bwd_cloud_kernel, lds)) return rc;
     float* g4g = (float*)ws + (size_t)C * kPart;                   // [C * N, 128]
-    DPD_LAUNCH(pose_bwd_dh4_kernel, dim3((unsigned)(C * 16)), dim3(256), 0, s, df, ties, net->Wp[4], h4, N, OUT, g4g);
+    DPD_LAUNCH(pose_bwd_dh4_kernel, dim3((unsigned)(C * 8)), dim3(512), 0, s, df, ties, net->Wp[4], h4, N, OUT, g4g);
     DPD_CHECK_LAUNCH();
     DPD_LAUNCH(pose_bwd_cloud_kernel, dim3((unsigned)C), dim3(kBT), lds, s, ptsA, ptsB, nA, N, pw, (const float*)g4g, sv, (float*)ws);
     DPD_CHECK_LAUNCH();
@@ -895,7 +952,8 @@ extern "C" int dpd_pose_point_bwd(const dpd_pose_net* net, const float* ptsA, co
 //   forward   pose_fc_kernel (above) x 3 with the hidden activations kept, pose_fc4_fwd_kernel
 //   backward  pose_fc4_bwd_kernel: gradient of the 256-wide activation (dropout mask and ReLU gate applied) + dW4 / db4
 //             per wide layer: pose_fc_dw_kernel (dW = g^T x, db: 16 terms per entry, bound by the 8 MB it writes for fc1) and
-//             pose_fc_dx_kernel (gx = (g W) * [x > 0] on v_mfma_f32_16x16x4_f32; the weight is streamed once, 64 input columns per workgroup)
+//             pose_fc_dx_kernel (gx = (g W) * [x > 0] on v_mfma_f32_16x16x4_f32; the weight is streamed once: 16 input columns per workgroup,
+//             sixteen waves each contracting a sixteenth of the outputs, partial tiles added in wave order -- 128 / 64 / 32 workgroups)
 namespace dpd {
 
 // pred[b][o] = sum_k h3[b][k] W4[o][k] + b4[o], o < 7, K4 = 256: one wave per row
@@ -936,16 +994,25 @@ __global__ __launch_bounds__(256) void pose_fc4_bwd_kernel(const float* __restri
         }
         return;
     }
-    for (int e = t; e < 7 * K4; e += 256) {
-        const int o = e / K4, k = e % K4;
+    // workgroup B + o: row o of dW4 (and db4[o]); the batch's terms are requested eight at a time and added in batch order
+    const int o = blockIdx.x - B;
+    for (int k = t; k < K4; k += 256) {
         float v = 0.f;
-        for (int b = 0; b < B; ++b) v += dpred[(size_t)b * 7 + o] * h3[(size_t)b * K4 + k];
-        dW4[e] = v;
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {
+            float d[8], hh[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { d[u] = dpred[(size_t)(b + u) * 7 + o]; hh[u] = h3[(size_t)(b + u) * K4 + k]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += d[u] * hh[u];
+        }
+        for (; b < B; ++b) v += dpred[(size_t)b * 7 + o] * h3[(size_t)b * K4 + k];
+        dW4[(size_t)o * K4 + k] = v;
     }
-    if (t < 7) {
+    if (t == 0) {
         float v = 0.f;
-        for (int b = 0; b < B; ++b) v += dpred[(size_t)b * 7 + t];
-        db4[t] = v;
+        for (int b = 0; b < B; ++b) v += dpred[(size_t)b * 7 + o];
+        db4[o] = v;
     }
 }
 
@@ -962,6 +1029,7 @@ __global__ __launch_bounds__(256) void pose_fc_dw_kernel(const float* __restrict
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
     for (int r = 0; r < R; ++r) {
         const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx);
         const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)r * J + j0);
@@ -988,47 +1056,38 @@ __global__ __launch_bounds__(256) void pose_fc_dw_kernel(const float* __restrict
 // order through LDS (deterministic).  xprev == NULL: no gate (the pooled features).  out rows: row r -> out + r * ldo (+ column k); for the
 // first layer the columns >= split go to the rows of the second cloud set: out[(R + r) * ldo + k - split].
 template <int NIT>
-__global__ __launch_bounds__(512) void pose_fc_dx_kernel(const float* __restrict__ g, const float* __restrict__ W, const float* __restrict__ xprev,
-                                                          int K, int R, float* __restrict__ out, int ldo, int split) {
-    constexpr int J = NIT * 32;
-    __shared__ float part[8][1024];
-    const int k0 = blockIdx.x * 64, r0 = blockIdx.y * 16, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+__global__ __launch_bounds__(1024) void pose_fc_dx_kernel(const float* __restrict__ g, const float* __restrict__ W, const float* __restrict__ xprev,
+                                                           int K, int R, float* __restrict__ out, int ldo, int split) {
+    constexpr int J = NIT * 64;
+    __shared__ float part[16][256];
+    const int k0 = blockIdx.x * 16, r0 = blockIdx.y * 16, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int n = l & 15, kk = l >> 4;
     const int row = min(r0 + n, R - 1);
-    const int jw = wv * (J / 8);
-    float4 wr[NIT];
-    float gr[NIT];
+    const int jw = wv * (J / 16);
+    // the epilogue's element (threads 0..255): row r0 + (t / 4) % 16, column k0 + 4 (t / 64) + t % 4; its ReLU gate is requested with the operands
+    const int et = threadIdx.x, err = r0 + ((et >> 2) & 15), ek = k0 + 4 * (et >> 6) + (et & 3);
+    const float gate = (et < 256 && err < R && xprev) ? xprev[(size_t)err * K + ek] : 1.f;
+    float wr[NIT], gr[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        wr[i] = *reinterpret_cast<const float4*>(W + (size_t)(jw + 4 * i + kk) * K + k0 + 4 * n);
+        wr[i] = W[(size_t)(jw + 4 * i + kk) * K + k0 + n];
         gr[i] = g[(size_t)row * J + jw + 4 * i + kk];
     }
-    f32x4 c[4];
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) c[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NIT; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i], gr[i], c, 0, 0, 0);
+    // lane l holds C[i = 4 (l / 16) + r][n = l % 16]: column k0 + i of row n
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].x, gr[i], c[0], 0, 0, 0);
-        c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].y, gr[i], c[1], 0, 0, 0);
-        c[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].z, gr[i], c[2], 0, 0, 0);
-        c[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i].w, gr[i], c[3], 0, 0, 0);
-    }
-    // lane l holds C_e[i = 4 (l / 16) + r][n = l % 16]: column k0 + 16 (l / 16) + 4 r + e of row n
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) part[wv][l * 16 + 4 * r + e] = c[e][r];
+    for (int r = 0; r < 4; ++r) part[wv][l * 4 + r] = c[r];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 1024; idx += 512) {
-        float v = part[0][idx];
+    if (et < 256) {
+        float v = part[0][et];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) v += part[q][idx];
-        const int ll = idx >> 4, off = idx & 15;
-        const int rr = r0 + (ll & 15), k = k0 + 16 * (ll >> 4) + off;
-        if (rr < R) {
-            if (xprev && !(xprev[(size_t)rr * K + k] > 0.f)) v = 0.f;
-            if (k < split) out[(size_t)rr * ldo + k] = v;
-            else out[(size_t)(R + rr) * ldo + k - split] = v;
+        for (int q = 1; q < 16; ++q) v += part[q][et];
+        if (err < R) {
+            if (!(gate > 0.f)) v = 0.f;
+            if (ek < split) out[(size_t)err * ldo + ek] = v;
+            else out[(size_t)(R + err) * ldo + ek - split] = v;
         }
     }
 }
@@ -1078,22 +1137,22 @@ extern "C" int dpd_pose_head_bwd(const dpd_pose_net* net, const float* f, int B,
     float* g2 = g3 + (size_t)B * 256;        // [B, 512]
     float* g1 = g2 + (size_t)B * 512;        // [B, 1024]
     const unsigned ry = (unsigned)((B + 15) / 16);
-    DPD_LAUNCH(pose_fc4_bwd_kernel, dim3((unsigned)B + 1), dim3(256), 0, s, dpred, net->Wh[3], h3, drop_mask, B, 256, g3, dW[3], db[3]);
+    DPD_LAUNCH(pose_fc4_bwd_kernel, dim3((unsigned)B + 7), dim3(256), 0, s, dpred, net->Wh[3], h3, drop_mask, B, 256, g3, dW[3], db[3]);
     DPD_CHECK_LAUNCH();
     // fc3: W [256, 512]
     DPD_LAUNCH(pose_fc_dw_kernel, dim3(512 / 256, 256 / 16), dim3(256), 0, s, (const float*)g3, h2, (const float*)nullptr, 512, 256, 512, B, dW[2], db[2]);
     DPD_CHECK_LAUNCH();
-    DPD_LAUNCH(pose_fc_dx_kernel<8>, dim3(512 / 64, ry), dim3(512), 0, s, (const float*)g3, net->Wh[2], h2, 512, B, g2, 512, 512);
+    DPD_LAUNCH(pose_fc_dx_kernel<4>, dim3(512 / 16, ry), dim3(1024), 0, s, (const float*)g3, net->Wh[2], h2, 512, B, g2, 512, 512);
     DPD_CHECK_LAUNCH();
     // fc2: W [512, 1024]
     DPD_LAUNCH(pose_fc_dw_kernel, dim3(1024 / 256, 512 / 16), dim3(256), 0, s, (const float*)g2, h1, (const float*)nullptr, 1024, 512, 1024, B, dW[1], db[1]);
     DPD_CHECK_LAUNCH();
-    DPD_LAUNCH(pose_fc_dx_kernel<16>, dim3(1024 / 64, ry), dim3(512), 0, s, (const float*)g2, net->Wh[1], h1, 1024, B, g1, 1024, 1024);
+    DPD_LAUNCH(pose_fc_dx_kernel<8>, dim3(1024 / 16, ry), dim3(1024), 0, s, (const float*)g2, net->Wh[1], h1, 1024, B, g1, 1024, 1024);
     DPD_CHECK_LAUNCH();
     // fc1: W [1024, 2048], input = [features of the first B clouds | of the second B clouds]; its dX is d features [2B, 1024] (no gate)
     DPD_LAUNCH(pose_fc_dw_kernel, dim3(2048 / 256, 1024 / 16), dim3(256), 0, s, (const float*)g1, f, f + (size_t)B * OUT, OUT, 1024, 2048, B, dW[0], db[0]);
     DPD_CHECK_LAUNCH();
-    DPD_LAUNCH(pose_fc_dx_kernel<32>, dim3(2048 / 64, ry), dim3(512), 0, s, (const float*)g1, net->Wh[0], (const float*)nullptr, 2048, B, df, OUT, OUT);
+    DPD_LAUNCH(pose_fc_dx_kernel<16>, dim3(2048 / 16, ry), dim3(1024), 0, s, (const float*)g1, net->Wh[0], (const float*)nullptr, 2048, B, df, OUT, OUT);
     DPD_CHECK_LAUNCH();
     return 0;
 }
