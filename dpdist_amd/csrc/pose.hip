@@ -65,8 +65,21 @@ __global__ __launch_bounds__(64) void pose_apply_fwd_kernel(const float* __restr
                                                             const float* __restrict__ W4, const float* __restrict__ b4, int K4,
                                                             float* __restrict__ pred_out) {
     const int b = blockIdx.x;
+    // what the tail needs from global memory is requested here, before the head's products (N <= 64: one point per lane, else the loop below)
+    const int n0 = threadIdx.x;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (moved && n0 < N) { const float* s = src + ((size_t)b * N + n0) * 3; sx = s[0]; sy = s[1]; sz = s[2]; }
+    float Tc[4] = {0.f, 0.f, 0.f, 0.f};              // column j of T_in (nullptr: the identity, the first loop of a refinement), lanes 0..15
+    if (T_out && threadIdx.x < 16) {
+        const int j = threadIdx.x & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tc[r] = T_in ? T_in[(size_t)b * 16 + r * 4 + j] : (r == j ? 1.f : 0.f);
+    }
     float pr[7];
     if (h3) {
+        float bb[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) bb[j] = b4[j];
         float acc[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) acc[j] = 0.f;
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(64) void pose_apply_fwd_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int j = 0; j < 7; ++j) pr[j] = wave_sum(acc[j]) + b4[j];
+        for (int j = 0; j < 7; ++j) pr[j] = wave_sum(acc[j]) + bb[j];
         if (pred_out && threadIdx.x < 7) {
             float v = pr[0];
 #pragma unroll
@@ -99,9 +112,9 @@ __global__ __launch_bounds__(64) void pose_apply_fwd_kernel(const float* __restr
     float R[3][3];
     quat_to_mat_dev(qm, R);
     if (moved) {
-        for (int n = threadIdx.x; n < N; n += 64) {
-            const float* s = src + ((size_t)b * N + n) * 3;
-            const float x = s[0], y = s[1], z = s[2];
+        for (int n = n0; n < N; n += 64) {
+            float x = sx, y = sy, z = sz;
+            if (n != n0) { const float* s = src + ((size_t)b * N + n) * 3; x = s[0]; y = s[1]; z = s[2]; }
             float* o = moved + ((size_t)b * N + n) * 3;
             o[0] = (x * R[0][0] + y * R[0][1] + z * R[0][2]) + P.t[0];
             o[1] = (x * R[1][0] + y * R[1][1] + z * R[1][2]) + P.t[1];
@@ -115,10 +128,7 @@ __global__ __launch_bounds__(64) void pose_apply_fwd_kernel(const float* __restr
     if (T_out && threadIdx.x < 16) {         // helper.py:309-329: T <- [R(qc) t; 0 1] @ T
         float Rc[3][3];
         quat_to_mat_dev(qc, Rc);
-        const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
-        float Tc[4];                              // column j of T_in (nullptr: the identity, the first loop of a refinement)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tc[r] = T_in ? T_in[(size_t)b * 16 + r * 4 + j] : (r == j ? 1.f : 0.f);
+        const int i = threadIdx.x >> 2;
         float v;
         if (i < 3) v = ((Rc[i][0] * Tc[0] + Rc[i][1] * Tc[1]) + Rc[i][2] * Tc[2]) + P.t[i] * Tc[3];
         else v = Tc[3];
@@ -407,6 +417,11 @@ __global__ __launch_bounds__(1024) void pose_fc_kernel(const float* __restrict__
     const int kw = wv * (K / 16);                              // this wave's K range: [kw, kw + 16 NIT)
     const float* x = kw < KA ? inA + (size_t)row * KA + kw : inB + (size_t)row * (K - KA) + (kw - KA);
     const float* w = W + (size_t)(j0 + n) * K + kw;
+    // the epilogue's element (threads 0..255) and what it needs from global memory, requested with the operands
+    const int e = threadIdx.x, el = e >> 2, er = e & 3, en = el & 15, ej = j0 + 4 * (el >> 4) + er, orow = r0 + en;
+    const bool live = e < 256 && orow < R && ej < J;
+    const float bj = live ? bias[ej] : 0.f;
+    const float mk = (live && mask) ? mask[(size_t)orow * J + ej] : 1.f;
     float4 wr[NIT], xr[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -425,19 +440,14 @@ __global__ __launch_bounds__(1024) void pose_fc_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wv][l * 4 + r] = c[r];
     __syncthreads();
-    if (threadIdx.x < 256) {
-        const int e = threadIdx.x;
+    if (live) {
         float v = part[0][e];
 #pragma unroll
         for (int q = 1; q < 16; ++q) v += part[q][e];
-        const int el = e >> 2, er = e & 3;
-        const int en = el & 15, ej = j0 + 4 * (el >> 4) + er, orow = r0 + en;
-        if (orow < R && ej < J) {
-            v += bias[ej];
-            if (relu) v = fmaxf(v, 0.f);
-            if (mask) v *= mask[(size_t)orow * J + ej];
-            out[(size_t)orow * J + ej] = v;
-        }
+        v += bj;
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask) v *= mk;
+        out[(size_t)orow * J + ej] = v;
     }
 }
 

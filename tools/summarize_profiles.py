@@ -99,16 +99,18 @@ if os.path.exists(f):
     groups = defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         n = r["Name"]
-        if "dpd::pose_" in n:
-            g = "pose chain + refinement pose network (csrc/pose.hip)"
+        if "dpd::pose_" in n and ("_bwd" in n or "pose_fc_dw" in n or "pose_fc_dx" in n):
+            g = "pose network + pose chain, backward of the training evaluation (csrc/pose.hip)"
+        elif "dpd::pose_" in n:
+            g = "pose network + pose chain, forward: 7 refinements + the training evaluation (csrc/pose.hip)"
         elif "dpd::adam" in n:
             g = "TF-form Adam (dpd_adam_tf)"
         elif "dpd::" in n:
             g = "DPDist forward + backward (as-loss engine)"
         elif n.startswith("Cijk_"):
-            g = "training evaluation: pose network GEMMs (hipBLASLt, fwd + bwd)"
+            g = "torch GEMMs (hipBLASLt)"
         else:
-            g = "training evaluation: torch element-wise / reductions / copies"
+            g = "torch kernels (dropout mask, gradient gather into Adam's flat buffer, fills)"
         groups[g][0] += float(r["TotalDurationNs"]) / 1e3
         groups[g][1] += int(r["Calls"])
     tot = sum(v[0] for v in groups.values())
