@@ -65,6 +65,8 @@ python $R/tools/determinism_check.py f32 > $OUT/determinism.txt 2>&1
 for dt in f32 bf16; do stats stats_asloss_$dt python $R/tools/asloss_bench.py --batch 16 --dtype $dt --steps 100 --warmup 20; done
 # config 5: the registration step in its forms (eager torch ... the captured default), the eager default's kernel stats, the demo
 python $R/tools/registration_step_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/registration_step_bench.txt
+# the same captured step with DPDist on the bf16 matrix cores (a numerics choice of the consumer: 5e-2 output tolerance; not the default)
+{ for dt in f32x3 bf16; do echo "dpdist_dtype=$dt $(python $R/tools/registration_step_bench.py --forms graph --dtype $dt 2>&1 | grep '^graph')"; done; } > $OUT/registration_step_bench_dtypes.txt
 stats stats_registration python $R/tools/registration_step_bench.py --forms eager_native --steps 50 --train-only
 ( cd $R; DPD_FORCE_DIST=1 MASTER_PORT=29535 timeout 900 python tools/registration_demo.py --loss ours 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" > $OUT/registration_demo.txt )
 python $R/tools/ramp_probe.py > $OUT/ramp_probe.txt 2>/dev/null
