@@ -96,15 +96,16 @@ class _PoseNetRawFn(torch.autograd.Function):
     """The whole pose network of a training evaluation -- shared MLP + max pool (_PointFeaturesFn's kernels) and the head (models/ipcr_model.py:
     273-284) -- as ONE autograd node on the library: five launches forward (dpd_pose_point_fwd_train, dpd_pose_head_fwd_train), eleven backward
     (dpd_pose_head_bwd, dpd_pose_point_bwd), gradients w.r.t. the 18 weight tensors only.  `mask` [B,256]: the dropout mask (0 or 1 / keep)
-    drawn by the caller, or None (evaluation mode)."""
+    drawn by the caller, or None (evaluation mode).  `sink`: None, or {id(parameter): tensor of its shape} -- the backward then WRITES the
+    gradient of that parameter there (views of the optimizer's flat gradient buffer: no gather copy afterwards) and returns it."""
 
     @staticmethod
-    def forward(ctx, clouds, mask, *wb):
+    def forward(ctx, source, template, mask, sink, *wb):
         from ctypes import byref
         from . import lib as L
-        C, N, _ = clouds.shape
-        B = C // 2
-        L.req(clouds, name="clouds", shape=(C, N, 3))
+        B, N, _ = source.shape
+        C = 2 * B
+        L.req(source, name="source", shape=(B, N, 3)), L.req(template, name="template", shape=(B, N, 3))
         if mask is not None:
             L.req(mask, name="mask", shape=(B, 256))
         w = L.PoseNetW()
@@ -113,18 +114,19 @@ class _PoseNetRawFn(torch.autograd.Function):
         for i in range(4):
             w.Wh[i], w.bh[i] = L.req(wb[10 + 2 * i], name="weight").data_ptr(), L.req(wb[11 + 2 * i], name="bias").data_ptr()
         w.out_features = wb[8].shape[0]
-        dev, lib, st = clouds.device, L.load(), L.cur_stream()
+        dev, lib, st = source.device, L.load(), L.cur_stream()
         e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)      # noqa: E731
         f = e(C, w.out_features)
         h = [e(C * N, k) for k in (64, 64, 64, 128)]
         ties = torch.empty(C, w.out_features, device=dev, dtype=torch.int64)
-        L.check(lib.dpd_pose_point_fwd_train(byref(w), L.ptr(clouds), None, C, 0, N, L.ptr(f), L.ptr(h[0]), L.ptr(h[1]), L.ptr(h[2]), L.ptr(h[3]),
-                                             ties.data_ptr(), st), "dpd_pose_point_fwd_train")
+        L.check(lib.dpd_pose_point_fwd_train(byref(w), L.ptr(source), L.ptr(template), B, B, N, L.ptr(f), L.ptr(h[0]), L.ptr(h[1]), L.ptr(h[2]),
+                                             L.ptr(h[3]), ties.data_ptr(), st), "dpd_pose_point_fwd_train")
         a1, a2, a3, pred = e(B, 1024), e(B, 512), e(B, 256), e(B, 7)
         L.check(lib.dpd_pose_head_fwd_train(byref(w), L.ptr(f), B, L.ptr(mask), L.ptr(a1), L.ptr(a2), L.ptr(a3), L.ptr(pred), st),
                 "dpd_pose_head_fwd_train")
         ctx.has_mask = mask is not None
-        ctx.save_for_backward(clouds, ties, f, a1, a2, a3, *h, *wb, *([mask] if mask is not None else []))
+        ctx.sink = sink
+        ctx.save_for_backward(source, template, ties, f, a1, a2, a3, *h, *wb, *([mask] if mask is not None else []))
         return pred
 
     @staticmethod
@@ -133,20 +135,23 @@ class _PoseNetRawFn(torch.autograd.Function):
         from ctypes import byref
         from . import lib as L
         sv = ctx.saved_tensors
-        clouds, ties, f, a1, a2, a3, h1, h2, h3, h4 = sv[:10]
-        wb = sv[10:28]
-        mask = sv[28] if ctx.has_mask else None
-        C, N, _ = clouds.shape
-        B = C // 2
+        source, template, ties, f, a1, a2, a3, h1, h2, h3, h4 = sv[:11]
+        wb = sv[11:29]
+        mask = sv[29] if ctx.has_mask else None
+        B, N, _ = source.shape
+        C = 2 * B
         w = L.PoseNetW()
         for i in range(5):
             w.Wp[i], w.bp[i] = wb[2 * i].data_ptr(), wb[2 * i + 1].data_ptr()
         for i in range(4):
             w.Wh[i], w.bh[i] = wb[10 + 2 * i].data_ptr(), wb[11 + 2 * i].data_ptr()
         w.out_features = wb[8].shape[0]
-        dev, lib, st = clouds.device, L.load(), L.cur_stream()
+        dev, lib, st = source.device, L.load(), L.cur_stream()
         dpred = dpred.contiguous()
-        grads = [torch.empty_like(t) for t in wb]
+        sink = ctx.sink or {}
+        grads = [sink.get(id(t)) for t in wb]
+        grads = [g if (g is not None and g.shape == t.shape and g.is_contiguous() and g.data_ptr() % 16 == 0) else torch.empty_like(t)
+                 for g, t in zip(grads, wb)]
         vp = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])      # noqa: E731
         df = torch.empty_like(f)
         nb = lib.dpd_pose_head_bwd_workspace_bytes(B)
@@ -155,13 +160,15 @@ class _PoseNetRawFn(torch.autograd.Function):
                                       L.ptr(df), L.ptr(ws), nb, st), "dpd_pose_head_bwd")
         nb2 = lib.dpd_pose_point_bwd_workspace_bytes(C)
         ws2 = torch.empty(nb2 // 4, device=dev, dtype=torch.float32)
-        L.check(lib.dpd_pose_point_bwd(byref(w), L.ptr(clouds), None, C, 0, N, L.ptr(df), L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(h4), ties.data_ptr(),
-                                       vp(grads[0:10:2]), vp(grads[1:10:2]), L.ptr(ws2), nb2, st), "dpd_pose_point_bwd")
-        return (None, None) + tuple(grads)
+        L.check(lib.dpd_pose_point_bwd(byref(w), L.ptr(source), L.ptr(template), B, B, N, L.ptr(df), L.ptr(h1), L.ptr(h2), L.ptr(h3), L.ptr(h4),
+                                       ties.data_ptr(), vp(grads[0:10:2]), vp(grads[1:10:2]), L.ptr(ws2), nb2, st), "dpd_pose_point_bwd")
+        return (None, None, None, None) + tuple(grads)
 
 
 class PoseNet(nn.Module):
     """models/ipcr_model.py:198-233 + :273-284 (1xW convs == per-point linear layers)."""
+    next_mask = None         # a dropout mask [B,256] already drawn for the next training evaluation of `raw` (consumed by it)
+    grad_sink = None         # set by IterativeRegistration for the span of one training evaluation (see _PoseNetRawFn)
     native_train = True      # the training evaluation's shared MLP + max pool on the library (_PointFeaturesFn) when the shape allows it
 
     def __init__(self, out_features=1024, lim_rot=45.0, keep_prob=0.7):
@@ -221,18 +228,22 @@ class PoseNet(nn.Module):
 
     def raw(self, source, template):
         """get_pose's fc4 output (:273-284) BEFORE quat_normalize: [B,7] = (t, angle, axis)."""
-        clouds = torch.cat([source, template], 0)
-        if self._native_raw_ok(clouds):
+        if self._native_raw_ok(source) and template.shape == source.shape and template.dtype == source.dtype and not template.requires_grad:
             # the training evaluation on the library (one autograd node): the dropout mask is drawn here (torch's Philox stream, as the
             # refinements' masks are), everything else is csrc/pose.hip
             mask = None
             drop = next((m for m in self.head if isinstance(m, nn.Dropout)), None)
+            given, self.next_mask = self.next_mask, None
             if self.training and drop is not None and drop.p > 0:
                 keep = 1.0 - drop.p
-                mask = torch.empty(source.shape[0], 256, device=source.device).bernoulli_(keep).div_(keep)
+                if given is not None and given.shape == (source.shape[0], 256) and given.device == source.device:
+                    mask = given                                   # drawn with the refinements' masks (IterativeRegistration.refine)
+                else:
+                    mask = torch.empty(source.shape[0], 256, device=source.device).bernoulli_(keep).div_(keep)
             lin = [m for m in self.point if isinstance(m, nn.Linear)] + [m for m in self.head if isinstance(m, nn.Linear)]
-            return _PoseNetRawFn.apply(clouds.contiguous(), mask, *[t for m in lin for t in (m.weight, m.bias)])
-        f = self._pooled(clouds)                                            # max pool over the points
+            return _PoseNetRawFn.apply(source.contiguous(), template.contiguous(), mask, getattr(self, "grad_sink", None),
+                                       *[t for m in lin for t in (m.weight, m.bias)])
+        f = self._pooled(torch.cat([source, template], 0))                  # max pool over the points
         B = source.shape[0]
         return self.head(torch.cat([f[:B], f[B:]], 1))
 
@@ -369,6 +380,7 @@ class _PoseApplyFn(torch.autograd.Function):
                                             L.ptr(moved), L.ptr(T_out), L.cur_stream()), "dpd_pose_apply_fwd")
         ctx.save_for_backward(pred, source)
         ctx.lim_rot, ctx.mode = float(lim_rot or 0.0), int(mode)
+        ctx.set_materialize_grads(False)           # (pose / T_out carry no gradient: no zero tensors made for them in the backward)
         ctx.mark_non_differentiable(pose)
         if T_out is None:
             return pose, moved
@@ -382,6 +394,8 @@ class _PoseApplyFn(torch.autograd.Function):
             raise RuntimeError("pose_apply: only the training evaluation (mode 1) is differentiable; the refinements are forward-only")
         pred, source = ctx.saved_tensors
         B, N, _ = source.shape
+        if grads[1] is None:
+            return None, None, None, None, None
         dmoved = grads[1].contiguous()
         dpred = torch.empty_like(pred)
         L.check(L.load().dpd_pose_apply_bwd(L.ptr(pred), L.ptr(source), L.ptr(dmoved), B, N, ctx.lim_rot, L.ptr(dpred), L.cur_stream()),
@@ -504,6 +518,8 @@ class IterativeRegistration:
             self.reducer = make_reducer(self._flat_grad, [0, self._flat_grad.numel()], group,
                                         force=os.environ.get("DPD_FORCE_DIST") == "1", mode="allreduce")
         self.concat_grads = bool(concat_grads)
+        dev0 = next(pose_net.parameters()).device
+        self._one = torch.ones((), device=dev0) if dev0.type == "cuda" else None      # d loss / d loss of every step
         self.fused_pose = bool(fused_pose)
         self.native_refine = bool(native_refine) and self.fused_pose and native_refine_supported(pose_net)
         self.use_graph = bool(graph) and isinstance(self.opt, TFAdam) and bool(getattr(dpdist_loss, "capturable", False))
@@ -521,14 +537,19 @@ class IterativeRegistration:
     def _fused(self, source):
         return self.fused_pose and source.is_cuda and hasattr(self.net, "raw")
 
-    def refine(self, source, template, loops):
+    def refine(self, source, template, loops, train_mask=False):
+        """`loops` forward-only refinements.  train_mask (a training step on the library's pose network): the dropout masks of the refinements
+        and of the training evaluation that follows are ONE draw of [loops + 1, B, 256]; the last one waits in `net.next_mask` for `raw`."""
         if self.native_refine and source.is_cuda and loops > 0 and source.dtype == torch.float32:
             with torch.no_grad():
                 mask = None
                 drop = next((m for m in self.net.head if isinstance(m, nn.Dropout)), None)
                 if self.net.training and drop is not None and drop.p > 0:      # torch's dropout: keep with probability 1 - p, scale by 1 / (1 - p)
                     keep = 1.0 - drop.p
-                    mask = torch.empty(loops, source.shape[0], 256, device=source.device).bernoulli_(keep).div_(keep)
+                    extra = 1 if (train_mask and hasattr(self.net, "next_mask")) else 0
+                    mask = torch.empty(loops + extra, source.shape[0], 256, device=source.device).bernoulli_(keep).div_(keep)
+                    if extra:
+                        self.net.next_mask, mask = mask[loops], mask[:loops]
                 return pose_refine_native(self.net, source.contiguous(), template.contiguous(), loops, mask)
         T = torch.eye(4, device=source.device).repeat(source.shape[0], 1, 1)
         fused = self._fused(source)
@@ -557,6 +578,21 @@ class IterativeRegistration:
         """forward + backward of the training evaluation (:468 without the collective and the update): (loss, pose, T' or None);
         this rank's gradients are left in the parameters' `.grad`."""
         Tn = None
+        flat, params = getattr(self.opt, "grad", None), getattr(self.opt, "_params", None)
+        in_place = (self.concat_grads and isinstance(flat, torch.Tensor) and params is not None
+                    and all(p.grad is not None and p.grad.data_ptr() == flat.data_ptr() + 4 * o for p, o in zip(params, self._offsets(params))))
+        if in_place and hasattr(self.net, "grad_sink"):
+            # for THIS evaluation only (the node keeps the mapping it was built with): its gradients are taken by torch.autograd.grad below,
+            # never accumulated into the very views they were written to
+            self.net.grad_sink = {id(p): p.grad for p in params}
+        try:
+            return self._evaluate_grad_body(refined_source, template, T, flat, params, in_place)
+        finally:
+            if hasattr(self.net, "grad_sink"):
+                self.net.grad_sink = None
+
+    def _evaluate_grad_body(self, refined_source, template, T, flat, params, in_place):
+        Tn = None
         if self._fused(refined_source):
             pred = self.net.raw(refined_source, template)
             out = pose_apply(pred, refined_source, T, self.net.lim_rot, 1)
@@ -570,14 +606,16 @@ class IterativeRegistration:
                     pn = torch.cat([pose[:, :3], pose[:, 3:7] / pose[:, 3:7].norm(dim=1, keepdim=True).clamp_min(1e-12)], 1)
                     Tn = compose(T, pn)
         loss = self.loss_fn(moved, template)                 # (mean(AB[...,0]) + mean(BA[...,0])) / 2, :248-251
-        flat, params = getattr(self.opt, "grad", None), getattr(self.opt, "_params", None)
-        if self.concat_grads and isinstance(flat, torch.Tensor) and params is not None and all(p.grad is not None and p.grad.data_ptr() == flat.data_ptr() + 4 * o
-                                                                         for p, o in zip(params, self._offsets(params))):
+        if in_place:
             # TFAdam's flat gradient: the 18 gradients are WRITTEN into it by one concatenation instead of being accumulated into 18 views
             # of a zeroed buffer (19 in-place adds and a fill per step: 70 us of the captured step at batch 16).  0 + g == g: the same update
-            grads = torch.autograd.grad(loss, params)
-            n = sum(p.numel() for p in params)
-            torch.cat([g.reshape(-1) for g in grads], out=flat[:n])
+            # The pose network's node writes them straight into the views (grad_sink): no copy at all; the concatenation is the fallback for
+            # whatever did not come back in place (torch pose network, a foreign graph).  The root gradient is a persistent one (no fill).
+            one = self._one if (self._one is not None and self._one.device == loss.device and loss.dim() == 0) else None
+            grads = torch.autograd.grad(loss, params, grad_outputs=one)
+            if not all(g.data_ptr() == p.grad.data_ptr() for g, p in zip(grads, params)):
+                n = sum(p.numel() for p in params)
+                torch.cat([g.reshape(-1) for g in grads], out=flat[:n])
         else:
             self.opt.zero_grad()
             self._rebind_flat_gradient()
@@ -607,7 +645,7 @@ class IterativeRegistration:
 
     def _train_step_eager(self, source, template):
         self.net.train()
-        src, T = self.refine(source, template, self.max_loops - 1)
+        src, T = self.refine(source, template, self.max_loops - 1, train_mask=self._fused(source))
         loss, _, Tn = self._evaluate_grad(src, template, T)
         self._reduce()
         self.opt.step()
@@ -679,7 +717,7 @@ class IterativeRegistration:
                         moved, rec.T = self.refine(rec.src, rec.tmpl, self.max_loops)
                         rec.loss = self.loss_fn(moved, rec.tmpl)
                 else:
-                    src, T = self.refine(rec.src, rec.tmpl, self.max_loops - 1)
+                    src, T = self.refine(rec.src, rec.tmpl, self.max_loops - 1, train_mask=self._fused(rec.src))
                     rec.loss, _, rec.T = self._evaluate_grad(src, rec.tmpl, T)
                     if self.reducer is None or not self.reducer.active:
                         self.opt.step()                      # captured: dpd_adam_tf_dev, lr_t from device memory (TFAdam.prepare_replay)

@@ -690,11 +690,19 @@ def test_pose_network_training_evaluation_is_one_node_on_the_library(B, N, with_
     up = torch.randn(B, 7, generator=g).to(dev)
     lin = [m for m in net.point if isinstance(m, torch.nn.Linear)] + [m for m in net.head if isinstance(m, torch.nn.Linear)]
     params = [t for m in lin for t in (m.weight, m.bias)]
-    pred = _PoseNetRawFn.apply(clouds, mask, *params)
+    pred = _PoseNetRawFn.apply(clouds[:B].contiguous(), clouds[B:].contiguous(), mask, None, *params)
     grads = torch.autograd.grad((pred * up).sum(), params)
-    pred2 = _PoseNetRawFn.apply(clouds, mask, *params)
+    # a second evaluation whose gradients are WRITTEN into caller storage (the optimizer's flat buffer in the registration step): the very
+    # tensors come back from autograd, with the same bits (fixed summation orders)
+    flat = torch.full((sum(p.numel() for p in params) + 3,), float("nan"), device=dev)
+    sink, off = {}, 0
+    for p in params:
+        sink[id(p)] = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    pred2 = _PoseNetRawFn.apply(clouds[:B].contiguous(), clouds[B:].contiguous(), mask, sink, *params)
     grads2 = torch.autograd.grad((pred2 * up).sum(), params)
-    assert torch.equal(pred, pred2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))          # fixed summation orders
+    assert torch.equal(pred, pred2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+    assert all(g.data_ptr() == sink[id(p)].data_ptr() for g, p in zip(grads2, params)) and bool(torch.isnan(flat[off:]).all())
     net64 = PoseNet().double().to(dev)
     net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
     lin64 = [m for m in net64.point if isinstance(m, torch.nn.Linear)] + [m for m in net64.head if isinstance(m, torch.nn.Linear)]
