@@ -14,12 +14,13 @@
 //
 // The forward-only refinements (7 of the 8 pose-network evaluations of a step, :414-441, and all 8 of an evaluation batch) also run the
 // pose NETWORK here -- models/ipcr_model.py:198-233 (shared MLP 3-64-64-64-128-1024 + max pool) and :273-284 (fc 2048-1024-512-256-7,
-// dropout before the last layer) -- in five launches per loop instead of ~25 (dpd_pose_refine):
+// dropout before the last layer) -- in four launches per loop (+ one per call) instead of ~25 (dpd_pose_refine):
 //   pose_point_kernel   one workgroup per (cloud, 128-column slice of the last layer): all five layers for the cloud's points in LDS,
 //                       max pool in the epilogue; the template's features are computed once per call (the template does not move)
 //   pose_fc_kernel      the three wide head layers for <= 16 rows: one wave per 4 output columns streams its weight rows once
-//   pose_apply_fwd_kernel   fc4 (256 x 7) as its prologue, then the pose chain above
-// fp32 FMA throughout.  The training evaluation keeps torch autograd for the network (its backward is torch's).
+//   pose_apply_fwd_kernel   fc4 (256 x 7) as its prologue, then the pose chain above: the LAST loop's pose only -- the pose of every other loop
+//                       (fc4, chain, move, T composition) is the prologue of the NEXT loop's pose_point_kernel (PoseMove), not a launch
+// fp32 throughout (MFMA fp32 / FMA).  The training evaluation of the network and its backward: further down (round 6).
 #include "common.h"
 
 namespace dpd {
@@ -298,6 +299,22 @@ struct PointSave {
     float* h[4];                    // [clouds * N, 64] x 3, [clouds * N, 128]
     unsigned long long* ties;       // [clouds, OUT]
 };
+// Refinement loops 2..n (dpd_pose_refine): the cloud a workgroup reads is the PREVIOUS loop's source moved by the pose the head made of it --
+// fc4 (pred = W4 h3 + b4), quat_normalize, R, the move and the T composition are a prologue of the next loop's shared MLP instead of a launch
+// of their own (pose_apply_fwd_kernel: 5-9 us per loop for a microsecond of work).  Every (cloud, slice) workgroup recomputes its pair's pose
+// (wave 0: the apply kernel's own instruction sequence, so the same bits) while the weight images are in flight; slice 0 stores the moved
+// cloud, T and the raw prediction.  h3 == nullptr: no move (first loop, training evaluation).
+struct PoseMove {
+    const float* h3;                // [B, K4] activations of the head's last hidden layer (previous loop)
+    const float* W4;                // [7, K4]
+    const float* b4;                // [7]
+    const float* T_in;              // [B, 16] or nullptr (identity)
+    float* moved;                   // [B, N, 3]
+    float* T_out;                   // [B, 16]
+    float* pred_out;                // [B, 7] or nullptr
+    float lim_rad;
+    int K4;
+};
 template <bool TRAIN>
 __device__ __forceinline__ void save_rows(float* __restrict__ dst, const float* __restrict__ src_lds, int np, int W, int stride, int t) {
     for (int e = t; e < np * (W / 4); e += 256) {
@@ -307,7 +324,7 @@ __device__ __forceinline__ void save_rows(float* __restrict__ dst, const float* 
 }
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void pose_point_kernel(const float* __restrict__ ptsA, const float* __restrict__ ptsB, int nA, int N,
-                                                         PointNetW net, int OUT, int row0, float* __restrict__ f, PointSave sv) {
+                                                         PointNetW net, int OUT, int row0, float* __restrict__ f, PointSave sv, PoseMove mv) {
     extern __shared__ float lds[];
     const int c = blockIdx.x, slice = blockIdx.y, t = threadIdx.x, og = t & 15, pg = t >> 4, l = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -323,6 +340,54 @@ __global__ __launch_bounds__(256) void pose_point_kernel(const float* __restrict
     if (t < 192) lds[kW1 + t] = net.W[0][t];
     if (t < 64) { lds[kBias + t] = net.b[0][t]; lds[kBias + 64 + t] = net.b[1][t]; lds[kBias + 128 + t] = net.b[2][t]; }
     if (t < 128) { lds[kBias + 192 + t] = net.b[3][t]; lds[kBias + 320 + t] = net.b[4][slice * kSlice + t]; }
+    const bool move = !TRAIN && mv.h3 != nullptr && c < nA;
+    float R[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, tr[3] = {0.f, 0.f, 0.f};
+    if (move) {
+        float* prs = lds + kHA;                                // scratch until layer 1 writes hA (after the loop's first barrier)
+        if (wv == 0) {                                         // pose_apply_fwd_kernel's fc4, lane for lane
+            float bb[7], acc[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { bb[j] = mv.b4[j]; acc[j] = 0.f; }
+            for (int k = l * 4; k < mv.K4; k += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(mv.h3 + (size_t)c * mv.K4 + k);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float4 w = *reinterpret_cast<const float4*>(mv.W4 + (size_t)j * mv.K4 + k);
+                    acc[j] = fmaf(x.x, w.x, fmaf(x.y, w.y, fmaf(x.z, w.z, fmaf(x.w, w.w, acc[j]))));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float v = wave_sum(acc[j]) + bb[j];
+                if (l == 0) prs[j] = v;
+            }
+        }
+        __syncthreads();
+        float pr[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) pr[j] = prs[j];
+        const Pose7 P = quat_normalize_dev(pr, mv.lim_rad);
+        const float nrm = sqrtf(P.q[0] * P.q[0] + P.q[1] * P.q[1] + P.q[2] * P.q[2] + P.q[3] * P.q[3]);
+        const float dc = fmaxf(nrm, 1e-12f);
+        float qc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qc[i] = P.q[i] / dc;
+        quat_to_mat_dev(qc, R);
+        tr[0] = P.t[0]; tr[1] = P.t[1]; tr[2] = P.t[2];
+        if (slice == 0) {
+            if (mv.pred_out && t < 7) mv.pred_out[(size_t)c * 7 + t] = pr[t];
+            if (t < 16) {                                      // helper.py:309-329: T <- [R(qc) t; 0 1] @ T
+                const int i = t >> 2, j = t & 3;
+                float Tc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tc[r] = mv.T_in ? mv.T_in[(size_t)c * 16 + r * 4 + j] : (r == j ? 1.f : 0.f);
+                float v;
+                if (i < 3) v = ((R[i][0] * Tc[0] + R[i][1] * Tc[1]) + R[i][2] * Tc[2]) + P.t[i] * Tc[3];
+                else v = Tc[3];
+                mv.T_out[(size_t)c * 16 + t] = v;
+            }
+        }
+    }
     for (int p0 = 0; p0 < N; p0 += kPP) {
         const int np = min(kPP, N - p0);
         if (p0 > 0) {
@@ -330,7 +395,23 @@ __global__ __launch_bounds__(256) void pose_point_kernel(const float* __restrict
             dma_weights<64, 64>(net.W[1], lds_base, kW2, wv, l);
             dma_weights<64, 64>(net.W[2], lds_base, kW3, wv, l);
         }
-        if (t < 192) lds[kPts + t] = t < np * 3 ? pts[(size_t)p0 * 3 + t] : 0.f;
+        if (!move) {
+            if (t < 192) lds[kPts + t] = t < np * 3 ? pts[(size_t)p0 * 3 + t] : 0.f;
+        } else if (t < kPP) {                                  // one point per thread: moved like pose_apply_fwd_kernel moves it (mode 0)
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+            if (t < np) {
+                const float* sp = pts + (size_t)(p0 + t) * 3;
+                const float x = sp[0], y = sp[1], z = sp[2];
+                o0 = (x * R[0][0] + y * R[0][1] + z * R[0][2]) + tr[0];
+                o1 = (x * R[1][0] + y * R[1][1] + z * R[1][2]) + tr[1];
+                o2 = (x * R[2][0] + y * R[2][1] + z * R[2][2]) + tr[2];
+                if (slice == 0) {
+                    float* o = mv.moved + ((size_t)c * N + p0 + t) * 3;
+                    o[0] = o0; o[1] = o1; o[2] = o2;
+                }
+            }
+            lds[kPts + t * 3] = o0; lds[kPts + t * 3 + 1] = o1; lds[kPts + t * 3 + 2] = o2;
+        }
         dma_wait();
         __syncthreads();
         // layer 1: 3 -> 64 into hA (K = 3: vector ALU; 4 points x 4 outputs per thread)
@@ -522,28 +603,29 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
     if (int rc = ensure_dyn_lds(g_point_lds, (const void*)pose_point_kernel<false>, lds)) return rc;
     PointNetW pw{};
     for (int i = 0; i < 5; ++i) { pw.W[i] = net->Wp[i]; pw.b[i] = net->bp[i]; }
+    // loop it: features of source_it (and of the template, once) -> head up to its last hidden layer h3_it.  The pose of loop it - 1 -- fc4,
+    // quat_normalize, the move source_{it-1} -> source_it, T <- M T -- is the PROLOGUE of loop it's shared MLP (PoseMove); the last loop's pose is
+    // the one pose_apply_fwd_kernel launch of the call: 4 loops + 1 launches.
+    const float* cur = src;                 // source_{it-1} while loop it is being enqueued
+    const float* Tcur = nullptr;
     for (int it = 0; it < loops; ++it) {
-        const float* cur = it == 0 ? src : w.cloud[(it - 1) & 1];
-        const float* Tin = it == 0 ? nullptr : w.T[(it - 1) & 1];
-        const bool last = it == loops - 1;
-        float* nxt = last ? moved : w.cloud[it & 1];
-        float* Tn = last ? T_out : w.T[it & 1];
-        // shared MLP + max pool: source features every loop; the template's once (the template never moves)
         if (it == 0) {
-            DPD_LAUNCH(pose_point_kernel<false>, dim3((unsigned)(2 * B), (unsigned)(OUT / kSlice)), dim3(256), lds, s, cur, tmpl, B, N, pw, OUT, 0, w.f, PointSave{});
+            DPD_LAUNCH(pose_point_kernel<false>, dim3((unsigned)(2 * B), (unsigned)(OUT / kSlice)), dim3(256), lds, s, cur, tmpl, B, N, pw, OUT, 0, w.f, PointSave{},
+                       PoseMove{});
         } else {
+            float* nxt = w.cloud[(it - 1) & 1];
+            float* Tn = w.T[(it - 1) & 1];
+            const PoseMove mv{w.h3, net->Wh[3], net->bh[3], Tcur, nxt, Tn, pred_out ? pred_out + (size_t)(it - 1) * B * 7 : (float*)nullptr, lim_rad, 256};
             DPD_LAUNCH(pose_point_kernel<false>, dim3((unsigned)B, (unsigned)(OUT / kSlice)), dim3(256), lds, s, cur, (const float*)nullptr, B, N, pw, OUT, 0,
-                       w.f, PointSave{});
+                       w.f, PointSave{}, mv);
+            cur = nxt;
+            Tcur = Tn;
         }
         DPD_CHECK_LAUNCH();
         const unsigned ry = (unsigned)((B + 15) / 16);
         const float* dm = drop_mask ? drop_mask + (size_t)it * B * 256 : (const float*)nullptr;
-        if (OUT == 1024) {
-            DPD_LAUNCH(pose_fc_kernel<8>, dim3(1024 / 16, ry), dim3(1024), 0, s, (const float*)w.f, (const float*)(w.f + (size_t)B * OUT), OUT,
-                       net->Wh[0], net->bh[0], 1024, B, 1, (const float*)nullptr, w.h1);
-        } else {      // other feature widths (multiples of 128): the same kernel, K = 2 OUT in 256-column steps
-            return DPD_E_UNSUPPORTED;
-        }
+        DPD_LAUNCH(pose_fc_kernel<8>, dim3(1024 / 16, ry), dim3(1024), 0, s, (const float*)w.f, (const float*)(w.f + (size_t)B * OUT), OUT,
+                   net->Wh[0], net->bh[0], 1024, B, 1, (const float*)nullptr, w.h1);
         DPD_CHECK_LAUNCH();
         DPD_LAUNCH(pose_fc_kernel<4>, dim3(512 / 16, ry), dim3(1024), 0, s, (const float*)w.h1, (const float*)nullptr, 1024, net->Wh[1], net->bh[1],
                    512, B, 1, (const float*)nullptr, w.h2);
@@ -551,10 +633,10 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
         DPD_LAUNCH(pose_fc_kernel<2>, dim3(256 / 16, ry), dim3(1024), 0, s, (const float*)w.h2, (const float*)nullptr, 512, net->Wh[2], net->bh[2], 256,
                    B, 1, dm, w.h3);
         DPD_CHECK_LAUNCH();
-        DPD_LAUNCH(pose_apply_fwd_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)nullptr, cur, Tin, N, lim_rad, 0, (float*)nullptr, nxt,
-                   Tn, (const float*)w.h3, net->Wh[3], net->bh[3], 256, pred_out ? pred_out + (size_t)it * B * 7 : (float*)nullptr);
-        DPD_CHECK_LAUNCH();
     }
+    DPD_LAUNCH(pose_apply_fwd_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)nullptr, cur, Tcur, N, lim_rad, 0, (float*)nullptr, moved,
+               T_out, (const float*)w.h3, net->Wh[3], net->bh[3], 256, pred_out ? pred_out + (size_t)(loops - 1) * B * 7 : (float*)nullptr);
+    DPD_CHECK_LAUNCH();
     return 0;
 }
 
@@ -920,7 +1002,7 @@ extern "C" int dpd_pose_point_fwd_train(const dpd_pose_net* net, const float* pt
     for (int i = 0; i < 5; ++i) { pw.W[i] = net->Wp[i]; pw.b[i] = net->bp[i]; }
     PointSave sv{{h1, h2, h3, h4}, ties};
     DPD_LAUNCH(pose_point_kernel<true>, dim3((unsigned)(nA + nB), (unsigned)(OUT / kSlice)), dim3(256), lds, (hipStream_t)stream, ptsA, ptsB, nA, N, pw,
-               OUT, 0, f, sv);
+               OUT, 0, f, sv, PoseMove{});
     DPD_CHECK_LAUNCH();
     return 0;
 }

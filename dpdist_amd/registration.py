@@ -426,7 +426,7 @@ def native_refine_supported(net):
 
 def pose_refine_native(net, source, template, loops, drop_mask=None, want_pred=False):
     """`loops` forward-only refinements (iterative_PCRNet_ours.py:414-441) with the pose network, quat_normalize, the cloud move and the T
-    composition all on the library (include/dpdist_capi.h: dpd_pose_refine, five launches per loop): (moved source, T[, raw outputs
+    composition all on the library (include/dpdist_capi.h: dpd_pose_refine, four launches per loop + one per call): (moved source, T[, raw outputs
     [loops,B,7]]).  drop_mask [loops,B,256] (0 or 1/keep) or None; the caller draws it (IterativeRegistration.refine does, in train mode)."""
     from ctypes import byref
     from . import lib as L
@@ -484,8 +484,9 @@ class IterativeRegistration:
       * `fused_pose` (default on): quat_normalize / normalisation / Besl-McKay R / moved cloud / T composition are ONE
         launch of csrc/pose.hip per loop (dpd_pose_apply_fwd; backward dpd_pose_apply_bwd) instead of ~115 element-wise launches;
       * `native_refine` (default on): the forward-only refinements run the pose NETWORK on the library too (shared MLP +
-        max pool in one launch per loop, the template's features once per call, three head launches, fc4 folded into the pose launch:
-        dpd_pose_refine, five launches per loop instead of ~25); the training evaluation keeps torch autograd;
+        max pool in one launch per loop, the template's features once per call, three head launches; fc4 + pose chain + cloud move as
+        the prologue of the next loop's shared MLP: dpd_pose_refine, four launches per loop instead of ~25); the training evaluation is
+        one autograd node on the library too (PoseNet.native_train);
       * `concat_grads` (default on, TFAdam only): the pose network's 18 gradients are written into the optimizer's flat buffer by ONE
         concatenation instead of 18 in-place accumulations into a zeroed buffer (bit for bit the same update);
       * `graph` (default on; needs optim.TFAdam and a loss with `capturable = True`, e.g. DPDistLoss): after

@@ -504,7 +504,7 @@ def test_registration_training_is_bitwise_with_and_without_the_as_loss_engine(mo
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,N,loops", [(16, 64, 3), (5, 50, 2), (3, 150, 2), (33, 64, 1)])
 def test_native_pose_refinement_matches_the_torch_network(B, N, loops):
-    """dpd_pose_refine (pose network + quat_normalize + cloud move + T composition on the library, five launches per loop) against the torch
+    """dpd_pose_refine (pose network + quat_normalize + cloud move + T composition on the library, four launches per loop + one per call) against the torch
     PoseNet driven through the torch algebra: raw network outputs of every loop, the moved source and the accumulated transform; ragged
     batches (more than 16 rows: two row groups in the head) and point counts (more than one 64-point pass of the shared MLP); with an
     explicit dropout mask against the same mask applied in torch."""

@@ -4,7 +4,7 @@ forward/backward + TF-form Adam, pcrnet-registration/iterative_PCRNet_ours.py:41
 
     eager_torch     torch pose network + torch pose algebra (round 5: ~1300 launches, host-bound)
     eager_fused     torch pose network, one launch per loop for the quaternion chain (csrc/pose.hip: dpd_pose_apply_*)
-    eager_native    + the forward-only refinements' pose network on the library (dpd_pose_refine: 5 launches per loop)
+    eager_native    + the forward-only refinements' pose network on the library (dpd_pose_refine: 4 launches per loop + 1) and its training evaluation
     graph_fused     eager_fused captured once as a hipGraph and replayed
     graph           eager_native captured (the default form; bitwise its eager training: tests/test_registration.py)
 
