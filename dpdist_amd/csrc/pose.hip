@@ -647,8 +647,9 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
 //   dpd_pose_point_bwd         d features [clouds, OUT] -> dW1..dW5, db1..db5 (TF / torch autodiff of five 1x1 convolutions, ReLU, reduce_max)
 // The max pool makes the last layer's gradient SPARSE: per (cloud, column) only the points that attain a positive maximum carry gradient
 // (evenly shared among ties, like tf.reduce_max), i.e. one 128-vector per (cloud, column) instead of a [points, 1024] matrix:
-//   pose_bwd_w5_kernel      wave = output column c: dW5[c, :] = sum over clouds of coef * h4[tied point, :], db5[c] = sum of the column's gradient
-//   pose_bwd_dh4_kernel     the gradient of layer 4's output, g4 = S W5 with the selection matrix S built from the tie masks, on the fp32
+//   pose_bwd_w5_dh4_kernel  ONE launch, two block roles:
+//     (w5)  wave = output column c: dW5[c, :] = sum over clouds of coef * h4[tied point, :], db5[c] = sum of the column's gradient
+//     (dh4) the gradient of layer 4's output, g4 = S W5 with the selection matrix S built from the tie masks, on the fp32
 //                           matrix cores (workgroup = cloud x 32x32 tile, wave = 128 columns): independent of how the maxima spread over points
 //   pose_bwd_cloud_kernel   workgroup = cloud: layers 4..1 on v_mfma_f32_32x32x2_f32 out of LDS; per-cloud partial weight gradients
 //   pose_bwd_reduce_kernel  sums the partials over the clouds in cloud order
@@ -657,10 +658,10 @@ namespace dpd {
 
 constexpr int kPart = 128 * 64 + 128 + 64 * 64 + 64 + 64 * 64 + 64 + 64 * 3 + 64;      // dW4 | db4 | dW3 | db3 | dW2 | db2 | dW1 | db1 per cloud
 
-__global__ __launch_bounds__(256) void pose_bwd_w5_kernel(const float* __restrict__ df, const unsigned long long* __restrict__ ties,
-                                                           const float* __restrict__ h4, int C, int N, int OUT, float* __restrict__ dW5,
-                                                           float* __restrict__ db5) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+// (wave = output column c; the blocks after the g4 tiles of pose_bwd_w5_dh4_kernel, eight columns each)
+__device__ __forceinline__ void bwd_w5_wave(const float* __restrict__ df, const unsigned long long* __restrict__ ties, const float* __restrict__ h4,
+                                            int C, int N, int OUT, float* __restrict__ dW5, float* __restrict__ db5, int c) {
+    const int l = threadIdx.x & 63;
     if (c >= OUT) return;
     float a0 = 0.f, a1 = 0.f, bsum = 0.f;
     for (int cl0 = 0; cl0 < C; cl0 += 64) {
@@ -721,12 +722,18 @@ __global__ __launch_bounds__(256) void pose_bwd_w5_kernel(const float* __restric
 // word and the coefficient of its column (LDS broadcasts), the B operand W5[col][n0 + lane % 32] is read straight from global memory (coalesced:
 // v_mfma_f32_32x32x2_f32 wants one k per lane half), all 64 of them requested before the first product.  The eight partial tiles are added in
 // wave order: columns ascending, deterministic; adding an exact zero changes nothing, so this IS the ascending-column sum of the sparse forms.
-__global__ __launch_bounds__(512) void pose_bwd_dh4_kernel(const float* __restrict__ df, const unsigned long long* __restrict__ ties,
-                                                            const float* __restrict__ W5, const float* __restrict__ h4, int N, int OUT,
-                                                            float* __restrict__ g4g) {
+// ONE launch for both consumers of d features: blocks [0, 8 clouds) the g4 tiles, the rest dW5 / db5 (eight columns per block) -- two launches of
+// 10.6 + 5.6 us that read the same df / ties and write disjoint outputs.
+__global__ __launch_bounds__(512) void pose_bwd_w5_dh4_kernel(const float* __restrict__ df, const unsigned long long* __restrict__ ties,
+                                                               const float* __restrict__ W5, const float* __restrict__ h4, int C, int N, int OUT,
+                                                               float* __restrict__ g4g, float* __restrict__ dW5, float* __restrict__ db5) {
     __shared__ unsigned long long sT[1024];
     __shared__ float sC[1024];
     __shared__ float part[8][1024];
+    if ((int)blockIdx.x >= C * 8) {
+        bwd_w5_wave(df, ties, h4, C, N, OUT, dW5, db5, ((int)blockIdx.x - C * 8) * 8 + (int)(threadIdx.x >> 6));
+        return;
+    }
     const int c = blockIdx.x >> 3, tile = blockIdx.x & 7, m0 = (tile >> 2) * 32, n0 = (tile & 3) * 32;
     const int t = threadIdx.x, wv = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
     const int kb = wv * 128;
@@ -1024,12 +1031,10 @@ extern "C" int dpd_pose_point_bwd(const dpd_pose_net* net, const float* ptsA, co
     for (int i = 0; i < 5; ++i) { pw.W[i] = net->Wp[i]; pw.b[i] = net->bp[i]; }
     PointSave sv{{const_cast<float*>(h1), const_cast<float*>(h2), const_cast<float*>(h3), const_cast<float*>(h4)},
                  const_cast<unsigned long long*>(ties)};
-    DPD_LAUNCH(pose_bwd_w5_kernel, dim3((unsigned)((OUT + 3) / 4)), dim3(256), 0, s, df, ties, h4, C, N, OUT, dW[4], db[4]);
-    DPD_CHECK_LAUNCH();
     const size_t lds = (size_t)kBwdLds * sizeof(float);
     if (int rc = ensure_dyn_lds(g_point_bwd_lds, (const void*)pose_bwd_cloud_kernel, lds)) return rc;
     float* g4g = (float*)ws + (size_t)C * kPart;                   // [C * N, 128]
-    DPD_LAUNCH(pose_bwd_dh4_kernel, dim3((unsigned)(C * 8)), dim3(512), 0, s, df, ties, net->Wp[4], h4, N, OUT, g4g);
+    DPD_LAUNCH(pose_bwd_w5_dh4_kernel, dim3((unsigned)(C * 8 + (OUT + 7) / 8)), dim3(512), 0, s, df, ties, net->Wp[4], h4, C, N, OUT, g4g, dW[4], db[4]);
     DPD_CHECK_LAUNCH();
     DPD_LAUNCH(pose_bwd_cloud_kernel, dim3((unsigned)C), dim3(kBT), lds, s, ptsA, ptsB, nA, N, pw, (const float*)g4g, sv, (float*)ws);
     DPD_CHECK_LAUNCH();
@@ -1043,7 +1048,7 @@ extern "C" int dpd_pose_point_bwd(const dpd_pose_net* net, const float* ptsA, co
 // models/ipcr_model.py:273-284: fc 2048 -> 1024 -> 512 -> 256 (ReLU each, dropout on the last) -> 7, and TF / torch autodiff of it:
 //   forward   pose_fc_kernel (above) x 3 with the hidden activations kept, pose_fc4_fwd_kernel
 //   backward  pose_fc4_bwd_kernel: gradient of the 256-wide activation (dropout mask and ReLU gate applied) + dW4 / db4
-//             per wide layer: pose_fc_dw_kernel (dW = g^T x, db: 16 terms per entry, bound by the 8 MB it writes for fc1) and
+//             pose_fc_dw3_kernel (dW = g^T x, db of the three wide layers in one launch: 16 terms per entry, bound by the 8 MB fc1 writes), per layer
 //             pose_fc_dx_kernel (gx = (g W) * [x > 0] on v_mfma_f32_16x16x4_f32; the weight is streamed once: 16 input columns per workgroup,
 //             sixteen waves each contracting a sixteenth of the outputs, partial tiles added in wave order -- 128 / 64 / 32 workgroups)
 namespace dpd {
@@ -1110,10 +1115,19 @@ __global__ __launch_bounds__(256) void pose_fc4_bwd_kernel(const float* __restri
 
 // dW[j][k] = sum_r g[r][j] x[r][k] (r ascending), db[j] = sum_r g[r][j].  x = [xA (KA columns) | xB (K - KA)] like pose_fc_kernel's input.
 // block = 16 output rows x 256 columns: thread = (four rows j, one float4 of columns)
-__global__ __launch_bounds__(256) void pose_fc_dw_kernel(const float* __restrict__ g, const float* __restrict__ xA, const float* __restrict__ xB,
-                                                          int KA, int J, int K, int R, float* __restrict__ dW, float* __restrict__ db) {
+struct FcDwJob {               // dW [J,K] = g^T [J,R] x [R,K] (x = [xA | xB], xA KA columns wide), db [J]; K / 256 x J / 16 blocks
+    const float* g;
+    const float* xA;
+    const float* xB;
+    float* dW;
+    float* db;
+    int KA, J, K;
+    int blocks;                 // (K / 256) * (J / 16)
+};
+__device__ __forceinline__ void fc_dw_block(const float* __restrict__ g, const float* __restrict__ xA, const float* __restrict__ xB, int KA, int J,
+                                            int K, int R, float* __restrict__ dW, float* __restrict__ db, int bx, int by) {
     const int t = threadIdx.x, kq = t & 63, jg = t >> 6;
-    const int k = blockIdx.x * 256 + 4 * kq, j0 = blockIdx.y * 16 + 4 * jg;
+    const int k = bx * 256 + 4 * kq, j0 = by * 16 + 4 * jg;
     if (k >= K) return;
     const float* x = k < KA ? xA + k : xB + (k - KA);
     const int ldx = k < KA ? KA : K - KA;
@@ -1134,10 +1148,20 @@ __global__ __launch_bounds__(256) void pose_fc_dw_kernel(const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(dW + (size_t)(j0 + u) * K + k) = acc[u];
-    if (blockIdx.x == 0 && kq == 0) {
+    if (bx == 0 && kq == 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) db[j0 + u] = bs[u];
     }
+}
+// the three wide layers' weight gradients in ONE launch (they depend on g3, g2, g1 only: after the second dx launch, beside nothing else --
+// three launches of 7-8 us each were mostly launch ramp): block ranges [0, n0) fc3, [n0, n0 + n1) fc2, the rest fc1
+__global__ __launch_bounds__(256) void pose_fc_dw3_kernel(FcDwJob a, FcDwJob b, FcDwJob c, int R) {
+    int id = blockIdx.x;
+    const FcDwJob* j = &a;
+    if (id >= a.blocks) { id -= a.blocks; j = &b; }
+    if (j == &b && id >= b.blocks) { id -= b.blocks; j = &c; }
+    const int nbx = j->K / 256;
+    fc_dw_block(j->g, j->xA, j->xB, j->KA, j->J, j->K, R, j->dW, j->db, id % nbx, id / nbx);
 }
 
 // gx[r][k] = (sum_j g[r][j] W[j][k]) * [xprev[r][k] > 0] for <= 16 rows per blockIdx.y and the 64 columns k0 .. k0 + 63 of blockIdx.x.
@@ -1232,18 +1256,19 @@ extern "C" int dpd_pose_head_bwd(const dpd_pose_net* net, const float* f, int B,
     DPD_LAUNCH(pose_fc4_bwd_kernel, dim3((unsigned)B + 7), dim3(256), 0, s, dpred, net->Wh[3], h3, drop_mask, B, 256, g3, dW[3], db[3]);
     DPD_CHECK_LAUNCH();
     // fc3: W [256, 512]
-    DPD_LAUNCH(pose_fc_dw_kernel, dim3(512 / 256, 256 / 16), dim3(256), 0, s, (const float*)g3, h2, (const float*)nullptr, 512, 256, 512, B, dW[2], db[2]);
-    DPD_CHECK_LAUNCH();
     DPD_LAUNCH(pose_fc_dx_kernel<4>, dim3(512 / 16, ry), dim3(1024), 0, s, (const float*)g3, net->Wh[2], h2, 512, B, g2, 512, 512);
     DPD_CHECK_LAUNCH();
     // fc2: W [512, 1024]
-    DPD_LAUNCH(pose_fc_dw_kernel, dim3(1024 / 256, 512 / 16), dim3(256), 0, s, (const float*)g2, h1, (const float*)nullptr, 1024, 512, 1024, B, dW[1], db[1]);
-    DPD_CHECK_LAUNCH();
     DPD_LAUNCH(pose_fc_dx_kernel<8>, dim3(1024 / 16, ry), dim3(1024), 0, s, (const float*)g2, net->Wh[1], h1, 1024, B, g1, 1024, 1024);
     DPD_CHECK_LAUNCH();
     // fc1: W [1024, 2048], input = [features of the first B clouds | of the second B clouds]; its dX is d features [2B, 1024] (no gate)
-    DPD_LAUNCH(pose_fc_dw_kernel, dim3(2048 / 256, 1024 / 16), dim3(256), 0, s, (const float*)g1, f, f + (size_t)B * OUT, OUT, 1024, 2048, B, dW[0], db[0]);
-    DPD_CHECK_LAUNCH();
+    {
+        const FcDwJob j3{g3, h2, nullptr, dW[2], db[2], 512, 256, 512, (512 / 256) * (256 / 16)};
+        const FcDwJob j2{g2, h1, nullptr, dW[1], db[1], 1024, 512, 1024, (1024 / 256) * (512 / 16)};
+        const FcDwJob j1{g1, f, f + (size_t)B * OUT, dW[0], db[0], OUT, 1024, 2048, (2048 / 256) * (1024 / 16)};
+        DPD_LAUNCH(pose_fc_dw3_kernel, dim3((unsigned)(j3.blocks + j2.blocks + j1.blocks)), dim3(256), 0, s, j3, j2, j1, B);
+        DPD_CHECK_LAUNCH();
+    }
     DPD_LAUNCH(pose_fc_dx_kernel<16>, dim3(2048 / 16, ry), dim3(1024), 0, s, (const float*)g1, net->Wh[0], (const float*)nullptr, 2048, B, df, OUT, OUT);
     DPD_CHECK_LAUNCH();
     return 0;
