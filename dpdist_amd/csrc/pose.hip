@@ -1115,46 +1115,65 @@ __global__ __launch_bounds__(256) void pose_fc4_bwd_kernel(const float* __restri
 
 // dW[j][k] = sum_r g[r][j] x[r][k] (r ascending), db[j] = sum_r g[r][j].  x = [xA (KA columns) | xB (K - KA)] like pose_fc_kernel's input.
 // block = 16 output rows x 256 columns: thread = (four rows j, one float4 of columns)
-struct FcDwJob {               // dW [J,K] = g^T [J,R] x [R,K] (x = [xA | xB], xA KA columns wide), db [J]; K / 256 x J / 16 blocks
+struct FcDwJob {               // dW [J,K] = g^T [J,R] x [R,K] (x = [xA | xB], xA KA columns wide), db [J]; K / 256 x J / 64 blocks
     const float* g;
     const float* xA;
     const float* xB;
     float* dW;
     float* db;
     int KA, J, K;
-    int blocks;                 // (K / 256) * (J / 16)
+    int blocks;                 // (K / 256) * (J / 64)
 };
 __device__ __forceinline__ void fc_dw_block(const float* __restrict__ g, const float* __restrict__ xA, const float* __restrict__ xB, int KA, int J,
                                             int K, int R, float* __restrict__ dW, float* __restrict__ db, int bx, int by) {
-    const int t = threadIdx.x, kq = t & 63, jg = t >> 6;
-    const int k = bx * 256 + 4 * kq, j0 = by * 16 + 4 * jg;
+    // block = 64 outputs j x 256 inputs k: wave w = outputs 16 w .. + 15 (its g values are wave-uniform: scalar loads), lane = four inputs.
+    // The first sixteen rows of x stay in registers for all sixteen outputs (one round of loads; a thread of the 4 j x 4 k form re-read them
+    // four times as often: 43 MB of L2 traffic for fc1); further rows (batch > 16) are read again per group of outputs.
+    const int t = threadIdx.x, kq = t & 63, jg = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int k = bx * 256 + 4 * kq, jw = by * 64 + 16 * jg;
     if (k >= K) return;
     const float* x = k < KA ? xA + k : xB + (k - KA);
     const int ldx = k < KA ? KA : K - KA;
-    float4 acc[4];
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 xr[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int r = 0; r < R; ++r) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx);
-        const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)r * J + j0);
-        const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    for (int r = 0; r < 16; ++r) xr[r] = r < R ? *reinterpret_cast<const float4*>(x + (size_t)r * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int jc = 0; jc < 4; ++jc) {
+        const int j0 = jw + 4 * jc;
+        float4 acc[4];
+        float bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[u].x += gg[u] * xv.x; acc[u].y += gg[u] * xv.y; acc[u].z += gg[u] * xv.z; acc[u].w += gg[u] * xv.w;
-            bs[u] += gg[u];
+        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 gv = r < R ? *reinterpret_cast<const float4*>(g + (size_t)r * J + j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[u].x += gg[u] * xr[r].x; acc[u].y += gg[u] * xr[r].y; acc[u].z += gg[u] * xr[r].z; acc[u].w += gg[u] * xr[r].w;
+                bs[u] += gg[u];
+            }
         }
-    }
+        for (int r = 16; r < R; ++r) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * ldx);
+            const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)r * J + j0);
+            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(dW + (size_t)(j0 + u) * K + k) = acc[u];
-    if (bx == 0 && kq == 0) {
+            for (int u = 0; u < 4; ++u) {
+                acc[u].x += gg[u] * xv.x; acc[u].y += gg[u] * xv.y; acc[u].z += gg[u] * xv.z; acc[u].w += gg[u] * xv.w;
+                bs[u] += gg[u];
+            }
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) db[j0 + u] = bs[u];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(dW + (size_t)(j0 + u) * K + k) = acc[u];
+        if (bx == 0 && kq == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) db[j0 + u] = bs[u];
+        }
     }
 }
 // the three wide layers' weight gradients in ONE launch (they depend on g3, g2, g1 only: after the second dx launch, beside nothing else --
-// three launches of 7-8 us each were mostly launch ramp): block ranges [0, n0) fc3, [n0, n0 + n1) fc2, the rest fc1
+// three launches of 7-8 us each were mostly launch ramp): block ranges [0, n0) fc3, [n0, n0 + n1) fc2, the rest fc1 (8 + 32 + 128 blocks)
 __global__ __launch_bounds__(256) void pose_fc_dw3_kernel(FcDwJob a, FcDwJob b, FcDwJob c, int R) {
     int id = blockIdx.x;
     const FcDwJob* j = &a;
@@ -1263,9 +1282,9 @@ extern "C" int dpd_pose_head_bwd(const dpd_pose_net* net, const float* f, int B,
     DPD_CHECK_LAUNCH();
     // fc1: W [1024, 2048], input = [features of the first B clouds | of the second B clouds]; its dX is d features [2B, 1024] (no gate)
     {
-        const FcDwJob j3{g3, h2, nullptr, dW[2], db[2], 512, 256, 512, (512 / 256) * (256 / 16)};
-        const FcDwJob j2{g2, h1, nullptr, dW[1], db[1], 1024, 512, 1024, (1024 / 256) * (512 / 16)};
-        const FcDwJob j1{g1, f, f + (size_t)B * OUT, dW[0], db[0], OUT, 1024, 2048, (2048 / 256) * (1024 / 16)};
+        const FcDwJob j3{g3, h2, nullptr, dW[2], db[2], 512, 256, 512, (512 / 256) * (256 / 64)};
+        const FcDwJob j2{g2, h1, nullptr, dW[1], db[1], 1024, 512, 1024, (1024 / 256) * (512 / 64)};
+        const FcDwJob j1{g1, f, f + (size_t)B * OUT, dW[0], db[0], OUT, 1024, 2048, (2048 / 256) * (1024 / 64)};
         DPD_LAUNCH(pose_fc_dw3_kernel, dim3((unsigned)(j3.blocks + j2.blocks + j1.blocks)), dim3(256), 0, s, j3, j2, j1, B);
         DPD_CHECK_LAUNCH();
     }
