@@ -94,7 +94,7 @@ class _PointFeaturesFn(torch.autograd.Function):
 
 class _PoseNetRawFn(torch.autograd.Function):
     """The whole pose network of a training evaluation -- shared MLP + max pool (_PointFeaturesFn's kernels) and the head (models/ipcr_model.py:
-    273-284) -- as ONE autograd node on the library: five launches forward (dpd_pose_point_fwd_train, dpd_pose_head_fwd_train), eleven backward
+    273-284) -- as ONE autograd node on the library: five launches forward (dpd_pose_point_fwd_train, dpd_pose_head_fwd_train), eight backward
     (dpd_pose_head_bwd, dpd_pose_point_bwd), gradients w.r.t. the 18 weight tensors only.  `mask` [B,256]: the dropout mask (0 or 1 / keep)
     drawn by the caller, or None (evaluation mode).  `sink`: None, or {id(parameter): tensor of its shape} -- the backward then WRITES the
     gradient of that parameter there (views of the optimizer's flat gradient buffer: no gather copy afterwards) and returns it."""

@@ -110,7 +110,7 @@ if os.path.exists(f):
         elif n.startswith("Cijk_"):
             g = "torch GEMMs (hipBLASLt)"
         else:
-            g = "torch kernels (dropout mask, gradient gather into Adam's flat buffer, fills)"
+            g = "torch kernels (the dropout mask draw)"
         groups[g][0] += float(r["TotalDurationNs"]) / 1e3
         groups[g][1] += int(r["Calls"])
     tot = sum(v[0] for v in groups.values())
