@@ -489,7 +489,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NIT>
 __global__ __launch_bounds__(1024) void pose_fc_kernel(const float* __restrict__ inA, const float* __restrict__ inB, int KA,
                                                        const float* __restrict__ W, const float* __restrict__ bias, int J, int R, int relu,
-                                                       const float* __restrict__ mask, float* __restrict__ out) {
+                                                       const float* __restrict__ mask, float* __restrict__ out, int ldw,
+                                                       const float* __restrict__ rowbias) {
     constexpr int K = NIT * 256;
     __shared__ float part[16][256];
     const int j0 = blockIdx.x * 16, r0 = blockIdx.y * 16, wv = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -497,11 +498,11 @@ __global__ __launch_bounds__(1024) void pose_fc_kernel(const float* __restrict__
     const int row = min(r0 + n, R - 1);
     const int kw = wv * (K / 16);                              // this wave's K range: [kw, kw + 16 NIT)
     const float* x = kw < KA ? inA + (size_t)row * KA + kw : inB + (size_t)row * (K - KA) + (kw - KA);
-    const float* w = W + (size_t)(j0 + n) * K + kw;
+    const float* w = W + (size_t)(j0 + n) * ldw + kw;       // ldw >= K: a column block of a wider weight matrix
     // the epilogue's element (threads 0..255) and what it needs from global memory, requested with the operands
     const int e = threadIdx.x, el = e >> 2, er = e & 3, en = el & 15, ej = j0 + 4 * (el >> 4) + er, orow = r0 + en;
     const bool live = e < 256 && orow < R && ej < J;
-    const float bj = live ? bias[ej] : 0.f;
+    const float bj = live ? (rowbias ? rowbias[(size_t)orow * J + ej] : bias[ej]) : 0.f;      // rowbias [R][J]: a precomputed part of the sum
     const float mk = (live && mask) ? mask[(size_t)orow * J + ej] : 1.f;
     float4 wr[NIT], xr[NIT];
 #pragma unroll
@@ -560,7 +561,7 @@ extern "C" int dpd_pose_apply_bwd(const float* pred, const float* src, const flo
 namespace {
 
 struct RefineWs {
-    float *f, *h1, *h2, *h3, *cloud[2], *T[2];
+    float *f, *h1, *h2, *h3, *cloud[2], *T[2], *tb;
     size_t total;
 };
 
@@ -570,6 +571,7 @@ RefineWs refine_ws(float* base, int B, int N, int OUT) {
     auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
     w.f = take((size_t)2 * B * OUT); w.h1 = take((size_t)B * 1024); w.h2 = take((size_t)B * 512); w.h3 = take((size_t)B * 256);
     w.cloud[0] = take((size_t)B * N * 3); w.cloud[1] = take((size_t)B * N * 3); w.T[0] = take((size_t)B * 16); w.T[1] = take((size_t)B * 16);
+    w.tb = take((size_t)B * 1024);
     w.total = off * sizeof(float);
     return w;
 }
@@ -624,14 +626,21 @@ extern "C" int dpd_pose_refine(const dpd_pose_net* net, const float* src, const 
         DPD_CHECK_LAUNCH();
         const unsigned ry = (unsigned)((B + 15) / 16);
         const float* dm = drop_mask ? drop_mask + (size_t)it * B * 256 : (const float*)nullptr;
-        DPD_LAUNCH(pose_fc_kernel<8>, dim3(1024 / 16, ry), dim3(1024), 0, s, (const float*)w.f, (const float*)(w.f + (size_t)B * OUT), OUT,
-                   net->Wh[0], net->bh[0], 1024, B, 1, (const float*)nullptr, w.h1);
+        if (it == 0) {
+            // the template never moves: its half of fc1's sum (W1[:, OUT:] f_tmpl + b1) once per call, every loop then contracts the source's
+            // half only (4 MB of weights per loop instead of 8)
+            DPD_LAUNCH(pose_fc_kernel<4>, dim3(1024 / 16, ry), dim3(1024), 0, s, (const float*)(w.f + (size_t)B * OUT), (const float*)nullptr, OUT,
+                       net->Wh[0] + OUT, net->bh[0], 1024, B, 0, (const float*)nullptr, w.tb, 2 * OUT, (const float*)nullptr);
+            DPD_CHECK_LAUNCH();
+        }
+        DPD_LAUNCH(pose_fc_kernel<4>, dim3(1024 / 16, ry), dim3(1024), 0, s, (const float*)w.f, (const float*)nullptr, OUT, net->Wh[0], net->bh[0], 1024, B, 1,
+                   (const float*)nullptr, w.h1, 2 * OUT, (const float*)w.tb);
         DPD_CHECK_LAUNCH();
         DPD_LAUNCH(pose_fc_kernel<4>, dim3(512 / 16, ry), dim3(1024), 0, s, (const float*)w.h1, (const float*)nullptr, 1024, net->Wh[1], net->bh[1],
-                   512, B, 1, (const float*)nullptr, w.h2);
+                   512, B, 1, (const float*)nullptr, w.h2, 1024, (const float*)nullptr);
         DPD_CHECK_LAUNCH();
         DPD_LAUNCH(pose_fc_kernel<2>, dim3(256 / 16, ry), dim3(1024), 0, s, (const float*)w.h2, (const float*)nullptr, 512, net->Wh[2], net->bh[2], 256,
-                   B, 1, dm, w.h3);
+                   B, 1, dm, w.h3, 512, (const float*)nullptr);
         DPD_CHECK_LAUNCH();
     }
     DPD_LAUNCH(pose_apply_fwd_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)nullptr, cur, Tcur, N, lim_rad, 0, (float*)nullptr, moved,
@@ -1241,13 +1250,13 @@ extern "C" int dpd_pose_head_fwd_train(const dpd_pose_net* net, const float* f, 
     hipStream_t s = (hipStream_t)stream;
     const unsigned ry = (unsigned)((B + 15) / 16);
     DPD_LAUNCH(pose_fc_kernel<8>, dim3(1024 / 16, ry), dim3(1024), 0, s, f, f + (size_t)B * OUT, OUT, net->Wh[0], net->bh[0], 1024, B, 1,
-               (const float*)nullptr, h1);
+               (const float*)nullptr, h1, 2048, (const float*)nullptr);
     DPD_CHECK_LAUNCH();
     DPD_LAUNCH(pose_fc_kernel<4>, dim3(512 / 16, ry), dim3(1024), 0, s, (const float*)h1, (const float*)nullptr, 1024, net->Wh[1], net->bh[1], 512, B, 1,
-               (const float*)nullptr, h2);
+               (const float*)nullptr, h2, 1024, (const float*)nullptr);
     DPD_CHECK_LAUNCH();
     DPD_LAUNCH(pose_fc_kernel<2>, dim3(256 / 16, ry), dim3(1024), 0, s, (const float*)h2, (const float*)nullptr, 512, net->Wh[2], net->bh[2], 256, B, 1,
-               drop_mask, h3);
+               drop_mask, h3, 512, (const float*)nullptr);
     DPD_CHECK_LAUNCH();
     DPD_LAUNCH(pose_fc4_fwd_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)h3, net->Wh[3], net->bh[3], 256, pred);
     DPD_CHECK_LAUNCH();
