@@ -14,10 +14,11 @@
 //
 // The forward-only refinements (7 of the 8 pose-network evaluations of a step, :414-441, and all 8 of an evaluation batch) also run the
 // pose NETWORK here -- models/ipcr_model.py:198-233 (shared MLP 3-64-64-64-128-1024 + max pool) and :273-284 (fc 2048-1024-512-256-7,
-// dropout before the last layer) -- in four launches per loop (+ one per call) instead of ~25 (dpd_pose_refine):
+// dropout before the last layer) -- in four launches per loop (+ two per call) instead of ~25 (dpd_pose_refine):
 //   pose_point_kernel   one workgroup per (cloud, 128-column slice of the last layer): all five layers for the cloud's points in LDS,
 //                       max pool in the epilogue; the template's features are computed once per call (the template does not move)
-//   pose_fc_kernel      the three wide head layers for <= 16 rows: one wave per 4 output columns streams its weight rows once
+//   pose_fc_kernel      the three wide head layers for <= 16 rows on v_mfma_f32_16x16x4_f32: workgroup = 16 outputs, sixteen waves split K;
+//                       the template's half of fc1's sum once per call (`rowbias`), every loop contracts the source's half only
 //   pose_apply_fwd_kernel   fc4 (256 x 7) as its prologue, then the pose chain above: the LAST loop's pose only -- the pose of every other loop
 //                       (fc4, chain, move, T composition) is the prologue of the NEXT loop's pose_point_kernel (PoseMove), not a launch
 // fp32 throughout (MFMA fp32 / FMA).  The training evaluation of the network and its backward: further down (round 6).

@@ -347,7 +347,8 @@ int dpd_pose_apply_bwd(const float* pred, const float* src, const float* dmoved,
  * only `predicted_transformation` is fetched) with the pose NETWORK on the library as well: per loop, shared MLP 3-64-64-64-128-out_features +
  * max pool over the points for source and template (models/ipcr_model.py:198-233; the template's features are computed once: it never
  * moves), fc 2*out_features-1024-512-256, dropout, fc 7 (:273-284), quat_normalize (:285-294), then the source is moved and T composed
- * (helper.py:309-329) -- four launches per loop + one per call (a loop's pose chain and cloud move are the prologue of the next loop's shared MLP).  Weights are torch.nn.Linear layout: W [out, in] row-major, fp32.
+ * (helper.py:309-329) -- four launches per loop + two per call (a loop's pose chain and cloud move are the prologue of the next loop's shared MLP; the
+ * template's half of the first dense layer's sum is computed once).  Weights are torch.nn.Linear layout: W [out, in] row-major, fp32.
  *   src, tmpl [B,N,3];  drop_mask [loops,B,256] or NULL: multiplied into the 256-wide layer (0 or 1/keep_prob: the caller draws it);
  *   ws: dpd_pose_refine_workspace_bytes(B, N, out_features) bytes, 16-byte aligned;
  *   moved [B,N,3], T_out [B,4,4]: the source and the accumulated transform after `loops` loops (T starts at the identity);
