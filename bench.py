@@ -517,7 +517,7 @@ def section8d_legs(L, tr, pcA, pcB, lab, dev, steps, warmup):
                       "gemm_frac_of_peak": round(tf / peak, 4), "gemm_tflops": round(tf, 1)})
         return r
 
-    n = max(steps, 20)
+    n = max(steps, 100)         # (sub-millisecond evaluations: 20 of them are 4 ms of wall clock, too few for a steady figure)
     # forward only on the headline trainer
     B = tr.B
     ms = timed(lambda: tr.evaluate(pcA, pcB, lab), n)
