@@ -517,6 +517,32 @@ def section8d_legs(L, tr, pcA, pcB, lab, dev, steps, warmup):
                       "gemm_frac_of_peak": round(tf / peak, 4), "gemm_tflops": round(tf, 1)})
         return r
 
+    def graph_replay_ms(loss_fn, src, tmpl, n):
+        from dpdist_amd import asloss
+        try:
+            pool = {}
+            with asloss.private_pool(pool):
+                for _ in range(3):
+                    torch.autograd.grad(loss_fn(src, tmpl), src)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    torch.autograd.grad(loss_fn(src, tmpl), src)
+            for _ in range(10):
+                g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            del g, pool
+            return round(ms, 4)
+        except Exception as e:      # reported evidence only: never fails the line
+            return "capture failed: %s" % (str(e).splitlines()[0][:120] if str(e) else type(e).__name__)
+
     n = max(steps, 100)         # (sub-millisecond evaluations: 20 of them are 4 ms of wall clock, too few for a steady figure)
     # forward only on the headline trainer
     B = tr.B
@@ -549,6 +575,10 @@ def section8d_legs(L, tr, pcA, pcB, lab, dev, steps, warmup):
             Q = 2 * Bx * N
             asl["b%d_%s" % (Bx, dt)] = {"fwd_bwd": record(timed(fb, n), Q, 2 * FWD_FLOP, pk, fb, n),
                                         "fwd_only": record(timed(fo, n), Q, FWD_FLOP, pk, fo, n)}
+            # the same forward + backward captured once as a hipGraph and replayed (how the registration step runs it): GPU time per
+            # evaluation by events, independent of the host (the eager figure above pays Python + autograd per evaluation, and a busy host
+            # shows in it)
+            asl["b%d_%s" % (Bx, dt)]["fwd_bwd"]["graph_replay_ms_per_eval"] = graph_replay_ms(loss_fn, src, tmpl, n)
     out["as_loss"] = asl
     return out
 
