@@ -677,6 +677,7 @@ def main():
         hb.beat("aux:schedule of the headline step")
         # collective; parameters and Adam state are restored afterwards.  Order x communication form (all bitwise-equivalent except
         # "grouped"); DPD_DP_SCHEDULE / DPD_DP_MODE pin either axis
+        tr.progress = lambda: hb.beat(hb.phase)       # every candidate refreshes the watchdog's heartbeat
         headline_sched = tr.select_dp_schedule(pcA, pcB, lab, modes=DP_MODES)
 
     keep = []
@@ -765,6 +766,7 @@ def main():
         sched = None
         if distributed:      # the order of the data-parallel backward: measured here, decided by all ranks together (unless DPD_DP_SCHEDULE pins it)
             hb.beat("aux:schedule " + label[:30])
+            tr2.progress = lambda: hb.beat(hb.phase)
             sched = tr2.select_dp_schedule(a2, b2, l2, modes=None if mode is not None else DP_MODES)
         for _ in range(a.warmup):
             tr2.step(a2, b2, l2)
@@ -781,10 +783,14 @@ def main():
             (sync if distributed else torch.cuda.synchronize)()
             cold2 = (time.perf_counter() - t1) / a.steps * 1e3
             t1 = time.perf_counter()
-            while (spin_steps < 150) if distributed else ((time.perf_counter() - t1) * 1e3 < spin2):
+            # (TEST MODE: N ranks time-share one GPU and reduce through the host -- a step can take 100 ms on a busy box and no timing means
+            # anything: no spin-up; the heartbeat is refreshed as the loop advances, so a slow but advancing leg is not taken for a hang)
+            while (spin_steps < (0 if share_gpu else 150)) if distributed else ((time.perf_counter() - t1) * 1e3 < spin2):
                 for _ in range(10):
                     tr2.step(a2, b2, l2)
                 spin_steps += 10
+                if distributed:
+                    hb.beat(hb.phase)
                 if not distributed:
                     torch.cuda.synchronize()
         e2 = float("inf")

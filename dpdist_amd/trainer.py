@@ -173,6 +173,7 @@ class DPDistTrainer:
         self._pref_key = None      # identity of the batch whose front end is (being) computed on the side stream
         self._ev_front = self._ev_xfree = self._ev_fwd = None
         self.front_launches = 0    # front ends (stack + encoder + gather) enqueued so far, on either stream
+        self.progress = None       # optional callable, called before every candidate of select_dp_schedule (bench.py: the watchdog's heartbeat)
         self.prefetch_hits = 0     # steps that found their front end already computed by the side stream
 
     def close(self):
@@ -573,6 +574,8 @@ class DPDistTrainer:
             self.P.invalidate_derived()
 
         def time_fn(name):
+            if self.progress is not None:       # (a launch watchdog's heartbeat: a candidate that runs is progress, whatever the phase limit)
+                self.progress()
             mode, _, order = name.rpartition("/")
             if mode:
                 self.set_dp_mode(mode)          # collective; every rank walks the same candidate list in the same order
