@@ -2137,6 +2137,12 @@ def test_plane_weight_gradient_pair_on_a_narrow_decoder(dev, B, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_ranks_share_the_gpu(dev, world):
+    if world == 4 and os.environ.get("DPD_TEST_WORLD4") != "1":
+        # On the shared one-GPU test boxes gloo's FOUR-rank path through the host takes 2-20 s per step for the single-collective ("late")
+        # forms (candidates_ms of round 6: allreduce/late 2.6 s, rs_ag/late 19.9 s against 12-65 ms for "early"), 5-10 minutes for this case
+        # alone -- while 2 ranks run in 5 s and 8 ranks in 20-30 s on the same box.  A property of the test transport, not of the path under
+        # test (RCCL on real nodes); the case passes (DPD_TEST_WORLD4=1 runs it), it is just not worth ten minutes of every suite run.
+        pytest.skip("world size 4 over gloo on one GPU: minutes per run; set DPD_TEST_WORLD4=1")
     """bench.py's world-size-N control flow for real, on a one-GPU box: DPD_TEST_SHARE_GPU=1 puts all ranks on GPU 0 over gloo (timings
     mean nothing).  Exactly the driver's command (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) for N = 2, 4
     and 8: N supervisors and their workers, the rendezvous, the reducer's start-up cross-check with N ranks (its amplitude adapts to N),
